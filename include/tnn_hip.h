@@ -1,0 +1,232 @@
+/*
+ * tnn_hip.h — C-ABI of the MI355X (gfx950) dense-tensor backend for tinynn-autograd.
+ *
+ * The reference (borgwang/tinynn-autograd) has no FFI of its own: its seam is the Python module
+ * pair core/tensor.py + core/ops.py whose numpy expressions are listed below next to the entry
+ * point that replaces each of them.  This header is that seam restated as a plain C interface:
+ * `extern "C"`, raw device pointers + sizes, no torch / numpy types.  The ctypes binding lives in
+ * tinynn-autograd_amd/_lib.py; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; tnn_last_error() gives the text
+ *     (thread-local).  Nothing is retained past a call except the stream, the pool and comm handles.
+ *   - all device work is enqueued on ONE library-owned HIP stream (tnn_stream_sync() waits for it);
+ *     calls are asynchronous unless stated otherwise.
+ *   - arrays are dense row-major ("C order"); leading dimensions are in ELEMENTS.
+ *   - dtype codes: TNN_F32 (compute type of the hot path), TNN_F64 (exact-test mode, the reference's
+ *     de-facto type), TNN_I64 (indices), TNN_U8 (numpy bool masks).
+ */
+#ifndef TNN_HIP_H_
+#define TNN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TNN_API __attribute__((visibility("default")))
+
+enum { TNN_F32 = 0, TNN_F64 = 1, TNN_I64 = 2, TNN_U8 = 3 };
+
+/* binary elementwise ops — reference core/ops.py:33 (add), :66 (mul), :94 (div), :122 (pow),
+ * :167 (maximum), :192 (minimum) and the arithmetic inside their vjp bodies */
+enum { TNN_ADD = 0, TNN_SUB = 1, TNN_MUL = 2, TNN_DIV = 3, TNN_POW = 4, TNN_MAX = 5, TNN_MIN = 6 };
+/* comparisons — core/tensor.py:48-58 (raw bool arrays), core/ops.py:170,173,195,198,229,238,338,340 */
+enum { TNN_GT = 0, TNN_GE = 1, TNN_LT = 2, TNN_LE = 3, TNN_EQ = 4, TNN_NE = 5 };
+/* unary ops — core/ops.py:217 (exp), :244 (log), :294 (neg); sqrt/square/abs/recip are the pieces of
+ * core/optimizer.py:70-77; sigmoid/tanh are fast paths for core/layers.py:79-80,88-89 */
+enum { TNN_NEG = 0, TNN_EXP = 1, TNN_LOG = 2, TNN_SQRT = 3, TNN_SQUARE = 4, TNN_ABS = 5,
+       TNN_RECIP = 6, TNN_SIGMOID = 7, TNN_TANH = 8, TNN_COPY = 9 };
+/* reductions — core/ops.py:42,46,51,54 (un-broadcast sums), :226 (max), :235 (min), :253 (sum) */
+enum { TNN_RSUM = 0, TNN_RMAX = 1, TNN_RMIN = 2 };
+/* activation codes for fused epilogues — core/layers.py:97-98 (ReLU = clip(x, 0.0)) */
+enum { TNN_ACT_NONE = 0, TNN_ACT_RELU = 1 };
+
+/* ------------------------------------------------------------------ runtime ------------------ */
+TNN_API int tnn_init(int device);                 /* idempotent; creates the stream + pool         */
+TNN_API int tnn_shutdown(void);
+TNN_API const char* tnn_last_error(void);
+TNN_API int tnn_backend_kind(void);               /* 1 = HIP gfx950 library, 2 = CPU test twin      */
+TNN_API int tnn_device_props(int* cu_count, int* clock_khz, int64_t* hbm_bytes,
+                             char* name, int name_len);
+
+/* caching pool allocator (replaces numpy's malloc behind every op output, core/tensor.py:20) */
+TNN_API int tnn_malloc(size_t bytes, void** out);
+TNN_API int tnn_free(void* p);
+TNN_API int tnn_pool_stats(int64_t* live_bytes, int64_t* cached_bytes, int64_t* device_allocs);
+TNN_API int tnn_pool_trim(void);
+
+TNN_API int tnn_memcpy_h2d(void* dst, const void* src, size_t bytes);  /* returns when src is reusable */
+TNN_API int tnn_memcpy_d2h(void* dst, const void* src, size_t bytes);  /* synchronises the stream      */
+TNN_API int tnn_memcpy_d2d(void* dst, const void* src, size_t bytes);
+TNN_API int tnn_memset(void* dst, int byte, size_t bytes);
+TNN_API int tnn_fill(void* dst, double value, int64_t n, int dtype);   /* np.zeros / np.ones_like */
+TNN_API int tnn_stream_sync(void);
+
+/* HIP events on the library stream (bench.py times kernels with these) */
+TNN_API int tnn_event_create(void** ev);
+TNN_API int tnn_event_record(void* ev);
+TNN_API int tnn_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises on stop */
+TNN_API int tnn_event_destroy(void* ev);
+
+/* hipGraph capture of everything enqueued between begin/end on the library stream.
+ * Buffers allocated while capturing stay owned by the graph until tnn_graph_destroy. */
+TNN_API int tnn_graph_capture_begin(void);
+TNN_API int tnn_graph_capture_end(void** graph_exec);
+TNN_API int tnn_graph_launch(void* graph_exec);
+TNN_API int tnn_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------------------ GEMM (K1) ----------------- */
+/* C[M,N] = alpha * op(A) * op(B) + beta * C.  op(A) is [M,K]: transA=0 -> A stored [M,K] (lda>=K),
+ * transA=1 -> A stored [K,M] (lda>=M).  op(B) is [K,N]: transB=0 -> B stored [K,N], transB=1 ->
+ * B stored [N,K].  Replaces core/ops.py:151 (A@B, NN), :157 (G@B.T, NT), :160 (A.T@G, TN) without
+ * materialising a transpose.  f32: MFMA v_mfma_f32_32x32x2_f32, LDS-staged.  f64: VALU tiles. */
+TNN_API int tnn_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha,
+                     const void* A, int64_t lda, const void* B, int64_t ldb, double beta,
+                     void* C, int64_t ldc, int dtype);
+
+/* Fused epilogues (K8).  C = act(op(A)*op(B) + bias[N]).  relu_sign=1 additionally stores
+ * negative pre-activations as -0.0f so the ReLU mask (x >= 0, core/ops.py:338) survives in the
+ * sign bit of the output; used only by the whole-step trainer.  Replaces core/layers.py:49 + :98. */
+TNN_API int tnn_gemm_bias_act(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                              const void* A, int64_t lda, const void* B, int64_t ldb,
+                              const void* bias, int act, int relu_sign,
+                              void* C, int64_t ldc, int dtype);
+/* C = (op(A)*op(B)) * mask(Y) with mask = !signbit(Y[M,N]) (Y produced with relu_sign=1):
+ * dX·[x>=0] of core/ops.py:157 + :342-343 in one pass. */
+TNN_API int tnn_gemm_mask(int transA, int transB, int64_t M, int64_t N, int64_t K,
+                          const void* A, int64_t lda, const void* B, int64_t ldb,
+                          const void* Y, int64_t ldy, void* C, int64_t ldc, int dtype);
+
+/* ------------------------------------------------------------------ elementwise (K2,K3) ------- */
+/* out[shape] = a (op) b with numpy broadcasting expressed as element strides (0 = broadcast dim).
+ * ndim <= 6; out is dense row-major of `shape`. */
+TNN_API int tnn_ewise_binary(int op, const void* a, const int64_t* stride_a,
+                             const void* b, const int64_t* stride_b,
+                             void* out, int ndim, const int64_t* shape, int dtype);
+/* out = a (op) s  (scalar_lhs=0)  or  s (op) a  (scalar_lhs=1); s is a host scalar kernel argument
+ * (Python numbers wrapped by as_tensor, core/tensor.py:7-10, never become device buffers). */
+TNN_API int tnn_ewise_scalar(int op, const void* a, double s, int scalar_lhs,
+                             void* out, int64_t n, int dtype);
+/* out_u8 = a (cmp) b, same broadcasting contract */
+TNN_API int tnn_ewise_compare(int cmp, const void* a, const int64_t* stride_a,
+                              const void* b, const int64_t* stride_b,
+                              void* out_u8, int ndim, const int64_t* shape, int dtype);
+TNN_API int tnn_compare_scalar(int cmp, const void* a, double s, void* out_u8, int64_t n, int dtype);
+TNN_API int tnn_ewise_unary(int op, const void* in, void* out, int64_t n, int dtype);
+/* numpy ndarray.clip(min,max) with either bound optional — core/ops.py:334 */
+TNN_API int tnn_clip(const void* in, int has_min, double vmin, int has_max, double vmax,
+                     void* out, int64_t n, int dtype);
+/* out = g * [(!has_min || x>=min) && (!has_max || x<=max)] — core/ops.py:336-343 (mask recomputed
+ * from the saved input instead of being stored as a bool array) */
+TNN_API int tnn_clip_bwd(const void* g, const void* x, int has_min, double vmin, int has_max,
+                         double vmax, void* out, int64_t n, int dtype);
+/* out = g * mask_u8 (grad * (a >= b) style vjps, core/ops.py:170,173,195,198,229,238) */
+TNN_API int tnn_mul_mask(const void* g, const void* mask_u8, void* out, int64_t n, int dtype);
+/* y += alpha * x — core/tensor.py:163 (self.grad += grad) and :66-68 (param += step) */
+TNN_API int tnn_axpy(void* y, double alpha, const void* x, int64_t n, int dtype);
+TNN_API int tnn_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n);
+
+/* ------------------------------------------------------------------ reductions (K4) ----------- */
+/* in viewed as [outer, red, inner] -> out [outer, inner]; covers axis=None (1,n,1), axis=0 of a
+ * matrix (1,R,C) = bias gradient, axis=1 (R,C,1).  Deterministic (no atomics). */
+TNN_API int tnn_reduce(int rop, const void* in, void* out, int64_t outer, int64_t red,
+                       int64_t inner, int dtype);
+/* first-max index per row (np.argmax(x, axis=1), examples/mnist/run.py:89) -> int64 */
+TNN_API int tnn_argmax_rows(const void* in, void* out_i64, int64_t rows, int64_t cols, int dtype);
+
+/* ------------------------------------------------------------------ data movement (K5,K6) ----- */
+/* out (dense, `shape`) = in gathered with element strides: N-d transpose (core/ops.py:269),
+ * broadcast-back of the sum vjp (:257-263, stride 0), basic slices (:283) */
+TNN_API int tnn_strided_copy(const void* in, const int64_t* in_stride, void* out, int ndim,
+                             const int64_t* shape, int dtype);
+/* out (strided view, `shape`) = in (dense): pad forward (core/ops.py:313) and getitem vjp (:286-288) */
+TNN_API int tnn_strided_scatter(const void* in, void* out, const int64_t* out_stride, int ndim,
+                                const int64_t* shape, int dtype);
+/* out[i,:] = src[idx[i],:]  — utils/data_iterator.py:27-28 (inputs[idx]) */
+TNN_API int tnn_gather_rows(const void* src, const void* idx_i64, void* out, int64_t n_idx,
+                            int64_t row_elems, int64_t src_rows, int dtype);
+/* dst[idx[i],:] = src[i,:]  — core/ops.py:287 (recover_grad[key] = grad) */
+TNN_API int tnn_scatter_rows(const void* src, const void* idx_i64, void* dst, int64_t n_idx,
+                             int64_t row_elems, int64_t dst_rows, int dtype);
+/* onehot[i, labels[i]] = 1 — examples/mnist/run.py:27-28 (np.eye(n)[targets]) */
+TNN_API int tnn_one_hot(const void* labels_i64, void* out, int64_t n, int64_t classes, int dtype);
+
+/* ------------------------------------------------------------------ fused hot-path ops -------- */
+/* y = act(x + bias[N]) for x [M,N] — core/layers.py:49 (+ b) and :98 */
+TNN_API int tnn_bias_act(const void* x, const void* bias, int act, void* y, int64_t M, int64_t N,
+                         int dtype);
+
+/* Whole-batch softmax NLL, core/losses.py:24-32 (max and sum-exp are GLOBAL over [m,c]).
+ * stats = device [2] {M = max z, S = sum exp(z - M)} of this shard.  A data-parallel caller merges
+ * the shards' stats (tnn_lse_merge after an all-gather) before calling the backward. */
+TNN_API int tnn_softmax_nll_stats(const void* z, int64_t m, int64_t c, void* stats, int dtype);
+/* stats_all = [n_shards,2] -> stats = global {M, S} (log-sum-exp merge S = sum S_r e^{M_r-M}) */
+TNN_API int tnn_lse_merge(const void* stats_all, int n_shards, void* stats, int dtype);
+/* loss_out[0] = sum_i -log(sum_k p_ik y_ik) / m_global over THIS shard's rows,
+ * dz = p - (e*y/q)/m_global with p = exp(z-M)/S, q_i = sum_k e_ik y_ik (= p - y/m for one-hot y).
+ * dz may be NULL (loss only). */
+TNN_API int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c,
+                                    int64_t m_global, const void* stats, void* loss_out,
+                                    void* dz, int dtype);
+
+/* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
+ * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global
+ * (the ops chain sub_ -> pow_(2) -> sum_ -> div_ of core/ops.py:61,121,252,93 in one pass). */
+TNN_API int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t m_global,
+                            void* loss_out, void* dpred, int dtype);
+
+/* SGD: p += -lr * g — core/optimizer.py:46-47 + core/model.py:59-61 */
+TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);
+/* Fused Adam on the flat arena, core/optimizer.py:67-79 + core/model.py:59-61:
+ *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); p += -lr*(m/(1-b1^t))/(sqrt(v/(1-b2^t))+eps)
+ * pows = device double[4] {b1^(t-1), b2^(t-1), ticket, pad}; initialise to {1, 1, 0, 0}.  The call
+ * itself advances it (the last block to finish stores b^t), so that a captured hipGraph replays the
+ * right bias correction every step without a host-side step counter.  If step_out != NULL
+ * the step is written there and p is left untouched (the reference's _compute_step contract). */
+TNN_API int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
+                     double b2, double eps, void* pows_f64, void* step_out, int dtype);
+
+/* ------------------------------------------------------------------ whole-step MLP trainer ---- */
+/* One object = Dense/ReLU stack + whole-batch softmax NLL (loss_kind 0) or sum-of-squares/m
+ * (loss_kind 1, the (err**2).sum()/m of test/test_autograd.py:119-121) + SGD (opt 0) / Adam (opt 1),
+ * i.e. the loop body of examples/mnist/run.py:79-83 as ~10 launches on device-resident state:
+ * params | grads | m | v live in one flat arena each, ordered layer by layer, "w" then "b"
+ * (core/layers.py:35, core/optimizer.py:14-15). */
+TNN_API int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int loss_kind,
+                           int opt_kind, double lr, double b1, double b2, double eps, int dtype,
+                           void** handle);
+TNN_API int tnn_mlp_destroy(void* handle);
+TNN_API int tnn_mlp_arena(void* handle, void** params, void** grads, void** m, void** v,
+                          int64_t* n_params);
+TNN_API int tnn_mlp_param_offset(void* handle, int layer, int which, int64_t* offset, int64_t* count);
+/* logits[rows, widths[n]] = net(x[rows, widths[0]]) */
+TNN_API int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits);
+/* forward + loss stats of this shard (phase 1); stats = device [2] */
+TNN_API int tnn_mlp_forward_stats(void* handle, const void* x, int64_t rows, void* stats);
+/* loss + full backward into the grad arena (phase 2); y = targets [rows, widths[n]] */
+TNN_API int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows,
+                             int64_t m_global, const void* stats, void* loss_out);
+/* optimizer update from the grad arena (phase 3) */
+TNN_API int tnn_mlp_update(void* handle);
+/* phases 1-3 back to back for the single-GPU case; loss_out = device scalar (may be NULL) */
+TNN_API int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
+/* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
+TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
+
+/* ------------------------------------------------------------------ RCCL over xGMI (C1, C2) --- */
+/* New relative to the reference (it has no communication).  One process per GPU. */
+TNN_API int tnn_comm_unique_id(void* id128);                /* rank 0: ncclGetUniqueId (128 bytes) */
+TNN_API int tnn_comm_init(int rank, int world, const void* id128);
+TNN_API int tnn_comm_destroy(void);
+TNN_API int tnn_comm_world(int* rank, int* world);
+/* in-place all-reduce on the library stream; rop = TNN_RSUM / TNN_RMAX */
+TNN_API int tnn_allreduce(void* buf, int64_t n, int dtype, int rop);
+TNN_API int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TNN_HIP_H_ */

@@ -1,0 +1,626 @@
+// TEST INFRASTRUCTURE — NOT PART OF THE PRODUCT.
+// CPU twin of include/tnn_hip.h: the same C-ABI implemented with plain scalar C++ loops on host
+// memory ("device pointers" are malloc'ed host buffers).  It exists so that the host-side logic of
+// tinynn-autograd_amd (DeviceArray / Tensor / ops / optimizers / data-parallel sharding) can be
+// exercised by `pytest -m "not gpu"` in a container without a GPU.  Only tests/ may load it, through
+// tinynn_autograd_amd._lib.install_test_twin(); the product loader never looks for it and fails
+// loudly when libtnn_hip.so or a GPU is missing.  Each function restates the numpy expression of the
+// reference it stands for (same citations as the header).  The whole-step trainer (tnn_mlp_*) is the
+// product's own host code (csrc/tnn_mlp.cpp) compiled against these primitives.
+#include <math.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <functional>
+#include <unordered_map>
+#include <vector>
+
+#include "tnn_hip.h"
+
+namespace tnn {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace tnn
+
+namespace {
+bool g_ready = false;
+std::unordered_map<void*, size_t> g_blocks;
+int64_t g_live = 0, g_allocs = 0;
+
+// "graph": a recorded list of closures replayed in order (captures the call sequence like a hipGraph)
+struct Graph { std::vector<std::function<int()>> calls; };
+Graph* g_capturing = nullptr;
+
+#define REQ(cond, ...) do { if (!(cond)) { tnn::set_error(__VA_ARGS__); return 2; } } while (0)
+#define NEED_INIT() REQ(g_ready, "tnn_init() has not been called")
+// record-and-run: while capturing, every primitive call is also stored for replay
+#define RECORD(...) do { if (g_capturing) g_capturing->calls.push_back([=]() -> int { __VA_ARGS__; return 0; }); } while (0)
+
+constexpr int kMaxDim = 6;
+
+template <typename F>
+void nd_loop(int ndim, const int64_t* shape, F f) {
+    int64_t n = 1;
+    for (int k = 0; k < ndim; ++k) n *= shape[k];
+    int64_t idx[kMaxDim] = {0};
+    for (int64_t i = 0; i < n; ++i) {
+        f(i, idx);
+        for (int k = ndim - 1; k >= 0; --k) {
+            if (++idx[k] < shape[k]) break;
+            idx[k] = 0;
+        }
+    }
+}
+inline int64_t dot_idx(int ndim, const int64_t* idx, const int64_t* st) {
+    int64_t o = 0;
+    for (int k = 0; k < ndim; ++k) o += idx[k] * (st ? st[k] : 0);
+    return o;
+}
+
+template <typename T> T bin(int op, T a, T b) {
+    switch (op) {
+        case TNN_ADD: return a + b;
+        case TNN_SUB: return a - b;
+        case TNN_MUL: return a * b;
+        case TNN_DIV: return a / b;
+        case TNN_POW: return (T)pow((double)a, (double)b);
+        case TNN_MAX: return a >= b ? a : b;
+        case TNN_MIN: return a <= b ? a : b;
+    }
+    return a;
+}
+template <typename T> uint8_t cmpf(int c, T a, T b) {
+    switch (c) {
+        case TNN_GT: return a > b;
+        case TNN_GE: return a >= b;
+        case TNN_LT: return a < b;
+        case TNN_LE: return a <= b;
+        case TNN_EQ: return a == b;
+        case TNN_NE: return a != b;
+    }
+    return 0;
+}
+template <typename T> T una(int op, T a) {
+    switch (op) {
+        case TNN_NEG: return -a;
+        case TNN_EXP: return (T)exp((double)a);
+        case TNN_LOG: return (T)log((double)a);
+        case TNN_SQRT: return (T)sqrt((double)a);
+        case TNN_SQUARE: return a * a;
+        case TNN_ABS: return a < 0 ? -a : a;
+        case TNN_RECIP: return T(1) / a;
+        case TNN_SIGMOID: return (T)(1.0 / (1.0 + exp(-(double)a)));
+        case TNN_TANH: return (T)tanh((double)a);
+    }
+    return a;
+}
+
+size_t dsize(int dtype) { return dtype == TNN_F32 ? 4 : dtype == TNN_U8 ? 1 : 8; }
+
+#define FLOAT_SWITCH(dtype, fn, ...)                                          \
+    switch (dtype) {                                                          \
+        case TNN_F32: { using T = float; __VA_ARGS__; break; }                       \
+        case TNN_F64: { using T = double; __VA_ARGS__; break; }                      \
+        default: tnn::set_error(fn ": dtype %d is not a float type", dtype); return 2; \
+    }
+#define ANY_SWITCH(dtype, fn, ...)                                            \
+    switch (dtype) {                                                          \
+        case TNN_F32: { using T = float; __VA_ARGS__; break; }                       \
+        case TNN_F64: { using T = double; __VA_ARGS__; break; }                      \
+        case TNN_I64: { using T = int64_t; __VA_ARGS__; break; }                     \
+        case TNN_U8: { using T = uint8_t; __VA_ARGS__; break; }                      \
+        default: tnn::set_error(fn ": unknown dtype %d", dtype); return 2;    \
+    }
+
+template <typename T>
+void gemm_ref(int tA, int tB, int64_t M, int64_t N, int64_t K, const T* A, int64_t lda, const T* B,
+              int64_t ldb, std::vector<T>& acc) {
+    acc.assign((size_t)(M * N), T(0));
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t k = 0; k < K; ++k) {
+            T a = tA ? A[k * lda + i] : A[i * lda + k];
+            for (int64_t j = 0; j < N; ++j) {
+                T b = tB ? B[j * ldb + k] : B[k * ldb + j];
+                acc[(size_t)(i * N + j)] += a * b;
+            }
+        }
+}
+
+struct Strides { int64_t v[kMaxDim]; bool null; };
+Strides keep(const int64_t* s, int nd) {
+    Strides r;
+    r.null = s == nullptr;
+    for (int k = 0; k < kMaxDim; ++k) r.v[k] = (s && k < nd) ? s[k] : 0;
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+const char* tnn_last_error(void) { return tnn::g_err; }
+int tnn_backend_kind(void) { return 2; }
+int tnn_init(int) { g_ready = true; return 0; }
+int tnn_shutdown(void) { return 0; }
+int tnn_device_props(int* cu, int* clk, int64_t* hbm, char* name, int n) {
+    if (cu) *cu = 0;
+    if (clk) *clk = 0;
+    if (hbm) *hbm = 0;
+    if (name && n > 0) snprintf(name, n, "cpu-twin (tests only)");
+    return 0;
+}
+int tnn_malloc(size_t bytes, void** out) {
+    NEED_INIT();
+    void* p = nullptr;
+    if (posix_memalign(&p, 64, bytes ? bytes : 1)) { tnn::set_error("tnn_malloc: out of memory"); return 1; }
+    g_blocks[p] = bytes;
+    g_live += (int64_t)bytes;
+    g_allocs++;
+    *out = p;
+    return 0;
+}
+int tnn_free(void* p) {
+    if (!p) return 0;
+    auto it = g_blocks.find(p);
+    REQ(it != g_blocks.end(), "tnn_free: %p was not allocated by tnn_malloc", p);
+    g_live -= (int64_t)it->second;
+    g_blocks.erase(it);
+    if (!g_capturing) free(p);   // buffers touched by a recorded graph stay valid (leaked in tests)
+    return 0;
+}
+int tnn_pool_stats(int64_t* live, int64_t* cached, int64_t* allocs) {
+    if (live) *live = g_live;
+    if (cached) *cached = 0;
+    if (allocs) *allocs = g_allocs;
+    return 0;
+}
+int tnn_pool_trim(void) { return 0; }
+int tnn_memcpy_h2d(void* d, const void* s, size_t n) { NEED_INIT(); memcpy(d, s, n); return 0; }
+int tnn_memcpy_d2h(void* d, const void* s, size_t n) { NEED_INIT(); memcpy(d, s, n); return 0; }
+int tnn_memcpy_d2d(void* d, const void* s, size_t n) { NEED_INIT(); RECORD(memmove(d, s, n)); memmove(d, s, n); return 0; }
+int tnn_memset(void* d, int b, size_t n) { NEED_INIT(); RECORD(memset(d, b, n)); memset(d, b, n); return 0; }
+int tnn_stream_sync(void) { return 0; }
+int tnn_event_create(void** ev) { *ev = malloc(sizeof(double)); return 0; }
+int tnn_event_record(void* ev) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    *(double*)ev = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    return 0;
+}
+int tnn_event_elapsed_ms(void* a, void* b, float* ms) { *ms = (float)(*(double*)b - *(double*)a); return 0; }
+int tnn_event_destroy(void* ev) { free(ev); return 0; }
+
+int tnn_graph_capture_begin(void) {
+    REQ(!g_capturing, "tnn_graph_capture_begin: a capture is already open");
+    g_capturing = new Graph();
+    return 0;
+}
+int tnn_graph_capture_end(void** ge) {
+    REQ(g_capturing, "tnn_graph_capture_end: no capture is open");
+    *ge = g_capturing;
+    g_capturing = nullptr;
+    return 0;
+}
+int tnn_graph_launch(void* ge) {
+    REQ(ge, "tnn_graph_launch: invalid graph");
+    for (auto& c : ((Graph*)ge)->calls)
+        if (int rc = c()) return rc;
+    return 0;
+}
+int tnn_graph_destroy(void* ge) { delete (Graph*)ge; return 0; }
+
+int tnn_fill(void* dst, double value, int64_t n, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_fill(dst, value, n, dtype));
+    ANY_SWITCH(dtype, "tnn_fill", { T* o = (T*)dst; for (int64_t i = 0; i < n; ++i) o[i] = (T)value; });
+    return 0;
+}
+
+// ---- GEMM ----
+static int gemm_common(int tA, int tB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                       const void* B, int64_t ldb, void* C, int64_t ldc, int dtype, int epi,
+                       double alpha, double beta, const void* bias, int act, int relu_sign,
+                       const void* Y, int64_t ldy) {
+    FLOAT_SWITCH(dtype, "tnn_gemm", {
+        std::vector<T> acc;
+        gemm_ref<T>(tA, tB, M, N, K, (const T*)A, lda, (const T*)B, ldb, acc);
+        T* c = (T*)C;
+        for (int64_t i = 0; i < M; ++i)
+            for (int64_t j = 0; j < N; ++j) {
+                T v = acc[(size_t)(i * N + j)];
+                if (epi == 0) {
+                    v = (T)alpha * v;
+                    if (beta != 0.0) v += (T)beta * c[i * ldc + j];
+                } else if (epi == 1) {
+                    v += bias ? ((const T*)bias)[j] : T(0);
+                    if (act == TNN_ACT_RELU) {
+                        if (relu_sign) v = v < 0 ? (T)-0.0 : (T)fabs((double)v);
+                        else v = v < 0 ? T(0) : v;
+                    }
+                } else {
+                    v = signbit((double)((const T*)Y)[i * ldy + j]) ? T(0) : v;
+                }
+                c[i * ldc + j] = v;
+            }
+    });
+    return 0;
+}
+int tnn_gemm(int tA, int tB, int64_t M, int64_t N, int64_t K, double alpha, const void* A, int64_t lda,
+             const void* B, int64_t ldb, double beta, void* C, int64_t ldc, int dtype) {
+    NEED_INIT();
+    REQ(lda >= (tA ? M : K) && ldb >= (tB ? K : N) && ldc >= N, "tnn_gemm: leading dimension too small");
+    RECORD(tnn_gemm(tA, tB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, dtype));
+    return gemm_common(tA, tB, M, N, K, A, lda, B, ldb, C, ldc, dtype, 0, alpha, beta, nullptr, 0, 0, nullptr, 0);
+}
+int tnn_gemm_bias_act(int tA, int tB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                      const void* B, int64_t ldb, const void* bias, int act, int relu_sign, void* C,
+                      int64_t ldc, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_gemm_bias_act(tA, tB, M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, dtype));
+    return gemm_common(tA, tB, M, N, K, A, lda, B, ldb, C, ldc, dtype, 1, 1, 0, bias, act, relu_sign, nullptr, 0);
+}
+int tnn_gemm_mask(int tA, int tB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                  const void* B, int64_t ldb, const void* Y, int64_t ldy, void* C, int64_t ldc, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_gemm_mask(tA, tB, M, N, K, A, lda, B, ldb, Y, ldy, C, ldc, dtype));
+    return gemm_common(tA, tB, M, N, K, A, lda, B, ldb, C, ldc, dtype, 2, 1, 0, nullptr, 0, 0, Y, ldy);
+}
+
+// ---- elementwise ----
+int tnn_ewise_binary(int op, const void* a, const int64_t* sa, const void* b, const int64_t* sb,
+                     void* out, int ndim, const int64_t* shape, int dtype) {
+    NEED_INIT();
+    REQ(ndim >= 0 && ndim <= kMaxDim, "tnn_ewise_binary: ndim %d", ndim);
+    REQ(op >= TNN_ADD && op <= TNN_MIN, "tnn_ewise_binary: unknown op %d", op);
+    Strides ka = keep(sa, ndim), kb = keep(sb, ndim), ks = keep(shape, ndim);
+    RECORD(tnn_ewise_binary(op, a, ka.null ? nullptr : ka.v, b, kb.null ? nullptr : kb.v, out, ndim, ks.v, dtype));
+    FLOAT_SWITCH(dtype, "tnn_ewise_binary", {
+        nd_loop(ndim, shape, [&](int64_t i, const int64_t* idx) {
+            ((T*)out)[i] = bin<T>(op, ((const T*)a)[dot_idx(ndim, idx, sa)], ((const T*)b)[dot_idx(ndim, idx, sb)]);
+        });
+    });
+    return 0;
+}
+int tnn_ewise_compare(int c, const void* a, const int64_t* sa, const void* b, const int64_t* sb,
+                      void* out, int ndim, const int64_t* shape, int dtype) {
+    NEED_INIT();
+    REQ(ndim >= 0 && ndim <= kMaxDim, "tnn_ewise_compare: ndim %d", ndim);
+    REQ(c >= TNN_GT && c <= TNN_NE, "tnn_ewise_compare: unknown comparison %d", c);
+    Strides ka = keep(sa, ndim), kb = keep(sb, ndim), ks = keep(shape, ndim);
+    RECORD(tnn_ewise_compare(c, a, ka.null ? nullptr : ka.v, b, kb.null ? nullptr : kb.v, out, ndim, ks.v, dtype));
+    FLOAT_SWITCH(dtype, "tnn_ewise_compare", {
+        nd_loop(ndim, shape, [&](int64_t i, const int64_t* idx) {
+            ((uint8_t*)out)[i] = cmpf<T>(c, ((const T*)a)[dot_idx(ndim, idx, sa)], ((const T*)b)[dot_idx(ndim, idx, sb)]);
+        });
+    });
+    return 0;
+}
+int tnn_ewise_scalar(int op, const void* a, double s, int lhs, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    REQ(op >= TNN_ADD && op <= TNN_MIN, "tnn_ewise_scalar: unknown op %d", op);
+    RECORD(tnn_ewise_scalar(op, a, s, lhs, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_ewise_scalar", {
+        for (int64_t i = 0; i < n; ++i) {
+            T x = ((const T*)a)[i];
+            T r;
+            if (op == TNN_POW && !lhs && s == 2.0) r = x * x;
+            else if (op == TNN_POW && !lhs && s == 0.5) r = (T)sqrt((double)x);
+            else r = lhs ? bin<T>(op, (T)s, x) : bin<T>(op, x, (T)s);
+            ((T*)out)[i] = r;
+        }
+    });
+    return 0;
+}
+int tnn_compare_scalar(int c, const void* a, double s, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    REQ(c >= TNN_GT && c <= TNN_NE, "tnn_compare_scalar: unknown comparison %d", c);
+    RECORD(tnn_compare_scalar(c, a, s, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_compare_scalar", {
+        for (int64_t i = 0; i < n; ++i) ((uint8_t*)out)[i] = cmpf<T>(c, ((const T*)a)[i], (T)s);
+    });
+    return 0;
+}
+int tnn_ewise_unary(int op, const void* in, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    REQ(op >= TNN_NEG && op <= TNN_COPY, "tnn_ewise_unary: unknown op %d", op);
+    RECORD(tnn_ewise_unary(op, in, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_ewise_unary", {
+        for (int64_t i = 0; i < n; ++i) ((T*)out)[i] = una<T>(op, ((const T*)in)[i]);
+    });
+    return 0;
+}
+int tnn_clip(const void* in, int hmin, double vmin, int hmax, double vmax, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_clip(in, hmin, vmin, hmax, vmax, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_clip", {
+        for (int64_t i = 0; i < n; ++i) {
+            T x = ((const T*)in)[i];
+            if (hmin && x < (T)vmin) x = (T)vmin;
+            if (hmax && x > (T)vmax) x = (T)vmax;
+            ((T*)out)[i] = x;
+        }
+    });
+    return 0;
+}
+int tnn_clip_bwd(const void* g, const void* x, int hmin, double vmin, int hmax, double vmax, void* out,
+                 int64_t n, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_clip_bwd(g, x, hmin, vmin, hmax, vmax, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_clip_bwd", {
+        for (int64_t i = 0; i < n; ++i) {
+            T xv = ((const T*)x)[i];
+            bool keepv = (!hmin || xv >= (T)vmin) && (!hmax || xv <= (T)vmax);
+            ((T*)out)[i] = keepv ? ((const T*)g)[i] : T(0);
+        }
+    });
+    return 0;
+}
+int tnn_mul_mask(const void* g, const void* mask, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_mul_mask(g, mask, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_mul_mask", {
+        for (int64_t i = 0; i < n; ++i) ((T*)out)[i] = ((const uint8_t*)mask)[i] ? ((const T*)g)[i] : T(0);
+    });
+    return 0;
+}
+int tnn_axpy(void* y, double alpha, const void* x, int64_t n, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_axpy(y, alpha, x, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_axpy", {
+        for (int64_t i = 0; i < n; ++i) ((T*)y)[i] = ((T*)y)[i] + (T)alpha * ((const T*)x)[i];
+    });
+    return 0;
+}
+int tnn_cast(const void* in, int idt, void* out, int odt, int64_t n) {
+    NEED_INIT();
+    RECORD(tnn_cast(in, idt, out, odt, n));
+    for (int64_t i = 0; i < n; ++i) {
+        double v;
+        switch (idt) {
+            case TNN_F32: v = ((const float*)in)[i]; break;
+            case TNN_F64: v = ((const double*)in)[i]; break;
+            case TNN_I64: v = (double)((const int64_t*)in)[i]; break;
+            case TNN_U8: v = ((const uint8_t*)in)[i]; break;
+            default: tnn::set_error("tnn_cast: unknown input dtype %d", idt); return 2;
+        }
+        switch (odt) {
+            case TNN_F32: ((float*)out)[i] = (float)v; break;
+            case TNN_F64: ((double*)out)[i] = v; break;
+            case TNN_I64: ((int64_t*)out)[i] = idt == TNN_I64 ? ((const int64_t*)in)[i] : (int64_t)v; break;
+            case TNN_U8: ((uint8_t*)out)[i] = v != 0.0; break;
+            default: tnn::set_error("tnn_cast: unknown output dtype %d", odt); return 2;
+        }
+    }
+    return 0;
+}
+
+// ---- reductions ----
+int tnn_reduce(int rop, const void* in, void* out, int64_t outer, int64_t red, int64_t inner, int dtype) {
+    NEED_INIT();
+    REQ(rop >= TNN_RSUM && rop <= TNN_RMIN, "tnn_reduce: unknown reduction %d", rop);
+    REQ(red > 0 || rop == TNN_RSUM, "tnn_reduce: max/min of an empty axis");
+    RECORD(tnn_reduce(rop, in, out, outer, red, inner, dtype));
+    FLOAT_SWITCH(dtype, "tnn_reduce", {
+        for (int64_t o = 0; o < outer; ++o)
+            for (int64_t i = 0; i < inner; ++i) {
+                double acc = rop == TNN_RSUM ? 0.0 : rop == TNN_RMAX ? -INFINITY : INFINITY;
+                for (int64_t r = 0; r < red; ++r) {
+                    double v = ((const T*)in)[(o * red + r) * inner + i];
+                    acc = rop == TNN_RSUM ? acc + v : rop == TNN_RMAX ? (v > acc ? v : acc) : (v < acc ? v : acc);
+                }
+                ((T*)out)[o * inner + i] = (T)acc;
+            }
+    });
+    return 0;
+}
+int tnn_argmax_rows(const void* in, void* out, int64_t rows, int64_t cols, int dtype) {
+    NEED_INIT();
+    REQ(cols > 0 || rows == 0, "tnn_argmax_rows: empty rows");
+    RECORD(tnn_argmax_rows(in, out, rows, cols, dtype));
+    FLOAT_SWITCH(dtype, "tnn_argmax_rows", {
+        for (int64_t r = 0; r < rows; ++r) {
+            const T* p = (const T*)in + r * cols;
+            int64_t bi = 0;
+            for (int64_t k = 1; k < cols; ++k) if (p[k] > p[bi]) bi = k;
+            ((int64_t*)out)[r] = bi;
+        }
+    });
+    return 0;
+}
+
+// ---- data movement ----
+int tnn_strided_copy(const void* in, const int64_t* st, void* out, int ndim, const int64_t* shape, int dtype) {
+    NEED_INIT();
+    REQ(ndim >= 0 && ndim <= kMaxDim, "tnn_strided_copy: ndim %d", ndim);
+    Strides k1 = keep(st, ndim), ks = keep(shape, ndim);
+    RECORD(tnn_strided_copy(in, k1.v, out, ndim, ks.v, dtype));
+    ANY_SWITCH(dtype, "tnn_strided_copy", {
+        nd_loop(ndim, shape, [&](int64_t i, const int64_t* idx) { ((T*)out)[i] = ((const T*)in)[dot_idx(ndim, idx, st)]; });
+    });
+    return 0;
+}
+int tnn_strided_scatter(const void* in, void* out, const int64_t* st, int ndim, const int64_t* shape, int dtype) {
+    NEED_INIT();
+    REQ(ndim >= 0 && ndim <= kMaxDim, "tnn_strided_scatter: ndim %d", ndim);
+    Strides k1 = keep(st, ndim), ks = keep(shape, ndim);
+    RECORD(tnn_strided_scatter(in, out, k1.v, ndim, ks.v, dtype));
+    ANY_SWITCH(dtype, "tnn_strided_scatter", {
+        nd_loop(ndim, shape, [&](int64_t i, const int64_t* idx) { ((T*)out)[dot_idx(ndim, idx, st)] = ((const T*)in)[i]; });
+    });
+    return 0;
+}
+int tnn_gather_rows(const void* src, const void* idx, void* out, int64_t n, int64_t re, int64_t rows, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_gather_rows(src, idx, out, n, re, rows, dtype));
+    size_t es = dsize(dtype);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t j = ((const int64_t*)idx)[i];
+        if (j < 0) j += rows;
+        if (j < 0 || j >= rows) continue;
+        memcpy((char*)out + i * re * es, (const char*)src + j * re * es, re * es);
+    }
+    return 0;
+}
+int tnn_scatter_rows(const void* src, const void* idx, void* dst, int64_t n, int64_t re, int64_t rows, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_scatter_rows(src, idx, dst, n, re, rows, dtype));
+    size_t es = dsize(dtype);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t j = ((const int64_t*)idx)[i];
+        if (j < 0) j += rows;
+        if (j < 0 || j >= rows) continue;
+        memcpy((char*)dst + j * re * es, (const char*)src + i * re * es, re * es);
+    }
+    return 0;
+}
+int tnn_one_hot(const void* labels, void* out, int64_t n, int64_t classes, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_one_hot(labels, out, n, classes, dtype));
+    FLOAT_SWITCH(dtype, "tnn_one_hot", {
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t c = 0; c < classes; ++c) ((T*)out)[i * classes + c] = ((const int64_t*)labels)[i] == c ? T(1) : T(0);
+    });
+    return 0;
+}
+
+// ---- fused ----
+int tnn_bias_act(const void* x, const void* bias, int act, void* y, int64_t M, int64_t N, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_bias_act(x, bias, act, y, M, N, dtype));
+    FLOAT_SWITCH(dtype, "tnn_bias_act", {
+        for (int64_t i = 0; i < M; ++i)
+            for (int64_t j = 0; j < N; ++j) {
+                T v = ((const T*)x)[i * N + j] + ((const T*)bias)[j];
+                if (act == TNN_ACT_RELU && v < 0) v = 0;
+                ((T*)y)[i * N + j] = v;
+            }
+    });
+    return 0;
+}
+int tnn_softmax_nll_stats(const void* z, int64_t m, int64_t c, void* stats, int dtype) {
+    NEED_INIT();
+    REQ(m * c > 0, "tnn_softmax_nll_stats: empty logits");
+    RECORD(tnn_softmax_nll_stats(z, m, c, stats, dtype));
+    FLOAT_SWITCH(dtype, "tnn_softmax_nll_stats", {
+        double mx = -INFINITY;
+        for (int64_t i = 0; i < m * c; ++i) mx = fmax(mx, (double)((const T*)z)[i]);
+        double s = 0;
+        for (int64_t i = 0; i < m * c; ++i) s += exp((double)((const T*)z)[i] - mx);
+        ((T*)stats)[0] = (T)mx;
+        ((T*)stats)[1] = (T)s;
+    });
+    return 0;
+}
+int tnn_lse_merge(const void* all, int n, void* stats, int dtype) {
+    NEED_INIT();
+    REQ(n > 0, "tnn_lse_merge: n_shards %d", n);
+    RECORD(tnn_lse_merge(all, n, stats, dtype));
+    FLOAT_SWITCH(dtype, "tnn_lse_merge", {
+        double mx = -INFINITY;
+        for (int i = 0; i < n; ++i) mx = fmax(mx, (double)((const T*)all)[2 * i]);
+        double s = 0;
+        for (int i = 0; i < n; ++i) s += (double)((const T*)all)[2 * i + 1] * exp((double)((const T*)all)[2 * i] - mx);
+        ((T*)stats)[0] = (T)mx;
+        ((T*)stats)[1] = (T)s;
+    });
+    return 0;
+}
+int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c, int64_t mg, const void* stats,
+                            void* loss_out, void* dz, int dtype) {
+    NEED_INIT();
+    REQ(m > 0 && c > 0 && mg > 0, "tnn_softmax_nll_fwd_bwd: empty batch");
+    RECORD(tnn_softmax_nll_fwd_bwd(z, y, m, c, mg, stats, loss_out, dz, dtype));
+    FLOAT_SWITCH(dtype, "tnn_softmax_nll_fwd_bwd", {
+        double M = ((const T*)stats)[0], S = ((const T*)stats)[1], loss = 0;
+        for (int64_t r = 0; r < m; ++r) {
+            double q = 0;
+            for (int64_t k = 0; k < c; ++k) q += exp((double)((const T*)z)[r * c + k] - M) * (double)((const T*)y)[r * c + k];
+            loss += (log(S) - log(q)) / (double)mg;
+            if (dz)
+                for (int64_t k = 0; k < c; ++k) {
+                    double e = exp((double)((const T*)z)[r * c + k] - M);
+                    ((T*)dz)[r * c + k] = (T)(e / S - e * (double)((const T*)y)[r * c + k] / q / (double)mg);
+                }
+        }
+        if (loss_out) ((T*)loss_out)[0] = (T)loss;
+    });
+    return 0;
+}
+int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t mg, void* loss_out, void* dpred, int dtype) {
+    NEED_INIT();
+    REQ(n > 0 && mg > 0, "tnn_mse_fwd_bwd: empty batch");
+    RECORD(tnn_mse_fwd_bwd(pred, y, n, mg, loss_out, dpred, dtype));
+    FLOAT_SWITCH(dtype, "tnn_mse_fwd_bwd", {
+        double loss = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            T e = ((const T*)pred)[i] - ((const T*)y)[i];
+            loss += (double)e * (double)e;
+            if (dpred) ((T*)dpred)[i] = (T)(2.0 / (double)mg) * e;
+        }
+        if (loss_out) ((T*)loss_out)[0] = (T)(loss / (double)mg);
+    });
+    return 0;
+}
+int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_sgd(p, g, n, lr, dtype));
+    FLOAT_SWITCH(dtype, "tnn_sgd", {
+        for (int64_t i = 0; i < n; ++i) ((T*)p)[i] = ((T*)p)[i] + (-(T)lr * ((const T*)g)[i]);
+    });
+    return 0;
+}
+int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2, double eps,
+             void* pows, void* step_out, int dtype) {
+    NEED_INIT();
+    REQ(pows, "tnn_adam: pows state is NULL");
+    RECORD(tnn_adam(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype));
+    double* st = (double*)pows;
+    double p1 = st[0] * b1, p2 = st[1] * b2;
+    FLOAT_SWITCH(dtype, "tnn_adam", {
+        T ic1 = (T)(1.0 / (1.0 - p1)), ic2 = (T)(1.0 / (1.0 - p2));
+        for (int64_t i = 0; i < n; ++i) {
+            T gi = ((const T*)g)[i];
+            T mi = ((T*)m)[i], vi = ((T*)v)[i];
+            mi = mi + ((T)1 - (T)b1) * (gi - mi);
+            vi = vi + ((T)1 - (T)b2) * (gi * gi - vi);
+            ((T*)m)[i] = mi;
+            ((T*)v)[i] = vi;
+            T s = -(T)lr * (mi * ic1) / ((T)sqrt((double)(vi * ic2)) + (T)eps);
+            if (step_out) ((T*)step_out)[i] = s;
+            else ((T*)p)[i] = ((T*)p)[i] + s;
+        }
+    });
+    st[0] = p1;
+    st[1] = p2;
+    return 0;
+}
+
+// ---- comm: single-process identity (multi-process CPU tests use gloo at the Python layer) ----
+static int g_comm = 0;
+int tnn_comm_unique_id(void* id) { memset(id, 0, 128); return 0; }
+int tnn_comm_init(int rank, int world, const void*) {
+    REQ(world == 1 && rank == 0, "cpu twin: tnn_comm supports world size 1 only");
+    g_comm = 1;
+    return 0;
+}
+int tnn_comm_destroy(void) { g_comm = 0; return 0; }
+int tnn_comm_world(int* r, int* w) { if (r) *r = 0; if (w) *w = 1; return 0; }
+int tnn_allreduce(void*, int64_t, int, int) { REQ(g_comm, "tnn_allreduce: tnn_comm_init() has not been called"); return 0; }
+int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
+    REQ(g_comm, "tnn_allgather: tnn_comm_init() has not been called");
+    memmove(r, s, (size_t)n * dsize(dtype));
+    return 0;
+}
+
+}  // extern "C"
+
+// the product's own trainer host code on top of the primitives above
+#include "../../tinynn-autograd_amd/csrc/tnn_mlp.cpp"

@@ -1,0 +1,143 @@
+// C1/C2: RCCL over xGMI.  New relative to the reference, which has no communication at all
+// (SURVEY F1): one process per GPU, the flat gradient arena is all-reduced in place on the library
+// stream between backward() and the optimizer update (the hook sits between examples/mnist/run.py:82
+// and :83), and the whole-batch softmax (core/losses.py:26-27) exchanges one {max, sum-exp} pair per
+// rank.  librccl is dlopen()ed on first use so that single-GPU users, the CPU container and the
+// symbol test never need it, and so that a process which already loaded torch's copy reuses it.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include "tnn_internal.h"
+
+namespace {
+
+struct Rccl {
+    void* so = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+Rccl R;
+
+int load_rccl() {
+    if (R.so) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        R.so = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (R.so) break;
+    }
+    TNN_REQUIRE(R.so != nullptr, "tnn_comm: cannot dlopen librccl (%s)", dlerror());
+#define SYM(field, name)                                                         \
+    R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.so, name));            \
+    TNN_REQUIRE(R.field != nullptr, "tnn_comm: librccl lacks symbol %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(AllGather, "ncclAllGather");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return 0;
+}
+
+#define TNN_CHECK_NCCL(expr)                                                              \
+    do {                                                                                  \
+        ncclResult_t r__ = (expr);                                                        \
+        if (r__ != ncclSuccess) {                                                         \
+            tnn::set_error("%s -> %s", #expr, R.GetErrorString ? R.GetErrorString(r__) : "?"); \
+            return 1;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+int nccl_type(int dtype, ncclDataType_t* t) {
+    switch (dtype) {
+        case TNN_F32: *t = ncclFloat32; return 0;
+        case TNN_F64: *t = ncclFloat64; return 0;
+        case TNN_I64: *t = ncclInt64; return 0;
+        case TNN_U8: *t = ncclUint8; return 0;
+    }
+    tnn::set_error("tnn_comm: unknown dtype %d", dtype);
+    return 2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnn_comm_unique_id(void* id128) {
+    TNN_NEED_INIT();
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    if (int rc = load_rccl()) return rc;
+    ncclUniqueId id;
+    TNN_CHECK_NCCL(R.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+
+int tnn_comm_init(int rank, int world, const void* id128) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(world >= 1 && rank >= 0 && rank < world, "tnn_comm_init: rank %d / world %d", rank, world);
+    TNN_REQUIRE(R.comm == nullptr, "tnn_comm_init: communicator already initialised");
+    if (int rc = load_rccl()) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    TNN_CHECK_NCCL(R.CommInitRank(&R.comm, world, id, rank));
+    R.rank = rank;
+    R.world = world;
+    return 0;
+}
+
+int tnn_comm_destroy(void) {
+    if (R.comm && R.CommDestroy) {
+        if (tnn::initialised()) (void)hipStreamSynchronize(tnn::stream());
+        R.CommDestroy(R.comm);
+    }
+    R.comm = nullptr;
+    R.rank = 0;
+    R.world = 1;
+    return 0;
+}
+
+int tnn_comm_world(int* rank, int* world) {
+    if (rank) *rank = R.rank;
+    if (world) *world = R.world;
+    return 0;
+}
+
+int tnn_allreduce(void* buf, int64_t n, int dtype, int rop) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(R.comm != nullptr, "tnn_allreduce: tnn_comm_init() has not been called");
+    if (n <= 0) return 0;
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    ncclRedOp_t op;
+    switch (rop) {
+        case TNN_RSUM: op = ncclSum; break;
+        case TNN_RMAX: op = ncclMax; break;
+        case TNN_RMIN: op = ncclMin; break;
+        default: tnn::set_error("tnn_allreduce: unknown reduction %d", rop); return 2;
+    }
+    TNN_CHECK_NCCL(R.AllReduce(buf, buf, (size_t)n, t, op, R.comm, tnn::stream()));
+    return 0;
+}
+
+int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(R.comm != nullptr, "tnn_allgather: tnn_comm_init() has not been called");
+    if (n_per_rank <= 0) return 0;
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    TNN_CHECK_NCCL(R.AllGather(send, recv, (size_t)n_per_rank, t, R.comm, tnn::stream()));
+    return 0;
+}
+
+}  // extern "C"

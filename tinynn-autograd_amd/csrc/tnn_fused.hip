@@ -1,0 +1,447 @@
+// Fused hot-path kernels: bias(+ReLU) (K8), whole-batch softmax-NLL forward+backward (K9),
+// SGD / Adam on the flat parameter arena (K10).
+#include <math.h>
+
+#include "tnn_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------ bias + activation
+// y[r, c] = act(x[r, c] + b[c]).  HBM-bound, 8 B/element; float4 along the row when N % 4 == 0.
+template <typename T, int ACT, int VEC>
+__global__ __launch_bounds__(kThreads) void bias_act_kernel(const T* __restrict__ x,
+                                                            const T* __restrict__ bias,
+                                                            T* __restrict__ y, int64_t M,
+                                                            int64_t N) {
+    int64_t nv = N / VEC;
+    for (int64_t r = blockIdx.y; r < M; r += gridDim.y) {
+        const T* xr = x + r * N;
+        T* yr = y + r * N;
+        for (int64_t cv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; cv < nv;
+             cv += (int64_t)gridDim.x * blockDim.x) {
+            T v[VEC], b[VEC];
+            if constexpr (VEC == 4) {
+                float4 t = *reinterpret_cast<const float4*>(xr + cv * 4);
+                float4 u = *reinterpret_cast<const float4*>(bias + cv * 4);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                b[0] = u.x; b[1] = u.y; b[2] = u.z; b[3] = u.w;
+            } else {
+                v[0] = xr[cv];
+                b[0] = bias[cv];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                v[k] = v[k] + b[k];
+                if (ACT == TNN_ACT_RELU) v[k] = v[k] < T(0) ? T(0) : v[k];   // clip(x, 0.0)
+            }
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<float4*>(yr + cv * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                yr[cv] = v[0];
+            }
+        }
+    }
+}
+
+template <typename T, int ACT>
+int bias_act_typed(const void* x, const void* bias, void* y, int64_t M, int64_t N) {
+    bool vec = sizeof(T) == 4 && (N % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                 reinterpret_cast<uintptr_t>(bias)) & 15) == 0;
+    int64_t per_row = vec ? N / 4 : N;
+    unsigned gx = (unsigned)((per_row + kThreads - 1) / kThreads);
+    int64_t cap = (int64_t)tnn::num_cus() * 8;
+    if (gx > cap) gx = (unsigned)cap;
+    int64_t gy = cap / gx;
+    if (gy > M) gy = M;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    if constexpr (sizeof(T) == 4) {
+        if (vec) {
+            hipLaunchKernelGGL((bias_act_kernel<T, ACT, 4>), dim3(gx, (unsigned)gy), kThreads, 0,
+                               tnn::stream(), (const T*)x, (const T*)bias, (T*)y, M, N);
+            TNN_LAUNCH_OK();
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((bias_act_kernel<T, ACT, 1>), dim3(gx, (unsigned)gy), kThreads, 0,
+                       tnn::stream(), (const T*)x, (const T*)bias, (T*)y, M, N);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ softmax NLL (F5)
+// core/losses.py:24-32 normalises over the WHOLE [m, c] batch:  M = max z,  S = sum exp(z - M).
+// Stage 1: per-block (M_b, S_b); stage 2 merges with S = sum S_b * exp(M_b - M).  Both in f64.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nll_stats_kernel(const T* __restrict__ z, int64_t n,
+                                                             double* __restrict__ partial) {
+    __shared__ double lds_m[kThreads / 64], lds_s[kThreads / 64];
+    double mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        double v = (double)z[i];
+        mx = v > mx ? v : mx;
+    }
+    mx = tnn::wave_max(mx);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds_m[w] = mx;
+    __syncthreads();
+    double bm = lds_m[0];
+#pragma unroll
+    for (int i = 1; i < kThreads / 64; ++i) bm = lds_m[i] > bm ? lds_m[i] : bm;
+    double s = 0.0;
+    if (bm > -INFINITY) {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+             i += (int64_t)gridDim.x * blockDim.x)
+            s += exp((double)z[i] - bm);
+    }
+    s = tnn::wave_sum(s);
+    if (lane == 0) lds_s[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 64; ++i) t += lds_s[i];
+        partial[2 * blockIdx.x] = bm;
+        partial[2 * blockIdx.x + 1] = t;
+    }
+}
+
+// stats_all [n,2] (TI) -> stats [2] (TO); one wave
+template <typename TI, typename TO>
+__global__ __launch_bounds__(64) void lse_merge_kernel(const TI* __restrict__ all, int n,
+                                                       TO* __restrict__ out) {
+    int lane = threadIdx.x;
+    double mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        double v = (double)all[2 * i];
+        mx = v > mx ? v : mx;
+    }
+    mx = tnn::wave_max(mx);
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        double mi = (double)all[2 * i], si = (double)all[2 * i + 1];
+        if (mi > -INFINITY) s += si * exp(mi - mx);
+    }
+    s = tnn::wave_sum(s);
+    if (lane == 0) {
+        out[0] = (TO)mx;
+        out[1] = (TO)s;
+    }
+}
+
+// one thread per row:  e = exp(z - M), q = sum_k e*y, nll = log S - log q,
+// dz = e/S - (e*y/q)/m_global;  block partial of nll/m_global -> partial[blockIdx.x]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restrict__ z,
+                                                               const T* __restrict__ y, int64_t m,
+                                                               int64_t c, double inv_m_global,
+                                                               const T* __restrict__ stats,
+                                                               double* __restrict__ partial,
+                                                               T* __restrict__ dz) {
+    __shared__ double lds[kThreads / 64];
+    const double M = (double)stats[0], S = (double)stats[1];
+    const double log_s = log(S), inv_s = 1.0 / S;
+    double local = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < m;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const T* zr = z + r * c;
+        const T* yr = y + r * c;
+        double q = 0.0;
+        for (int64_t k = 0; k < c; ++k) q += exp((double)zr[k] - M) * (double)yr[k];
+        local += (log_s - log(q)) * inv_m_global;
+        if (dz) {
+            T* dr = dz + r * c;
+            double inv_q = inv_m_global / q;
+            for (int64_t k = 0; k < c; ++k) {
+                double e = exp((double)zr[k] - M);
+                dr[k] = (T)(e * inv_s - e * (double)yr[k] * inv_q);
+            }
+        }
+    }
+    local = tnn::wave_sum(local);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 64; ++i) t += lds[i];
+        partial[blockIdx.x] = t;
+    }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ partial, int n,
+                                                          TO* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = tnn::wave_sum(s);
+    if (threadIdx.x == 0) out[0] = (TO)s;
+}
+
+// sum((pred-y)^2)/m and its gradient; block partials in f64, combined by sum_partials_kernel
+template <typename T>
+__global__ __launch_bounds__(kThreads) void mse_fwd_bwd_kernel(const T* __restrict__ pred,
+                                                               const T* __restrict__ y, int64_t n,
+                                                               double inv_m,
+                                                               double* __restrict__ partial,
+                                                               T* __restrict__ dpred) {
+    __shared__ double lds[kThreads / 64];
+    double local = 0.0;
+    const T two_inv_m = (T)(2.0 * inv_m);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        T e = pred[i] - y[i];
+        local += (double)e * (double)e;
+        if (dpred) dpred[i] = two_inv_m * e;
+    }
+    local = tnn::wave_sum(local);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 64; ++i) t += lds[i];
+        partial[blockIdx.x] = t * inv_m;
+    }
+}
+
+// ------------------------------------------------------------------------------ SGD / Adam
+template <typename T>
+__global__ __launch_bounds__(kThreads) void sgd_kernel(T* __restrict__ p, const T* __restrict__ g,
+                                                       int64_t n, T lr) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = p[i] + (-lr * g[i]);
+}
+
+// Adam, core/optimizer.py:67-79, one pass: read p,g,m,v / write p,m,v = 28 B per fp32 parameter.
+// state (device, f64): [0] = b1^(t-1), [1] = b2^(t-1), [2] = ticket counter (as raw uint64).
+// Every block reads state first; the LAST block to finish (atomic ticket) writes b^t back, so the
+// next launch — eager or replayed from a hipGraph — sees the advanced powers.  Nobody reads the
+// updated words inside the same launch, so no intra-launch visibility protocol is needed.
+template <typename T, int VEC>
+__global__ __launch_bounds__(kThreads) void adam_kernel(T* __restrict__ p, const T* __restrict__ g,
+                                                        T* __restrict__ m, T* __restrict__ v,
+                                                        int64_t n, T lr, T b1, T b2, T eps,
+                                                        double b1d, double b2d,
+                                                        double* __restrict__ state,
+                                                        T* __restrict__ step_out) {
+    const double p1 = state[0] * b1d, p2 = state[1] * b2d;
+    const T inv_c1 = (T)(1.0 / (1.0 - p1)), inv_c2 = (T)(1.0 / (1.0 - p2));
+    const T one_m_b1 = T(1) - b1, one_m_b2 = T(1) - b2;
+    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    auto upd = [&](T gi, T& mi, T& vi) -> T {
+        mi = mi + one_m_b1 * (gi - mi);
+        vi = vi + one_m_b2 * (gi * gi - vi);
+        T mh = mi * inv_c1, vh = vi * inv_c2;
+        return -lr * mh / (sqrt(vh) + eps);
+    };
+    if constexpr (VEC == 4) {
+        int64_t nv = n / 4;
+        for (int64_t i = tid; i < nv; i += nth) {
+            float4 g4 = reinterpret_cast<const float4*>(g)[i];
+            float4 m4 = reinterpret_cast<float4*>(m)[i];
+            float4 v4 = reinterpret_cast<float4*>(v)[i];
+            float4 s4;
+            s4.x = upd(g4.x, m4.x, v4.x);
+            s4.y = upd(g4.y, m4.y, v4.y);
+            s4.z = upd(g4.z, m4.z, v4.z);
+            s4.w = upd(g4.w, m4.w, v4.w);
+            reinterpret_cast<float4*>(m)[i] = m4;
+            reinterpret_cast<float4*>(v)[i] = v4;
+            if (step_out) {
+                reinterpret_cast<float4*>(step_out)[i] = s4;
+            } else {
+                float4 p4 = reinterpret_cast<float4*>(p)[i];
+                p4.x += s4.x; p4.y += s4.y; p4.z += s4.z; p4.w += s4.w;
+                reinterpret_cast<float4*>(p)[i] = p4;
+            }
+        }
+        for (int64_t i = nv * 4 + tid; i < n; i += nth) {
+            T mi = m[i], vi = v[i];
+            T s = upd(g[i], mi, vi);
+            m[i] = mi; v[i] = vi;
+            if (step_out) step_out[i] = s; else p[i] = p[i] + s;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nth) {
+            T mi = m[i], vi = v[i];
+            T s = upd(g[i], mi, vi);
+            m[i] = mi; v[i] = vi;
+            if (step_out) step_out[i] = s; else p[i] = p[i] + s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(state + 2);
+        unsigned long long t = atomicAdd(ticket, 1ULL);
+        if (t == (unsigned long long)gridDim.x - 1) {
+            state[0] = p1;
+            state[1] = p2;
+            *ticket = 0ULL;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnn_bias_act(const void* x, const void* bias, int act, void* y, int64_t M, int64_t N, int dtype) {
+    TNN_NEED_INIT();
+    if (M * N <= 0) return 0;
+    TNN_REQUIRE(act == TNN_ACT_NONE || act == TNN_ACT_RELU, "tnn_bias_act: unknown activation %d", act);
+    switch (dtype) {
+        case TNN_F32:
+            return act == TNN_ACT_RELU ? bias_act_typed<float, TNN_ACT_RELU>(x, bias, y, M, N)
+                                       : bias_act_typed<float, TNN_ACT_NONE>(x, bias, y, M, N);
+        case TNN_F64:
+            return act == TNN_ACT_RELU ? bias_act_typed<double, TNN_ACT_RELU>(x, bias, y, M, N)
+                                       : bias_act_typed<double, TNN_ACT_NONE>(x, bias, y, M, N);
+    }
+    tnn::set_error("tnn_bias_act: dtype %d is not a float type", dtype);
+    return 2;
+}
+
+int tnn_softmax_nll_stats(const void* z, int64_t m, int64_t c, void* stats, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_stats: dtype %d", dtype);
+    int64_t n = m * c;
+    TNN_REQUIRE(n > 0, "tnn_softmax_nll_stats: empty logits");
+    int64_t nb = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
+    if (nb > 1024) nb = 1024;
+    void* ws = nullptr;
+    if (tnn_malloc((size_t)nb * 2 * sizeof(double), &ws)) return 1;
+    hipStream_t s = tnn::stream();
+    if (dtype == TNN_F32) {
+        hipLaunchKernelGGL((nll_stats_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)z, n, (double*)ws);
+        hipLaunchKernelGGL((lse_merge_kernel<double, float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)stats);
+    } else {
+        hipLaunchKernelGGL((nll_stats_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)z, n, (double*)ws);
+        hipLaunchKernelGGL((lse_merge_kernel<double, double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)stats);
+    }
+    tnn_free(ws);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_lse_merge(const void* stats_all, int n_shards, void* stats, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(n_shards > 0, "tnn_lse_merge: n_shards %d", n_shards);
+    hipStream_t s = tnn::stream();
+    switch (dtype) {
+        case TNN_F32: hipLaunchKernelGGL((lse_merge_kernel<float, float>), 1, 64, 0, s, (const float*)stats_all, n_shards, (float*)stats); break;
+        case TNN_F64: hipLaunchKernelGGL((lse_merge_kernel<double, double>), 1, 64, 0, s, (const double*)stats_all, n_shards, (double*)stats); break;
+        default: tnn::set_error("tnn_lse_merge: dtype %d is not a float type", dtype); return 2;
+    }
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global,
+                            const void* stats, void* loss_out, void* dz, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fwd_bwd: dtype %d", dtype);
+    TNN_REQUIRE(m > 0 && c > 0 && m_global > 0, "tnn_softmax_nll_fwd_bwd: empty batch");
+    int64_t nb = (m + kThreads - 1) / kThreads;
+    if (nb > 1024) nb = 1024;
+    void* ws = nullptr;
+    if (tnn_malloc((size_t)nb * sizeof(double), &ws)) return 1;
+    hipStream_t s = tnn::stream();
+    double inv_m = 1.0 / (double)m_global;
+    if (dtype == TNN_F32) {
+        hipLaunchKernelGGL((nll_fwd_bwd_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)z,
+                           (const float*)y, m, c, inv_m, (const float*)stats, (double*)ws, (float*)dz);
+        if (loss_out)
+            hipLaunchKernelGGL((sum_partials_kernel<float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)loss_out);
+    } else {
+        hipLaunchKernelGGL((nll_fwd_bwd_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)z,
+                           (const double*)y, m, c, inv_m, (const double*)stats, (double*)ws, (double*)dz);
+        if (loss_out)
+            hipLaunchKernelGGL((sum_partials_kernel<double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)loss_out);
+    }
+    tnn_free(ws);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out,
+                    void* dpred, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_mse_fwd_bwd: dtype %d", dtype);
+    TNN_REQUIRE(n > 0 && m_global > 0, "tnn_mse_fwd_bwd: empty batch");
+    int64_t nb = tnn::stream_grid(n, kThreads);
+    if (nb > 1024) nb = 1024;
+    void* ws = nullptr;
+    if (tnn_malloc((size_t)nb * sizeof(double), &ws)) return 1;
+    hipStream_t s = tnn::stream();
+    double inv_m = 1.0 / (double)m_global;
+    if (dtype == TNN_F32) {
+        hipLaunchKernelGGL((mse_fwd_bwd_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)pred,
+                           (const float*)y, n, inv_m, (double*)ws, (float*)dpred);
+        if (loss_out)
+            hipLaunchKernelGGL((sum_partials_kernel<float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)loss_out);
+    } else {
+        hipLaunchKernelGGL((mse_fwd_bwd_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)pred,
+                           (const double*)y, n, inv_m, (double*)ws, (double*)dpred);
+        if (loss_out)
+            hipLaunchKernelGGL((sum_partials_kernel<double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)loss_out);
+    }
+    tnn_free(ws);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    unsigned grid = tnn::stream_grid(n, kThreads);
+    switch (dtype) {
+        case TNN_F32: hipLaunchKernelGGL((sgd_kernel<float>), grid, kThreads, 0, tnn::stream(), (float*)p, (const float*)g, n, (float)lr); break;
+        case TNN_F64: hipLaunchKernelGGL((sgd_kernel<double>), grid, kThreads, 0, tnn::stream(), (double*)p, (const double*)g, n, lr); break;
+        default: tnn::set_error("tnn_sgd: dtype %d is not a float type", dtype); return 2;
+    }
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2,
+             double eps, void* pows_f64, void* step_out, int dtype) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam: pows state is NULL");
+    hipStream_t s = tnn::stream();
+    if (dtype == TNN_F32) {
+        bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+                     reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                     reinterpret_cast<uintptr_t>(step_out)) & 15) == 0;
+        unsigned grid = tnn::stream_grid(vec ? (n + 3) / 4 : n, kThreads);
+        if (vec)
+            hipLaunchKernelGGL((adam_kernel<float, 4>), grid, kThreads, 0, s, (float*)p, (const float*)g,
+                               (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps, b1,
+                               b2, (double*)pows_f64, (float*)step_out);
+        else
+            hipLaunchKernelGGL((adam_kernel<float, 1>), grid, kThreads, 0, s, (float*)p, (const float*)g,
+                               (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps, b1,
+                               b2, (double*)pows_f64, (float*)step_out);
+    } else if (dtype == TNN_F64) {
+        unsigned grid = tnn::stream_grid(n, kThreads);
+        hipLaunchKernelGGL((adam_kernel<double, 1>), grid, kThreads, 0, s, (double*)p, (const double*)g,
+                           (double*)m, (double*)v, n, lr, b1, b2, eps, b1, b2, (double*)pows_f64,
+                           (double*)step_out);
+    } else {
+        tnn::set_error("tnn_adam: dtype %d is not a float type", dtype);
+        return 2;
+    }
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+}  // extern "C"

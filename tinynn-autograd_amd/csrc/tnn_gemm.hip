@@ -1,0 +1,516 @@
+// K1: GEMM for the three contractions of ops.dot_ (core/ops.py:151 NN, :157 NT, :160 TN) with the
+// fused epilogues of K8.  fp32 path = v_mfma_f32_32x32x2_f32 (exact f32, 256 FLOP/clk/CU, 157 TF
+// chip peak), LDS double-buffered, one barrier per K-tile, register-staged prefetch of the next
+// tile, XCD-aware tile order.  No operand is ever transposed in memory: each operand is staged in
+// the layout it already has and only the LDS read pattern differs.
+//
+// Operand layouts ("KC" = K is the contiguous axis of the stored matrix):
+//     NN: A[M,K] KC      B[K,N] N-contiguous
+//     NT: A[M,K] KC      B[N,K] KC
+//     TN: A[K,M] M-contig B[K,N] N-contiguous
+// LDS images:  KC operand      -> [rows][BK+4]   fragment = one ds_read_b128 per 8-deep k-chunk
+//                                  (row stride 144 B: conflict-free for the 16-lane b128 groups)
+//              MN-contig operand -> [BK][rows]    fragment = 4 ds_read_b32 (32 consecutive dwords)
+// k-assignment inside an 8-deep chunk: lanes 0-31 hold k = 0..3, lanes 32-63 hold k = 4..7; MFMA j
+// contracts {j, 4+j}.  A and B use the same assignment, so the sum is complete; only the fp32
+// summation order differs from a sequential loop (tolerance, not bit-exactness, is the f32 bar).
+#include <math.h>
+#include <stdlib.h>
+
+#include "tnn_internal.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_AXPBY = 0, EPI_BIAS_ACT = 1, EPI_MASK = 2 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    float alpha, beta;
+    int epi;
+    const float* bias;
+    int act, relu_sign;
+    const float* Y;
+    int64_t ldy;
+    int vecA, vecB;        // 16-B vector loads legal for this operand
+    int64_t k_per_split;   // multiple of BK
+    int splits;
+    float* ws;             // [splits, M, N] partial sums when splits > 1
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float apply_epilogue(const GemmArgs& g, float acc, int64_t row,
+                                                int64_t col) {
+    if (g.epi == EPI_AXPBY) {
+        float r = g.alpha * acc;
+        if (g.beta != 0.f) r += g.beta * g.C[row * g.ldc + col];
+        return r;
+    } else if (g.epi == EPI_BIAS_ACT) {
+        float v = acc + (g.bias ? g.bias[col] : 0.f);
+        if (g.act == TNN_ACT_RELU) {
+            if (g.relu_sign) v = v < 0.f ? -0.0f : fabsf(v);   // mask x>=0 kept in the sign bit
+            else v = v < 0.f ? 0.f : v;
+        }
+        return v;
+    } else {
+        float y = g.Y[row * g.ldy + col];
+        return (__float_as_uint(y) >> 31) ? 0.f : acc;
+    }
+}
+
+// bijective XCD remap (blocks b, b+8, b+16 ... share an XCD and therefore an L2): give every XCD a
+// contiguous range of tile ids so neighbouring tiles (same B panel, adjacent A panels) hit in L2.
+__device__ __forceinline__ int xcd_remap(int b, int nb) {
+    const int nx = 8;
+    if (nb < 2 * nx) return b;
+    int q = nb / nx, r = nb % nx;
+    int xcd = b % nx, local = b / nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int SA = AKC ? BK + 4 : BM;          // LDS row stride (floats)
+    constexpr int SB = BKC ? BK + 4 : BN;
+    constexpr int A_ELEMS = AKC ? BM * SA : BK * SA;
+    constexpr int B_ELEMS = BKC ? BN * SB : BK * SB;
+    constexpr int A_F4 = BM * BK / 4 / NT;         // float4 per thread per tile
+    constexpr int B_F4 = BN * BK / 4 / NT;
+    static_assert(A_F4 >= 1 && B_F4 >= 1, "tile too small for the block");
+    static_assert(BK % 8 == 0, "BK must be a multiple of 8");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * (A_ELEMS + B_ELEMS)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int nb = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap((int)blockIdx.x, nb);
+    const int64_t m0 = (int64_t)(t % g.tiles_m) * BM;
+    const int64_t n0 = (int64_t)(t / g.tiles_m) * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t kend = min(g.K, kbeg + g.k_per_split);
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+
+    float4 ra[A_F4], rb[B_F4];
+
+    auto load_tile = [&](int64_t k0) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            int f = tid + i * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (AKC) {
+                int row = f / (BK / 4), c4 = f % (BK / 4);
+                int64_t gm = m0 + row, gk = k0 + c4 * 4;
+                const float* p = g.A + gm * g.lda + gk;
+                if (gm < g.M) {
+                    if (g.vecA) {
+                        if (gk < kend) v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gk + 0 < kend) v.x = p[0];
+                        if (gk + 1 < kend) v.y = p[1];
+                        if (gk + 2 < kend) v.z = p[2];
+                        if (gk + 3 < kend) v.w = p[3];
+                    }
+                }
+            } else {
+                int row = f / (BM / 4), c4 = f % (BM / 4);
+                int64_t gk = k0 + row, gm = m0 + c4 * 4;
+                const float* p = g.A + gk * g.lda + gm;
+                if (gk < kend) {
+                    if (g.vecA) {
+                        if (gm < g.M) v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gm + 0 < g.M) v.x = p[0];
+                        if (gm + 1 < g.M) v.y = p[1];
+                        if (gm + 2 < g.M) v.z = p[2];
+                        if (gm + 3 < g.M) v.w = p[3];
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            int f = tid + i * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (BKC) {
+                int row = f / (BK / 4), c4 = f % (BK / 4);
+                int64_t gn = n0 + row, gk = k0 + c4 * 4;
+                const float* p = g.B + gn * g.ldb + gk;
+                if (gn < g.N) {
+                    if (g.vecB) {
+                        if (gk < kend) v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gk + 0 < kend) v.x = p[0];
+                        if (gk + 1 < kend) v.y = p[1];
+                        if (gk + 2 < kend) v.z = p[2];
+                        if (gk + 3 < kend) v.w = p[3];
+                    }
+                }
+            } else {
+                int row = f / (BN / 4), c4 = f % (BN / 4);
+                int64_t gk = k0 + row, gn = n0 + c4 * 4;
+                const float* p = g.B + gk * g.ldb + gn;
+                if (gk < kend) {
+                    if (g.vecB) {
+                        if (gn < g.N) v = *reinterpret_cast<const float4*>(p);
+                    } else {
+                        if (gn + 0 < g.N) v.x = p[0];
+                        if (gn + 1 < g.N) v.y = p[1];
+                        if (gn + 2 < g.N) v.z = p[2];
+                        if (gn + 3 < g.N) v.w = p[3];
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        float* As = lds + buf * (A_ELEMS + B_ELEMS);
+        float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i) {
+            int f = tid + i * NT;
+            int row = AKC ? f / (BK / 4) : f / (BM / 4);
+            int c4 = AKC ? f % (BK / 4) : f % (BM / 4);
+            *reinterpret_cast<float4*>(As + row * SA + c4 * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i) {
+            int f = tid + i * NT;
+            int row = BKC ? f / (BK / 4) : f / (BN / 4);
+            int c4 = BKC ? f % (BK / 4) : f % (BN / 4);
+            *reinterpret_cast<float4*>(Bs + row * SB + c4 * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        load_tile(kbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kbeg + (int64_t)(kt + 1) * BK);   // in flight during the MFMAs
+        const float* As = lds + cur * (A_ELEMS + B_ELEMS);
+        const float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float af[MI][4], bf[NI][4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (AKC) {
+                    float4 v = *reinterpret_cast<const float4*>(
+                        As + (wm * TM + i * 32 + l31) * SA + kk * 8 + lhi * 4);
+                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        af[i][j] = As[(kk * 8 + lhi * 4 + j) * SA + wm * TM + i * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                if constexpr (BKC) {
+                    float4 v = *reinterpret_cast<const float4*>(
+                        Bs + (wn * TN + i * 32 + l31) * SB + kk * 8 + lhi * 4);
+                    bf[i][0] = v.x; bf[i][1] = v.y; bf[i][2] = v.z; bf[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bf[i][j] = Bs[(kk * 8 + lhi * 4 + j) * SB + wn * TN + i * 32 + l31];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j],
+                                                                           acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);   // the other buffer was last read one barrier ago
+        __syncthreads();
+    }
+
+    // epilogue: lane holds col = l31, rows (r&3) + 8*(r>>2) + 4*lhi of each 32x32 block
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            int64_t col = n0 + wn * TN + ni * 32 + l31;
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= g.M) continue;
+                float a = acc[mi][ni][r];
+                if (g.splits > 1)
+                    g.ws[((int64_t)blockIdx.z * g.M + row) * g.N + col] = a;
+                else
+                    g.C[row * g.ldc + col] = apply_epilogue(g, a, row, col);
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+    int64_t total = g.M * g.N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < g.splits; ++z) s += g.ws[(int64_t)z * total + i];
+        int64_t row = i / g.N, col = i - row * g.N;
+        g.C[row * g.ldc + col] = apply_epilogue(g, s, row, col);
+    }
+}
+
+// ------------------------------------------------------------------------------ f64 (exact mode)
+// Plain LDS-tiled VALU kernel, 64x64 tile, 4x4 micro-tile per thread; not on the measured path.
+struct GemmArgsD {
+    const double* A;
+    const double* B;
+    double* C;
+    int64_t M, N, K, sam, sak, sbk, sbn, ldc;
+    double alpha, beta;
+    int epi;
+    const double* bias;
+    int act, relu_sign;
+    const double* Y;
+    int64_t ldy;
+};
+
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgsD g) {
+    __shared__ double As[16][64 + 1], Bs[16][64 + 1];
+    int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    int64_t m0 = (int64_t)blockIdx.y * 64, n0 = (int64_t)blockIdx.x * 64;
+    double acc[4][4] = {};
+    for (int64_t k0 = 0; k0 < g.K; k0 += 16) {
+        for (int f = threadIdx.x; f < 16 * 64; f += 256) {
+            int kk = f / 64, mm = f % 64;
+            int64_t gm = m0 + mm, gk = k0 + kk;
+            As[kk][mm] = (gm < g.M && gk < g.K) ? g.A[gm * g.sam + gk * g.sak] : 0.0;
+            int64_t gn = n0 + mm;
+            Bs[kk][mm] = (gn < g.N && gk < g.K) ? g.B[gk * g.sbk + gn * g.sbn] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int64_t row = m0 + ty * 4 + i, col = n0 + tx * 4 + j;
+            if (row >= g.M || col >= g.N) continue;
+            double v = acc[i][j];
+            if (g.epi == EPI_AXPBY) {
+                v = g.alpha * v;
+                if (g.beta != 0.0) v += g.beta * g.C[row * g.ldc + col];
+            } else if (g.epi == EPI_BIAS_ACT) {
+                v += g.bias ? g.bias[col] : 0.0;
+                if (g.act == TNN_ACT_RELU) {
+                    if (g.relu_sign) v = v < 0.0 ? -0.0 : fabs(v);
+                    else v = v < 0.0 ? 0.0 : v;
+                }
+            } else {
+                v = signbit(g.Y[row * g.ldy + col]) ? 0.0 : v;
+            }
+            g.C[row * g.ldc + col] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------ host dispatch
+template <int BM, int BN, int BK, int WM, int WN>
+int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
+    g.tiles_m = (int)((g.M + BM - 1) / BM);
+    g.tiles_n = (int)((g.N + BN - 1) / BN);
+    int64_t ktiles = (g.K + BK - 1) / BK;
+    if (splits > ktiles) splits = (int)ktiles;
+    if (splits < 1) splits = 1;
+    int64_t tiles_per_split = (ktiles + splits - 1) / splits;
+    if (tiles_per_split < 1) tiles_per_split = 1;   // K == 0: one empty pass, C = beta*C / bias
+    splits = ktiles > 0 ? (int)((ktiles + tiles_per_split - 1) / tiles_per_split) : 1;
+    g.k_per_split = tiles_per_split * BK;
+    g.splits = splits;
+    g.ws = nullptr;
+    void* ws = nullptr;
+    if (splits > 1) {
+        if (tnn_malloc((size_t)splits * g.M * g.N * sizeof(float), &ws)) return 1;
+        g.ws = (float*)ws;
+    }
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
+    constexpr int NT = WM * WN * 64;
+    hipStream_t s = tnn::stream();
+    if (!transA && !transB)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, true, false>), grid, NT, 0, s, g);
+    else if (!transA && transB)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, true, true>), grid, NT, 0, s, g);
+    else if (transA && !transB)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, false, false>), grid, NT, 0, s, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, false, true>), grid, NT, 0, s, g);
+    if (splits > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, tnn::stream_grid(g.M * g.N, 256), 256, 0, s, g);
+        tnn_free(ws);
+    }
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int gemm_f32(GemmArgs& g, int transA, int transB) {
+    // 16-B loads need: contiguous extent and leading dimension multiples of 4, base 16-B aligned
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    g.vecA = al(g.A) && g.lda % 4 == 0 && ((transA ? g.M : g.K) % 4 == 0);
+    g.vecB = al(g.B) && g.ldb % 4 == 0 && ((transB ? g.K : g.N) % 4 == 0);
+
+    const int cus = tnn::num_cus();
+    int cfg = -1, splits = 0;
+    if (const char* e = getenv("TNN_GEMM_CFG")) cfg = atoi(e);       // tuning override
+    if (const char* e = getenv("TNN_GEMM_SPLITK")) splits = atoi(e);
+    int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+    int64_t t64x128 = ((g.M + 63) / 64) * ((g.N + 127) / 128);
+    int64_t t64 = ((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (cfg < 0) {
+        if (t128 >= cus) cfg = 0;
+        else if (t64x128 >= cus) cfg = 1;
+        else cfg = 2;
+    }
+    if (splits <= 0) {
+        splits = 1;
+        int64_t tiles = cfg == 0 ? t128 : cfg == 1 ? t64x128 : t64;
+        if (tiles < cus) {
+            // fill the chip: about one block per CU, at least 2 K-tiles (64 deep) per split
+            splits = (int)((cus + tiles - 1) / tiles);
+            int64_t max_splits = g.K / 64;
+            if (splits > max_splits) splits = (int)max_splits;
+            if (splits < 1) splits = 1;
+            if (splits > 32) splits = 32;
+        }
+    }
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128, 32, 2, 2>(g, transA, transB, splits);
+        case 1: return launch_cfg<64, 128, 32, 2, 2>(g, transA, transB, splits);
+        case 2: return launch_cfg<64, 64, 32, 2, 2>(g, transA, transB, splits);
+        case 3: return launch_cfg<128, 64, 32, 2, 2>(g, transA, transB, splits);
+    }
+    tnn::set_error("tnn_gemm: unknown tile configuration %d", cfg);
+    return 2;
+}
+
+int gemm_f64(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+             const void* B, int64_t ldb, void* C, int64_t ldc, double alpha, double beta, int epi,
+             const void* bias, int act, int relu_sign, const void* Y, int64_t ldy) {
+    GemmArgsD g;
+    g.relu_sign = relu_sign;
+    g.A = (const double*)A; g.B = (const double*)B; g.C = (double*)C;
+    g.M = M; g.N = N; g.K = K;
+    g.sam = transA ? 1 : lda; g.sak = transA ? lda : 1;
+    g.sbk = transB ? 1 : ldb; g.sbn = transB ? ldb : 1;
+    g.ldc = ldc; g.alpha = alpha; g.beta = beta; g.epi = epi;
+    g.bias = (const double*)bias; g.act = act; g.Y = (const double*)Y; g.ldy = ldy;
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    hipLaunchKernelGGL(gemm_f64_kernel, grid, 256, 0, tnn::stream(), g);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int check_shapes(const char* fn, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                 int64_t lda, int64_t ldb, int64_t ldc) {
+    TNN_REQUIRE(M >= 0 && N >= 0 && K >= 0, "%s: negative extent", fn);
+    TNN_REQUIRE(lda >= (transA ? M : K), "%s: lda %lld too small", fn, (long long)lda);
+    TNN_REQUIRE(ldb >= (transB ? K : N), "%s: ldb %lld too small", fn, (long long)ldb);
+    TNN_REQUIRE(ldc >= N, "%s: ldc %lld too small", fn, (long long)ldc);
+    TNN_REQUIRE(M < (1LL << 31) && N < (1LL << 31), "%s: extent exceeds 2^31", fn);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnn_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const void* A,
+             int64_t lda, const void* B, int64_t ldb, double beta, void* C, int64_t ldc, int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_gemm", transA, transB, M, N, K, lda, ldb, ldc)) return rc;
+    if (M == 0 || N == 0) return 0;
+    if (dtype == TNN_F64)
+        return gemm_f64(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, alpha, beta, EPI_AXPBY,
+                        nullptr, 0, 0, nullptr, 0);
+    TNN_REQUIRE(dtype == TNN_F32, "tnn_gemm: dtype %d is not a float type", dtype);
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)B; g.C = (float*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = (float)alpha; g.beta = (float)beta; g.epi = EPI_AXPBY;
+    return gemm_f32(g, transA, transB);
+}
+
+int tnn_gemm_bias_act(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A,
+                      int64_t lda, const void* B, int64_t ldb, const void* bias, int act,
+                      int relu_sign, void* C, int64_t ldc, int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_gemm_bias_act", transA, transB, M, N, K, lda, ldb, ldc)) return rc;
+    TNN_REQUIRE(act == TNN_ACT_NONE || act == TNN_ACT_RELU, "tnn_gemm_bias_act: activation %d", act);
+    if (M == 0 || N == 0) return 0;
+    if (dtype == TNN_F64)
+        return gemm_f64(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, 1.0, 0.0, EPI_BIAS_ACT, bias,
+                        act, relu_sign, nullptr, 0);
+    TNN_REQUIRE(dtype == TNN_F32, "tnn_gemm_bias_act: dtype %d is not a float type", dtype);
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)B; g.C = (float*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_BIAS_ACT;
+    g.bias = (const float*)bias; g.act = act; g.relu_sign = relu_sign;
+    return gemm_f32(g, transA, transB);
+}
+
+int tnn_gemm_mask(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                  const void* B, int64_t ldb, const void* Y, int64_t ldy, void* C, int64_t ldc,
+                  int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_gemm_mask", transA, transB, M, N, K, lda, ldb, ldc)) return rc;
+    TNN_REQUIRE(Y != nullptr && ldy >= N, "tnn_gemm_mask: bad mask operand");
+    if (M == 0 || N == 0) return 0;
+    if (dtype == TNN_F64)
+        return gemm_f64(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, 1.0, 0.0, EPI_MASK, nullptr, 0,
+                        0, Y, ldy);
+    TNN_REQUIRE(dtype == TNN_F32, "tnn_gemm_mask: dtype %d is not a float type", dtype);
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)B; g.C = (float*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_MASK;
+    g.Y = (const float*)Y; g.ldy = ldy;
+    return gemm_f32(g, transA, transB);
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// Whole-step Dense-MLP trainer: the loop body of examples/mnist/run.py:79-83
+// (zero_grad -> forward -> loss -> backward -> step) as a fixed sequence of launches on
+// device-resident state.  Host-only C++ on top of the C-ABI primitives, so the same file is linked
+// into libtnn_hip.so (HIP kernels) and into the CPU test twin.
+//
+// State layout (HBM): four flat arenas  params | grads | m | v , each n_params(+pad) elements, in
+// the order core/optimizer.py:14-15 flattens them: layer by layer, "w" [in,out] then "b" [1,out]
+// (core/layers.py:34-35).  grads[n_params] is one extra slot that carries this shard's loss so the
+// data-parallel all-reduce of the gradient arena also sums the loss for free.
+//
+// Per step (L Dense layers, ReLU between them):
+//   forward  : L  x  gemm_bias_act (NN, bias + ReLU fused, ReLU mask kept in the sign bit of 0)
+//   loss     : softmax_nll_stats + softmax_nll_fwd_bwd   (or mse_fwd_bwd)
+//   backward : L  x  gemm TN (dW = X^T dZ)  +  L x column-sum (db)  +  (L-1) x gemm_mask NT (dX*mask)
+//   update   : 1  x  fused Adam / SGD over the whole arena
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "tnn_hip.h"
+
+namespace tnn {
+void set_error(const char* fmt, ...);
+}
+
+namespace {
+
+struct Mlp {
+    int L = 0;
+    std::vector<int64_t> w;          // widths, L+1
+    int64_t max_rows = 0;
+    int loss_kind = 0, opt_kind = 0, dtype = TNN_F32;
+    double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    int64_t n_params = 0, arena = 0;
+    size_t esz = 4;
+    char *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+    void* pows = nullptr;            // Adam state, double[4]
+    void* stats = nullptr;           // {M, S} of the last forward_stats
+    std::vector<int64_t> w_off, b_off;
+    std::vector<void*> act;          // act[l]  = output of layer l       [max_rows, w[l+1]]
+    std::vector<void*> dact;         // dact[l] = dLoss/d(pre-activation) [max_rows, w[l+1]]
+};
+
+#define MLP_TRY(call)            \
+    do {                         \
+        int rc__ = (call);       \
+        if (rc__) return rc__;   \
+    } while (0)
+
+inline void* at(char* base, int64_t elem_off, size_t esz) { return base + elem_off * (int64_t)esz; }
+
+int mlp_forward(Mlp* h, const void* x, int64_t rows) {
+    const void* in = x;
+    for (int l = 0; l < h->L; ++l) {
+        bool hidden = l < h->L - 1;
+        MLP_TRY(tnn_gemm_bias_act(0, 0, rows, h->w[l + 1], h->w[l], in, h->w[l],
+                                  at(h->params, h->w_off[l], h->esz), h->w[l + 1],
+                                  at(h->params, h->b_off[l], h->esz),
+                                  hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, h->act[l],
+                                  h->w[l + 1], h->dtype));
+        in = h->act[l];
+    }
+    return 0;
+}
+
+int check_rows(Mlp* h, int64_t rows, const char* fn) {
+    if (!h) { tnn::set_error("%s: NULL handle", fn); return 2; }
+    if (rows <= 0 || rows > h->max_rows) {
+        tnn::set_error("%s: rows %lld outside (0, %lld]", fn, (long long)rows, (long long)h->max_rows);
+        return 2;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int loss_kind,
+                   int opt_kind, double lr, double b1, double b2, double eps, int dtype,
+                   void** handle) {
+    if (n_layers < 1 || !widths || max_rows < 1 || !handle) {
+        tnn::set_error("tnn_mlp_create: bad arguments");
+        return 2;
+    }
+    if (dtype != TNN_F32 && dtype != TNN_F64) {
+        tnn::set_error("tnn_mlp_create: dtype %d is not a float type", dtype);
+        return 2;
+    }
+    if (loss_kind < 0 || loss_kind > 1 || opt_kind < 0 || opt_kind > 1) {
+        tnn::set_error("tnn_mlp_create: loss_kind %d / opt_kind %d unknown", loss_kind, opt_kind);
+        return 2;
+    }
+    Mlp* h = new Mlp();
+    h->L = n_layers;
+    h->w.assign(widths, widths + n_layers + 1);
+    h->max_rows = max_rows;
+    h->loss_kind = loss_kind;
+    h->opt_kind = opt_kind;
+    h->dtype = dtype;
+    h->lr = lr; h->b1 = b1; h->b2 = b2; h->eps = eps;
+    h->esz = dtype == TNN_F32 ? 4 : 8;
+    int64_t off = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (widths[l] < 1 || widths[l + 1] < 1) {
+            delete h;
+            tnn::set_error("tnn_mlp_create: layer widths must be positive");
+            return 2;
+        }
+        h->w_off.push_back(off);
+        off += widths[l] * widths[l + 1];
+        h->b_off.push_back(off);
+        off += widths[l + 1];
+    }
+    h->n_params = off;
+    h->arena = (off + 1 + 3) / 4 * 4;   // + loss slot, padded to 16 B
+    size_t bytes = (size_t)h->arena * h->esz;
+    int rc = 0;
+    rc |= tnn_malloc(bytes, (void**)&h->params);
+    rc |= tnn_malloc(bytes, (void**)&h->grads);
+    rc |= tnn_malloc(bytes, (void**)&h->m);
+    rc |= tnn_malloc(bytes, (void**)&h->v);
+    rc |= tnn_malloc(4 * sizeof(double), &h->pows);
+    rc |= tnn_malloc(2 * 8, &h->stats);
+    for (int l = 0; l < n_layers && !rc; ++l) {
+        void *a = nullptr, *d = nullptr;
+        rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * h->esz, &a);
+        rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * h->esz, &d);
+        h->act.push_back(a);
+        h->dact.push_back(d);
+    }
+    if (!rc) {
+        rc |= tnn_memset(h->params, 0, bytes);
+        rc |= tnn_memset(h->grads, 0, bytes);
+        rc |= tnn_memset(h->m, 0, bytes);
+        rc |= tnn_memset(h->v, 0, bytes);
+        const double init[4] = {1.0, 1.0, 0.0, 0.0};
+        rc |= tnn_memcpy_h2d(h->pows, init, sizeof(init));
+    }
+    if (rc) {
+        tnn_mlp_destroy(h);
+        return 1;
+    }
+    *handle = h;
+    return 0;
+}
+
+int tnn_mlp_destroy(void* handle) {
+    Mlp* h = (Mlp*)handle;
+    if (!h) return 0;
+    tnn_free(h->params); tnn_free(h->grads); tnn_free(h->m); tnn_free(h->v);
+    tnn_free(h->pows); tnn_free(h->stats);
+    for (void* p : h->act) tnn_free(p);
+    for (void* p : h->dact) tnn_free(p);
+    delete h;
+    return 0;
+}
+
+int tnn_mlp_arena(void* handle, void** params, void** grads, void** m, void** v, int64_t* n_params) {
+    Mlp* h = (Mlp*)handle;
+    if (!h) { tnn::set_error("tnn_mlp_arena: NULL handle"); return 2; }
+    if (params) *params = h->params;
+    if (grads) *grads = h->grads;
+    if (m) *m = h->m;
+    if (v) *v = h->v;
+    if (n_params) *n_params = h->n_params;
+    return 0;
+}
+
+int tnn_mlp_param_offset(void* handle, int layer, int which, int64_t* offset, int64_t* count) {
+    Mlp* h = (Mlp*)handle;
+    if (!h || layer < 0 || layer >= h->L || which < 0 || which > 1) {
+        tnn::set_error("tnn_mlp_param_offset: bad arguments");
+        return 2;
+    }
+    if (offset) *offset = which == 0 ? h->w_off[layer] : h->b_off[layer];
+    if (count) *count = which == 0 ? h->w[layer] * h->w[layer + 1] : h->w[layer + 1];
+    return 0;
+}
+
+int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits) {
+    Mlp* h = (Mlp*)handle;
+    MLP_TRY(check_rows(h, rows, "tnn_mlp_forward"));
+    MLP_TRY(mlp_forward(h, x, rows));
+    if (logits)
+        MLP_TRY(tnn_memcpy_d2d(logits, h->act[h->L - 1], (size_t)(rows * h->w[h->L]) * h->esz));
+    return 0;
+}
+
+int tnn_mlp_forward_stats(void* handle, const void* x, int64_t rows, void* stats) {
+    Mlp* h = (Mlp*)handle;
+    MLP_TRY(check_rows(h, rows, "tnn_mlp_forward_stats"));
+    MLP_TRY(mlp_forward(h, x, rows));
+    if (h->loss_kind == 0)
+        MLP_TRY(tnn_softmax_nll_stats(h->act[h->L - 1], rows, h->w[h->L], stats ? stats : h->stats,
+                                      h->dtype));
+    return 0;
+}
+
+int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, int64_t m_global,
+                     const void* stats, void* loss_out) {
+    Mlp* h = (Mlp*)handle;
+    MLP_TRY(check_rows(h, rows, "tnn_mlp_backward"));
+    const int L = h->L;
+    void* loss_slot = at(h->grads, h->n_params, h->esz);
+    if (h->loss_kind == 0)
+        MLP_TRY(tnn_softmax_nll_fwd_bwd(h->act[L - 1], y, rows, h->w[L], m_global,
+                                        stats ? stats : h->stats, loss_slot, h->dact[L - 1], h->dtype));
+    else
+        MLP_TRY(tnn_mse_fwd_bwd(h->act[L - 1], y, rows * h->w[L], m_global, loss_slot, h->dact[L - 1],
+                                h->dtype));
+    for (int l = L - 1; l >= 0; --l) {
+        const void* in = l == 0 ? x : h->act[l - 1];
+        void* d = h->dact[l];
+        // dW_l = in^T d   (core/ops.py:159-160): A stored [K=rows, M=w[l]]
+        MLP_TRY(tnn_gemm(1, 0, h->w[l], h->w[l + 1], rows, 1.0, in, h->w[l], d, h->w[l + 1], 0.0,
+                         at(h->grads, h->w_off[l], h->esz), h->w[l + 1], h->dtype));
+        // db_l = column sum of d   (core/ops.py:52-54)
+        MLP_TRY(tnn_reduce(TNN_RSUM, d, at(h->grads, h->b_off[l], h->esz), 1, rows, h->w[l + 1],
+                           h->dtype));
+        // dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]   (core/ops.py:156-157 + :342-343)
+        if (l > 0)
+            MLP_TRY(tnn_gemm_mask(0, 1, rows, h->w[l], h->w[l + 1], d, h->w[l + 1],
+                                  at(h->params, h->w_off[l], h->esz), h->w[l + 1], h->act[l - 1],
+                                  h->w[l], h->dact[l - 1], h->w[l], h->dtype));
+    }
+    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
+    return 0;
+}
+
+int tnn_mlp_update(void* handle) {
+    Mlp* h = (Mlp*)handle;
+    if (!h) { tnn::set_error("tnn_mlp_update: NULL handle"); return 2; }
+    if (h->opt_kind == 0) return tnn_sgd(h->params, h->grads, h->n_params, h->lr, h->dtype);
+    return tnn_adam(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps,
+                    h->pows, nullptr, h->dtype);
+}
+
+int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void* loss_out) {
+    MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+    MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows, nullptr, loss_out));
+    return tnn_mlp_update(handle);
+}
+
+int tnn_mlp_activation(void* handle, int layer, void** ptr) {
+    Mlp* h = (Mlp*)handle;
+    if (!h || layer < 0 || layer >= h->L || !ptr) {
+        tnn::set_error("tnn_mlp_activation: bad arguments");
+        return 2;
+    }
+    *ptr = h->act[layer];
+    return 0;
+}
+
+}  // extern "C"
