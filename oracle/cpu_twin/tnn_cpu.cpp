@@ -42,8 +42,8 @@ Graph* g_capturing = nullptr;
 
 #define REQ(cond, ...) do { if (!(cond)) { tnn::set_error(__VA_ARGS__); return 2; } } while (0)
 #define NEED_INIT() REQ(g_ready, "tnn_init() has not been called")
-// record-and-run: while capturing, every primitive call is also stored for replay
-#define RECORD(...) do { if (g_capturing) g_capturing->calls.push_back([=]() -> int { __VA_ARGS__; return 0; }); } while (0)
+// like hipStreamBeginCapture: while capturing, a primitive call is stored for replay and NOT executed
+#define RECORD(...) do { if (g_capturing) { g_capturing->calls.push_back([=]() -> int { __VA_ARGS__; return 0; }); return 0; } } while (0)
 
 constexpr int kMaxDim = 6;
 

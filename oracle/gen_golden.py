@@ -1,0 +1,284 @@
+"""TEST INFRASTRUCTURE — container-only generator of tests/golden/* from the REAL reference.
+
+    python oracle/gen_golden.py            (needs /root/reference; it is imported, never copied)
+
+It (1) runs every case of tests/op_cases.py and a set of seeded training trajectories through the
+reference's own core/ modules, (2) asserts that the numpy oracle (oracle/ref_autograd.py, ref_nn.py,
+closed_form.py) reproduces them — bit-for-bit for the op-graph restatement, to float64 round-off for the
+closed form — and (3) writes the reference's outputs as small fixtures.  The GPU box has no
+/root/reference: there the fixtures ARE the reference.
+
+Trajectory configs:  A = 784-256-128-10, bs 128, Adam 1e-3 and SGD 1e-2, 20 steps;
+D = same net, bs 1024, Adam, 5 steps;  C-small = 256-256-256 autoencoder, bs 64, sum-of-squares/m, Adam,
+5 steps;  eval = argmax + AccEvaluator on 1000 rows with forced ties.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("TNN_REFERENCE_DIR", "/root/reference")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference not found at %s — fixtures can only be generated in the build container" % REF)
+    sys.path.insert(0, REF)
+    import core.tensor as rt
+    import core.ops as rops
+    import core.layers as rlayers
+    import core.losses as rlosses
+    import core.optimizer as ropt
+    import core.model as rmodel
+    import core.nn as rnn
+    import core.evaluator as reval
+    return rt, rops, rlayers, rlosses, ropt, rmodel, rnn, reval
+
+
+# ---------------------------------------------------------------------------- synthetic data
+def batches(seed, steps, m, n_in, n_out, kind):
+    """Deterministic synthetic batches (legacy RandomState => stable across numpy versions)."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(steps):
+        x = rs.rand(m, n_in).astype(np.float32)
+        if kind == "softmax_nll":
+            # MNIST-like sparsity: ~19 % of the pixels are non-zero.  Dense uniform inputs make
+            # the Adam trajectory chaotic (every step shifts all pre-activations coherently, ReLU units flip
+            # for whole batches) and float32 vs float64 then diverges after ~8 steps for reasons unrelated to
+            # kernel correctness; with this mask float32 tracks the float64 reference to ~4e-8 over 40 steps.
+            x *= (rs.rand(m, n_in) < 0.19)
+        if kind == "softmax_nll":
+            y = np.eye(n_out)[rs.randint(0, n_out, m)]          # float64 one-hot, run.py:27-28
+        else:
+            y = x.copy()                                        # autoencoder target
+        out.append((x, y))
+    return out
+
+
+CONFIGS = {
+    "A_adam": dict(widths=[784, 256, 128, 10], m=128, steps=20, loss="softmax_nll", opt="adam", lr=1e-3, seed=0, data_seed=123),
+    "A_sgd": dict(widths=[784, 256, 128, 10], m=128, steps=20, loss="softmax_nll", opt="sgd", lr=1e-2, seed=0, data_seed=123),
+    "A_ragged": dict(widths=[784, 256, 128, 10], m=80, steps=3, loss="softmax_nll", opt="adam", lr=1e-3, seed=0, data_seed=321),
+    "D_adam": dict(widths=[784, 256, 128, 10], m=1024, steps=5, loss="softmax_nll", opt="adam", lr=1e-3, seed=0, data_seed=456),
+    "C_small": dict(widths=[256, 256, 256], m=64, steps=5, loss="mse", opt="adam", lr=1e-3, seed=0, data_seed=789),
+}
+
+
+def sample_idx(n, k=512):
+    """Fixed pseudo-random subset of a flat array (keeps fixtures small)."""
+    return np.sort(np.random.RandomState(n % 100003).choice(n, size=min(k, n), replace=False))
+
+
+def summarize(arr):
+    flat = np.asarray(arr, dtype=np.float64).ravel()
+    idx = sample_idx(flat.size)
+    return {"sum": flat.sum(), "abs_sum": np.abs(flat).sum(), "l2": np.sqrt((flat ** 2).sum()),
+            "idx": idx, "sample": flat[idx]}
+
+
+# ---------------------------------------------------------------------------- reference runs
+def run_reference(cfg, ref):
+    rt, rops, rlayers, rlosses, ropt, rmodel, rnn, _ = ref
+    w = cfg["widths"]
+    np.random.seed(cfg["seed"])
+    layers = []
+    for i in range(len(w) - 1):
+        layers.append(rlayers.Dense(w[i + 1], num_in=w[i]))        # eager init, layer order
+        if i < len(w) - 2:
+            layers.append(rlayers.ReLU())
+    net = rnn.Net(layers)
+    opt = ropt.Adam(lr=cfg["lr"]) if cfg["opt"] == "adam" else ropt.SGD(lr=cfg["lr"])
+    loss_layer = rlosses.SoftmaxCrossEntropyLoss()
+    model = rmodel.Model(net=net, loss=loss_layer, optimizer=opt)
+    init = [{k: np.array(v.values) for k, v in l.params.items()} for l in layers if l.params]
+    rec = {"loss": [], "logits": {}, "grads0": None, "argmax": {}}
+    data = batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])
+    for s, (x, y) in enumerate(data):
+        model.zero_grad()
+        pred = model.forward(rt.Tensor(x))
+        if cfg["loss"] == "softmax_nll":
+            loss = loss_layer.loss(pred, rt.Tensor(y))
+        else:
+            err = pred - rt.Tensor(y)
+            loss = (err ** 2).sum() / cfg["m"]
+        loss.backward()
+        if s == 0:
+            rec["grads0"] = [{k: np.array(v.grad) for k, v in l.params.items()} for l in layers if l.params]
+        model.step()
+        rec["loss"].append(float(loss.values))
+        if s in (0, 1, cfg["steps"] - 1):
+            rec["logits"][s] = np.array(pred.values)
+            rec["argmax"][s] = np.argmax(np.array(pred.values), axis=1)
+    final = [{k: np.array(v.values) for k, v in l.params.items()} for l in layers if l.params]
+    return init, rec, final
+
+
+def run_oracle(cfg):
+    from oracle import ref_nn
+    w = cfg["widths"]
+    np.random.seed(cfg["seed"])
+    layers = ref_nn.build_mlp(w)
+    opt = ref_nn.Adam(lr=cfg["lr"]) if cfg["opt"] == "adam" else ref_nn.SGD(lr=cfg["lr"])
+    loss_fn = ref_nn.softmax_nll if cfg["loss"] == "softmax_nll" else ref_nn.squared_error
+    losses, logits = [], {}
+    for s, (x, y) in enumerate(batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])):
+        lv, pred = ref_nn.train_step(layers, opt, loss_fn, x, y)
+        losses.append(float(lv))
+        logits[s] = np.array(pred)
+    final = [{k: np.array(v.values) for k, v in l.params.items()} for l in layers if l.params]
+    return losses, logits, final
+
+
+def run_closed_form(cfg, init):
+    from oracle.closed_form import ClosedFormMLP
+    w = cfg["widths"]
+    mlp = ClosedFormMLP([p["w"] for p in init], [p["b"] for p in init], loss=cfg["loss"],
+                        optimizer=cfg["opt"], lr=cfg["lr"])
+    losses, grads0 = [], None
+    for s, (x, y) in enumerate(batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])):
+        loss, _, gW, gb = mlp.step(x, y)
+        if s == 0:
+            grads0 = (gW, gb)
+        losses.append(loss)
+    return losses, grads0, mlp
+
+
+def trajectory_fixture(name, cfg, ref):
+    init, rec, final = run_reference(cfg, ref)
+    # --- pin the oracles on the reference
+    o_losses, o_logits, o_final = run_oracle(cfg)
+    assert np.array_equal(np.array(o_losses), np.array(rec["loss"])), "%s: ref_nn loss differs from the reference" % name
+    for s, z in rec["logits"].items():
+        assert np.array_equal(o_logits[s], z), "%s: ref_nn logits differ at step %d" % (name, s)
+    for a, b in zip(o_final, final):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), "%s: ref_nn final params differ" % name
+    c_losses, (gW, gb), mlp = run_closed_form(cfg, init)
+    # the reference's step-0 forward runs in float32 (params are float32 until the first `+=`),
+    # the closed form is float64 throughout: agreement is to float32 round-off of that one forward
+    np.testing.assert_allclose(c_losses, rec["loss"], rtol=1e-6, err_msg="%s closed-form loss" % name)
+    for l, g in enumerate(rec["grads0"]):
+        for mine, theirs in ((gW[l], g["w"]), (gb[l], g["b"])):
+            scale = np.abs(theirs).max()
+            assert np.abs(mine - theirs).max() <= 2e-5 * scale, "%s closed-form grad layer %d" % (name, l)
+    for l, p in enumerate(final):
+        np.testing.assert_allclose(mlp.W[l], p["w"], rtol=0, atol=1e-4)
+    # --- write the fixture
+    out = {"loss": np.array(rec["loss"], dtype=np.float64),
+           "config": np.array(json.dumps(cfg))}
+    for s, z in rec["logits"].items():
+        if z.size <= 4096:
+            out["logits_%d" % s] = z.astype(np.float64)
+        else:
+            summ = summarize(z)
+            for k, v in summ.items():
+                out["logits_%d_%s" % (s, k)] = v
+        out["argmax_%d" % s] = rec["argmax"][s].astype(np.int64)
+    for l, (p0, g0, p1) in enumerate(zip(init, rec["grads0"], final)):
+        for k in ("w", "b"):
+            out["init_%d%s_checksum" % (l, k)] = np.array([p0[k].astype(np.float64).sum(),
+                                                             np.abs(p0[k].astype(np.float64)).sum()])
+            for tag, arr in (("grad0", g0[k]), ("final", p1[k])):
+                if arr.size <= 4096:
+                    out["%s_%d%s" % (tag, l, k)] = np.asarray(arr, dtype=np.float64)
+                else:
+                    for kk, v in summarize(arr).items():
+                        out["%s_%d%s_%s" % (tag, l, k, kk)] = v
+    path = os.path.join(GOLDEN, "traj_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("  %-9s steps=%d loss[0]=%.6f loss[-1]=%.6f -> %s (%d KB)" % (
+        name, cfg["steps"], rec["loss"][0], rec["loss"][-1], os.path.relpath(path, ROOT),
+        os.path.getsize(path) // 1024))
+
+
+# ---------------------------------------------------------------------------- op cases
+class _RefOps(object):
+    def __init__(self, rops):
+        for n in ("exp", "log", "max", "maximum", "minimum", "reshape", "pad", "flatten", "clip", "sum"):
+            setattr(self, n, getattr(rops, n))
+        self.min = lambda obj, axis=None: rops.min_(rops.as_tensor(obj), axis=axis)
+
+
+class OracleOps(object):
+    """The same namespace over oracle/ref_autograd (also used by tests/test_oracle_golden.py)."""
+
+    def __init__(self):
+        from oracle import ref_autograd as ra
+        self.exp, self.log, self.max, self.min = ra.exp, ra.log, ra.rmax, ra.rmin
+        self.maximum, self.minimum = ra.maximum, ra.minimum
+        self.reshape, self.pad, self.flatten, self.clip, self.sum = ra.reshape, ra.pad, ra.flatten, ra.clip, ra.rsum
+
+
+def op_case_fixture(ref):
+    import op_cases
+    from oracle.ref_autograd import RefTensor
+    rt, rops = ref[0], ref[1]
+    out = {}
+    for name, fn in op_cases.CASES.items():
+        got = fn(rt.Tensor, _RefOps(rops))
+        mine = fn(RefTensor, OracleOps())
+        for k in got:
+            a, b = np.asarray(got[k]), np.asarray(mine[k])
+            assert a.shape == b.shape and np.array_equal(a, b), "oracle differs from reference: %s/%s" % (name, k)
+        out[name] = {k: {"shape": list(np.asarray(v).shape), "data": np.asarray(v, dtype=np.float64).ravel().tolist()}
+                     for k, v in got.items()}
+    path = os.path.join(GOLDEN, "op_cases.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("  %d op cases (reference == oracle, exact) -> %s" % (len(out), os.path.relpath(path, ROOT)))
+
+
+# ---------------------------------------------------------------------------- eval path
+def eval_fixture(ref):
+    reval = ref[7]
+    rs = np.random.RandomState(2024)
+    logits = rs.randn(1000, 10).astype(np.float32)
+    logits[::50, 3] = logits[::50].max(axis=1)          # forced ties: numpy argmax takes the FIRST maximum
+    logits[::50, 7] = logits[::50, 3]
+    targets = rs.randint(0, 10, 1000)
+    pred = np.argmax(logits, axis=1)
+    res = reval.AccEvaluator.evaluate(pred, targets)
+    np.savez_compressed(os.path.join(GOLDEN, "eval.npz"), argmax=pred.astype(np.int64),
+                        targets=targets.astype(np.int64), total_num=res["total_num"], hit_num=res["hit_num"],
+                        accuracy=res["accuracy"])
+    print("  eval: %s" % res)
+
+
+def reference_own_tests():
+    """The reference's own unit tests must pass in this container (pins the import itself)."""
+    import subprocess
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=REF)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider",
+                        os.path.join(REF, "test", "test_autograd.py")], capture_output=True, text=True, env=env,
+                       cwd="/tmp")
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-200:]
+    print("  reference test/test_autograd.py: %s" % tail)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    ref = import_reference()
+    print("generating golden fixtures from %s (numpy %s)" % (REF, np.__version__))
+    reference_own_tests()
+    op_case_fixture(ref)
+    only = sys.argv[1:]
+    for name, cfg in CONFIGS.items():
+        if only and name not in only:
+            continue
+        trajectory_fixture(name, cfg, ref)
+    eval_fixture(ref)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

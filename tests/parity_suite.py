@@ -1,0 +1,424 @@
+"""Parity checks of the device path (through the C-ABI) against the reference's golden fixtures and
+numpy.  Not collected directly: tests/test_host_logic.py runs these bodies on the CPU twin in the build
+container, tests/test_gpu_parity.py runs the very same bodies on libtnn_hip.so on the MI355X.
+
+Tolerances (north_star: "fp32 within 1e-5 rtol on identical init/batches; integer argmax bit-exact"):
+  loss            rtol 1e-5                        logits / grads   1e-5 of the tensor's max-norm
+  Adam parameters atol 0.1*lr (the update m/(sqrt(v)+eps) is sign-like where |g| ~ 0)
+  SGD parameters  1e-5 of max-norm                 argmax, counts   exact
+"""
+
+import numpy as np
+
+import helpers as H
+import op_cases
+import tinynn_autograd_amd as tn
+from tinynn_autograd_amd import device_array as da
+from tinynn_autograd_amd.core import ops
+from tinynn_autograd_amd.core.evaluator import AccEvaluator
+from tinynn_autograd_amd.core.tensor import Tensor
+from tinynn_autograd_amd.fused import MLPTrainer, trainer_from_net
+
+RTOL = 1e-5
+
+
+# ------------------------------------------------------------------------------------ op cases
+def _run_op_cases(dtype):
+    golden = H.load_op_cases()
+    tn.set_default_float(dtype)
+    exact_all = np.dtype(dtype) == np.float64
+    for name, fn in op_cases.CASES.items():
+        got = fn(Tensor, ops)
+        for key, ref in golden[name].items():
+            val = np.asarray(got[key], dtype=np.float64)
+            assert val.shape == ref.shape, "%s/%s: shape %s vs %s" % (name, key, val.shape, ref.shape)
+            if name in op_cases.EXACT_IN_F32:
+                assert np.array_equal(val, ref), "%s/%s: %s != %s" % (name, key, val.tolist(), ref.tolist())
+            else:
+                tol = 1e-12 if exact_all else RTOL
+                np.testing.assert_allclose(val, ref, rtol=tol, atol=tol * np.abs(ref).max(),
+                                           err_msg="%s/%s" % (name, key))
+
+
+def op_cases_float32():
+    _run_op_cases(np.float32)
+
+
+def op_cases_float64():
+    _run_op_cases(np.float64)
+
+
+# ------------------------------------------------------------------------------------ trajectories
+def _check_traj(name, fused, use_arena=True):
+    cfg, gold = H.load_traj(name)
+    model, loss_layer = H.build_model(cfg, fused=fused, use_arena=use_arena)
+    w = cfg["widths"]
+    dense = H.dense_layers(model)
+    for l, layer in enumerate(dense):                       # same init as the reference (RNG parity)
+        for k in ("w", "b"):
+            v = np.asarray(layer.params[k].values, dtype=np.float64)
+            np.testing.assert_allclose([v.sum(), np.abs(v).sum()], gold["init_%d%s_checksum" % (l, k)], rtol=1e-7)
+    lr = cfg["lr"]
+    for s, (x, y) in enumerate(H.batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])):
+        model.zero_grad()
+        pred = model.forward(Tensor(x))
+        loss = loss_layer.loss(pred, Tensor(y))
+        loss.backward()
+        if s == 0:
+            for l, layer in enumerate(dense):
+                for k in ("w", "b"):
+                    g = np.asarray(layer.params[k].grad)
+                    scale = float(gold.get("grad0_%d%s" % (l, k), gold.get("grad0_%d%s_sample" % (l, k))).__abs__().max())
+                    H.check_summary(g, gold, "grad0_%d%s" % (l, k), rtol=0, atol=RTOL * scale)
+        model.step()
+        np.testing.assert_allclose(float(loss.values), gold["loss"][s], rtol=RTOL, err_msg="%s loss step %d" % (name, s))
+        if "argmax_%d" % s in gold:
+            z = np.asarray(pred.values)
+            zscale = np.abs(z).max()
+            H.check_summary(z, gold, "logits_%d" % s, rtol=0, atol=RTOL * zscale)
+            assert np.array_equal(np.argmax(pred, axis=1), gold["argmax_%d" % s]), "%s argmax step %d" % (name, s)
+    for l, layer in enumerate(dense):
+        for k in ("w", "b"):
+            p = np.asarray(layer.params[k].values)
+            if cfg["opt"] == "adam":
+                H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * lr)
+            else:
+                H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=RTOL * max(np.abs(p).max(), 1e-3))
+
+
+def traj_A_adam_fused():
+    _check_traj("A_adam", fused=True)
+
+
+def traj_A_adam_generic_ops():
+    """Literal reference expressions: x@w+b, 12-op loss, 13-op Adam — all through DeviceArray ops."""
+    _check_traj("A_adam", fused=False)
+
+
+def traj_A_adam_no_arena():
+    _check_traj("A_adam", fused=True, use_arena=False)
+
+
+def traj_A_sgd():
+    _check_traj("A_sgd", fused=True)
+
+
+def traj_A_ragged_batch():
+    _check_traj("A_ragged", fused=True)
+
+
+def traj_D_bs1024():
+    _check_traj("D_adam", fused=True)
+
+
+def traj_C_small_mse():
+    _check_traj("C_small", fused=True)
+
+
+# ------------------------------------------------------------------------------------ whole-step trainer
+def _check_trainer(name, use_graph):
+    cfg, gold = H.load_traj(name)
+    model, _ = H.build_model(cfg)
+    w = cfg["widths"]
+    trainer = trainer_from_net(model.net, max_rows=cfg["m"], loss=cfg["loss"], optimizer=cfg["opt"],
+                               lr=cfg["lr"], use_graph=use_graph)
+    lr = cfg["lr"]
+    losses = []
+    for s, (x, y) in enumerate(H.batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])):
+        xd, yd = tn.asarray(x), tn.asarray(y)
+        if "argmax_%d" % s in gold:
+            z = trainer.forward(xd)                           # logits BEFORE this step's update
+            H.check_summary(np.asarray(z), gold, "logits_%d" % s, rtol=0, atol=RTOL * np.abs(np.asarray(z)).max())
+            assert np.array_equal(np.asarray(da.argmax(z, axis=1)), gold["argmax_%d" % s])
+        loss = trainer.step(xd, yd)
+        losses.append(float(loss))
+        if s == 0:
+            for l in range(trainer.n_layers):
+                for k in ("w", "b"):
+                    g = np.asarray(trainer.grad_view(l, k))
+                    ref = gold.get("grad0_%d%s" % (l, k), gold.get("grad0_%d%s_sample" % (l, k)))
+                    H.check_summary(g, gold, "grad0_%d%s" % (l, k), rtol=0, atol=RTOL * np.abs(ref).max())
+    np.testing.assert_allclose(losses, gold["loss"], rtol=RTOL, err_msg="%s trainer loss" % name)
+    for l in range(trainer.n_layers):
+        for k in ("w", "b"):
+            p = np.asarray(trainer.param_view(l, k))
+            atol = 0.1 * lr if cfg["opt"] == "adam" else RTOL * max(np.abs(p).max(), 1e-3)
+            H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=atol)
+
+
+def trainer_A_adam_eager():
+    _check_trainer("A_adam", use_graph=False)
+
+
+def trainer_A_adam_graph():
+    _check_trainer("A_adam", use_graph=True)
+
+
+def trainer_A_sgd_graph():
+    _check_trainer("A_sgd", use_graph=True)
+
+
+def trainer_A_ragged():
+    _check_trainer("A_ragged", use_graph=False)
+
+
+def trainer_D_bs1024():
+    _check_trainer("D_adam", use_graph=True)
+
+
+def trainer_C_small_mse():
+    _check_trainer("C_small", use_graph=False)
+
+
+def trainer_relu_zero_preactivation():
+    """A pre-activation that is EXACTLY zero keeps gradient 1 (mask is x >= 0, core/ops.py:338): the
+    trainer's sign-bit mask encoding must agree with the op-level path on an all-zero input row."""
+    cfg = dict(widths=[8, 6, 4], seed=3, opt="sgd", lr=0.1, loss="softmax_nll")
+    model, loss_layer = H.build_model(cfg)
+    trainer = trainer_from_net(model.net, max_rows=5, loss="softmax_nll", optimizer="sgd", lr=0.1)
+    rs = np.random.RandomState(5)
+    x = rs.rand(5, 8).astype(np.float32)
+    x[2] = 0.0                                   # z1[2] = 0*W + b(=0) = exactly 0
+    y = np.eye(4)[[0, 1, 2, 3, 0]]
+    model.zero_grad()
+    loss = loss_layer.loss(model.forward(Tensor(x)), Tensor(y))
+    loss.backward()
+    trainer.step(tn.asarray(x), tn.asarray(y))
+    for l, layer in enumerate(H.dense_layers(model)):
+        for k in ("w", "b"):
+            a, b = np.asarray(layer.params[k].grad), np.asarray(trainer.grad_view(l, k))
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-6 * max(np.abs(a).max(), 1e-6), err_msg="layer %d %s" % (l, k))
+    assert np.abs(np.asarray(H.dense_layers(model)[0].params["w"].grad)).max() > 0
+
+
+# ------------------------------------------------------------------------------------ kernels vs numpy
+def gemm_shapes_and_transposes():
+    rs = np.random.RandomState(11)
+    shapes = [(128, 256, 784), (80, 10, 128), (128, 10, 128), (33, 17, 5), (1, 1, 1), (64, 64, 32),
+              (130, 70, 100), (256, 128, 1), (7, 300, 9), (200, 129, 257)]
+    for (M, N, K) in shapes:
+        a = rs.randn(M, K).astype(np.float32)
+        b = rs.randn(K, N).astype(np.float32)
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        bound = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+        A, B = tn.asarray(a), tn.asarray(b)
+        AT, BT = tn.asarray(np.ascontiguousarray(a.T)), tn.asarray(np.ascontiguousarray(b.T))
+        for label, got in (("NN", A @ B), ("TN", AT.T @ B), ("NT", A @ BT.T), ("TT", AT.T @ BT.T)):
+            err = np.abs(np.asarray(got, dtype=np.float64) - ref)
+            assert (err <= 2e-6 * bound + 1e-30).all(), "%s %s: max err %g" % (label, (M, N, K), err.max())
+    # alpha / beta through the ABI
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    a = rs.randn(40, 24).astype(np.float32); b = rs.randn(24, 12).astype(np.float32); c = rs.randn(40, 12).astype(np.float32)
+    A, B, C = tn.asarray(a), tn.asarray(b), tn.asarray(c)
+    _lib.get().gemm(0, 0, 40, 12, 24, 0.5, A._ptr, 24, B._ptr, 12, -2.0, C._ptr, 12, _lib.F32)
+    np.testing.assert_allclose(np.asarray(C), 0.5 * (a @ b) - 2.0 * c, rtol=1e-5, atol=1e-5)
+    # float64 path
+    tn.set_default_float(np.float64)
+    a = rs.randn(37, 19); b = rs.randn(19, 23)
+    np.testing.assert_allclose(np.asarray(tn.asarray(a) @ tn.asarray(b)), a @ b, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(np.asarray(tn.asarray(a).T @ tn.asarray(a)), a.T @ a, rtol=1e-13, atol=1e-13)
+
+
+def gemm_linearity_property():
+    """Size-independent property: (A1 + A2) B == A1 B + A2 B and A (s B) == s (A B) to fp32 round-off."""
+    rs = np.random.RandomState(12)
+    M, N, K = 192, 320, 448
+    a1, a2 = rs.randn(M, K).astype(np.float32), rs.randn(M, K).astype(np.float32)
+    b = rs.randn(K, N).astype(np.float32)
+    A1, A2, B = tn.asarray(a1), tn.asarray(a2), tn.asarray(b)
+    lhs = np.asarray((A1 + A2) @ B, dtype=np.float64)
+    rhs = np.asarray(A1 @ B, dtype=np.float64) + np.asarray(A2 @ B, dtype=np.float64)
+    bound = (np.abs(a1) + np.abs(a2)).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(lhs - rhs) <= 4e-6 * bound).all()
+    s = 0.37
+    np.testing.assert_allclose(np.asarray(A1 @ (B * s)), s * np.asarray(A1 @ B), rtol=2e-5, atol=1e-4)
+
+
+def elementwise_broadcast_reduce():
+    rs = np.random.RandomState(13)
+    a = rs.randn(6, 1, 5).astype(np.float32)
+    b = rs.randn(4, 1).astype(np.float32)
+    A, B = tn.asarray(a), tn.asarray(b)
+    for fn in (np.add, np.subtract, np.multiply, np.true_divide, np.maximum, np.minimum):
+        np.testing.assert_allclose(np.asarray(fn(A, B)), fn(a, b), rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(np.exp(A)), np.exp(a), rtol=2e-6)
+    np.testing.assert_allclose(np.asarray(np.log(np.abs(A) + 1.0)), np.log(np.abs(a) + 1.0), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(np.asarray(A ** 2), a ** 2, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray((np.abs(A) + 1e-3) ** 0.5), (np.abs(a) + 1e-3) ** 0.5, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(2.0 / (A * A + 1.0)), 2.0 / (a * a + 1.0), rtol=1e-6)
+    assert np.array_equal(np.asarray(A > 0.1), a > 0.1) and np.array_equal(np.asarray(A >= B), a >= b)
+    assert np.array_equal(np.asarray(0.2 < A), 0.2 < a) and np.array_equal(np.asarray(A == A), a == a)
+    big = rs.randn(300, 257).astype(np.float32)
+    G = tn.asarray(big)
+    for axis in (None, 0, 1):
+        for name in ("sum", "max", "min"):
+            got = np.asarray(getattr(G, name)(axis=axis))
+            ref = getattr(big.astype(np.float64), name)(axis=axis)
+            np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-5, err_msg="%s axis=%s" % (name, axis))
+    np.testing.assert_allclose(np.asarray(G.sum(axis=0, keepdims=True)), big.astype(np.float64).sum(0, keepdims=True), rtol=2e-6, atol=2e-5)
+    long_vec = rs.randn(1, 70001).astype(np.float32)
+    np.testing.assert_allclose(float(tn.asarray(long_vec).sum()), long_vec.astype(np.float64).sum(), rtol=1e-6, atol=1e-4)
+    tall = rs.randn(5000, 3).astype(np.float32)
+    np.testing.assert_allclose(np.asarray(tn.asarray(tall).sum(axis=0)), tall.astype(np.float64).sum(0), rtol=1e-6, atol=1e-4)
+    t3 = rs.randn(3, 4, 5).astype(np.float32)
+    np.testing.assert_allclose(np.asarray(tn.asarray(t3).sum(axis=1)), t3.sum(1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(tn.asarray(t3).sum(axis=(0, 2))), t3.sum((0, 2)), rtol=1e-5, atol=1e-6)
+
+
+def views_indexing_and_numpy_protocol():
+    rs = np.random.RandomState(14)
+    a = rs.randn(10, 6).astype(np.float32)
+    A = tn.asarray(a)
+    assert np.array_equal(np.asarray(A[2:7]), a[2:7]) and np.array_equal(np.asarray(A[3]), a[3])
+    assert np.array_equal(np.asarray(A[:, 1:4]), a[:, 1:4]) and np.array_equal(np.asarray(A[::2, ::3]), a[::2, ::3])
+    idx = np.array([9, 0, 0, 4, -1])
+    assert np.array_equal(np.asarray(A[idx]), a[idx])
+    assert np.array_equal(np.asarray(A.T), a.T) and np.array_equal(np.asarray(A.reshape(3, 20)), a.reshape(3, 20))
+    assert np.array_equal(np.asarray(np.transpose(tn.asarray(a.reshape(2, 5, 6)), (2, 0, 1))), a.reshape(2, 5, 6).transpose(2, 0, 1))
+    assert np.array_equal(np.asarray(np.pad(A, [(1, 2), (0, 3)])), np.pad(a, [(1, 2), (0, 3)]))
+    assert np.array_equal(np.asarray(np.repeat(np.expand_dims(A[0], 0), 4, 0)), np.repeat(a[:1], 4, 0))
+    B = tn.zeros((10, 6))
+    B[2:4] = A[5:7]
+    B[idx[:2]] = A[:2]
+    b = np.zeros((10, 6), np.float32); b[2:4] = a[5:7]; b[idx[:2]] = a[:2]
+    assert np.array_equal(np.asarray(B), b)
+    # flatten of consecutive arena views is zero-copy (the optimizer's flatten, core/optimizer.py:14-15)
+    arena = tn.asarray(rs.randn(50).astype(np.float32))
+    v1, v2 = arena[0:20].reshape(4, 5), arena[20:50].reshape(5, 6)
+    flat = np.concatenate([np.ravel(v1), np.ravel(v2)])
+    assert flat._ptr == arena._ptr and flat.shape == (50,)
+    other = np.concatenate([np.ravel(v2), np.ravel(v1)])
+    assert other._ptr != arena._ptr and np.array_equal(np.asarray(other), np.concatenate([np.asarray(v2).ravel(), np.asarray(v1).ravel()]))
+    # no silent host fallback for unsupported numpy functions
+    try:
+        np.linalg.norm(A)
+    except TypeError:
+        pass
+    else:
+        raise AssertionError("np.linalg.norm on a DeviceArray must raise, not fall back to the host")
+
+
+def eval_argmax_and_accuracy():
+    gold = dict(np.load(H.GOLDEN + "/eval.npz"))
+    rs = np.random.RandomState(2024)                       # same construction as oracle/gen_golden.py
+    logits = rs.randn(1000, 10).astype(np.float32)
+    logits[::50, 3] = logits[::50].max(axis=1)
+    logits[::50, 7] = logits[::50, 3]
+    pred = np.argmax(Tensor(logits), axis=1)               # examples/mnist/run.py:89
+    assert pred.dtype == np.int64 and np.array_equal(pred, gold["argmax"])
+    res = AccEvaluator.evaluate(pred, gold["targets"])
+    assert res["total_num"] == int(gold["total_num"]) and res["hit_num"] == int(gold["hit_num"])
+    assert res["accuracy"] == float(gold["accuracy"])
+    dev = da.argmax(tn.asarray(logits), axis=1)
+    assert np.array_equal(np.asarray(dev), gold["argmax"])
+
+
+def sigmoid_closed_form():
+    """No reference output exists (its Sigmoid raises): pinned to the closed form."""
+    from tinynn_autograd_amd.core.layers import Sigmoid
+    x = np.linspace(-6, 6, 25).reshape(5, 5)
+    t = Tensor(x, requires_grad=True)
+    s = Sigmoid().forward(t)
+    s.backward(np.ones((5, 5)))
+    ref = 1.0 / (1.0 + np.exp(-x))
+    np.testing.assert_allclose(np.asarray(s.values), ref, rtol=2e-6)
+    np.testing.assert_allclose(np.asarray(t.grad), ref * (1 - ref), rtol=1e-5, atol=1e-7)
+    # the reference's literal expression also works through Tensor.__array_ufunc__
+    t2 = Tensor(x, requires_grad=True)
+    s2 = 1.0 / (1.0 + np.exp(-t2))
+    s2.backward(np.ones((5, 5)))
+    np.testing.assert_allclose(np.asarray(s2.values), ref, rtol=2e-6)
+    np.testing.assert_allclose(np.asarray(t2.grad), ref * (1 - ref), rtol=1e-5, atol=1e-7)
+
+
+def fused_ops_match_generic_chain():
+    """softmax_nll_ / dense_ / fused Adam against the literal op chains on the same device."""
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.optimizer import Adam
+    rs = np.random.RandomState(15)
+    z = rs.randn(37, 10).astype(np.float32) * 3
+    y = np.eye(10)[rs.randint(0, 10, 37)]
+    outs = []
+    for fused in (True, False):
+        t = Tensor(z, requires_grad=True)
+        loss = SoftmaxCrossEntropyLoss(fused=fused).loss(t, Tensor(y))
+        loss.backward()
+        outs.append((float(loss.values), np.asarray(t.grad)))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-6 * np.abs(outs[1][1]).max())
+    # soft (non one-hot) labels: the general formula dz = p - (e*y/q)/m
+    ysoft = rs.rand(37, 10)
+    outs = []
+    for fused in (True, False):
+        t = Tensor(z, requires_grad=True)
+        loss = SoftmaxCrossEntropyLoss(fused=fused).loss(t, Tensor(ysoft))
+        loss.backward()
+        outs.append((float(loss.values), np.asarray(t.grad)))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-6 * np.abs(outs[1][1]).max())
+    g = tn.asarray(rs.randn(1000).astype(np.float32))
+    a1, a2 = Adam(lr=1e-3, fused=True), Adam(lr=1e-3, fused=False)
+    for _ in range(5):
+        s1, s2 = a1._compute_step(g), a2._compute_step(g)
+        np.testing.assert_allclose(np.asarray(s1), np.asarray(s2), rtol=2e-5, atol=1e-9)
+        g = g * 0.9 + 0.01
+
+
+def error_behaviour():
+    """Same failure modes as the reference: backward on a non-requires-grad tensor asserts
+    (core/tensor.py:158), bad broadcasts raise ValueError, and native errors surface as exceptions."""
+    t = Tensor([1.0, 2.0])
+    try:
+        t.backward()
+    except AssertionError:
+        pass
+    else:
+        raise AssertionError("backward() on a non-requires-grad tensor must assert")
+    try:
+        Tensor(np.ones((2, 3))) + Tensor(np.ones((4,)))
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("incompatible broadcast must raise ValueError")
+    try:
+        Tensor(np.ones((2, 3))) @ Tensor(np.ones((4, 2)))
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("matmul shape mismatch must raise ValueError")
+    from tinynn_autograd_amd import _lib
+    try:
+        _lib.get().reduce(99, None, None, 1, 1, 1, _lib.F32)
+    except _lib.TnnError as e:
+        assert "unknown reduction" in str(e)
+    else:
+        raise AssertionError("a bad op code must come back as TnnError")
+    w = Tensor([1.0, 2.0], requires_grad=True)
+    w += 1.0                                   # value assignment drops the gradient (core/tensor.py:38)
+    assert w.grad is None
+    try:
+        (w * 2.0).backward([1.0, 1.0])
+    except TypeError:
+        pass
+    else:
+        raise AssertionError("accumulating into a dropped gradient must raise like None += array")
+
+
+def model_save_load_roundtrip():
+    import tempfile, os
+    cfg = dict(widths=[12, 8, 4], seed=1, opt="sgd", lr=0.1, loss="softmax_nll")
+    m1, _ = H.build_model(cfg)
+    cfg2 = dict(cfg, seed=2)
+    m2, _ = H.build_model(cfg2)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "net.npz")
+        m1.save(path)
+        m2.load(path)
+    for a, b in zip(H.dense_layers(m1), H.dense_layers(m2)):
+        for k in ("w", "b"):
+            assert np.array_equal(np.asarray(a.params[k].values), np.asarray(b.params[k].values))
+
+
+SUITE = {name: fn for name, fn in list(globals().items())
+         if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", None) == __name__}

@@ -1,0 +1,345 @@
+"""Differentiable ops on device-backed Tensors (reference: core/ops.py:12-384).
+
+Every public name of the reference module exists here with the same signature and the same vjp
+semantics (tie rules of maximum_/minimum_/max_/min_, inclusive clip mask, un-broadcast rule, saved
+inputs held by reference in the closures).  Forward values and vjps are DeviceArray expressions, i.e.
+HIP kernels behind the C-ABI; nothing is computed on the host.  Cited line numbers point at the
+reference expression each piece replaces.
+
+Extra fused nodes used by this package's own layers/losses (parity-tested against the generic chain):
+`dense_` (GEMM + bias epilogue), `sigmoid_`, `softmax_nll_` (whole-batch softmax NLL).
+"""
+
+import numpy as np
+
+from .. import _lib
+from .. import device_array as da
+
+
+def as_tensor(obj):
+    from .tensor import as_tensor as _as_tensor   # lazy: tensor imports ops
+    return _as_tensor(obj)
+
+
+# ---------------------------------------------------------------------- graph construction
+def build_binary_ops_tensor(ts1, ts2, grad_fn_ts1, grad_fn_ts2, values):
+    """reference: core/ops.py:12-20"""
+    parents = [(ts1, grad_fn_ts1), (ts2, grad_fn_ts2)]
+    return _make_node(ts1.__class__, values, parents)
+
+
+def build_unary_ops_tensor(ts, grad_fn, values):
+    """reference: core/ops.py:23-29"""
+    return _make_node(ts.__class__, values, [(ts, grad_fn)])
+
+
+def _make_node(cls, values, parents):
+    # only inputs that require grad become edges, so e.g. dX of the first Dense layer is never computed
+    edges = [dict(tensor=t, grad_fn=fn) for t, fn in parents if t.requires_grad]
+    return cls(values, bool(edges), edges)
+
+
+def _unbroadcast(grad, shape):
+    """Undo numpy broadcasting of an operand of `shape` (core/ops.py:41-46): sum away the leading axes
+    the operand did not have, then sum (keepdims) over the axes where it had extent 1."""
+    grad = da.asarray(grad)
+    if grad.shape == tuple(shape):
+        return grad
+    extra = grad.ndim - len(shape)
+    if extra > 0:
+        grad = grad.sum(axis=tuple(range(extra)))
+    for axis, dim in enumerate(shape):
+        if dim == 1 and grad.shape[axis] != 1:
+            grad = grad.sum(axis=axis, keepdims=True)
+    return grad
+
+
+# ---------------------------------------------------------------------- arithmetic
+def add_(ts1, ts2):
+    """reference: core/ops.py:32-58"""
+    values = ts1.values + ts2.values
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: _unbroadcast(g, ts1.shape),
+        lambda g: _unbroadcast(g, ts2.shape),
+        values)
+
+
+def sub_(ts1, ts2):
+    """reference: core/ops.py:61-62 (a + (-b)); one node here, same values and vjps."""
+    values = ts1.values - ts2.values
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: _unbroadcast(g, ts1.shape),
+        lambda g: _unbroadcast(-da.asarray(g), ts2.shape),
+        values)
+
+
+def mul_(ts1, ts2):
+    """reference: core/ops.py:65-90"""
+    values = ts1.values * ts2.values
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: _unbroadcast(g * ts2.values, ts1.shape),
+        lambda g: _unbroadcast(g * ts1.values, ts2.shape),
+        values)
+
+
+def div_(ts1, ts2):
+    """reference: core/ops.py:93-118"""
+    values = ts1.values / ts2.values
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: _unbroadcast(g / ts2.values, ts1.shape),
+        lambda g: _unbroadcast(-da.asarray(g) * ts1.values / ts2.values ** 2, ts2.shape),
+        values)
+
+
+def pow_(ts1, ts2):
+    """reference: core/ops.py:121-147"""
+    values = ts1.values ** ts2.values
+
+    def grad_base(g):
+        return _unbroadcast(g * ts2.values * ts1.values ** (ts2.values - 1), ts1.shape)
+
+    def grad_exponent(g):
+        return _unbroadcast(g * (da.log(ts1.values) * values), ts2.shape)
+
+    return build_binary_ops_tensor(ts1, ts2, grad_base, grad_exponent, values)
+
+
+def dot_(ts1, ts2):
+    """reference: core/ops.py:150-163.  `.T` is a lazy flag, so the vjps run as NT / TN GEMMs."""
+    values = ts1.values @ ts2.values
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: da.asarray(g) @ ts2.values.T,
+        lambda g: ts1.values.T @ da.asarray(g),
+        values)
+
+
+def maximum_(ts1, ts2):
+    """reference: core/ops.py:166-188 — ties send the gradient to ts1 (>=)."""
+    values = da.maximum(ts1.values, ts2.values)
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: _unbroadcast(da.mul_mask(g, ts1.values >= ts2.values), ts1.shape),
+        lambda g: _unbroadcast(da.mul_mask(g, ts2.values > ts1.values), ts2.shape),
+        values)
+
+
+def minimum_(ts1, ts2):
+    """reference: core/ops.py:191-213 — ties send the gradient to ts1 (<=)."""
+    values = da.minimum(ts1.values, ts2.values)
+    return build_binary_ops_tensor(
+        ts1, ts2,
+        lambda g: _unbroadcast(da.mul_mask(g, ts1.values <= ts2.values), ts1.shape),
+        lambda g: _unbroadcast(da.mul_mask(g, ts2.values < ts1.values), ts2.shape),
+        values)
+
+
+# ---------------------------------------------------------------------- unary
+def exp_(ts):
+    """reference: core/ops.py:216-222 (the vjp reuses the saved output)"""
+    values = da.exp(ts.values)
+    return build_unary_ops_tensor(ts, lambda g: values * g, values)
+
+
+def log_(ts):
+    """reference: core/ops.py:243-249"""
+    values = da.log(ts.values)
+    return build_unary_ops_tensor(ts, lambda g: g / ts.values, values)
+
+
+def neg_(ts):
+    """reference: core/ops.py:293-299"""
+    return build_unary_ops_tensor(ts, lambda g: -da.asarray(g), -ts.values)
+
+
+def _extreme(ts, axis, rmax):
+    x = ts.values
+    values = x.max(axis=axis) if rmax else x.min(axis=axis)
+
+    def grad_fn(g):
+        # every element equal to the extreme receives the full gradient (core/ops.py:229,238)
+        ext = x.max(axis=axis, keepdims=True) if rmax else x.min(axis=axis, keepdims=True)
+        return da.mul_mask(g, ext == x)
+
+    return build_unary_ops_tensor(ts, grad_fn, values)
+
+
+def max_(ts, axis=None):
+    """reference: core/ops.py:225-231"""
+    return _extreme(ts, axis, True)
+
+
+def min_(ts, axis=None):
+    """reference: core/ops.py:234-240"""
+    return _extreme(ts, axis, False)
+
+
+def sum_(ts, axis):
+    """reference: core/ops.py:252-265"""
+    x = ts.values
+    values = x.sum(axis=axis)
+
+    def grad_fn(g):
+        g = da.asarray(g)
+        if axis is None:
+            if g.ndim > x.ndim:
+                raise ValueError("gradient of a full sum must be broadcastable to the input")
+            return g._as_float(x.dtype if x.dtype.kind == "f" else None)._broadcast_to(x.shape)
+        return np.expand_dims(g._contig(), axis)._broadcast_to(x.shape)
+
+    return build_unary_ops_tensor(ts, grad_fn, values)
+
+
+def transpose_(ts, axes=None):
+    """reference: core/ops.py:268-279"""
+    values = ts.values.transpose(axes)
+    perm = list(reversed(range(ts.values.ndim))) if axes is None else [int(a) for a in axes]
+    inverse = [int(i) for i in np.argsort(perm)]
+    return build_unary_ops_tensor(ts, lambda g: da.asarray(g).transpose(inverse), values)
+
+
+def getitem_(ts, key):
+    """reference: core/ops.py:282-290 (slice = view, integer array = row gather kernel)"""
+    x = ts.values
+    if isinstance(key, ts.__class__):
+        key = key.values
+    values = x[key]
+
+    def grad_fn(g):
+        recovered = da.zeros(x.shape, x.dtype if x.dtype.kind == "f" else None)
+        recovered[key] = g
+        return recovered
+
+    return build_unary_ops_tensor(ts, grad_fn, values)
+
+
+def reshape_(ts, newshape):
+    """reference: core/ops.py:302-309"""
+    shape = ts.values.shape
+    return build_unary_ops_tensor(ts, lambda g: da.asarray(g).reshape(shape), ts.values.reshape(newshape))
+
+
+def pad_(ts, pad_width, mode):
+    """reference: core/ops.py:312-321"""
+    values = np.pad(ts.values, pad_width=pad_width, mode=mode)
+    window = tuple(slice(int(before), int(size - after))
+                   for size, (before, after) in zip(values.shape, pad_width))
+    return build_unary_ops_tensor(ts, lambda g: da.asarray(g)[window], values)
+
+
+def flatten_(ts):
+    """reference: core/ops.py:324-330"""
+    shape = ts.shape
+    return build_unary_ops_tensor(ts, lambda g: da.asarray(g).reshape(shape), ts.values.ravel())
+
+
+def clip_(ts, min, max):
+    """reference: core/ops.py:333-344.  The inclusive mask (x >= min) & (x <= max) is recomputed from the
+    saved input inside the vjp kernel instead of being stored as a bool array."""
+    x = ts.values
+    values = da.clip(x, min, max)
+    return build_unary_ops_tensor(ts, lambda g: da.clip_bwd(g, x, min, max), values)
+
+
+# ---------------------------------------------------------------------- fused nodes (this package's own)
+def dense_(x, w, b):
+    """x @ w + b as ONE GEMM with a bias epilogue (core/layers.py:49); the vjps are the NT / TN GEMMs of
+    dot_ (core/ops.py:156-160) and the column-sum of add_'s un-broadcast (:49-55)."""
+    xv, wv, bv = x.values, w.values, b.values
+    if xv.ndim != 2 or wv.ndim != 2 or xv.shape[1] != wv.shape[0] or bv.size != wv.shape[1]:
+        raise ValueError("dense_: shapes %s @ %s + %s do not line up" % (xv.shape, wv.shape, bv.shape))
+    m, k = xv.shape
+    n = wv.shape[1]
+    dt = da._float_result_dtype(xv, wv)
+    xv, wv, bv = xv._as_float(dt)._contig(), wv._as_float(dt)._contig(), bv._as_float(dt)._contig()
+    out = da.empty((m, n), dt)
+    if out.size:
+        _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_NONE, 0,
+                                 out._ptr, n, out._code())
+    parents = [
+        (x, lambda g: da.asarray(g) @ wv.T),
+        (w, lambda g: xv.T @ da.asarray(g)),
+        (b, lambda g: _unbroadcast(g, b.shape)),
+    ]
+    return _make_node(x.__class__, out, parents)
+
+
+def sigmoid_(ts):
+    """1 / (1 + exp(-x)) in one kernel; vjp g * s * (1 - s) (closed form; the reference's Sigmoid raises,
+    SURVEY F7)."""
+    s = da.sigmoid(ts.values)
+    return build_unary_ops_tensor(ts, lambda g: g * (s * (1.0 - s)), s)
+
+
+def softmax_nll_(logits, labels, comm=None):
+    """core/losses.py:24-32 as one node: whole-batch max / sum-exp, loss and dz = p - (e*y/q)/m.
+
+    With a communicator the {max, sum-exp} pair of every shard is all-gathered and merged, m is the GLOBAL
+    batch size, and the returned loss is this shard's share (the shares add up to the global loss)."""
+    z, y = logits.values, as_tensor(labels).values
+    dt = z.dtype if z.dtype.kind == "f" else da.get_default_float()
+    z, y = z._as_float(dt)._contig(), y._as_float(dt)._contig()
+    if z.ndim != 2 or y.shape != z.shape:
+        raise ValueError("softmax_nll_: logits %s and labels %s must be equal 2-D shapes" % (z.shape, y.shape))
+    m, c = z.shape
+    lib = _lib.get()
+    stats = da.empty((2,), dt)
+    lib.softmax_nll_stats(z._ptr, m, c, stats._ptr, stats._code())
+    m_global = m
+    if comm is not None and comm.world > 1:
+        stats = comm.merge_softmax_stats(stats)
+        m_global = m * comm.world
+    loss = da.empty((), dt)
+    dz = da.empty((m, c), dt)
+    lib.softmax_nll_fwd_bwd(z._ptr, y._ptr, m, c, m_global, stats._ptr, loss._ptr, dz._ptr, z._code())
+    return build_unary_ops_tensor(logits, lambda g: g * dz, loss)
+
+
+# ---------------------------------------------------------------------- anything-in wrappers
+def max(obj, axis=None):
+    return max_(as_tensor(obj), axis=axis)
+
+
+def min(obj, axis=None):
+    """not in the reference's wrapper list (it only has min_); added for symmetry with max"""
+    return min_(as_tensor(obj), axis=axis)
+
+
+def maximum(obj1, obj2):
+    return maximum_(as_tensor(obj1), as_tensor(obj2))
+
+
+def minimum(obj1, obj2):
+    return minimum_(as_tensor(obj1), as_tensor(obj2))
+
+
+def exp(obj):
+    return exp_(as_tensor(obj))
+
+
+def sum(obj, axis=None):
+    return sum_(as_tensor(obj), axis=axis)
+
+
+def log(obj):
+    return log_(as_tensor(obj))
+
+
+def reshape(obj, newshape):
+    return reshape_(as_tensor(obj), newshape)
+
+
+def pad(obj, pad_width, mode="constant"):
+    return pad_(as_tensor(obj), pad_width, mode=mode)
+
+
+def flatten(obj):
+    return flatten_(as_tensor(obj))
+
+
+def clip(obj, min=None, max=None):
+    return clip_(as_tensor(obj), min, max)

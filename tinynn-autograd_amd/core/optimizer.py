@@ -1,0 +1,147 @@
+"""Optimizers (reference: core/optimizer.py:6-164).
+
+Same contract as the reference: `compute_step(grads, params)` flattens every gradient in layer order
+(dict order "w", "b"), calls `_compute_step(flat)` and hands back per-parameter steps that the caller
+ADDS to the parameters (core/model.py:59-61).  All state lives in HBM.
+
+  * When the gradients are views into one flat arena (Model binds them that way) the flatten is a
+    zero-copy view (core/optimizer.py:14-15 is a concatenate copy in the reference).
+  * `Adam` / `SGD` compute the step with ONE fused kernel (tnn_adam with step_out / tnn_ewise_scalar)
+    instead of 13 / 1 array expressions; `fused=False` evaluates the reference's literal expressions
+    through DeviceArray arithmetic — the two are parity-tested against each other and the oracle.
+  * Adam's epsilon is added OUTSIDE the square root, after bias correction (core/optimizer.py:77).
+"""
+
+import ctypes
+
+import numpy as np
+
+from .. import _lib
+from .. import device_array as da
+
+
+class BaseOptimizer(object):
+
+    def __init__(self, lr, weight_decay):
+        self.lr = lr
+        self.weight_decay = weight_decay      # stored, unused: the reference's use is commented out (:28-29)
+        self._last_flat_step = None
+
+    def compute_step(self, grads, params):
+        flat_grad = np.concatenate([np.ravel(g) for layer in grads for g in layer.values()])
+        flat_step = self._compute_step(flat_grad)
+        self._last_flat_step = flat_step
+        steps, offset = [], 0
+        for layer in params:
+            restored = {}
+            for key, p in layer.items():
+                count = int(np.prod(p.shape))
+                restored[key] = flat_step[offset:offset + count].reshape(p.shape)
+                offset += count
+            steps.append(restored)
+        return steps
+
+    def _compute_step(self, grad):
+        raise NotImplementedError
+
+
+class SGD(BaseOptimizer):
+    """step = -lr * g (core/optimizer.py:46-47)"""
+
+    def __init__(self, lr, weight_decay=0.0):
+        super().__init__(lr, weight_decay)
+
+    def _compute_step(self, grad):
+        return -self.lr * grad
+
+
+class Adam(BaseOptimizer):
+    """reference: core/optimizer.py:50-79"""
+
+    def __init__(self, lr=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, weight_decay=0.0, fused=True):
+        super().__init__(lr, weight_decay)
+        self._b1, self._b2, self._eps = beta1, beta2, epsilon
+        self.fused = fused
+        self._t = 0
+        self._m = 0
+        self._v = 0
+        self._pows = None      # device double[4]: {b1^(t-1), b2^(t-1), ticket, pad}
+
+    def _compute_step(self, grad):
+        self._t += 1
+        if self.fused and isinstance(grad, da.DeviceArray) and grad.dtype.kind == "f":
+            return self._fused_step(grad._contig())
+        self._m += (1.0 - self._b1) * (grad - self._m)
+        self._v += (1.0 - self._b2) * (grad ** 2 - self._v)
+        m_hat = self._m / (1 - self._b1 ** self._t)
+        v_hat = self._v / (1 - self._b2 ** self._t)
+        return -self.lr * m_hat / (v_hat ** 0.5 + self._eps)
+
+    def _fused_step(self, grad):
+        lib = _lib.get()
+        if self._pows is None:
+            self._m = da.zeros(grad.shape, grad.dtype)
+            self._v = da.zeros(grad.shape, grad.dtype)
+            self._pows = da.asarray(np.array([1.0, 1.0, 0.0, 0.0]), dtype=np.float64)
+        step = da.empty(grad.shape, grad.dtype)
+        lib.adam(None, grad._ptr, self._m._ptr, self._v._ptr, grad.size, self.lr, self._b1, self._b2,
+                 self._eps, self._pows._ptr, step._ptr, grad._code())
+        return step
+
+
+class Momentum(BaseOptimizer):
+    """acc = momentum * acc + g; step = -lr * acc (core/optimizer.py:111-124)"""
+
+    def __init__(self, lr, momentum=0.9, weight_decay=0.0):
+        super().__init__(lr, weight_decay)
+        self._momentum = momentum
+        self._acc = 0
+
+    def _compute_step(self, grad):
+        self._acc = self._momentum * self._acc + grad
+        return -self.lr * self._acc
+
+
+class RMSProp(BaseOptimizer):
+    """reference: core/optimizer.py:82-108"""
+
+    def __init__(self, lr=0.01, decay=0.99, momentum=0.0, epsilon=1e-8, weight_decay=0.0):
+        super().__init__(lr, weight_decay)
+        self._decay, self._momentum, self._eps = decay, momentum, epsilon
+        self._ms = 0
+        self._mom = 0
+
+    def _compute_step(self, grad):
+        self._ms += (1 - self._decay) * (grad ** 2 - self._ms)
+        self._mom = self._momentum * self._mom + self.lr * grad / (self._ms + self._eps) ** 0.5
+        return -self._mom
+
+
+class Adagrad(BaseOptimizer):
+    """reference: core/optimizer.py:127-142"""
+
+    def __init__(self, lr, weight_decay=0.0, epsilon=1e-8):
+        super().__init__(lr, weight_decay)
+        self._G = 0
+        self._eps = epsilon
+
+    def _compute_step(self, grad):
+        self._G += grad ** 2
+        return -(self.lr / (self._G + self._eps) ** 0.5) * grad
+
+
+class Adadelta(BaseOptimizer):
+    """reference: core/optimizer.py:145-164"""
+
+    def __init__(self, lr=1.0, weight_decay=0.0, decay=0.9, epsilon=1e-8):
+        super().__init__(lr, weight_decay)
+        self._eps, self._decay = epsilon, decay
+        self._Eg = 0
+        self._delta = 0
+
+    def _compute_step(self, grad):
+        self._Eg += (1 - self._decay) * (grad ** 2 - self._Eg)
+        std = (self._delta + self._eps) ** 0.5
+        delta = grad * (std / (self._Eg + self._eps) ** 0.5)
+        self._delta += (1 - self._decay) * (delta ** 2 - self._delta)
+        return -self.lr * delta

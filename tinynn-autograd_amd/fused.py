@@ -1,0 +1,167 @@
+"""Whole-step Dense-MLP trainer: the loop body of examples/mnist/run.py:79-83 as ~16 launches.
+
+Python face of the tnn_mlp_* entry points (csrc/tnn_mlp.cpp).  It owns four flat HBM arenas
+(params | grads | m | v, core/optimizer.py:14-15 order) and per-layer activation buffers, and exposes the
+parameters as DeviceArray views so a `Net` built from the reference-style layers can share them.
+
+The step can be replayed from a hipGraph (`use_graph=True`): the batch is copied into static staging
+buffers and the captured launch sequence — including Adam's device-side bias-correction state — is
+replayed with one hipGraphLaunch, which is what makes the dispatch-bound MNIST-size step fast.
+
+Data parallel (comm given): forward + local {max, sum-exp}  ->  all-gather/merge (C2)  ->  loss +
+backward with the GLOBAL batch size  ->  in-place all-reduce of grads (+ the loss slot) (C1)  ->  update.
+"""
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import device_array as da
+
+_LOSS = {"softmax_nll": 0, "mse": 1}
+_OPT = {"sgd": 0, "adam": 1}
+
+
+class MLPTrainer(object):
+
+    def __init__(self, widths, max_rows, loss="softmax_nll", optimizer="adam", lr=1e-3, beta1=0.9,
+                 beta2=0.999, epsilon=1e-8, dtype=np.float32, comm=None, use_graph=False):
+        self.widths = [int(w) for w in widths]
+        self.n_layers = len(self.widths) - 1
+        self.max_rows = int(max_rows)
+        self.dtype = np.dtype(dtype)
+        self.comm = comm if (comm is not None and comm.world > 1) else None
+        self.use_graph = bool(use_graph) and self.comm is None
+        self._lib = _lib.get()
+        self._h = ctypes.c_void_p()
+        code = da._CODE[self.dtype]
+        self._lib.mlp_create(self.n_layers, da._i64arr(self.widths), self.max_rows, _LOSS[loss],
+                             _OPT[optimizer], float(lr), float(beta1), float(beta2), float(epsilon),
+                             code, ctypes.byref(self._h))
+        p, g, m, v = (ctypes.c_void_p() for _ in range(4))
+        n = ctypes.c_int64(0)
+        self._lib.mlp_arena(self._h, ctypes.byref(p), ctypes.byref(g), ctypes.byref(m), ctypes.byref(v),
+                            ctypes.byref(n))
+        self.n_params = n.value
+        self.params = da.from_ptr(p.value, (self.n_params,), self.dtype, self)
+        self.grads = da.from_ptr(g.value, (self.n_params,), self.dtype, self)
+        self._grads_and_loss = da.from_ptr(g.value, (self.n_params + 1,), self.dtype, self)
+        self.loss_slot = da.from_ptr(g.value + self.n_params * self.dtype.itemsize, (), self.dtype, self)
+        self.adam_m = da.from_ptr(m.value, (self.n_params,), self.dtype, self)
+        self.adam_v = da.from_ptr(v.value, (self.n_params,), self.dtype, self)
+        self._graph = None
+        self._graph_rows = None
+        self._x_stage = None
+        self._y_stage = None
+        self._stats = da.empty((2,), self.dtype)
+
+    def __del__(self):
+        try:
+            self._graph = None
+            if _lib._lib is not None and self._h:
+                _lib._lib.mlp_destroy(self._h)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def _offset(self, layer, which):
+        off, cnt = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._lib.mlp_param_offset(self._h, layer, which, ctypes.byref(off), ctypes.byref(cnt))
+        return off.value, cnt.value
+
+    def param_view(self, layer, key, arena=None):
+        off, cnt = self._offset(layer, 0 if key == "w" else 1)
+        shape = (self.widths[layer], self.widths[layer + 1]) if key == "w" else (1, self.widths[layer + 1])
+        base = self.params if arena is None else arena
+        return base[off:off + cnt].reshape(shape)
+
+    def grad_view(self, layer, key):
+        return self.param_view(layer, key, arena=self.grads)
+
+    def set_parameters(self, layers):
+        """layers: list of {"w": array [in,out], "b": array [1,out]} (host or device)."""
+        for i, layer in enumerate(layers):
+            for key in ("w", "b"):
+                src = layer[key]
+                src = src.values if hasattr(src, "values") and not isinstance(src, np.ndarray) else src
+                view = self.param_view(i, key)
+                view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
+
+    def get_parameters(self):
+        return [{"w": self.param_view(i, "w"), "b": self.param_view(i, "b")} for i in range(self.n_layers)]
+
+    def activation(self, layer, rows):
+        p = ctypes.c_void_p()
+        self._lib.mlp_activation(self._h, layer, ctypes.byref(p))
+        return da.from_ptr(p.value, (rows, self.widths[layer + 1]), self.dtype, self)
+
+    # ------------------------------------------------------------------ compute
+    def _prep(self, x, y=None):
+        x = da.asarray(x, dtype=self.dtype)._contig()
+        rows = x.shape[0]
+        if x.ndim != 2 or x.shape[1] != self.widths[0] or not 0 < rows <= self.max_rows:
+            raise ValueError("inputs %s do not fit a [<=%d, %d] batch" % (x.shape, self.max_rows, self.widths[0]))
+        if y is not None:
+            y = da.asarray(y, dtype=self.dtype)._contig()
+            if y.shape != (rows, self.widths[-1]):
+                raise ValueError("targets %s must be [%d, %d]" % (y.shape, rows, self.widths[-1]))
+        return x, y, rows
+
+    def forward(self, x):
+        x, _, rows = self._prep(x)
+        out = da.empty((rows, self.widths[-1]), self.dtype)
+        self._lib.mlp_forward(self._h, x._ptr, rows, out._ptr)
+        return out
+
+    def step(self, x, y):
+        """One training step; returns the loss as a 0-d DeviceArray (no host sync)."""
+        x, y, rows = self._prep(x, y)
+        if self.comm is not None:
+            return self._step_dp(x, y, rows)
+        if self.use_graph:
+            return self._step_graph(x, y, rows)
+        self._lib.mlp_step(self._h, x._ptr, y._ptr, rows, None)
+        return self.loss_slot
+
+    def _step_dp(self, x, y, rows):
+        lib = self._lib
+        lib.mlp_forward_stats(self._h, x._ptr, rows, self._stats._ptr)
+        stats = self.comm.merge_softmax_stats(self._stats)
+        lib.mlp_backward(self._h, x._ptr, y._ptr, rows, rows * self.comm.world, stats._ptr, None)
+        self.comm.allreduce(self._grads_and_loss)      # gradients and the loss share one collective
+        lib.mlp_update(self._h)
+        return self.loss_slot
+
+    def _step_graph(self, x, y, rows):
+        lib = self._lib
+        if self._graph is None or self._graph_rows != rows:
+            self._x_stage = da.empty((rows, self.widths[0]), self.dtype)
+            self._y_stage = da.empty((rows, self.widths[-1]), self.dtype)
+            self._x_stage[...] = x
+            self._y_stage[...] = y
+            # one eager step first would advance the optimizer; capture records without executing
+            g = _lib.Graph()
+            with g:
+                lib.mlp_step(self._h, self._x_stage._ptr, self._y_stage._ptr, rows, None)
+            self._graph, self._graph_rows = g, rows
+        else:
+            lib.memcpy_d2d(self._x_stage._ptr, x._ptr, x.nbytes)
+            lib.memcpy_d2d(self._y_stage._ptr, y._ptr, y.nbytes)
+        self._graph.launch()
+        return self.loss_slot
+
+
+def trainer_from_net(net, max_rows, loss="softmax_nll", optimizer="adam", lr=1e-3, **kwargs):
+    """Build an MLPTrainer from an initialised Dense/ReLU `Net` (parameters are copied into the arena)."""
+    from .core.layers import Dense, ReLU
+    dense = [l for l in net.layers if isinstance(l, Dense)]
+    others = [l for l in net.layers if not isinstance(l, Dense)]
+    if not dense or any(not isinstance(l, ReLU) for l in others) or len(others) != len(dense) - 1:
+        raise ValueError("trainer_from_net supports Dense layers separated by ReLU only")
+    if any(not l.is_init for l in dense):
+        raise ValueError("initialise the net first (pass num_in to Dense or run one forward)")
+    widths = [dense[0].params["w"].shape[0]] + [l.params["w"].shape[1] for l in dense]
+    trainer = MLPTrainer(widths, max_rows, loss=loss, optimizer=optimizer, lr=lr, **kwargs)
+    trainer.set_parameters([l.params for l in dense])
+    return trainer
