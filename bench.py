@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py — training samples/sec of the MNIST-shape MLP (784-256-128-10, bs=128 per GPU, Adam 1e-3),
+the metric BASELINE.json names, on N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload A|C] [--path fused|ops]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: zero_grad -> forward -> whole-batch softmax NLL ->
+backward -> [RCCL all-reduce] -> Adam update (examples/mnist/run.py:79-83).  Inputs are synthetic
+(MNIST-like sparsity), resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+  --workload A (default)  configs[1]/[3] of BASELINE.json: 128 rows per GPU (N=8 -> global batch 1024)
+  --workload C            configs[2]: Dense 4096->4096->4096 autoencoder, bs 512, sum-of-squares loss —
+                          the MFMA roofline run (one GPU)
+  --path fused (default)  whole-step trainer (tnn_mlp_*), hipGraph replay at N=1
+  --path ops              the drop-in Tensor/ops/Model path (same maths, one launch per op)
+
+Extra objects on the line:
+  roofline      the dominant kernel of the step (the fp32 MFMA GEMM family): algorithmic FLOPs of the
+                step's GEMMs / their summed average durations, each measured with HIP events on the
+                library stream; peak = 157.3 TFLOP/s (MI355X fp32 MFMA, guide)
+  roofline_gemm4096  the same measurement on the five 512x4096x4096 GEMMs of config C (north_star's
+                ">= 50 % of fp32 MFMA roofline" target), always reported
+  cpu_baseline  the numpy port of the reference (oracle/ref_nn.py: same op graph, 4x backward traversal,
+                float64) timed on this host for a bounded number of steps (rank 0, N=1 only)
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import tinynn_autograd_amd as tn                      # noqa: E402
+from tinynn_autograd_amd import _lib                  # noqa: E402
+from tinynn_autograd_amd import device_array as da    # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+WIDTHS_A = [784, 256, 128, 10]
+WIDTHS_C = [4096, 4096, 4096]
+
+
+def synth_batches(n_batches, rows, widths, kind, rank, world, seed=1234):
+    """Global batches of rows*world samples from one seeded stream; this rank keeps its row block."""
+    rs = np.random.RandomState(seed)
+    xs, ys = [], []
+    for _ in range(n_batches):
+        x = rs.rand(rows * world, widths[0]).astype(np.float32)
+        if kind == "softmax_nll":
+            x *= (rs.rand(rows * world, widths[0]) < 0.19)
+            y = np.eye(widths[-1], dtype=np.float32)[rs.randint(0, widths[-1], rows * world)]
+        else:
+            y = x
+        sl = slice(rank * rows, (rank + 1) * rows)
+        xs.append(x[sl])
+        ys.append(y[sl])
+    return np.concatenate(xs), np.concatenate(ys)
+
+
+def build_net(widths):
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.nn import Net
+    np.random.seed(0)
+    layers = []
+    for i in range(len(widths) - 1):
+        layers.append(Dense(widths[i + 1], num_in=widths[i]))
+        if i < len(widths) - 2:
+            layers.append(ReLU())
+    return Net(layers)
+
+
+def gemm_list(widths, rows):
+    """(transA, transB, M, N, K) of every GEMM in one step: fwd NN, dW TN, dX NT (no dX for layer 1)."""
+    out = []
+    for l in range(len(widths) - 1):
+        out.append(("fwd%d" % l, 0, 0, rows, widths[l + 1], widths[l]))
+    for l in reversed(range(len(widths) - 1)):
+        out.append(("dW%d" % l, 1, 0, widths[l], widths[l + 1], rows))
+        if l > 0:
+            out.append(("dX%d" % l, 0, 1, rows, widths[l], widths[l + 1]))
+    return out
+
+
+def time_gemms(widths, rows, reps=20):
+    """Average duration of each GEMM of the step: HIP events on the library stream around `reps`
+    back-to-back launches replayed from one hipGraph (for the microsecond-sized GEMMs of config A the
+    figure therefore still contains the ~1.3 us dependent-kernel boundary; profiles/ has the rocprofv3
+    kernel-only durations)."""
+    lib = _lib.get()
+    rs = np.random.RandomState(7)
+    results, tot_flops, tot_ms = [], 0.0, 0.0
+    for name, ta, tb, M, N, K in gemm_list(widths, rows):
+        a = da.asarray(rs.randn(*((K, M) if ta else (M, K))).astype(np.float32))
+        b = da.asarray(rs.randn(*((N, K) if tb else (K, N))).astype(np.float32))
+        c = da.empty((M, N), np.float32)
+        lda, ldb = (M if ta else K), (K if tb else N)
+        for _ in range(3):
+            lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32)
+        graph = _lib.Graph()                           # replayed from a hipGraph: no host launch cost inside
+        with graph:
+            for _ in range(reps):
+                lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32)
+        graph.launch()
+        e0, e1 = _lib.Event(), _lib.Event()
+        e0.record()
+        graph.launch()
+        e1.record()
+        ms = e0.elapsed_ms(e1) / reps
+        flops = 2.0 * M * N * K
+        results.append({"gemm": name, "layout": "NT"[ta] + "NT"[tb], "M": M, "N": N, "K": K,
+                        "us": round(ms * 1e3, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 3)})
+        tot_flops += flops
+        tot_ms += ms
+    achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
+            "algorithmic_gflop_per_step": round(tot_flops / 1e9, 4),
+            "gemm_us_per_step": round(tot_ms * 1e3, 2), "per_gemm": results}
+
+
+def cpu_baseline(widths, rows, kind, budget_s=12.0):
+    """The numpy port of the reference on this host (bounded sample of the same workload)."""
+    from oracle import ref_nn                              # the reported baseline, never the measured path
+    np.random.seed(0)
+    layers = ref_nn.build_mlp(widths)
+    opt = ref_nn.Adam(lr=1e-3)
+    loss_fn = ref_nn.softmax_nll if kind == "softmax_nll" else ref_nn.squared_error
+    x, y = synth_batches(4, rows, widths, kind, 0, 1)
+    y = y.astype(np.float64)
+    for i in range(2):
+        ref_nn.train_step(layers, opt, loss_fn, x[i * rows:(i + 1) * rows], y[i * rows:(i + 1) * rows])
+    t0, steps = time.perf_counter(), 0
+    while True:
+        i = steps % 4
+        ref_nn.train_step(layers, opt, loss_fn, x[i * rows:(i + 1) * rows], y[i * rows:(i + 1) * rows])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or (steps >= 400 and el > 5.0):
+            break
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
+        if blas:
+            threads = blas[0]["num_threads"]
+    except Exception:
+        pass
+    return {"value": round(steps * rows / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of the same %s step (bs=%d) through oracle/ref_nn.py (numpy %s, float64, "
+                      "reference's per-edge backward) in %.1f s; host has %d logical CPUs"
+                      % (steps, "-".join(map(str, widths)), rows, np.__version__, el, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="A", choices=["A", "C"])
+    ap.add_argument("--path", default="fused", choices=["fused", "ops"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+        args.gpus = world
+
+    lib = _lib.get()                                    # binds LOCAL_RANK's GPU; raises without HIP
+    assert tn.backend_name() == "hip-gfx950", "bench.py measures the HIP library only"
+    # torch is imported only for N > 1 and only as the gloo control plane.  torch.cuda is never touched:
+    # this process runs on ROCm 7.2's libamdhip64 (loaded by libtnn_hip.so above) and torch's bundled HIP
+    # 7.0 runtime reports "No HIP GPUs" once that copy is in the process.  All device work (kernels and
+    # RCCL) is on the library's one stream, so tnn_stream_sync() is the device fence of the contract.
+    comm = tn.dist.init_from_env() if world > 1 else None
+
+    if args.workload == "A":
+        widths, rows, kind, loss = WIDTHS_A, 128, "softmax_nll", "softmax_nll"
+        steps = args.steps if args.steps is not None else 2000
+        warmup = args.warmup if args.warmup is not None else 50
+        n_batches = 64
+    else:
+        widths, rows, kind, loss = WIDTHS_C, 512, "mse", "mse"
+        steps = args.steps if args.steps is not None else 50
+        warmup = args.warmup if args.warmup is not None else 5
+        n_batches = 2
+
+    x_host, y_host = synth_batches(n_batches, rows, widths, kind, rank, world)
+    X, Y = da.asarray(x_host), da.asarray(y_host)      # resident in HBM before the timed region
+    batches = [(X[i * rows:(i + 1) * rows], Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
+
+    net = build_net(widths)
+    if args.path == "fused":
+        trainer = tn.trainer_from_net(net, max_rows=rows, loss=loss, optimizer="adam", lr=1e-3, comm=comm,
+                                      use_graph=not args.no_graph)
+
+        def step(i):
+            return trainer.step(*batches[i % n_batches])
+    else:
+        from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss, SquaredErrorLoss
+        from tinynn_autograd_amd.core.model import Model
+        from tinynn_autograd_amd.core.optimizer import Adam
+        from tinynn_autograd_amd.core.tensor import Tensor
+        loss_layer = SoftmaxCrossEntropyLoss(comm=comm) if kind == "softmax_nll" else SquaredErrorLoss()
+        model = Model(net=net, loss=loss_layer, optimizer=Adam(lr=1e-3), comm=comm)
+        tbatches = [(Tensor(a), Tensor(b)) for a, b in batches]
+
+        def step(i):
+            xb, yb = tbatches[i % n_batches]
+            model.zero_grad()
+            out = loss_layer.loss(model.forward(xb), yb)
+            out.backward()
+            model.step()
+            return out.values
+
+    def fence():
+        if comm is not None:
+            comm.barrier()
+        _lib.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        last = step(warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(last)
+
+    if rank == 0:
+        value = steps * rows * world / elapsed
+        line = {
+            "metric": "training samples/sec, MNIST 3-layer MLP (784-256-128-10), bs=128, at 1/2/4/8 GPUs"
+                      if args.workload == "A" else "training samples/sec, Dense 4096-4096-4096 autoencoder, bs=512",
+            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: Dense/ReLU MLP %s, %d rows per GPU (global batch %d), whole-batch "
+                                   "softmax NLL%s, Adam lr=1e-3" % (
+                                       "configs[1]" if args.workload == "A" else "configs[2]",
+                                       "-".join(map(str, widths)), rows, rows * world,
+                                       "" if kind == "softmax_nll" else " replaced by sum-of-squares/m"),
+                       "path": args.path + ("+hipGraph" if (args.path == "fused" and world == 1 and not args.no_graph) else ""),
+                       "parallelism": "dp%d" % world, "global_batch": rows * world,
+                       "data_resident_in_hbm": True},
+            "final_loss": round(final_loss, 6),
+            "device": _lib.device_props()["name"],
+        }
+        line["roofline"] = time_gemms(widths, rows, reps=200 if args.workload == "A" else 20)
+        if args.workload == "A":
+            line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=12.0 if args.workload == "A" else 20.0)
+        print(json.dumps(line))
+    if comm is not None:
+        comm.barrier()
+
+
+if __name__ == "__main__":
+    main()

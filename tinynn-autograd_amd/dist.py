@@ -110,6 +110,11 @@ def init_from_env(backend="rccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return None
+    if backend == "rccl":
+        # load ROCm's librccl (through the C-ABI) BEFORE torch is imported, so that the one RCCL copy in the
+        # process is the one built against the HIP runtime libtnn_hip.so runs on (same-soname libraries are
+        # deduplicated by the loader; torch bundles its own librccl/libamdhip64)
+        RcclCommunicator.new_unique_id()
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
