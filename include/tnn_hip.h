@@ -100,6 +100,12 @@ TNN_API int tnn_gemm_mask(int transA, int transB, int64_t M, int64_t N, int64_t 
                           const void* A, int64_t lda, const void* B, int64_t ldb,
                           const void* Y, int64_t ldy, void* C, int64_t ldc, int dtype);
 
+/* dW[M,N] = A^T G with A stored [K,M], G stored [K,N] (core/ops.py:159-160) and, in the same launch for
+ * MNIST-size layers, db[N] = column-sum of G (the un-broadcast of the bias add, core/ops.py:52-54).
+ * db may be NULL.  Large shapes run the GEMM and the column reduction as two launches. */
+TNN_API int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
+                               const void* G, int64_t ldg, void* dW, int64_t ldc, void* db, int dtype);
+
 /* ------------------------------------------------------------------ elementwise (K2,K3) ------- */
 /* out[shape] = a (op) b with numpy broadcasting expressed as element strides (0 = broadcast dim).
  * ndim <= 6; out is dense row-major of `shape`. */
@@ -171,6 +177,11 @@ TNN_API int tnn_lse_merge(const void* stats_all, int n_shards, void* stats, int 
 TNN_API int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c,
                                     int64_t m_global, const void* stats, void* loss_out,
                                     void* dz, int dtype);
+
+/* stats + loss + dz of one UNSHARDED batch in a single launch when m*c is small (falls back to the
+ * three-kernel sequence otherwise); stats_out (device [2], may be NULL) receives {M, S}. */
+TNN_API int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, void* stats_out,
+                                  void* loss_out, void* dz, int dtype);
 
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global

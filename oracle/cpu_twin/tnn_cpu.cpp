@@ -274,6 +274,15 @@ int tnn_gemm_mask(int tA, int tB, int64_t M, int64_t N, int64_t K, const void* A
     return gemm_common(tA, tB, M, N, K, A, lda, B, ldb, C, ldc, dtype, 2, 1, 0, nullptr, 0, 0, Y, ldy);
 }
 
+int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg,
+                       void* dW, int64_t ldc, void* db, int dtype) {
+    NEED_INIT();
+    REQ(ldg == N || db == nullptr, "tnn_gemm_tn_colsum: the column sum needs a dense G (ldg == N)");
+    RECORD(tnn_gemm_tn_colsum(M, N, K, A, lda, G, ldg, dW, ldc, db, dtype));
+    if (int rc = gemm_common(1, 0, M, N, K, A, lda, G, ldg, dW, ldc, dtype, 0, 1.0, 0.0, nullptr, 0, 0, nullptr, 0)) return rc;
+    return db ? tnn_reduce(TNN_RSUM, G, db, 1, K, N, dtype) : 0;
+}
+
 // ---- elementwise ----
 int tnn_ewise_binary(int op, const void* a, const int64_t* sa, const void* b, const int64_t* sb,
                      void* out, int ndim, const int64_t* shape, int dtype) {
@@ -553,6 +562,16 @@ int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c, 
         if (loss_out) ((T*)loss_out)[0] = (T)loss;
     });
     return 0;
+}
+int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, void* stats_out, void* loss_out,
+                          void* dz, int dtype) {
+    NEED_INIT();
+    REQ(m > 0 && c > 0, "tnn_softmax_nll_fused: empty batch");
+    RECORD(tnn_softmax_nll_fused(z, y, m, c, stats_out, loss_out, dz, dtype));
+    double tmp[2];
+    void* st = stats_out ? stats_out : (void*)tmp;
+    if (int rc = tnn_softmax_nll_stats(z, m, c, st, dtype)) return rc;
+    return tnn_softmax_nll_fwd_bwd(z, y, m, c, m, st, loss_out, dz, dtype);
 }
 int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t mg, void* loss_out, void* dpred, int dtype) {
     NEED_INIT();

@@ -174,6 +174,74 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restri
     }
 }
 
+
+// Single-launch whole-batch softmax NLL for small m*c (the MNIST head is 128 x 10): one 1024-thread block
+// does max -> sum-exp -> per-row loss and dz; three block reductions instead of four launches.
+template <typename T>
+__global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z, const T* __restrict__ y,
+                                                         int64_t m, int64_t c, T* __restrict__ stats_out,
+                                                         T* __restrict__ loss_out, T* __restrict__ dz) {
+    __shared__ double lds[16];
+    __shared__ double bcast;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
+    const int64_t n = m * c;
+    double mx = -INFINITY;
+    for (int64_t i = tid; i < n; i += blockDim.x) {
+        double v = (double)z[i];
+        mx = v > mx ? v : mx;
+    }
+    mx = tnn::wave_max(mx);
+    if (lane == 0) lds[w] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        double r = lds[0];
+        for (int i = 1; i < nw; ++i) r = lds[i] > r ? lds[i] : r;
+        bcast = r;
+    }
+    __syncthreads();
+    const double M = bcast;
+    double s = 0.0;
+    for (int64_t i = tid; i < n; i += blockDim.x) s += exp((double)z[i] - M);
+    s = tnn::wave_sum(s);
+    __syncthreads();
+    if (lane == 0) lds[w] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double r = 0.0;
+        for (int i = 0; i < nw; ++i) r += lds[i];
+        bcast = r;
+    }
+    __syncthreads();
+    const double S = bcast;
+    const double log_s = log(S), inv_s = 1.0 / S, inv_m = 1.0 / (double)m;
+    double local = 0.0;
+    for (int64_t r = tid; r < m; r += blockDim.x) {
+        const T* zr = z + r * c;
+        const T* yr = y + r * c;
+        double q = 0.0;
+        for (int64_t k = 0; k < c; ++k) q += exp((double)zr[k] - M) * (double)yr[k];
+        local += (log_s - log(q)) * inv_m;
+        if (dz) {
+            T* dr = dz + r * c;
+            double inv_q = inv_m / q;
+            for (int64_t k = 0; k < c; ++k) {
+                double e = exp((double)zr[k] - M);
+                dr[k] = (T)(e * inv_s - e * (double)yr[k] * inv_q);
+            }
+        }
+    }
+    local = tnn::wave_sum(local);
+    __syncthreads();
+    if (lane == 0) lds[w] = local;
+    __syncthreads();
+    if (tid == 0) {
+        double r = 0.0;
+        for (int i = 0; i < nw; ++i) r += lds[i];
+        if (loss_out) loss_out[0] = (T)r;
+        if (stats_out) { stats_out[0] = (T)M; stats_out[1] = (T)S; }
+    }
+}
+
 template <typename TO>
 __global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ partial, int n,
                                                           TO* __restrict__ out) {
@@ -368,6 +436,34 @@ int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c, 
             hipLaunchKernelGGL((sum_partials_kernel<double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)loss_out);
     }
     tnn_free(ws);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, void* stats_out,
+                          void* loss_out, void* dz, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fused: dtype %d", dtype);
+    TNN_REQUIRE(m > 0 && c > 0, "tnn_softmax_nll_fused: empty batch");
+    if (m * c > 65536) {   // too big for one block: the general multi-block sequence
+        void* st = stats_out;
+        void* tmp = nullptr;
+        if (!st) {
+            if (tnn_malloc(16, &tmp)) return 1;
+            st = tmp;
+        }
+        int rc = tnn_softmax_nll_stats(z, m, c, st, dtype);
+        if (!rc) rc = tnn_softmax_nll_fwd_bwd(z, y, m, c, m, st, loss_out, dz, dtype);
+        if (tmp) tnn_free(tmp);
+        return rc;
+    }
+    int threads = m * c >= 4096 ? 1024 : 256;
+    if (dtype == TNN_F32)
+        hipLaunchKernelGGL((nll_fused_kernel<float>), 1, threads, 0, tnn::stream(), (const float*)z,
+                           (const float*)y, m, c, (float*)stats_out, (float*)loss_out, (float*)dz);
+    else
+        hipLaunchKernelGGL((nll_fused_kernel<double>), 1, threads, 0, tnn::stream(), (const double*)z,
+                           (const double*)y, m, c, (double*)stats_out, (double*)loss_out, (double*)dz);
     TNN_LAUNCH_OK();
     return 0;
 }

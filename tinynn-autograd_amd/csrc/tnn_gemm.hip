@@ -286,6 +286,129 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
     }
 }
 
+
+// ------------------------------------------------------------------------------ small / latency GEMM
+// MNIST-size layers (2MNK <= ~160 MFLOP) are latency-bound: the 64x64 LDS-tiled kernel needs split-K
+// plus a second launch and still leaves most CUs idle.  Here one workgroup owns ONE 16x16 output tile
+// (v_mfma_f32_16x16x4_f32, 4 accumulator VGPRs) and its WAVES waves split K between them in 16-deep
+// chunks (round-robin, so neighbouring waves touch neighbouring lines); fragments are loaded straight
+// from global memory in MFMA layout (everything is L2-resident at this size, an LDS round trip would
+// only add latency), the WAVES partial tiles are summed through LDS and the epilogue is applied once.
+// Optionally the workgroups of the first tile row also emit colsum[n] = sum_k B[k][n] — the bias
+// gradient (core/ops.py:52-54) — from the B fragments they already hold (B = dZ in dW = X^T dZ).
+//   lane l: i = l & 15 (row of A / column of B), grp = l >> 4 holds k = 16c + 4 grp + j, j = 0..3
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool AKC, bool BKC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, float* __restrict__ colsum) {
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int tm = (int)blockIdx.x % g.tiles_m, tn = (int)blockIdx.x / g.tiles_m;
+    const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
+    const int64_t am = m0 + i16, bn = n0 + i16;
+    const bool a_ok = am < g.M, b_ok = bn < g.N;
+    const int nchunks = (int)((g.K + 15) / 16);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bs = 0.f;
+#pragma unroll 2
+    for (int c = wid; c < nchunks; c += WAVES) {
+        const int64_t k = (int64_t)c * 16 + grp * 4;
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (AKC) {
+            const float* p = g.A + am * g.lda + k;
+            if (a_ok) {
+                if (g.vecA && k + 3 < g.K) {
+                    float4 v = *reinterpret_cast<const float4*>(p);
+                    a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < g.K) a[j] = p[j];
+                }
+            }
+        } else {
+            if (a_ok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k + j < g.K) a[j] = g.A[(k + j) * g.lda + am];
+            }
+        }
+        if constexpr (BKC) {
+            const float* p = g.B + bn * g.ldb + k;
+            if (b_ok) {
+                if (g.vecB && k + 3 < g.K) {
+                    float4 v = *reinterpret_cast<const float4*>(p);
+                    b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (k + j < g.K) b[j] = p[j];
+                }
+            }
+        } else {
+            if (b_ok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k + j < g.K) b[j] = g.B[(k + j) * g.ldb + bn];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+        bs += (b[0] + b[1]) + (b[2] + b[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wid][r][lane] = acc[r];
+    bsum[wid][lane] = bs;
+    __syncthreads();
+    if (tid < 256) {
+        const int r = tid >> 6, ln = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += red[w][r][ln];
+        const int64_t row = m0 + (ln >> 4) * 4 + r, col = n0 + (ln & 15);   // 16x16x4 C/D layout
+        if (row < g.M && col < g.N) g.C[row * g.ldc + col] = apply_epilogue(g, s, row, col);
+    }
+    if (colsum != nullptr && tm == 0 && tid < 16 && n0 + tid < g.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) s += (bsum[w][tid] + bsum[w][16 + tid]) + (bsum[w][32 + tid] + bsum[w][48 + tid]);
+        colsum[n0 + tid] = s;
+    }
+}
+
+template <int WAVES>
+int launch_small(GemmArgs& g, int transA, int transB, float* colsum) {
+    g.tiles_m = (int)((g.M + 15) / 16);
+    g.tiles_n = (int)((g.N + 15) / 16);
+    g.splits = 1;
+    g.ws = nullptr;
+    dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
+    hipStream_t s = tnn::stream();
+    if (!transA && !transB)
+        hipLaunchKernelGGL((gemm_small_f32_kernel<true, false, WAVES>), grid, WAVES * 64, 0, s, g, colsum);
+    else if (!transA && transB)
+        hipLaunchKernelGGL((gemm_small_f32_kernel<true, true, WAVES>), grid, WAVES * 64, 0, s, g, colsum);
+    else if (transA && !transB)
+        hipLaunchKernelGGL((gemm_small_f32_kernel<false, false, WAVES>), grid, WAVES * 64, 0, s, g, colsum);
+    else
+        hipLaunchKernelGGL((gemm_small_f32_kernel<false, true, WAVES>), grid, WAVES * 64, 0, s, g, colsum);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+bool use_small_path(const GemmArgs& g) {
+    if (const char* e = getenv("TNN_GEMM_SMALL")) return atoi(e) != 0;
+    if (getenv("TNN_GEMM_CFG")) return false;
+    double flop = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    int64_t tiles = ((g.M + 15) / 16) * ((g.N + 15) / 16);
+    return flop <= 1.6e8 && tiles <= 8192;
+}
+
+int gemm_small(GemmArgs& g, int transA, int transB, float* colsum) {
+    int nchunks = (int)((g.K + 15) / 16);
+    if (nchunks <= 16) return launch_small<4>(g, transA, transB, colsum);
+    if (nchunks <= 48) return launch_small<8>(g, transA, transB, colsum);
+    return launch_small<16>(g, transA, transB, colsum);
+}
+
 // ------------------------------------------------------------------------------ f64 (exact mode)
 // Plain LDS-tiled VALU kernel, 64x64 tile, 4x4 micro-tile per thread; not on the measured path.
 struct GemmArgsD {
@@ -388,11 +511,15 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
     return 0;
 }
 
-int gemm_f32(GemmArgs& g, int transA, int transB) {
+int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     // 16-B loads need: contiguous extent and leading dimension multiples of 4, base 16-B aligned
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     g.vecA = al(g.A) && g.lda % 4 == 0 && ((transA ? g.M : g.K) % 4 == 0);
     g.vecB = al(g.B) && g.ldb % 4 == 0 && ((transB ? g.K : g.N) % 4 == 0);
+    if (use_small_path(g)) return gemm_small(g, transA, transB, colsum);
+    if (colsum != nullptr) {   // large shapes: the column sum is a separate (HBM-bound, <1 % of the time) pass
+        if (int rc = tnn_reduce(TNN_RSUM, g.B, colsum, 1, g.K, g.N, TNN_F32)) return rc;
+    }
 
     const int cus = tnn::num_cus();
     int cfg = -1, splits = 0;
@@ -473,6 +600,28 @@ int tnn_gemm(int transA, int transB, int64_t M, int64_t N, int64_t K, double alp
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.alpha = (float)alpha; g.beta = (float)beta; g.epi = EPI_AXPBY;
     return gemm_f32(g, transA, transB);
+}
+
+int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G,
+                       int64_t ldg, void* dW, int64_t ldc, void* db, int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_gemm_tn_colsum", 1, 0, M, N, K, lda, ldg, ldc)) return rc;
+    TNN_REQUIRE(ldg == N || db == nullptr, "tnn_gemm_tn_colsum: the column sum needs a dense G (ldg == N)");
+    if (N == 0) return 0;
+    if (dtype == TNN_F64) {
+        if (M > 0)
+            if (int rc = gemm_f64(1, 0, M, N, K, A, lda, G, ldg, dW, ldc, 1.0, 0.0, EPI_AXPBY, nullptr, 0, 0,
+                                  nullptr, 0))
+                return rc;
+        return db ? tnn_reduce(TNN_RSUM, G, db, 1, K, N, TNN_F64) : 0;
+    }
+    TNN_REQUIRE(dtype == TNN_F32, "tnn_gemm_tn_colsum: dtype %d is not a float type", dtype);
+    if (M == 0) return db ? tnn_reduce(TNN_RSUM, G, db, 1, K, N, TNN_F32) : 0;
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)G; g.C = (float*)dW;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldg; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_AXPBY;
+    return gemm_f32(g, 1, 0, (float*)db);
 }
 
 int tnn_gemm_bias_act(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A,

@@ -10,8 +10,8 @@
 //
 // Per step (L Dense layers, ReLU between them):
 //   forward  : L  x  gemm_bias_act (NN, bias + ReLU fused, ReLU mask kept in the sign bit of 0)
-//   loss     : softmax_nll_stats + softmax_nll_fwd_bwd   (or mse_fwd_bwd)
-//   backward : L  x  gemm TN (dW = X^T dZ)  +  L x column-sum (db)  +  (L-1) x gemm_mask NT (dX*mask)
+//   loss     : softmax_nll_fused (sharded: softmax_nll_stats | exchange | softmax_nll_fwd_bwd) or mse_fwd_bwd
+//   backward : L  x  gemm_tn_colsum (dW = X^T dZ and db = column-sum dZ)  +  (L-1) x gemm_mask NT (dX*mask)
 //   update   : 1  x  fused Adam / SGD over the whole arena
 #include <stdarg.h>
 #include <stdint.h>
@@ -61,6 +61,25 @@ int mlp_forward(Mlp* h, const void* x, int64_t rows) {
                                   hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, h->act[l],
                                   h->w[l + 1], h->dtype));
         in = h->act[l];
+    }
+    return 0;
+}
+
+// gradients of every layer from dact[L-1] (set by the loss kernel) down to layer 0
+int mlp_backward_layers(Mlp* h, const void* x, int64_t rows) {
+    for (int l = h->L - 1; l >= 0; --l) {
+        const void* in = l == 0 ? x : h->act[l - 1];
+        void* d = h->dact[l];
+        // dW_l = in^T d (core/ops.py:159-160, A stored [K=rows, M=w[l]]) and db_l = column sum of d
+        // (core/ops.py:52-54) — one launch for MNIST-size layers
+        MLP_TRY(tnn_gemm_tn_colsum(h->w[l], h->w[l + 1], rows, in, h->w[l], d, h->w[l + 1],
+                                   at(h->grads, h->w_off[l], h->esz), h->w[l + 1],
+                                   at(h->grads, h->b_off[l], h->esz), h->dtype));
+        // dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]   (core/ops.py:156-157 + :342-343)
+        if (l > 0)
+            MLP_TRY(tnn_gemm_mask(0, 1, rows, h->w[l], h->w[l + 1], d, h->w[l + 1],
+                                  at(h->params, h->w_off[l], h->esz), h->w[l + 1], h->act[l - 1],
+                                  h->w[l], h->dact[l - 1], h->w[l], h->dtype));
     }
     return 0;
 }
@@ -211,21 +230,7 @@ int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, i
     else
         MLP_TRY(tnn_mse_fwd_bwd(h->act[L - 1], y, rows * h->w[L], m_global, loss_slot, h->dact[L - 1],
                                 h->dtype));
-    for (int l = L - 1; l >= 0; --l) {
-        const void* in = l == 0 ? x : h->act[l - 1];
-        void* d = h->dact[l];
-        // dW_l = in^T d   (core/ops.py:159-160): A stored [K=rows, M=w[l]]
-        MLP_TRY(tnn_gemm(1, 0, h->w[l], h->w[l + 1], rows, 1.0, in, h->w[l], d, h->w[l + 1], 0.0,
-                         at(h->grads, h->w_off[l], h->esz), h->w[l + 1], h->dtype));
-        // db_l = column sum of d   (core/ops.py:52-54)
-        MLP_TRY(tnn_reduce(TNN_RSUM, d, at(h->grads, h->b_off[l], h->esz), 1, rows, h->w[l + 1],
-                           h->dtype));
-        // dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]   (core/ops.py:156-157 + :342-343)
-        if (l > 0)
-            MLP_TRY(tnn_gemm_mask(0, 1, rows, h->w[l], h->w[l + 1], d, h->w[l + 1],
-                                  at(h->params, h->w_off[l], h->esz), h->w[l + 1], h->act[l - 1],
-                                  h->w[l], h->dact[l - 1], h->w[l], h->dtype));
-    }
+    MLP_TRY(mlp_backward_layers(h, x, rows));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;
 }
@@ -239,8 +244,21 @@ int tnn_mlp_update(void* handle) {
 }
 
 int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void* loss_out) {
-    MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
-    MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows, nullptr, loss_out));
+    Mlp* h = (Mlp*)handle;
+    MLP_TRY(check_rows(h, rows, "tnn_mlp_step"));
+    if (h->loss_kind != 0) {
+        MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+        MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows, nullptr, loss_out));
+        return tnn_mlp_update(handle);
+    }
+    // unsharded softmax head: stats + loss + dz in one launch
+    const int L = h->L;
+    void* loss_slot = at(h->grads, h->n_params, h->esz);
+    MLP_TRY(mlp_forward(h, x, rows));
+    MLP_TRY(tnn_softmax_nll_fused(h->act[L - 1], y, rows, h->w[L], h->stats, loss_slot, h->dact[L - 1],
+                                  h->dtype));
+    MLP_TRY(mlp_backward_layers(h, x, rows));
+    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return tnn_mlp_update(handle);
 }
 
