@@ -158,6 +158,29 @@ def trainer_A_sgd_graph():
     _check_trainer("A_sgd", use_graph=True)
 
 
+def trainer_A_adam_multi_step_graph():
+    """All 20 steps captured into ONE hipGraph (each step bound to its own resident batch), replayed once;
+    then a second replay must continue the optimizer (device-side Adam state), not restart it."""
+    cfg, gold = H.load_traj("A_adam")
+    model, _ = H.build_model(cfg)
+    w = cfg["widths"]
+    trainer = trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"])
+    data = H.batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])
+    graph = trainer.capture_steps([(tn.asarray(x), tn.asarray(y)) for x, y in data])
+    losses = np.asarray(graph.launch())
+    np.testing.assert_allclose(losses, gold["loss"], rtol=RTOL)
+    for l in range(trainer.n_layers):
+        for k in ("w", "b"):
+            H.check_summary(np.asarray(trainer.param_view(l, k)), gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * cfg["lr"])
+    # reference for the continuation: an eager trainer fed the same 40 batches
+    model2, _ = H.build_model(cfg)
+    eager = trainer_from_net(model2.net, max_rows=cfg["m"], lr=cfg["lr"])
+    ref = [float(eager.step(tn.asarray(x), tn.asarray(y))) for x, y in data + data]
+    again = np.asarray(graph.launch())
+    np.testing.assert_allclose(again, ref[cfg["steps"]:], rtol=RTOL)
+    assert again[0] < losses[0]                      # it kept training, it did not replay step 0's state
+
+
 def trainer_A_ragged():
     _check_trainer("A_ragged", use_graph=False)
 

@@ -175,69 +175,66 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restri
 }
 
 
-// Single-launch whole-batch softmax NLL for small m*c (the MNIST head is 128 x 10): one 1024-thread block
-// does max -> sum-exp -> per-row loss and dz; three block reductions instead of four launches.
+// Single-launch whole-batch softmax NLL for small batches (the MNIST head is 128 x 10): one 1024-thread
+// block, element-parallel.  exp(z - M) is evaluated ONCE per element and kept in LDS; the per-row q and the
+// three block reductions (max, sum-exp, loss) go through wave shuffles + one LDS hop each.
+constexpr int kNllMaxElems = 8192, kNllMaxRows = 1024;
+
+template <bool IS_MAX>
+__device__ __forceinline__ double block_reduce_1024(double v, double* lds, double* bcast) {
+    v = IS_MAX ? tnn::wave_max(v) : tnn::wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();                       // lds/bcast may still be read from the previous reduction
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    if (w == 0) {
+        double r = lane < nw ? lds[lane] : (IS_MAX ? -INFINITY : 0.0);
+        r = IS_MAX ? tnn::wave_max(r) : tnn::wave_sum(r);
+        if (lane == 0) *bcast = r;
+    }
+    __syncthreads();
+    return *bcast;
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z, const T* __restrict__ y,
-                                                         int64_t m, int64_t c, T* __restrict__ stats_out,
+                                                         int m, int c, T* __restrict__ stats_out,
                                                          T* __restrict__ loss_out, T* __restrict__ dz) {
-    __shared__ double lds[16];
+    __shared__ T e_lds[kNllMaxElems];
+    __shared__ double q_lds[kNllMaxRows];
+    __shared__ double red[16];
     __shared__ double bcast;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-    const int64_t n = m * c;
+    const int tid = threadIdx.x, n = m * c;
     double mx = -INFINITY;
-    for (int64_t i = tid; i < n; i += blockDim.x) {
+    for (int i = tid; i < n; i += blockDim.x) {
         double v = (double)z[i];
         mx = v > mx ? v : mx;
     }
-    mx = tnn::wave_max(mx);
-    if (lane == 0) lds[w] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        double r = lds[0];
-        for (int i = 1; i < nw; ++i) r = lds[i] > r ? lds[i] : r;
-        bcast = r;
-    }
-    __syncthreads();
-    const double M = bcast;
+    const double M = block_reduce_1024<true>(mx, red, &bcast);
     double s = 0.0;
-    for (int64_t i = tid; i < n; i += blockDim.x) s += exp((double)z[i] - M);
-    s = tnn::wave_sum(s);
-    __syncthreads();
-    if (lane == 0) lds[w] = s;
-    __syncthreads();
-    if (tid == 0) {
-        double r = 0.0;
-        for (int i = 0; i < nw; ++i) r += lds[i];
-        bcast = r;
+    for (int i = tid; i < n; i += blockDim.x) {
+        double e = exp((double)z[i] - M);
+        e_lds[i] = (T)e;
+        s += e;
     }
-    __syncthreads();
-    const double S = bcast;
+    const double S = block_reduce_1024<false>(s, red, &bcast);      // its barriers also publish e_lds
     const double log_s = log(S), inv_s = 1.0 / S, inv_m = 1.0 / (double)m;
     double local = 0.0;
-    for (int64_t r = tid; r < m; r += blockDim.x) {
-        const T* zr = z + r * c;
-        const T* yr = y + r * c;
+    for (int r = tid; r < m; r += blockDim.x) {
         double q = 0.0;
-        for (int64_t k = 0; k < c; ++k) q += exp((double)zr[k] - M) * (double)yr[k];
+        for (int k = 0; k < c; ++k) q += (double)e_lds[r * c + k] * (double)y[r * c + k];
+        q_lds[r] = q;
         local += (log_s - log(q)) * inv_m;
-        if (dz) {
-            T* dr = dz + r * c;
-            double inv_q = inv_m / q;
-            for (int64_t k = 0; k < c; ++k) {
-                double e = exp((double)zr[k] - M);
-                dr[k] = (T)(e * inv_s - e * (double)yr[k] * inv_q);
-            }
+    }
+    const double loss = block_reduce_1024<false>(local, red, &bcast);   // barriers publish q_lds
+    if (dz) {
+        for (int i = tid; i < n; i += blockDim.x) {
+            const double e = (double)e_lds[i];
+            dz[i] = (T)(e * inv_s - e * (double)y[i] * (inv_m / q_lds[i / c]));
         }
     }
-    local = tnn::wave_sum(local);
-    __syncthreads();
-    if (lane == 0) lds[w] = local;
-    __syncthreads();
     if (tid == 0) {
-        double r = 0.0;
-        for (int i = 0; i < nw; ++i) r += lds[i];
-        if (loss_out) loss_out[0] = (T)r;
+        if (loss_out) loss_out[0] = (T)loss;
         if (stats_out) { stats_out[0] = (T)M; stats_out[1] = (T)S; }
     }
 }
@@ -445,7 +442,7 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
     TNN_NEED_INIT();
     TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fused: dtype %d", dtype);
     TNN_REQUIRE(m > 0 && c > 0, "tnn_softmax_nll_fused: empty batch");
-    if (m * c > 65536) {   // too big for one block: the general multi-block sequence
+    if (m * c > kNllMaxElems || m > kNllMaxRows) {   // too big for one block: the multi-block sequence
         void* st = stats_out;
         void* tmp = nullptr;
         if (!st) {
@@ -457,13 +454,13 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
         if (tmp) tnn_free(tmp);
         return rc;
     }
-    int threads = m * c >= 4096 ? 1024 : 256;
+    int threads = m * c >= 512 ? 1024 : 256;
     if (dtype == TNN_F32)
         hipLaunchKernelGGL((nll_fused_kernel<float>), 1, threads, 0, tnn::stream(), (const float*)z,
-                           (const float*)y, m, c, (float*)stats_out, (float*)loss_out, (float*)dz);
+                           (const float*)y, (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz);
     else
         hipLaunchKernelGGL((nll_fused_kernel<double>), 1, threads, 0, tnn::stream(), (const double*)z,
-                           (const double*)y, m, c, (double*)stats_out, (double*)loss_out, (double*)dz);
+                           (const double*)y, (int)m, (int)c, (double*)stats_out, (double*)loss_out, (double*)dz);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -251,14 +251,14 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows, nullptr, loss_out));
         return tnn_mlp_update(handle);
     }
-    // unsharded softmax head: stats + loss + dz in one launch
+    // unsharded softmax head: stats + loss + dz in one launch; the loss goes straight to loss_out
+    // (e.g. one slot of a per-step loss history) or, by default, to the slot behind the gradient arena
     const int L = h->L;
-    void* loss_slot = at(h->grads, h->n_params, h->esz);
+    void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
     MLP_TRY(mlp_forward(h, x, rows));
-    MLP_TRY(tnn_softmax_nll_fused(h->act[L - 1], y, rows, h->w[L], h->stats, loss_slot, h->dact[L - 1],
+    MLP_TRY(tnn_softmax_nll_fused(h->act[L - 1], y, rows, h->w[L], h->stats, loss_dst, h->dact[L - 1],
                                   h->dtype));
     MLP_TRY(mlp_backward_layers(h, x, rows));
-    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return tnn_mlp_update(handle);
 }
 

@@ -124,6 +124,10 @@ class MLPTrainer(object):
         self._lib.mlp_step(self._h, x._ptr, y._ptr, rows, None)
         return self.loss_slot
 
+    def capture_steps(self, batches):
+        """Capture one training step per (x, y) batch into a single replayable hipGraph."""
+        return StepGraph(self, batches)
+
     def _step_dp(self, x, y, rows):
         lib = self._lib
         lib.mlp_forward_stats(self._h, x._ptr, rows, self._stats._ptr)
@@ -150,6 +154,37 @@ class MLPTrainer(object):
             lib.memcpy_d2d(self._y_stage._ptr, y._ptr, y.nbytes)
         self._graph.launch()
         return self.loss_slot
+
+
+class StepGraph(object):
+    """hipGraph of several consecutive training steps, each bound to its own HBM-resident batch.
+
+    A hipGraph bakes kernel arguments in, so replaying ONE captured step on a new batch needs the batch
+    copied into staging buffers first.  When the batches of an epoch already sit in HBM at fixed addresses
+    (row slices of the resident dataset, utils/data_iterator.py:30-33) a whole run of steps can be captured
+    once and replayed with a single hipGraphLaunch: no staging copies and no per-step host work.  Adam's
+    bias-correction state lives on the device, so every replay continues the optimizer correctly.  The loss of
+    step i lands in `losses[i]` (the loss_list of examples/mnist/run.py:84, kept in HBM)."""
+
+    def __init__(self, trainer, batches):
+        if trainer.comm is not None:
+            raise ValueError("StepGraph is the single-GPU path (collectives are not captured)")
+        self.trainer = trainer
+        self.batches = [trainer._prep(x, y) for x, y in batches]      # keeps the buffers alive
+        self.losses = da.empty((len(self.batches),), trainer.dtype)
+        lib, esz = trainer._lib, trainer.dtype.itemsize
+        self._graph = _lib.Graph()
+        with self._graph:
+            for i, (x, y, rows) in enumerate(self.batches):
+                lib.mlp_step(trainer._h, x._ptr, y._ptr, rows, self.losses._ptr + i * esz)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def launch(self):
+        """Run all captured steps (asynchronous); returns the device array of their losses."""
+        self._graph.launch()
+        return self.losses
 
 
 def trainer_from_net(net, max_rows, loss="softmax_nll", optimizer="adam", lr=1e-3, **kwargs):
