@@ -106,6 +106,13 @@ TNN_API int tnn_gemm_mask(int transA, int transB, int64_t M, int64_t N, int64_t 
 TNN_API int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                                const void* G, int64_t ldg, void* dW, int64_t ldc, void* db, int dtype);
 
+/* Backward of one Dense layer y = x w + b given dz = dL/dy (all dense row-major):
+ *   dw[n_in,n_out] = x^T dz (core/ops.py:159-160),  db[n_out] = column-sum dz (:52-54),
+ *   dx[rows,n_in]  = (dz w^T) * !signbit(mask_src[rows,n_in])  (:156-157 + ReLU vjp :342-343); dx may be NULL.
+ * One launch for MNIST-size layers, the three separate kernels otherwise. */
+TNN_API int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz,
+                          const void* w, void* dw, void* db, void* dx, const void* mask_src, int dtype);
+
 /* ------------------------------------------------------------------ elementwise (K2,K3) ------- */
 /* out[shape] = a (op) b with numpy broadcasting expressed as element strides (0 = broadcast dim).
  * ndim <= 6; out is dense row-major of `shape`. */
@@ -182,6 +189,15 @@ TNN_API int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int
  * three-kernel sequence otherwise); stats_out (device [2], may be NULL) receives {M, S}. */
 TNN_API int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, void* stats_out,
                                   void* loss_out, void* dz, int dtype);
+
+/* Classifier head of an unsharded step in one launch (MNIST-size heads: n_classes <= 16, n_hidden % 16 == 0,
+ * the activations fit in LDS; anything else runs as gemm_bias_act + softmax_nll_fused + dense_bwd):
+ *   logits = a w + b (core/layers.py:49), whole-batch softmax NLL -> loss, dz (core/losses.py:24-32),
+ *   dw = a^T dz, db = column-sum dz, da = (dz w^T) * !signbit(a)   (core/ops.py:156-160, :52-54, :342-343).
+ * a is the previous layer's sign-encoded ReLU output; da may be NULL (single-layer net). */
+TNN_API int tnn_mlp_head(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* a, const void* w,
+                         const void* b, const void* y, void* logits, void* dz, void* stats, void* loss,
+                         void* dw, void* db, void* da, int dtype);
 
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global

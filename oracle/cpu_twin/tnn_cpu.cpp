@@ -283,6 +283,15 @@ int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
     return db ? tnn_reduce(TNN_RSUM, G, db, 1, K, N, dtype) : 0;
 }
 
+int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, const void* w,
+                  void* dw, void* db, void* dx, const void* mask_src, int dtype) {
+    NEED_INIT();
+    REQ(dx == nullptr || mask_src != nullptr, "tnn_dense_bwd: dx needs mask_src");
+    if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
+    if (dx) return tnn_gemm_mask(0, 1, rows, n_in, n_out, dz, n_out, w, n_out, mask_src, n_in, dx, n_in, dtype);
+    return 0;
+}
+
 // ---- elementwise ----
 int tnn_ewise_binary(int op, const void* a, const int64_t* sa, const void* b, const int64_t* sb,
                      void* out, int ndim, const int64_t* shape, int dtype) {
@@ -572,6 +581,14 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
     void* st = stats_out ? stats_out : (void*)tmp;
     if (int rc = tnn_softmax_nll_stats(z, m, c, st, dtype)) return rc;
     return tnn_softmax_nll_fwd_bwd(z, y, m, c, m, st, loss_out, dz, dtype);
+}
+int tnn_mlp_head(int64_t rows, int64_t nh, int64_t nc, const void* a, const void* w, const void* b, const void* y,
+                 void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* da, int dtype) {
+    NEED_INIT();
+    REQ(logits && dz && dw && db, "tnn_mlp_head: logits, dz, dw and db buffers are required");
+    if (int rc = tnn_gemm_bias_act(0, 0, rows, nc, nh, a, nh, w, nc, b, TNN_ACT_NONE, 0, logits, nc, dtype)) return rc;
+    if (int rc = tnn_softmax_nll_fused(logits, y, rows, nc, stats, loss, dz, dtype)) return rc;
+    return tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da, a, dtype);
 }
 int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t mg, void* loss_out, void* dpred, int dtype) {
     NEED_INIT();

@@ -214,6 +214,60 @@ def trainer_relu_zero_preactivation():
     assert np.abs(np.asarray(H.dense_layers(model)[0].params["w"].grad)).max() > 0
 
 
+def classifier_head_kernel_vs_numpy():
+    """tnn_mlp_head (one launch on the GPU) against float64 numpy on an awkward shape: 100 rows (not a
+    multiple of 16), 64 hidden units with sign-encoded ReLU zeros, 7 classes, soft labels."""
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    rs = np.random.RandomState(21)
+    m, H, C = 100, 64, 7
+    pre = rs.randn(m, H).astype(np.float32)
+    a = np.where(pre < 0, np.float32(-0.0), np.abs(pre)).astype(np.float32)       # relu with the mask in the sign bit
+    a[3, 5] = 0.0                                                                  # exactly-zero pre-activation: mask = 1
+    w = (rs.randn(H, C) * 0.3).astype(np.float32)
+    b = rs.randn(C).astype(np.float32)
+    y = rs.rand(m, C).astype(np.float32)
+    A, W, B, Y = (tn.asarray(v) for v in (a, w, b, y))
+    logits, dz = tn.empty((m, C)), tn.empty((m, C))
+    stats, loss = tn.empty((2,)), tn.empty(())
+    dw, db, dA = tn.empty((H, C)), tn.empty((C,)), tn.empty((m, H))
+    _lib.get().mlp_head(m, H, C, A._ptr, W._ptr, B._ptr, Y._ptr, logits._ptr, dz._ptr, stats._ptr, loss._ptr,
+                        dw._ptr, db._ptr, dA._ptr, _lib.F32)
+    a64, w64, y64 = a.astype(np.float64), w.astype(np.float64), y.astype(np.float64)
+    z = a64 @ w64 + b
+    e = np.exp(z - z.max()); S = e.sum(); q = (e * y64).sum(1, keepdims=True)
+    ref_loss = (np.log(S) - np.log(q)).sum() / m
+    ref_dz = e / S - (e * y64 / q) / m
+    mask = ~np.signbit(a)
+    np.testing.assert_allclose(np.asarray(logits), z, rtol=0, atol=2e-5 * np.abs(z).max())
+    np.testing.assert_allclose(float(loss), ref_loss, rtol=1e-5)
+    np.testing.assert_allclose(np.asarray(stats), [z.max(), S], rtol=1e-5)
+    np.testing.assert_allclose(np.asarray(dz), ref_dz, rtol=0, atol=1e-5 * np.abs(ref_dz).max())
+    np.testing.assert_allclose(np.asarray(dw), a64.T @ ref_dz, rtol=0, atol=1e-5 * np.abs(a64.T @ ref_dz).max())
+    np.testing.assert_allclose(np.asarray(db), ref_dz.sum(0), rtol=0, atol=1e-5 * np.abs(ref_dz.sum(0)).max() + 1e-9)
+    ref_da = (ref_dz @ w64.T) * mask
+    np.testing.assert_allclose(np.asarray(dA), ref_da, rtol=0, atol=1e-5 * np.abs(ref_da).max())
+    assert mask[3, 5] and np.asarray(dA)[3, 5] != 0.0
+
+
+def dense_backward_one_launch_vs_numpy():
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    rs = np.random.RandomState(22)
+    for rows, n_in, n_out in ((128, 256, 128), (80, 784, 256), (37, 20, 10)):
+        x = rs.randn(rows, n_in).astype(np.float32)
+        pre = rs.randn(rows, n_in).astype(np.float32)
+        msk = np.where(pre < 0, np.float32(-0.0), np.abs(pre)).astype(np.float32)
+        dzv = rs.randn(rows, n_out).astype(np.float32)
+        w = rs.randn(n_in, n_out).astype(np.float32)
+        X, D, W, Mk = (tn.asarray(v) for v in (x, dzv, w, msk))
+        dw, db, dx = tn.empty((n_in, n_out)), tn.empty((n_out,)), tn.empty((rows, n_in))
+        _lib.get().dense_bwd(rows, n_in, n_out, X._ptr, D._ptr, W._ptr, dw._ptr, db._ptr, dx._ptr, Mk._ptr, _lib.F32)
+        x64, d64, w64 = x.astype(np.float64), dzv.astype(np.float64), w.astype(np.float64)
+        for got, ref in ((dw, x64.T @ d64), (db, d64.sum(0)), (dx, (d64 @ w64.T) * ~np.signbit(msk))):
+            np.testing.assert_allclose(np.asarray(got), ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+
+
 # ------------------------------------------------------------------------------------ kernels vs numpy
 def gemm_shapes_and_transposes():
     rs = np.random.RandomState(11)

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "tnn_gemm_mask": [c_int, c_int, c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p,
                       c_int64, _p, c_int64, c_int],
     "tnn_gemm_tn_colsum": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, _p, c_int],
+    "tnn_dense_bwd": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_ewise_binary": [c_int, _p, _i64p, _p, _i64p, _p, c_int, _i64p, c_int],
     "tnn_ewise_scalar": [c_int, _p, c_double, c_int, _p, c_int64, c_int],
     "tnn_ewise_compare": [c_int, _p, _i64p, _p, _i64p, _p, c_int, _i64p, c_int],
@@ -77,6 +78,7 @@ _SIGNATURES = {
     "tnn_lse_merge": [_p, c_int, _p, c_int],
     "tnn_softmax_nll_fwd_bwd": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
     "tnn_softmax_nll_fused": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int],
+    "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],

@@ -17,6 +17,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "tnn_internal.h"
 
 namespace {
@@ -300,19 +302,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <bool AKC, bool BKC, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, float* __restrict__ colsum) {
-    __shared__ float red[WAVES][4][64];
-    __shared__ float bsum[WAVES][64];
+__device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict__ colsum, int block,
+                                           float (*red)[4][64], float (*bsum)[64]) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
-    const int tm = (int)blockIdx.x % g.tiles_m, tn = (int)blockIdx.x / g.tiles_m;
+    const int tm = block % g.tiles_m, tn = block / g.tiles_m;
     const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
     const int64_t am = m0 + i16, bn = n0 + i16;
     const bool a_ok = am < g.M, b_ok = bn < g.N;
     const int nchunks = (int)((g.K + 15) / 16);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
-#pragma unroll 2
     for (int c = wid; c < nchunks; c += WAVES) {
         const int64_t k = (int64_t)c * 16 + grp * 4;
         float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -372,6 +372,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, 
         for (int w = 0; w < WAVES; ++w) s += (bsum[w][tid] + bsum[w][16 + tid]) + (bsum[w][32 + tid] + bsum[w][48 + tid]);
         colsum[n0 + tid] = s;
     }
+}
+
+template <bool AKC, bool BKC, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, float* __restrict__ colsum) {
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    small_tile<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum);
+}
+
+// Backward of one Dense layer in ONE launch: blocks [0, n_dw) compute dW = X^T dZ (TN) + db = colsum(dZ),
+// blocks [n_dw, n_dw + n_dx) compute dX = (dZ W^T) * mask (NT, sign-bit mask epilogue).  The two products
+// only share their input dZ, so they are independent grids fused to save a kernel boundary.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_bwd_small_kernel(GemmArgs gw, float* __restrict__ db,
+                                                                     GemmArgs gx, int n_dw) {
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    if ((int)blockIdx.x < n_dw)
+        small_tile<false, false, WAVES>(gw, db, (int)blockIdx.x, red, bsum);
+    else
+        small_tile<true, true, WAVES>(gx, nullptr, (int)blockIdx.x - n_dw, red, bsum);
 }
 
 template <int WAVES>
@@ -622,6 +643,44 @@ int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldg; g.ldc = ldc;
     g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_AXPBY;
     return gemm_f32(g, 1, 0, (float*)db);
+}
+
+int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, const void* w,
+                  void* dw, void* db, void* dx, const void* mask_src, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(rows > 0 && n_in > 0 && n_out > 0, "tnn_dense_bwd: empty layer");
+    TNN_REQUIRE(dx == nullptr || mask_src != nullptr, "tnn_dense_bwd: dx needs mask_src");
+    if (dtype == TNN_F32 && dx != nullptr) {
+        auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        GemmArgs gw = {}, gx = {};
+        gw.A = (const float*)x; gw.B = (const float*)dz; gw.C = (float*)dw;
+        gw.M = n_in; gw.N = n_out; gw.K = rows; gw.lda = n_in; gw.ldb = n_out; gw.ldc = n_out;
+        gw.alpha = 1.f; gw.beta = 0.f; gw.epi = EPI_AXPBY;
+        gw.vecA = al(x) && n_in % 4 == 0; gw.vecB = al(dz) && n_out % 4 == 0;
+        gx.A = (const float*)dz; gx.B = (const float*)w; gx.C = (float*)dx;
+        gx.M = rows; gx.N = n_in; gx.K = n_out; gx.lda = n_out; gx.ldb = n_out; gx.ldc = n_in;
+        gx.alpha = 1.f; gx.beta = 0.f; gx.epi = EPI_MASK; gx.Y = (const float*)mask_src; gx.ldy = n_in;
+        gx.vecA = al(dz) && n_out % 4 == 0; gx.vecB = al(w) && n_out % 4 == 0;
+        if (use_small_path(gw) && use_small_path(gx)) {
+            gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1;
+            gx.tiles_m = (int)((gx.M + 15) / 16); gx.tiles_n = (int)((gx.N + 15) / 16); gx.splits = 1;
+            int n_dw = gw.tiles_m * gw.tiles_n, n_dx = gx.tiles_m * gx.tiles_n;
+            int nchunks = (int)((std::max(gw.K, gx.K) + 15) / 16);
+            hipStream_t s = tnn::stream();
+            if (nchunks <= 16)
+                hipLaunchKernelGGL((dense_bwd_small_kernel<4>), n_dw + n_dx, 256, 0, s, gw, (float*)db, gx, n_dw);
+            else if (nchunks <= 48)
+                hipLaunchKernelGGL((dense_bwd_small_kernel<8>), n_dw + n_dx, 512, 0, s, gw, (float*)db, gx, n_dw);
+            else
+                hipLaunchKernelGGL((dense_bwd_small_kernel<16>), n_dw + n_dx, 1024, 0, s, gw, (float*)db, gx, n_dw);
+            TNN_LAUNCH_OK();
+            return 0;
+        }
+    }
+    if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
+    if (dx != nullptr)
+        return tnn_gemm_mask(0, 1, rows, n_in, n_out, dz, n_out, w, n_out, mask_src, n_in, dx, n_in, dtype);
+    return 0;
 }
 
 int tnn_gemm_bias_act(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A,

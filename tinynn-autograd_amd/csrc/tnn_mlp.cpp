@@ -10,8 +10,10 @@
 //
 // Per step (L Dense layers, ReLU between them):
 //   forward  : L  x  gemm_bias_act (NN, bias + ReLU fused, ReLU mask kept in the sign bit of 0)
-//   loss     : softmax_nll_fused (sharded: softmax_nll_stats | exchange | softmax_nll_fwd_bwd) or mse_fwd_bwd
-//   backward : L  x  gemm_tn_colsum (dW = X^T dZ and db = column-sum dZ)  +  (L-1) x gemm_mask NT (dX*mask)
+//   head     : mlp_head = last Dense forward + softmax NLL + its backward in one launch (unsharded);
+//              sharded: gemm_bias_act | softmax_nll_stats | exchange | softmax_nll_fwd_bwd | dense_bwd
+//   (loss    : softmax_nll_fused (sharded: softmax_nll_stats | exchange | softmax_nll_fwd_bwd) or mse_fwd_bwd
+//   backward : L  x  dense_bwd (dW = X^T dZ, db = column-sum dZ, dX = (dZ W^T)*mask in one launch when small)
 //   update   : 1  x  fused Adam / SGD over the whole arena
 #include <stdarg.h>
 #include <stdint.h>
@@ -51,9 +53,10 @@ struct Mlp {
 
 inline void* at(char* base, int64_t elem_off, size_t esz) { return base + elem_off * (int64_t)esz; }
 
-int mlp_forward(Mlp* h, const void* x, int64_t rows) {
+int mlp_forward(Mlp* h, const void* x, int64_t rows, int n_layers = -1) {
     const void* in = x;
-    for (int l = 0; l < h->L; ++l) {
+    if (n_layers < 0) n_layers = h->L;
+    for (int l = 0; l < n_layers; ++l) {
         bool hidden = l < h->L - 1;
         MLP_TRY(tnn_gemm_bias_act(0, 0, rows, h->w[l + 1], h->w[l], in, h->w[l],
                                   at(h->params, h->w_off[l], h->esz), h->w[l + 1],
@@ -66,20 +69,14 @@ int mlp_forward(Mlp* h, const void* x, int64_t rows) {
 }
 
 // gradients of every layer from dact[L-1] (set by the loss kernel) down to layer 0
-int mlp_backward_layers(Mlp* h, const void* x, int64_t rows) {
-    for (int l = h->L - 1; l >= 0; --l) {
+int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1) {
+    if (from_layer < 0) from_layer = h->L - 1;
+    for (int l = from_layer; l >= 0; --l) {
         const void* in = l == 0 ? x : h->act[l - 1];
-        void* d = h->dact[l];
-        // dW_l = in^T d (core/ops.py:159-160, A stored [K=rows, M=w[l]]) and db_l = column sum of d
-        // (core/ops.py:52-54) — one launch for MNIST-size layers
-        MLP_TRY(tnn_gemm_tn_colsum(h->w[l], h->w[l + 1], rows, in, h->w[l], d, h->w[l + 1],
-                                   at(h->grads, h->w_off[l], h->esz), h->w[l + 1],
-                                   at(h->grads, h->b_off[l], h->esz), h->dtype));
-        // dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]   (core/ops.py:156-157 + :342-343)
-        if (l > 0)
-            MLP_TRY(tnn_gemm_mask(0, 1, rows, h->w[l], h->w[l + 1], d, h->w[l + 1],
-                                  at(h->params, h->w_off[l], h->esz), h->w[l + 1], h->act[l - 1],
-                                  h->w[l], h->dact[l - 1], h->w[l], h->dtype));
+        // dW_l = in^T d, db_l = column-sum d, dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]  — one launch per layer
+        MLP_TRY(tnn_dense_bwd(rows, h->w[l], h->w[l + 1], in, h->dact[l], at(h->params, h->w_off[l], h->esz),
+                              at(h->grads, h->w_off[l], h->esz), at(h->grads, h->b_off[l], h->esz),
+                              l > 0 ? h->dact[l - 1] : nullptr, l > 0 ? h->act[l - 1] : nullptr, h->dtype));
     }
     return 0;
 }
@@ -255,10 +252,15 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     // (e.g. one slot of a per-step loss history) or, by default, to the slot behind the gradient arena
     const int L = h->L;
     void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
-    MLP_TRY(mlp_forward(h, x, rows));
-    MLP_TRY(tnn_softmax_nll_fused(h->act[L - 1], y, rows, h->w[L], h->stats, loss_dst, h->dact[L - 1],
-                                  h->dtype));
-    MLP_TRY(mlp_backward_layers(h, x, rows));
+    // hidden layers forward; then the classifier head (last Dense forward + loss + its backward) in one
+    // launch; then one launch per remaining layer backward; then the optimizer
+    MLP_TRY(mlp_forward(h, x, rows, L - 1));
+    MLP_TRY(tnn_mlp_head(rows, h->w[L - 1], h->w[L], L > 1 ? h->act[L - 2] : x,
+                         at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
+                         h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
+                         at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                         L > 1 ? h->dact[L - 2] : nullptr, h->dtype));
+    MLP_TRY(mlp_backward_layers(h, x, rows, L - 2));
     return tnn_mlp_update(handle);
 }
 
