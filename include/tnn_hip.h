@@ -209,9 +209,10 @@ TNN_API int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t 
 TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);
 /* Fused Adam on the flat arena, core/optimizer.py:67-79 + core/model.py:59-61:
  *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); p += -lr*(m/(1-b1^t))/(sqrt(v/(1-b2^t))+eps)
- * pows = device double[4] {b1^(t-1), b2^(t-1), ticket, pad}; initialise to {1, 1, 0, 0}.  The call
- * itself advances it (the last block to finish stores b^t), so that a captured hipGraph replays the
- * right bias correction every step without a host-side step counter.  If step_out != NULL
+ * pows = device double[4] {b1^(t-1), b2^(t-1), reserved, reserved}; initialise to {1, 1, 0, 0}.  The call
+ * itself advances it on the device (a one-thread kernel multiplies in b1, b2 before the update reads it), so
+ * that a captured hipGraph replays the right bias correction every step without a host-side step counter.
+ * If step_out != NULL
  * the step is written there and p is left untouched (the reference's _compute_step contract). */
 TNN_API int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
                      double b2, double eps, void* pows_f64, void* step_out, int dtype);

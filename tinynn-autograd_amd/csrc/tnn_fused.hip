@@ -178,59 +178,103 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restri
 // Single-launch whole-batch softmax NLL for small batches (the MNIST head is 128 x 10): one 1024-thread
 // block, element-parallel.  exp(z - M) is evaluated ONCE per element and kept in LDS; the per-row q and the
 // three block reductions (max, sum-exp, loss) go through wave shuffles + one LDS hop each.
-constexpr int kNllMaxElems = 8192, kNllMaxRows = 1024;
+constexpr int kNllMaxRows = 1024;
+// transcendental in the array's own precision (f32: hardware v_exp/v_log based expf/logf, <= 1 ulp; the sums
+// they feed are still accumulated in f64); f64 arrays keep f64 throughout (exact-mode parity)
+__device__ __forceinline__ double nll_exp(float x) { return (double)expf(x); }
+__device__ __forceinline__ double nll_exp(double x) { return exp(x); }
+__device__ __forceinline__ double nll_log(float x) { return (double)logf(x); }
+__device__ __forceinline__ double nll_log(double x) { return log(x); }
+template <typename T> struct NllCap { static constexpr int elems = sizeof(T) == 4 ? 4096 : 2048; };
 
-template <bool IS_MAX>
-__device__ __forceinline__ double block_reduce_1024(double v, double* lds, double* bcast) {
-    v = IS_MAX ? tnn::wave_max(v) : tnn::wave_sum(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();                       // lds/bcast may still be read from the previous reduction
-    if (lane == 0) lds[w] = v;
-    __syncthreads();
-    if (w == 0) {
-        double r = lane < nw ? lds[lane] : (IS_MAX ? -INFINITY : 0.0);
-        r = IS_MAX ? tnn::wave_max(r) : tnn::wave_sum(r);
-        if (lane == 0) *bcast = r;
+// Block reduction tuned for latency (measured on MI355X: a 64-bit __shfl_xor is two ds_bpermute round trips
+// per step and a two-level tree needs three barriers — ~1700 cycles per reduction, and the kernel needs
+// three).  Here the cross-lane tree runs on R (float for f32 arrays: one ds_bpermute per step), every wave
+// leaves one partial in its own LDS slot, ONE barrier follows, and every thread then sums the <= 16 partials
+// itself in f64 (broadcast LDS reads) — no second tree, no broadcast barrier.  Each reduction of a kernel
+// uses its own slot array, so no barrier is needed to recycle them.
+template <bool IS_MAX, typename R>
+__device__ __forceinline__ double block_reduce_fast(R v, R* slots) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        R other = __shfl_xor(v, o, 64);
+        v = IS_MAX ? (other > v ? other : v) : v + other;
     }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) slots[w] = v;
     __syncthreads();
-    return *bcast;
+    // all 16 slots are fetched with independent loads issued back to back (a dependent 16-iteration loop of
+    // LDS reads alone measured ~1100 cycles); slots beyond nw hold the reduction's identity
+    R part[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[i] = slots[i];
+    double r = (double)part[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        const double x = (double)part[i];
+        if (i < nw) r = IS_MAX ? (x > r ? x : r) : r + x;
+    }
+    return r;
 }
 
+// z and y are fetched ONCE, up front and coalesced, into LDS; every later phase touches only LDS, so the
+// kernel has a single global-memory round trip before its final store.
 template <typename T>
 __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z, const T* __restrict__ y,
                                                          int m, int c, T* __restrict__ stats_out,
                                                          T* __restrict__ loss_out, T* __restrict__ dz) {
-    __shared__ T e_lds[kNllMaxElems];
+    constexpr int kMax = NllCap<T>::elems;
+    __shared__ T e_lds[kMax];              // z -> exp(z - M)
+    __shared__ T y_lds[kMax];              // y -> e * y
     __shared__ double q_lds[kNllMaxRows];
-    __shared__ double red[16];
-    __shared__ double bcast;
+    __shared__ T red_max[16], red_sum[16], red_loss[16];
     const int tid = threadIdx.x, n = m * c;
-    double mx = -INFINITY;
+    T mx = -INFINITY;
     for (int i = tid; i < n; i += blockDim.x) {
-        double v = (double)z[i];
-        mx = v > mx ? v : mx;
+        const T zi = z[i];
+        y_lds[i] = y[i];
+        e_lds[i] = zi;
+        mx = zi > mx ? zi : mx;
     }
-    const double M = block_reduce_1024<true>(mx, red, &bcast);
+    const double M = block_reduce_fast<true, T>(mx, red_max);   // exact: a max of T values
+    const T Mt = (T)M;
     double s = 0.0;
     for (int i = tid; i < n; i += blockDim.x) {
-        double e = exp((double)z[i] - M);
+        const double e = nll_exp((T)(e_lds[i] - Mt));
         e_lds[i] = (T)e;
+        y_lds[i] = (T)((double)(T)e * (double)y_lds[i]);
         s += e;
     }
-    const double S = block_reduce_1024<false>(s, red, &bcast);      // its barriers also publish e_lds
-    const double log_s = log(S), inv_s = 1.0 / S, inv_m = 1.0 / (double)m;
+    const double S = block_reduce_fast<false, T>((T)s, red_sum);    // its barrier also publishes e/y_lds
+    __shared__ double scal[2];
+    if (tid == 0) { scal[0] = log(S); scal[1] = 1.0 / S; }           // once, not once per wave
+    const double inv_m = 1.0 / (double)m;
     double local = 0.0;
     for (int r = tid; r < m; r += blockDim.x) {
         double q = 0.0;
-        for (int k = 0; k < c; ++k) q += (double)e_lds[r * c + k] * (double)y[r * c + k];
-        q_lds[r] = q;
-        local += (log_s - log(q)) * inv_m;
+        if (c <= 16) {                       // classifier heads: the row's values in independent LDS reads
+            T row[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) row[k] = k < c ? y_lds[r * c + k] : T(0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) q += (double)row[k];
+        } else {
+            for (int k = 0; k < c; ++k) q += (double)y_lds[r * c + k];
+        }
+        q_lds[r] = sizeof(T) == 4 ? (double)((float)inv_m / (float)q) : inv_m / q;
+        local -= nll_log((T)q);
     }
-    const double loss = block_reduce_1024<false>(local, red, &bcast);   // barriers publish q_lds
+    const double sum_log_q = block_reduce_fast<false, T>((T)local, red_loss);   // barrier publishes q_lds, scal
+    const double loss = scal[0] + sum_log_q * inv_m;                          // log S - mean(log q)
+    const double inv_s = scal[1];
     if (dz) {
-        for (int i = tid; i < n; i += blockDim.x) {
-            const double e = (double)e_lds[i];
-            dz[i] = (T)(e * inv_s - e * (double)y[i] * (inv_m / q_lds[i / c]));
+        if (sizeof(T) == 4) {
+            const float inv_sf = (float)inv_s;
+            for (int i = tid; i < n; i += blockDim.x)
+                dz[i] = (T)((float)e_lds[i] * inv_sf - (float)y_lds[i] * (float)q_lds[i / c]);
+        } else {
+            for (int i = tid; i < n; i += blockDim.x)
+                dz[i] = (T)((double)e_lds[i] * inv_s - (double)y_lds[i] * q_lds[i / c]);
         }
     }
     if (tid == 0) {
@@ -286,18 +330,22 @@ __global__ __launch_bounds__(kThreads) void sgd_kernel(T* __restrict__ p, const 
 }
 
 // Adam, core/optimizer.py:67-79, one pass: read p,g,m,v / write p,m,v = 28 B per fp32 parameter.
-// state (device, f64): [0] = b1^(t-1), [1] = b2^(t-1), [2] = ticket counter (as raw uint64).
-// Every block reads state first; the LAST block to finish (atomic ticket) writes b^t back, so the
-// next launch — eager or replayed from a hipGraph — sees the advanced powers.  Nobody reads the
-// updated words inside the same launch, so no intra-launch visibility protocol is needed.
+// state (device, f64): [0] = b1^t, [1] = b2^t of the CURRENT step, advanced on the device by
+// adam_advance_kernel (one thread) right before this kernel, so that a captured hipGraph replays the right
+// bias correction without any host-side step counter.  (A first version advanced the state inside this
+// kernel with an atomic ticket per block: 230 same-address atomics cost ~3 us, more than the whole update.)
+__global__ void adam_advance_kernel(double* __restrict__ state, double b1, double b2) {
+    state[0] *= b1;
+    state[1] *= b2;
+}
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(kThreads) void adam_kernel(T* __restrict__ p, const T* __restrict__ g,
                                                         T* __restrict__ m, T* __restrict__ v,
                                                         int64_t n, T lr, T b1, T b2, T eps,
-                                                        double b1d, double b2d,
-                                                        double* __restrict__ state,
+                                                        const double* __restrict__ state,
                                                         T* __restrict__ step_out) {
-    const double p1 = state[0] * b1d, p2 = state[1] * b2d;
+    const double p1 = state[0], p2 = state[1];
     const T inv_c1 = (T)(1.0 / (1.0 - p1)), inv_c2 = (T)(1.0 / (1.0 - p2));
     const T one_m_b1 = T(1) - b1, one_m_b2 = T(1) - b2;
     int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -341,16 +389,6 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(T* __restrict__ p, const
             T s = upd(g[i], mi, vi);
             m[i] = mi; v[i] = vi;
             if (step_out) step_out[i] = s; else p[i] = p[i] + s;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(state + 2);
-        unsigned long long t = atomicAdd(ticket, 1ULL);
-        if (t == (unsigned long long)gridDim.x - 1) {
-            state[0] = p1;
-            state[1] = p2;
-            *ticket = 0ULL;
         }
     }
 }
@@ -442,7 +480,7 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
     TNN_NEED_INIT();
     TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fused: dtype %d", dtype);
     TNN_REQUIRE(m > 0 && c > 0, "tnn_softmax_nll_fused: empty batch");
-    if (m * c > kNllMaxElems || m > kNllMaxRows) {   // too big for one block: the multi-block sequence
+    if (m * c > (dtype == TNN_F32 ? NllCap<float>::elems : NllCap<double>::elems) || m > kNllMaxRows) {   // too big for one block: the multi-block sequence
         void* st = stats_out;
         void* tmp = nullptr;
         if (!st) {
@@ -511,6 +549,7 @@ int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, dou
     if (n <= 0) return 0;
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam: pows state is NULL");
     hipStream_t s = tnn::stream();
+    hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
     if (dtype == TNN_F32) {
         bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                      reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
@@ -518,16 +557,16 @@ int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, dou
         unsigned grid = tnn::stream_grid(vec ? (n + 3) / 4 : n, kThreads);
         if (vec)
             hipLaunchKernelGGL((adam_kernel<float, 4>), grid, kThreads, 0, s, (float*)p, (const float*)g,
-                               (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps, b1,
-                               b2, (double*)pows_f64, (float*)step_out);
+                               (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps,
+                               (const double*)pows_f64, (float*)step_out);
         else
             hipLaunchKernelGGL((adam_kernel<float, 1>), grid, kThreads, 0, s, (float*)p, (const float*)g,
-                               (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps, b1,
-                               b2, (double*)pows_f64, (float*)step_out);
+                               (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps,
+                               (const double*)pows_f64, (float*)step_out);
     } else if (dtype == TNN_F64) {
         unsigned grid = tnn::stream_grid(n, kThreads);
         hipLaunchKernelGGL((adam_kernel<double, 1>), grid, kThreads, 0, s, (double*)p, (const double*)g,
-                           (double*)m, (double*)v, n, lr, b1, b2, eps, b1, b2, (double*)pows_f64,
+                           (double*)m, (double*)v, n, lr, b1, b2, eps, (const double*)pows_f64,
                            (double*)step_out);
     } else {
         tnn::set_error("tnn_adam: dtype %d is not a float type", dtype);

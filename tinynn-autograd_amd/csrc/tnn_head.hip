@@ -5,6 +5,10 @@
 //     M, S, loss, dz = whole-batch softmax NLL      core/losses.py:24-32
 //     dW = a^T dz,  db = column-sum dz              core/ops.py:159-160, :52-54
 //     da = (dz W^T) * [pre-activation >= 0]         core/ops.py:156-157, :342-343 (mask = sign bit of a)
+// MEASURED (MI355X): 14.7 us as one launch vs 2.4 + 5.3 + 2.8 us for the three-launch sequence below it —
+// a single workgroup pays every phase's LDS / barrier / load latency serially on one CU, while multi-block
+// kernels of this size cost only ~0.3-1 us over the 1.6 us launch floor.  The fused form is therefore OFF by
+// default (TNN_HEAD_FUSION=1 enables it; it stays parity-tested) and the entry point runs the sequence.
 // One 1024-thread workgroup on one CU; a, W, z/e/dz live in LDS (dynamic, up to ~120 KiB of the 160 KiB);
 // the three small GEMMs run on v_mfma_f32_16x16x4_f32 out of LDS, the softmax part is element-parallel.
 //   a  : [m, H]  H % 16 == 0 (rows padded to 16 in LDS with zeros)      W : [H, C], C <= 16 (padded to 16)
@@ -48,9 +52,10 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
     float* a_s = reinterpret_cast<float*>(smem);         // [mp][SA]
     float* w_s = a_s + (size_t)mp * SA;                  // [H][16]
     float* z_s = w_s + (size_t)H * kCP;                  // [mp][16]  logits -> exp -> dz (in place)
-    double* q_s = reinterpret_cast<double*>(z_s + (size_t)mp * kCP);   // [mp]
-    double* red = q_s + mp;                              // [16]
-    double* bcast = red + 16;
+    float* y_s = z_s + (size_t)mp * kCP;                 // [mp][16]  labels -> e * y
+    double* q_s = reinterpret_cast<double*>(y_s + (size_t)mp * kCP);   // [mp]
+    double* red = q_s + mp;                              // [16] wave partials + [4] block scalars
+    double* bcast = red + 20;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
@@ -67,21 +72,27 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
         const int h = f >> 4, c = f & 15;
         w_s[f] = c < C ? p.w[(size_t)h * C + c] : 0.f;
     }
+    for (int f = tid; f < mp * kCP; f += kThreads) {          // labels too: no global reads after this point
+        const int r = f >> 4, c = f & 15;
+        y_s[f] = (r < m && c < C) ? p.y[(size_t)r * C + c] : 0.f;
+    }
     __syncthreads();
 
     // ---- z = a W + b : one 16-row tile per wave iteration, K = H
     const int row_tiles = mp / 16;
     for (int t = wid; t < row_tiles; t += kThreads / 64) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // two chains hide the 40-cycle MFMA latency
         const float* arow = a_s + (size_t)(t * 16 + i16) * SA + grp * 4;
+#pragma unroll 4
         for (int k = 0; k < H; k += 16) {
             const float4 av = *reinterpret_cast<const float4*>(arow + k);
             const float* wp = w_s + (size_t)(k + grp * 4) * kCP + i16;
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wp[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wp[kCP], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wp[kCP], acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wp[2 * kCP], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wp[3 * kCP], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wp[3 * kCP], acc2, 0, 0, 0);
         }
+        acc += acc2;
         const float bias = i16 < C ? p.b[i16] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -101,35 +112,39 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
         if (r < m && c < C) { double v = (double)z_s[f]; mx = v > mx ? v : mx; }
     }
     const double M = block_reduce<true>(mx, red, bcast);
+    const float Mf = (float)M;
     double s = 0.0;
     for (int f = tid; f < n16; f += kThreads) {
         const int r = f >> 4, c = f & 15;
         float e = 0.f;
-        if (r < m && c < C) { double ed = exp((double)z_s[f] - M); e = (float)ed; s += ed; }
+        if (r < m && c < C) { e = expf(z_s[f] - Mf); s += (double)e; }   // f32 exp, f64 accumulation
         z_s[f] = e;                                            // exp values replace the logits
+        y_s[f] = e * y_s[f];                                   // e * y (zero in the padding)
     }
     const double S = block_reduce<false>(s, red, bcast);
-    const double log_s = log(S), inv_s = 1.0 / S, inv_m = 1.0 / (double)m;
+    if (tid == 0) { red[18] = log(S); red[19] = 1.0 / S; }    // scalars once per block (slots beyond the 16 waves' use)
+    const double inv_m = 1.0 / (double)m;
     double local = 0.0;
     for (int r = tid; r < mp; r += kThreads) {
-        double q = 1.0;
+        double qinv = 0.0;
         if (r < m) {
-            q = 0.0;
-            for (int c = 0; c < C; ++c) q += (double)z_s[r * kCP + c] * (double)p.y[(size_t)r * C + c];
-            local += (log_s - log(q)) * inv_m;
+            double q = 0.0;
+#pragma unroll
+            for (int c = 0; c < kCP; ++c) q += (double)y_s[r * kCP + c];
+            local -= (double)logf((float)q);
+            qinv = inv_m / q;
         }
-        q_s[r] = q;
+        q_s[r] = qinv;
     }
-    const double loss = block_reduce<false>(local, red, bcast);
+    __syncthreads();
+    const double log_s = red[18];
+    const float inv_s = (float)red[19];
+    const double loss = log_s + block_reduce<false>(local, red, bcast) * inv_m;   // log S - mean(log q)
     for (int f = tid; f < n16; f += kThreads) {
+        const float d = z_s[f] * inv_s - y_s[f] * (float)q_s[f >> 4];               // 0 in the padding
         const int r = f >> 4, c = f & 15;
-        float d = 0.f;
-        if (r < m && c < C) {
-            const double e = (double)z_s[f];
-            d = (float)(e * inv_s - e * (double)p.y[(size_t)r * C + c] * (inv_m / q_s[r]));
-            if (p.dz) p.dz[(size_t)r * C + c] = d;
-        }
-        z_s[f] = d;                                            // dz replaces the exp values (zero padded)
+        if (p.dz && r < m && c < C) p.dz[(size_t)r * C + c] = d;
+        z_s[f] = d;                                            // dz replaces the exp values
     }
     if (tid == 0) {
         if (p.loss) p.loss[0] = (float)loss;
@@ -140,14 +155,17 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
     // ---- dW = a^T dz  (M = H, N = 16, K = rows), db = column sums of dz
     const int h_tiles = H / 16;
     for (int t = wid; t < h_tiles; t += kThreads / 64) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
         for (int k = 0; k < mp; k += 16) {
             const float* ap = a_s + (size_t)(k + grp * 4) * SA + t * 16 + i16;     // a[k+4g+j][h0+i]
             const float* dp = z_s + (size_t)(k + grp * 4) * kCP + i16;             // dz[k+4g+j][c=i]
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[j * SA], dp[j * kCP], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], dp[0], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[SA], dp[kCP], acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[2 * SA], dp[2 * kCP], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[3 * SA], dp[3 * kCP], acc2, 0, 0, 0);
         }
+        acc += acc2;
         if (i16 < C) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) p.dw[(size_t)(t * 16 + grp * 4 + r) * C + i16] = acc[r];
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
 
 size_t head_lds_bytes(int64_t m, int64_t H) {
     int64_t mp = (m + 15) & ~int64_t(15);
-    return (size_t)(mp * (H + 4) + H * kCP + mp * kCP) * 4 + (size_t)(mp + 16 + 2) * 8;
+    return (size_t)(mp * (H + 4) + H * kCP + 2 * mp * kCP) * 4 + (size_t)(mp + 20 + 2) * 8;
 }
 
 bool g_attr_set = false;
@@ -203,7 +221,7 @@ int tnn_mlp_head(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* 
                 "tnn_mlp_head: logits, dz, dw and db buffers are required");
     const bool aligned = ((reinterpret_cast<uintptr_t>(a)) & 15) == 0;
     const bool fused = dtype == TNN_F32 && n_classes <= kCP && n_hidden % 16 == 0 && aligned &&
-                       head_lds_bytes(rows, n_hidden) <= 120 * 1024 && getenv("TNN_NO_HEAD_FUSION") == nullptr;
+                       head_lds_bytes(rows, n_hidden) <= 120 * 1024 && getenv("TNN_HEAD_FUSION") != nullptr;
     if (fused) {
         size_t lds = head_lds_bytes(rows, n_hidden);
         if (!g_attr_set) {
