@@ -75,7 +75,12 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
     return base + local;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC>
+// VEC = both operands allow 16-B loads (aligned base, leading dimension and contiguous extent multiples
+// of 4): the main loop is then branch-free — per-thread source pointers, row-validity flags and LDS
+// offsets are computed once before the loop, out-of-range rows read a clamped (valid) address and are
+// zeroed with a select, and only the last, partial K-tile goes through the guarded element-wise loader.
+// VEC = false is the fully guarded element-wise variant for odd shapes / unaligned views.
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -103,99 +108,115 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
     const int64_t kend = min(g.K, kbeg + g.k_per_split);
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    const int nk_full = (int)((kend - kbeg) / BK);      // tiles that need no K guard
+
+    // ---- per-thread staging geometry, fixed for the whole K loop
+    // element (row, c4) of the tile: KC operand -> row = m/n index, c4 = k/4;  MN-contig -> row = k, c4 = m/4
+    const float* a_src[A_F4];
+    const float* b_src[B_F4];
+    int a_dst[A_F4], b_dst[B_F4];
+    int a_row[A_F4], a_c4[A_F4], b_row[B_F4], b_c4[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) {
+        const int f = tid + i * NT;
+        a_row[i] = AKC ? f / (BK / 4) : f / (BM / 4);
+        a_c4[i] = AKC ? f % (BK / 4) : f % (BM / 4);
+        a_dst[i] = a_row[i] * SA + a_c4[i] * 4;
+        if constexpr (AKC) {
+            const int64_t gm = m0 + a_row[i];
+            a_src[i] = g.A + (gm < g.M ? gm : 0) * g.lda + kbeg + a_c4[i] * 4;
+        } else {
+            const int64_t gm = m0 + a_c4[i] * 4;       // VEC: M % 4 == 0, a float4 is wholly in or out of range
+            a_src[i] = g.A + (kbeg + a_row[i]) * g.lda + (gm < g.M ? gm : 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) {
+        const int f = tid + i * NT;
+        b_row[i] = BKC ? f / (BK / 4) : f / (BN / 4);
+        b_c4[i] = BKC ? f % (BK / 4) : f % (BN / 4);
+        b_dst[i] = b_row[i] * SB + b_c4[i] * 4;
+        if constexpr (BKC) {
+            const int64_t gn = n0 + b_row[i];
+            b_src[i] = g.B + (gn < g.N ? gn : 0) * g.ldb + kbeg + b_c4[i] * 4;
+        } else {
+            const int64_t gn = n0 + b_c4[i] * 4;
+            b_src[i] = g.B + (kbeg + b_row[i]) * g.ldb + (gn < g.N ? gn : 0);
+        }
+    }
+    const int64_t a_step = AKC ? (int64_t)BK : (int64_t)BK * g.lda;   // pointer advance per K-tile
+    const int64_t b_step = BKC ? (int64_t)BK : (int64_t)BK * g.ldb;
 
     float4 ra[A_F4], rb[B_F4];
 
-    auto load_tile = [&](int64_t k0) {
+    // fast loader: full K-tile, 16-B loads, no branches and NO use of the loaded value (a select here would
+    // put an s_waitcnt right behind the loads and expose the whole global latency before the MFMAs).  Rows /
+    // columns beyond M / N read a clamped, valid address: what they load only ever reaches accumulator rows /
+    // columns >= M / N, which the epilogue never stores (an output row depends on its own A row only).
+    auto load_full = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_F4; ++i)
+            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (int64_t)kt * a_step);
+#pragma unroll
+        for (int i = 0; i < B_F4; ++i)
+            rb[i] = *reinterpret_cast<const float4*>(b_src[i] + (int64_t)kt * b_step);
+    };
+    // guarded loader: element-wise bounds on every axis (K tail, odd shapes, unaligned operands)
+    auto load_guarded = [&](int kt) {
+        const int64_t k0 = kbeg + (int64_t)kt * BK;
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            int f = tid + i * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (AKC) {
-                int row = f / (BK / 4), c4 = f % (BK / 4);
-                int64_t gm = m0 + row, gk = k0 + c4 * 4;
-                const float* p = g.A + gm * g.lda + gk;
+                const int64_t gm = m0 + a_row[i], gk = k0 + a_c4[i] * 4;
                 if (gm < g.M) {
-                    if (g.vecA) {
-                        if (gk < kend) v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (gk + 0 < kend) v.x = p[0];
-                        if (gk + 1 < kend) v.y = p[1];
-                        if (gk + 2 < kend) v.z = p[2];
-                        if (gk + 3 < kend) v.w = p[3];
-                    }
+                    const float* p = g.A + gm * g.lda + gk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gk + j < kend) e[j] = p[j];
                 }
             } else {
-                int row = f / (BM / 4), c4 = f % (BM / 4);
-                int64_t gk = k0 + row, gm = m0 + c4 * 4;
-                const float* p = g.A + gk * g.lda + gm;
+                const int64_t gk = k0 + a_row[i], gm = m0 + a_c4[i] * 4;
                 if (gk < kend) {
-                    if (g.vecA) {
-                        if (gm < g.M) v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (gm + 0 < g.M) v.x = p[0];
-                        if (gm + 1 < g.M) v.y = p[1];
-                        if (gm + 2 < g.M) v.z = p[2];
-                        if (gm + 3 < g.M) v.w = p[3];
-                    }
+                    const float* p = g.A + gk * g.lda + gm;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gm + j < g.M) e[j] = p[j];
                 }
             }
-            ra[i] = v;
+            ra[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            int f = tid + i * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float e[4] = {0.f, 0.f, 0.f, 0.f};
             if constexpr (BKC) {
-                int row = f / (BK / 4), c4 = f % (BK / 4);
-                int64_t gn = n0 + row, gk = k0 + c4 * 4;
-                const float* p = g.B + gn * g.ldb + gk;
+                const int64_t gn = n0 + b_row[i], gk = k0 + b_c4[i] * 4;
                 if (gn < g.N) {
-                    if (g.vecB) {
-                        if (gk < kend) v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (gk + 0 < kend) v.x = p[0];
-                        if (gk + 1 < kend) v.y = p[1];
-                        if (gk + 2 < kend) v.z = p[2];
-                        if (gk + 3 < kend) v.w = p[3];
-                    }
+                    const float* p = g.B + gn * g.ldb + gk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gk + j < kend) e[j] = p[j];
                 }
             } else {
-                int row = f / (BN / 4), c4 = f % (BN / 4);
-                int64_t gk = k0 + row, gn = n0 + c4 * 4;
-                const float* p = g.B + gk * g.ldb + gn;
+                const int64_t gk = k0 + b_row[i], gn = n0 + b_c4[i] * 4;
                 if (gk < kend) {
-                    if (g.vecB) {
-                        if (gn < g.N) v = *reinterpret_cast<const float4*>(p);
-                    } else {
-                        if (gn + 0 < g.N) v.x = p[0];
-                        if (gn + 1 < g.N) v.y = p[1];
-                        if (gn + 2 < g.N) v.z = p[2];
-                        if (gn + 3 < g.N) v.w = p[3];
-                    }
+                    const float* p = g.B + gk * g.ldb + gn;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gn + j < g.N) e[j] = p[j];
                 }
             }
-            rb[i] = v;
+            rb[i] = make_float4(e[0], e[1], e[2], e[3]);
         }
+    };
+    auto load_tile = [&](int kt) {
+        if (VEC && kt < nk_full) load_full(kt);
+        else load_guarded(kt);
     };
 
     auto store_tile = [&](int buf) {
         float* As = lds + buf * (A_ELEMS + B_ELEMS);
         float* Bs = As + A_ELEMS;
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) {
-            int f = tid + i * NT;
-            int row = AKC ? f / (BK / 4) : f / (BM / 4);
-            int c4 = AKC ? f % (BK / 4) : f % (BM / 4);
-            *reinterpret_cast<float4*>(As + row * SA + c4 * 4) = ra[i];
-        }
+        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4*>(As + a_dst[i]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_F4; ++i) {
-            int f = tid + i * NT;
-            int row = BKC ? f / (BK / 4) : f / (BN / 4);
-            int c4 = BKC ? f % (BK / 4) : f % (BN / 4);
-            *reinterpret_cast<float4*>(Bs + row * SB + c4 * 4) = rb[i];
-        }
+        for (int i = 0; i < B_F4; ++i) *reinterpret_cast<float4*>(Bs + b_dst[i]) = rb[i];
     };
 
     f32x16 acc[MI][NI];
@@ -206,15 +227,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // LDS fragment base offsets (floats), fixed for the whole loop
+    const int a_frag = AKC ? (wm * TM + l31) * SA + lhi * 4 : (lhi * 4) * SA + wm * TM + l31;
+    const int b_frag = BKC ? (wn * TN + l31) * SB + lhi * 4 : (lhi * 4) * SB + wn * TN + l31;
+
     if (nk > 0) {
-        load_tile(kbeg);
+        load_tile(0);
         store_tile(0);
     }
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kbeg + (int64_t)(kt + 1) * BK);   // in flight during the MFMAs
+        if (kt + 1 < nk) load_tile(kt + 1);              // in flight during the MFMAs
         const float* As = lds + cur * (A_ELEMS + B_ELEMS);
         const float* Bs = As + A_ELEMS;
 #pragma unroll
@@ -223,25 +248,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 if constexpr (AKC) {
-                    float4 v = *reinterpret_cast<const float4*>(
-                        As + (wm * TM + i * 32 + l31) * SA + kk * 8 + lhi * 4);
+                    float4 v = *reinterpret_cast<const float4*>(As + a_frag + i * 32 * SA + kk * 8);
                     af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        af[i][j] = As[(kk * 8 + lhi * 4 + j) * SA + wm * TM + i * 32 + l31];
+                    for (int j = 0; j < 4; ++j) af[i][j] = As[a_frag + (kk * 8 + j) * SA + i * 32];
                 }
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 if constexpr (BKC) {
-                    float4 v = *reinterpret_cast<const float4*>(
-                        Bs + (wn * TN + i * 32 + l31) * SB + kk * 8 + lhi * 4);
+                    float4 v = *reinterpret_cast<const float4*>(Bs + b_frag + i * 32 * SB + kk * 8);
                     bf[i][0] = v.x; bf[i][1] = v.y; bf[i][2] = v.z; bf[i][3] = v.w;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        bf[i][j] = Bs[(kk * 8 + lhi * 4 + j) * SB + wn * TN + i * 32 + l31];
+                    for (int j = 0; j < 4; ++j) bf[i][j] = Bs[b_frag + (kk * 8 + j) * SB + i * 32];
                 }
             }
 #pragma unroll
@@ -516,14 +537,19 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n), 1, (unsigned)splits);
     constexpr int NT = WM * WN * 64;
     hipStream_t s = tnn::stream();
-    if (!transA && !transB)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, true, false>), grid, NT, 0, s, g);
-    else if (!transA && transB)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, true, true>), grid, NT, 0, s, g);
-    else if (transA && !transB)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, false, false>), grid, NT, 0, s, g);
-    else
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, false, true>), grid, NT, 0, s, g);
+    const bool vec = g.vecA && g.vecB;
+#define TNN_LAUNCH_GEMM(AKC, BKC)                                                                          \
+    do {                                                                                                   \
+        if (vec)                                                                                           \
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AKC, BKC, true>), grid, NT, 0, s, g); \
+        else                                                                                               \
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AKC, BKC, false>), grid, NT, 0, s, g); \
+    } while (0)
+    if (!transA && !transB) TNN_LAUNCH_GEMM(true, false);
+    else if (!transA && transB) TNN_LAUNCH_GEMM(true, true);
+    else if (transA && !transB) TNN_LAUNCH_GEMM(false, false);
+    else TNN_LAUNCH_GEMM(false, true);
+#undef TNN_LAUNCH_GEMM
     if (splits > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, tnn::stream_grid(g.M * g.N, 256), 256, 0, s, g);
         tnn_free(ws);
@@ -546,24 +572,24 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     int cfg = -1, splits = 0;
     if (const char* e = getenv("TNN_GEMM_CFG")) cfg = atoi(e);       // tuning override
     if (const char* e = getenv("TNN_GEMM_SPLITK")) splits = atoi(e);
-    int64_t t128 = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-    int64_t t64x128 = ((g.M + 63) / 64) * ((g.N + 127) / 128);
+    // Measured on MI355X (tools/gemm_sweep.py, 512x4096x4096 NN/NT and 4096x4096x512 TN): the 128x64 tile
+    // (4 waves of 64x32, 52 KB LDS, 3 workgroups per CU) is the fastest of the four on every layout
+    // (100-105 TFLOP/s); 64x64 only wins when the problem has too few 128x64 tiles to occupy the chip.
+    int64_t t128x64 = ((g.M + 127) / 128) * ((g.N + 63) / 64);
     int64_t t64 = ((g.M + 63) / 64) * ((g.N + 63) / 64);
-    if (cfg < 0) {
-        if (t128 >= cus) cfg = 0;
-        else if (t64x128 >= cus) cfg = 1;
-        else cfg = 2;
-    }
+    if (cfg < 0) cfg = (t128x64 >= cus / 2) ? 3 : 2;
     if (splits <= 0) {
         splits = 1;
-        int64_t tiles = cfg == 0 ? t128 : cfg == 1 ? t64x128 : t64;
-        if (tiles < cus) {
-            // fill the chip: about one block per CU, at least 2 K-tiles (64 deep) per split
-            splits = (int)((cus + tiles - 1) / tiles);
-            int64_t max_splits = g.K / 64;
+        int64_t tiles = cfg == 3 ? t128x64 : cfg == 2 ? t64 : cfg == 0 ? ((g.M + 127) / 128) * ((g.N + 127) / 128)
+                                                              : ((g.M + 63) / 64) * ((g.N + 127) / 128);
+        if (tiles < 2 * cus) {
+            // aim at >= 2 workgroups per CU, keeping >= 8 K-tiles (256 deep) per split so that the extra
+            // reduce pass (M*N*splits*4 B of traffic) stays small next to the GEMM itself
+            splits = (int)((2 * cus + tiles - 1) / tiles);
+            int64_t max_splits = g.K / 256;
             if (splits > max_splits) splits = (int)max_splits;
             if (splits < 1) splits = 1;
-            if (splits > 32) splits = 32;
+            if (splits > 16) splits = 16;
         }
     }
     switch (cfg) {
