@@ -230,52 +230,150 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // LDS fragment base offsets (floats), fixed for the whole loop
     const int a_frag = AKC ? (wm * TM + l31) * SA + lhi * 4 : (lhi * 4) * SA + wm * TM + l31;
     const int b_frag = BKC ? (wn * TN + l31) * SB + lhi * 4 : (lhi * 4) * SB + wn * TN + l31;
+    constexpr int KK = BK / 8;
 
+    // Fragment registers: one slot per 8-deep chunk of the K-tile, filled TWO chunks ahead of their MFMAs.
+    float af[KK][MI][4], bf[KK][NI][4];
+    auto read_frag = [&](int buf, int kk) {
+        const float* As = lds + buf * (A_ELEMS + B_ELEMS);
+        const float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (AKC) {
+                float4 v = *reinterpret_cast<const float4*>(As + a_frag + i * 32 * SA + kk * 8);
+                af[kk][i][0] = v.x; af[kk][i][1] = v.y; af[kk][i][2] = v.z; af[kk][i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[kk][i][j] = As[a_frag + (kk * 8 + j) * SA + i * 32];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if constexpr (BKC) {
+                float4 v = *reinterpret_cast<const float4*>(Bs + b_frag + i * 32 * SB + kk * 8);
+                bf[kk][i][0] = v.x; bf[kk][i][1] = v.y; bf[kk][i][2] = v.z; bf[kk][i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bf[kk][i][j] = Bs[b_frag + (kk * 8 + j) * SB + i * 32];
+            }
+        }
+    };
+    auto mfma_chunk = [&](int kk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][mi][j], bf[kk][ni][j],
+                                                                       acc[mi][ni], 0, 0, 0);
+    };
+
+    // Software pipeline — one barrier per K-tile and no exposed LDS or global latency in steady state.
+    // Chunk c runs the MFMAs of fragment c and, BEFORE them, issues the LDS reads of the fragment used two
+    // chunks later (sched_barrier(0) pins "memory ops first, then the chunk's MFMAs": left alone hipcc sinks
+    // the reads below the MFMAs and then drains them in front of the barrier):
+    //   chunk 0 : write tile kt+1 to the other buffer (its global loads were issued a whole tile ago),
+    //             issue the global loads of tile kt+2, read F(kt,2)                       | MFMA F(kt,0)
+    //   chunk 1 : read F(kt,3) (right behind the chunk's first MFMA)                      | MFMA F(kt,1)
+    //   ---- s_barrier ---- every LDS op issued so far is several MFMAs old: (almost) nothing to drain
+    //   chunk 2 : read F(kt+1,0) from the other buffer                                    | MFMA F(kt,2)
+    //   chunk 3 : read F(kt+1,1)                                                          | MFMA F(kt,3)
+    // Hazards: the buffer written in chunk 0 of tile kt was last read in chunks 0-1 of tile kt-1, i.e. before
+    // the barrier of tile kt-1 that every wave has passed; it is first read after the barrier of tile kt,
+    // which every wave reaches after its own writes.
+    static_assert(KK == 4, "the pipeline below is written for BK = 32");
     if (nk > 0) {
         load_tile(0);
         store_tile(0);
+        if (nk > 1) load_tile(1);
     }
     __syncthreads();
+    if (nk > 0) {
+        read_frag(0, 0);
+        read_frag(0, 1);
+    }
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // Interleave pattern for one chunk: each MFMA (64 cycles on the pipe) is followed by a few of the chunk's
+    // memory / address instructions, so that they issue in the MFMA's shadow instead of in a burst between MFMA
+    // groups (masks: 0x8 MFMA, 0x2 VALU, 0x4 SALU, 0x20 VMEM read, 0x100 DS read, 0x200 DS write).
+    constexpr int NMF = MI * NI * 4;           // MFMAs per chunk
+#define TNN_INTERLEAVE_LIGHT()                                             \
+    _Pragma("unroll") for (int q = 0; q < NMF; ++q) {                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 \
+    }
+#define TNN_INTERLEAVE_HEAVY()                                             \
+    _Pragma("unroll") for (int q = 0; q < NMF; ++q) {                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 \
+    }
+
+    // steady state: tiles kt+1 and kt+2 exist and tile kt+2 is a full, vector-loadable tile -> no branches
+    int kt = 0;
+    const int n_steady = VEC ? (nk_full - 2 < nk - 2 ? nk_full - 2 : nk - 2) : 0;
+    for (; kt < n_steady; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);              // in flight during the MFMAs
-        const float* As = lds + cur * (A_ELEMS + B_ELEMS);
-        const float* Bs = As + A_ELEMS;
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            float af[MI][4], bf[NI][4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                if constexpr (AKC) {
-                    float4 v = *reinterpret_cast<const float4*>(As + a_frag + i * 32 * SA + kk * 8);
-                    af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) af[i][j] = As[a_frag + (kk * 8 + j) * SA + i * 32];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                if constexpr (BKC) {
-                    float4 v = *reinterpret_cast<const float4*>(Bs + b_frag + i * 32 * SB + kk * 8);
-                    bf[i][0] = v.x; bf[i][1] = v.y; bf[i][2] = v.z; bf[i][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bf[i][j] = Bs[b_frag + (kk * 8 + j) * SB + i * 32];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j],
-                                                                           acc[mi][ni], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(cur ^ 1);   // the other buffer was last read one barrier ago
+        store_tile(cur ^ 1);
+        load_full(kt + 2);
+        read_frag(cur, 2);
+        mfma_chunk(0);
+        TNN_INTERLEAVE_HEAVY();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frag(cur, 3);
+        mfma_chunk(1);
+        TNN_INTERLEAVE_LIGHT();
+        __builtin_amdgcn_sched_barrier(0);
+
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frag(cur ^ 1, 0);
+        mfma_chunk(2);
+        TNN_INTERLEAVE_LIGHT();
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frag(cur ^ 1, 1);
+        mfma_chunk(3);
+        TNN_INTERLEAVE_LIGHT();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TNN_INTERLEAVE_LIGHT
+#undef TNN_INTERLEAVE_HEAVY
+
+    // remaining tiles (the last two, a partial K tail, or every tile of the guarded variant): same pipeline
+    // with its conditionals
+    for (; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+        if (has1) store_tile(cur ^ 1);
+        if (has2) load_tile(kt + 2);
+        read_frag(cur, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(0);
+        __builtin_amdgcn_sched_barrier(0);
+
+        read_frag(cur, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (has1) read_frag(cur ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(2);
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (has1) read_frag(cur ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // epilogue: lane holds col = l31, rows (r&3) + 8*(r>>2) + 4*lhi of each 32x32 block
@@ -582,10 +680,10 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
         splits = 1;
         int64_t tiles = cfg == 3 ? t128x64 : cfg == 2 ? t64 : cfg == 0 ? ((g.M + 127) / 128) * ((g.N + 127) / 128)
                                                               : ((g.M + 63) / 64) * ((g.N + 127) / 128);
-        if (tiles < 2 * cus) {
-            // aim at >= 2 workgroups per CU, keeping >= 8 K-tiles (256 deep) per split so that the extra
-            // reduce pass (M*N*splits*4 B of traffic) stays small next to the GEMM itself
-            splits = (int)((2 * cus + tiles - 1) / tiles);
+        if (tiles < cus) {
+            // fewer tiles than CUs: split K until every CU has a workgroup, keeping >= 8 K-tiles (256 deep)
+            // per split so that the extra reduce pass (M*N*splits*4 B of traffic) stays small
+            splits = (int)((cus + tiles - 1) / tiles);
             int64_t max_splits = g.K / 256;
             if (splits > max_splits) splits = (int)max_splits;
             if (splits < 1) splits = 1;
