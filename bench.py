@@ -125,6 +125,36 @@ def time_gemms(widths, rows, reps=20):
             "gemm_us_per_step": round(tot_ms * 1e3, 2), "per_gemm": results}
 
 
+def attach_traffic(roof, tag):
+    """roofline.traffic = HBM-side bytes per step of the GEMM launches, from the PMC passes committed under
+    profiles/ (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; collected with rocprofv3 --pmc on this same
+    command, see the file's _provenance).  None when no profile of this round is present."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if not os.path.exists(path):
+        return
+    table = json.load(open(path))["kernels"]
+    total, algorithmic = 0, 0
+    for gm in roof["per_gemm"]:
+        akc, bkc = gm["layout"][0] == "N", gm["layout"][1] == "T"
+        flags = "%s, %s" % ("true" if akc else "false", "true" if bkc else "false")
+        small = 2.0 * gm["M"] * gm["N"] * gm["K"] <= 1.6e8
+        hit = None
+        for name, per in table.items():
+            if tag not in per:
+                continue
+            if small and name.startswith("gemm_small_f32_kernel<" + flags):
+                hit = per[tag] if hit is None or per[tag]["launches"] > hit["launches"] else hit
+            if not small and name.startswith("gemm_f32_mfma_kernel<") and (", " + flags + ", true>") in name:
+                hit = per[tag]
+        if hit is None:
+            return
+        total += hit["fetch_bytes"] + hit["write_bytes"]
+        algorithmic += 4 * (gm["M"] * gm["K"] + gm["K"] * gm["N"] + gm["M"] * gm["N"])
+    roof["traffic"] = int(total)
+    roof["traffic_unit"] = "bytes per step over the step's GEMM launches (PMC, profiles/r01_traffic.json)"
+    roof["algorithmic_bytes"] = int(algorithmic)
+
+
 def cpu_baseline(widths, rows, kind, budget_s=12.0):
     """The numpy port of the reference on this host (bounded sample of the same workload)."""
     from oracle import ref_nn                              # the reported baseline, never the measured path
@@ -182,7 +212,8 @@ def main():
     # this process runs on ROCm 7.2's libamdhip64 (loaded by libtnn_hip.so above) and torch's bundled HIP
     # 7.0 runtime reports "No HIP GPUs" once that copy is in the process.  All device work (kernels and
     # RCCL) is on the library's one stream, so tnn_stream_sync() is the device fence of the contract.
-    comm = tn.dist.init_from_env() if world > 1 else None
+    comm = tn.dist.init_from_env() if (world > 1 or os.environ.get("TNN_FORCE_COMM") == "1") else None
+    force_dp = comm is not None and world == 1
 
     if args.workload == "A":
         widths, rows, kind, loss = WIDTHS_A, 128, "softmax_nll", "softmax_nll"
@@ -200,10 +231,10 @@ def main():
     batches = [(X[i * rows:(i + 1) * rows], Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
 
     net = build_net(widths)
+    chunk = None
     if args.path == "fused":
         trainer = tn.trainer_from_net(net, max_rows=rows, loss=loss, optimizer="adam", lr=1e-3, comm=comm,
-                                      use_graph=not args.no_graph)
-        chunk = None
+                                      use_graph=not args.no_graph, force_dp=force_dp)
         if comm is None and not args.no_graph:
             # every batch is resident at a fixed HBM address: capture one step per batch into ONE hipGraph
             # and replay it (n_batches steps per hipGraphLaunch, no staging copies)
@@ -272,16 +303,18 @@ def main():
                                        "configs[1]" if args.workload == "A" else "configs[2]",
                                        "-".join(map(str, widths)), rows, rows * world,
                                        "" if kind == "softmax_nll" else " replaced by sum-of-squares/m"),
-                       "path": args.path + ("+hipGraph(%d steps/launch)" % n_batches
-                                            if (args.path == "fused" and world == 1 and not args.no_graph) else ""),
+                       "path": args.path + ("+hipGraph(%d steps/launch)" % n_batches if chunk is not None else "")
+                               + ("+rccl(world=1, forced)" if force_dp else ""),
                        "parallelism": "dp%d" % world, "global_batch": rows * world,
                        "data_resident_in_hbm": True},
             "final_loss": round(final_loss, 6),
             "device": _lib.device_props()["name"],
         }
         line["roofline"] = time_gemms(widths, rows, reps=200 if args.workload == "A" else 20)
+        attach_traffic(line["roofline"], args.workload)
         if args.workload == "A":
             line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
+            attach_traffic(line["roofline_gemm4096"], "C")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=12.0 if args.workload == "A" else 20.0)
         print(json.dumps(line))

@@ -1,0 +1,53 @@
+"""RCCL through the C-ABI on the GPU box.  The box has ONE GPU, so the communicator has one rank: this checks
+library loading (dlopen of ROCm's librccl), unique-id / init / collectives / destroy, and that the sharded
+trainer and Model code paths (stats all-gather + merge, arena all-reduce) reproduce the single-process
+fixtures when every collective is the identity.  World sizes > 1 are covered on CPU by test_dist_gloo.py."""
+
+import numpy as np
+import pytest
+
+import helpers as H
+import tinynn_autograd_amd as tn
+from tinynn_autograd_amd.core.tensor import Tensor
+
+
+@pytest.fixture(scope="module")
+def comm():
+    from tinynn_autograd_amd.dist import RcclCommunicator
+    c = RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
+    yield c
+    c.close()
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_world1(comm):
+    x = np.arange(1000, dtype=np.float32)
+    d = tn.asarray(x)
+    comm.allreduce(d)
+    assert np.array_equal(np.asarray(d), x)
+    comm.allreduce(d, op="max")
+    assert np.array_equal(np.asarray(d), x)
+    g = comm.allgather(tn.asarray(np.array([1.5, 2.5], dtype=np.float32)))
+    assert g.shape == (1, 2) and np.array_equal(np.asarray(g), [[1.5, 2.5]])
+    merged = comm.merge_softmax_stats(tn.asarray(np.array([0.25, 7.0], dtype=np.float32)))
+    np.testing.assert_allclose(np.asarray(merged), [0.25, 7.0], rtol=1e-6)
+
+
+@pytest.mark.gpu
+def test_sharded_paths_with_rccl_world1(comm):
+    cfg, gold = H.load_traj("A_adam")
+    w = cfg["widths"]
+    model, loss_layer = H.build_model(cfg, comm=comm)
+    loss_layer.comm = comm
+    trainer = tn.trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"], comm=comm, force_dp=True)
+    assert trainer.comm is comm
+    for s, (x, y) in enumerate(H.batches(cfg["data_seed"], 6, cfg["m"], w[0], w[-1], cfg["loss"])):
+        model.zero_grad()
+        loss = loss_layer.loss(model.forward(Tensor(x)), Tensor(y))
+        loss.backward()
+        if model._grad_arena is not None:
+            comm.allreduce(model._grad_arena)               # what Model.step does when world > 1
+        model.step()
+        np.testing.assert_allclose(float(loss.values), gold["loss"][s], rtol=1e-5)
+        tl = float(trainer.step(tn.asarray(x), tn.asarray(y)))
+        np.testing.assert_allclose(tl, gold["loss"][s], rtol=1e-5)

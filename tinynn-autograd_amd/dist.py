@@ -109,6 +109,9 @@ def init_from_env(backend="rccl"):
     """Build the communicator for this rank from the torchrun environment (None when world == 1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
+        if backend == "rccl" and os.environ.get("TNN_FORCE_COMM") == "1":
+            # single-GPU boxes: a 1-rank RCCL communicator, so the collectives' code path can be run and timed
+            return RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
         return None
     if backend == "rccl":
         # load ROCm's librccl (through the C-ABI) BEFORE torch is imported, so that the one RCCL copy in the

@@ -26,12 +26,14 @@ _OPT = {"sgd": 0, "adam": 1}
 class MLPTrainer(object):
 
     def __init__(self, widths, max_rows, loss="softmax_nll", optimizer="adam", lr=1e-3, beta1=0.9,
-                 beta2=0.999, epsilon=1e-8, dtype=np.float32, comm=None, use_graph=False):
+                 beta2=0.999, epsilon=1e-8, dtype=np.float32, comm=None, use_graph=False, force_dp=False):
         self.widths = [int(w) for w in widths]
         self.n_layers = len(self.widths) - 1
         self.max_rows = int(max_rows)
         self.dtype = np.dtype(dtype)
-        self.comm = comm if (comm is not None and comm.world > 1) else None
+        # force_dp keeps the sharded code path (stats exchange, arena all-reduce) even at world size 1, which
+        # is how the RCCL path is exercised on a single-GPU box
+        self.comm = comm if (comm is not None and (comm.world > 1 or force_dp)) else None
         self.use_graph = bool(use_graph) and self.comm is None
         self._lib = _lib.get()
         self._h = ctypes.c_void_p()
