@@ -206,12 +206,18 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         args.gpus = world
 
+    # ORDER MATTERS: torch first, libtnn_hip.so second.  torch preloads its own bundled libamdhip64 / librccl by
+    # absolute path; loaded first, they are the process's ONE HIP runtime and libtnn_hip.so (DT_NEEDED
+    # libamdhip64.so.7) and RCCL (dlopen librccl.so.1) bind to them by soname.  The other order maps two HIP
+    # runtimes: torch.cuda then reports "No HIP GPUs" and the process aborts at exit ("double free") — measured
+    # on the MI355X box with tools/probes/rccl_torch_order_test.py.  torch itself is only the control plane
+    # (gloo rendezvous / barrier) and the contract's torch.cuda.synchronize().
+    import torch
+    import torch.distributed                              # noqa: F401
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
     lib = _lib.get()                                    # binds LOCAL_RANK's GPU; raises without HIP
     assert tn.backend_name() == "hip-gfx950", "bench.py measures the HIP library only"
-    # torch is imported only for N > 1 and only as the gloo control plane.  torch.cuda is never touched:
-    # this process runs on ROCm 7.2's libamdhip64 (loaded by libtnn_hip.so above) and torch's bundled HIP
-    # 7.0 runtime reports "No HIP GPUs" once that copy is in the process.  All device work (kernels and
-    # RCCL) is on the library's one stream, so tnn_stream_sync() is the device fence of the contract.
     comm = tn.dist.init_from_env() if (world > 1 or os.environ.get("TNN_FORCE_COMM") == "1") else None
     force_dp = comm is not None and world == 1
 
@@ -262,7 +268,8 @@ def main():
     def fence():
         if comm is not None:
             comm.barrier()
-        _lib.synchronize()
+        _lib.synchronize()                                   # the library's own stream (kernels + RCCL)
+        torch.cuda.synchronize()                             # device-wide, as the bench contract asks
 
     def run(first, count):
         """`count` consecutive steps starting at global step index `first`; returns the last loss."""
@@ -283,7 +290,6 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        import torch
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,6 +326,8 @@ def main():
         print(json.dumps(line))
     if comm is not None:
         comm.barrier()
+        if hasattr(comm, "close"):
+            comm.close()
 
 
 if __name__ == "__main__":

@@ -7,12 +7,15 @@ New relative to the reference (no communication there).  Two collecti
 
 `torch.distributed` (gloo) is used only as the control plane: rendezvous from the RANK / WORLD_SIZE /
 MASTER_* environment that `python -m torch.distributed.run` provides, broadcast of the RCCL unique id,
-barriers and the max-over-ranks of bench timings.  `GlooCommunicator` moves the same two collectives over
+barriers and the max-over-ranks of bench timings.  Import torch BEFORE the first device call of this package
+(single HIP runtime per process, see init_from_env).  `GlooCommunicator` moves the same two collectives over
 gloo through host memory; it exists for the world_size-2 CPU tests.
 """
 
+import atexit
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -49,6 +52,10 @@ class RcclCommunicator(Communicator):
         self.rank, self.world = int(rank), int(world)
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _lib.get().comm_init(self.rank, self.world, buf)
+        self._open = True
+        # RCCL must be torn down before the HIP runtime's own exit handlers run (otherwise the process aborts
+        # with "double free or corruption" at interpreter exit)
+        atexit.register(self.close)
 
     @staticmethod
     def new_unique_id():
@@ -69,12 +76,15 @@ class RcclCommunicator(Communicator):
 
     def barrier(self):
         _lib.synchronize()
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
+        dist = sys.modules.get("torch.distributed")
+        if dist is not None and dist.is_available() and dist.is_initialized():
             dist.barrier()
 
     def close(self):
-        _lib.get().comm_destroy()
+        if getattr(self, "_open", False):
+            self._open = False
+            _lib.synchronize()
+            _lib.get().comm_destroy()
 
 
 class GlooCommunicator(Communicator):
@@ -113,11 +123,12 @@ def init_from_env(backend="rccl"):
             # single-GPU boxes: a 1-rank RCCL communicator, so the collectives' code path can be run and timed
             return RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
         return None
-    if backend == "rccl":
-        # load ROCm's librccl (through the C-ABI) BEFORE torch is imported, so that the one RCCL copy in the
-        # process is the one built against the HIP runtime libtnn_hip.so runs on (same-soname libraries are
-        # deduplicated by the loader; torch bundles its own librccl/libamdhip64)
-        RcclCommunicator.new_unique_id()
+    if backend == "rccl" and _lib.is_loaded() and "torch" not in sys.modules:
+        # torch preloads its bundled libamdhip64 / librccl by absolute path: importing it AFTER libtnn_hip.so
+        # puts two HIP runtimes in the process (abort at exit, torch.cuda blind).  Imported first, they are the
+        # single runtime everything binds to.
+        raise RuntimeError("import torch before the first tinynn_autograd_amd device call when running "
+                           "data-parallel (see DESIGN.md §7)")
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
