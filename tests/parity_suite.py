@@ -442,6 +442,63 @@ def fused_ops_match_generic_chain():
         g = g * 0.9 + 0.01
 
 
+def other_optimizers_on_device():
+    """Momentum / RMSProp / Adagrad / Adadelta (core/optimizer.py:82-164) run as DeviceArray expressions — state
+    and steps stay in HBM — and match the same expressions evaluated by numpy in float64."""
+    from tinynn_autograd_amd.core import optimizer as O
+    rs = np.random.RandomState(31)
+    grads = [(rs.randn(300) * 0.1).astype(np.float32) for _ in range(4)]
+
+    def numpy_steps(kind):
+        st = {"a": 0.0, "b": 0.0}
+        out = []
+        for g in grads:
+            g = g.astype(np.float64)
+            if kind == "Momentum":
+                st["a"] = 0.9 * st["a"] + g; out.append(-0.05 * st["a"])
+            elif kind == "RMSProp":
+                st["a"] = st["a"] + (1 - 0.99) * (g ** 2 - st["a"])
+                st["b"] = 0.0 * st["b"] + 0.01 * g / (st["a"] + 1e-8) ** 0.5; out.append(-st["b"])
+            elif kind == "Adagrad":
+                st["a"] = st["a"] + g ** 2; out.append(-(0.05 / (st["a"] + 1e-8) ** 0.5) * g)
+            else:
+                st["a"] = st["a"] + (1 - 0.9) * (g ** 2 - st["a"])
+                std = (st["b"] + 1e-8) ** 0.5
+                delta = g * (std / (st["a"] + 1e-8) ** 0.5)
+                out.append(-1.0 * delta)
+                st["b"] = st["b"] + (1 - 0.9) * (delta ** 2 - st["b"])
+        return out
+
+    for kind, opt in (("Momentum", O.Momentum(lr=0.05)), ("RMSProp", O.RMSProp()), ("Adagrad", O.Adagrad(lr=0.05)),
+                      ("Adadelta", O.Adadelta())):
+        ref = numpy_steps(kind)
+        for g, r in zip(grads, ref):
+            step = opt._compute_step(tn.asarray(g))
+            assert isinstance(step, da.DeviceArray), kind
+            np.testing.assert_allclose(np.asarray(step), r, rtol=2e-4, atol=1e-7, err_msg=kind)
+
+
+def batch_iterator_on_device_tensors():
+    """utils/data_iterator.py:22-34 on device Tensors: one global-RNG shuffle per epoch, a row-gather kernel for
+    inputs[idx], zero-copy row slices per batch, ragged last batch."""
+    from tinynn_autograd_amd.utils.data_iterator import BatchIterator
+    rs = np.random.RandomState(32)
+    x = rs.rand(103, 7).astype(np.float32)
+    y = np.eye(5)[rs.randint(0, 5, 103)]
+    tx, ty = Tensor(x), Tensor(y)
+    np.random.seed(9)
+    batches = list(BatchIterator(batch_size=32)(tx, ty))
+    np.random.seed(9)
+    idx = np.arange(103); np.random.shuffle(idx)
+    assert [len(b.inputs) for b in batches] == [32, 32, 32, 7]
+    got_x = np.concatenate([np.asarray(b.inputs.values) for b in batches])
+    got_y = np.concatenate([np.asarray(b.targets.values) for b in batches])
+    assert np.array_equal(got_x, x[idx]) and np.array_equal(got_y, y[idx].astype(np.float32))
+    assert isinstance(batches[0].inputs, Tensor) and isinstance(batches[0].inputs.values, da.DeviceArray)
+    # batches of one epoch are views into ONE gathered buffer (no per-batch copies)
+    assert batches[1].inputs.values._ptr == batches[0].inputs.values._ptr + 32 * 7 * 4
+
+
 def error_behaviour():
     """Same failure modes as the reference: backward on a non-requires-grad tensor asserts
     (core/tensor.py:158), bad broadcasts raise ValueError, and native errors surface as exceptions."""

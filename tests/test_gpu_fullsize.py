@@ -1,0 +1,80 @@
+"""Full-size checks on the MI355X (BASELINE.json configs[2]: Dense 4096->4096->4096, bs 512): the whole-step
+trainer against the float64 closed-form oracle computed on the host, plus size-independent GEMM properties at
+the sizes the roofline is quoted on."""
+
+import numpy as np
+import pytest
+
+import tinynn_autograd_amd as tn
+from oracle.closed_form import ClosedFormMLP
+from tinynn_autograd_amd.fused import MLPTrainer
+
+
+@pytest.mark.gpu
+def test_config_C_two_steps_match_float64_closed_form():
+    rs = np.random.RandomState(4)
+    widths, m = [4096, 4096, 4096], 512
+    a = np.sqrt(6.0 / (4096 + 4096))
+    W = [rs.uniform(-a, a, (4096, 4096)).astype(np.float32) for _ in range(2)]
+    B = [np.zeros((1, 4096), np.float32) for _ in range(2)]
+    x = rs.rand(m, 4096).astype(np.float32)
+    trainer = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3)
+    trainer.set_parameters([{"w": W[i], "b": B[i]} for i in range(2)])
+    oracle = ClosedFormMLP(W, B, loss="mse", optimizer="adam", lr=1e-3)
+    xd = tn.asarray(x)
+    for step in range(2):
+        loss = float(trainer.step(xd, xd))
+        ref_loss, ref_out, gW, gb = oracle.step(x, x)
+        np.testing.assert_allclose(loss, ref_loss, rtol=1e-5, err_msg="step %d loss" % step)
+        for l in range(2):
+            g = np.asarray(trainer.grad_view(l, "w"))
+            assert np.abs(g - gW[l]).max() <= 1e-5 * np.abs(gW[l]).max(), "step %d dW%d" % (step, l)
+            gbd = np.asarray(trainer.grad_view(l, "b"))
+            assert np.abs(gbd - gb[l]).max() <= 1e-5 * np.abs(gb[l]).max(), "step %d db%d" % (step, l)
+    for l in range(2):
+        p = np.asarray(trainer.param_view(l, "w"))
+        assert np.abs(p - oracle.W[l]).max() <= 1e-4        # 0.1 * lr, sign-like Adam update where |g| ~ 0
+        assert np.abs(p - W[l]).max() > 1e-4                 # and it really moved
+
+
+@pytest.mark.gpu
+def test_gemm_4096_against_float64_and_linearity():
+    rs = np.random.RandomState(5)
+    M, N, K = 512, 4096, 4096
+    a = rs.uniform(-1, 1, (M, K)).astype(np.float32)
+    b = rs.uniform(-1, 1, (K, N)).astype(np.float32)
+    A, B = tn.asarray(a), tn.asarray(b)
+    c = np.asarray(A @ B, dtype=np.float64)
+    rows = rs.choice(M, 24, replace=False)
+    ref = a[rows].astype(np.float64) @ b.astype(np.float64)
+    bound = np.abs(a[rows]).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(c[rows] - ref) <= 1e-6 * bound).all()              # f32 round-off class (guide: ~3.5e-7 at K=4096)
+    # NT and TN on the same data: (A B)^T == B^T A^T
+    ct = np.asarray(tn.asarray(np.ascontiguousarray(b.T)) @ tn.asarray(np.ascontiguousarray(a.T)), dtype=np.float64)
+    assert (np.abs(ct.T - c) <= 2e-6 * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64))).all()
+    nt = np.asarray(A @ tn.asarray(np.ascontiguousarray(b.T)).T, dtype=np.float64)
+    assert np.array_equal(nt, c) or np.abs(nt - c).max() <= 1e-3     # same products, possibly another summation order
+    # linearity in A
+    a2 = rs.uniform(-1, 1, (M, K)).astype(np.float32)
+    lhs = np.asarray((A + tn.asarray(a2)) @ B, dtype=np.float64)
+    rhs = c + np.asarray(tn.asarray(a2) @ B, dtype=np.float64)
+    assert np.abs(lhs - rhs).max() <= 1e-2                            # |values| ~ 40, K = 4096
+
+
+@pytest.mark.gpu
+def test_fused_adam_33M_matches_numpy():
+    from tinynn_autograd_amd import _lib
+    n = 33562624
+    rs = np.random.RandomState(6)
+    p0 = rs.randn(n).astype(np.float32); g = (rs.randn(n) * 1e-2).astype(np.float32)
+    P, G = tn.asarray(p0), tn.asarray(g)
+    Mo, Vo = tn.zeros((n,)), tn.zeros((n,))
+    pows = tn.asarray(np.array([1.0, 1.0, 0, 0]), dtype=np.float64)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    m = np.zeros(n); v = np.zeros(n); p = p0.astype(np.float64)
+    for t in (1, 2):
+        _lib.get().adam(P._ptr, G._ptr, Mo._ptr, Vo._ptr, n, lr, b1, b2, eps, pows._ptr, None, _lib.F32)
+        m += (1 - b1) * (g - m); v += (1 - b2) * (g.astype(np.float64) ** 2 - v)
+        p += -lr * (m / (1 - b1 ** t)) / (np.sqrt(v / (1 - b2 ** t)) + eps)
+    np.testing.assert_allclose(np.asarray(P), p, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.asarray(pows)[:2], [b1 ** 2, b2 ** 2], rtol=1e-14)

@@ -1,0 +1,121 @@
+"""MNIST-style MLP training driver — this build's counterpart of examples/mnist/run.py:45-93.
+
+Same loop (zero_grad -> forward -> loss -> backward -> step per batch, per-epoch shuffle on numpy's global RNG,
+evaluation = argmax over the logits -> AccEvaluator) and the same flags, on device Tensors.  No MNIST file exists
+in this environment (no network), so `--data_dir` is accepted but the data are synthetic unless a
+`mnist.pkl.gz` is found there.
+
+    python -m tinynn_autograd_amd.examples.mnist_run --num_ep 2 --batch_size 128 --seed 0 [--trainer]
+
+--trainer    run the epoch through the whole-step trainer (one hipGraph per epoch) instead of the op-level path
+--widths     hidden widths (default 256,128 = BASELINE.json's 784-256-128-10; the reference example hard-codes
+             200,100,70,30, examples/mnist/run.py:59-69)
+"""
+
+import argparse
+import gzip
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(_HERE)))
+
+import tinynn_autograd_amd as tn                                             # noqa: E402
+from tinynn_autograd_amd.core.evaluator import AccEvaluator                  # noqa: E402
+from tinynn_autograd_amd.core.layers import Dense, ReLU                      # noqa: E402
+from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss         # noqa: E402
+from tinynn_autograd_amd.core.model import Model                             # noqa: E402
+from tinynn_autograd_amd.core.nn import Net                                  # noqa: E402
+from tinynn_autograd_amd.core.optimizer import Adam                          # noqa: E402
+from tinynn_autograd_amd.core.tensor import Tensor                           # noqa: E402
+from tinynn_autograd_amd.utils.data_iterator import BatchIterator            # noqa: E402
+from tinynn_autograd_amd.utils.seeder import random_seed                     # noqa: E402
+
+
+def get_one_hot(targets, nb_classes):
+    return np.eye(nb_classes)[np.array(targets).reshape(-1)]
+
+
+def prepare_dataset(data_dir, n_train=51200, n_test=10000):
+    path = os.path.join(data_dir, "mnist.pkl.gz")
+    if os.path.exists(path):
+        with gzip.open(path, "rb") as f:
+            train_set, _, test_set = pickle.load(f, encoding="latin1")
+        return train_set, test_set, "mnist.pkl.gz"
+    rs = np.random.RandomState(1234)                       # SURVEY §8d synthetic recipe
+    def make(n):
+        x = (rs.rand(n, 784) * (rs.rand(n, 784) < 0.19)).astype(np.float32)
+        return x, rs.randint(0, 10, n)
+    return make(n_train), make(n_test), "synthetic (MNIST-like sparsity)"
+
+
+def main(args):
+    if args.seed >= 0:
+        random_seed(args.seed)
+    (train_x, train_y), (test_x, test_y), source = prepare_dataset(args.data_dir)
+    print("data: %s, %d train / %d test rows; backend %s" % (source, len(train_x), len(test_x), "?"))
+    train_y = get_one_hot(train_y, 10)
+    train_x, train_y = Tensor(train_x), Tensor(train_y)    # resident in HBM for the whole run
+    test_x = Tensor(test_x)
+
+    widths = [int(w) for w in args.widths.split(",")]
+    layers = []
+    for w in widths:
+        layers += [Dense(w), ReLU()]
+    layers.append(Dense(10))
+    net = Net(layers)
+    model = Model(net=net, loss=SoftmaxCrossEntropyLoss(), optimizer=Adam(lr=args.lr))
+    loss_layer = SoftmaxCrossEntropyLoss()
+    iterator = BatchIterator(batch_size=args.batch_size)
+    evaluator = AccEvaluator()
+    print("backend:", tn.backend_name())
+
+    trainer = None
+    loss_list = []
+    for epoch in range(args.num_ep):
+        t_start = time.time()
+        if args.trainer and trainer is None:
+            model.forward(train_x[:1])                     # lazy Dense init from the first batch's width
+            trainer = tn.trainer_from_net(net, max_rows=args.batch_size, lr=args.lr)
+        if trainer is not None:
+            batches = [(b.inputs.values, b.targets.values) for b in iterator(train_x, train_y)]
+            full = [b for b in batches if b[0].shape[0] == args.batch_size]
+            graph = trainer.capture_steps(full)            # the epoch's steps as ONE hipGraph launch
+            loss_list.extend(list(np.asarray(graph.launch())))
+            for x, y in batches[len(full):]:               # ragged last batch
+                loss_list.append(float(trainer.step(x, y)))
+            for i, layer in enumerate(l for l in net.layers if isinstance(l, Dense)):
+                layer.params["w"].values = trainer.param_view(i, "w")
+                layer.params["b"].values = trainer.param_view(i, "b")
+        else:
+            for batch in iterator(train_x, train_y):
+                model.zero_grad()
+                pred = model.forward(batch.inputs)
+                loss = loss_layer.loss(pred, batch.targets)
+                loss.backward()
+                model.step()
+                loss_list.append(loss.values)              # a 0-d DeviceArray: no host sync inside the loop
+        tn.synchronize()
+        print("Epoch %d tim cost: %.4f" % (epoch, time.time() - t_start))
+        model.set_phase("TEST")
+        test_pred = model.forward(test_x)
+        test_pred_idx = np.argmax(test_pred, axis=1)
+        print(evaluator.evaluate(test_pred_idx, np.asarray(test_y)))
+        model.set_phase("TRAIN")
+    print("last loss: %.6f" % float(loss_list[-1]))
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--num_ep", default=2, type=int)
+    parser.add_argument("--data_dir", default="./examples/mnist/data", type=str)
+    parser.add_argument("--lr", default=1e-3, type=float)
+    parser.add_argument("--batch_size", default=128, type=int)
+    parser.add_argument("--seed", default=-1, type=int)
+    parser.add_argument("--widths", default="256,128", type=str)
+    parser.add_argument("--trainer", action="store_true")
+    main(parser.parse_args())
