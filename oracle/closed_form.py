@@ -32,7 +32,10 @@ class ClosedFormMLP(object):
             acts.append(np.clip(z, 0.0, None) if l < len(self.W) - 1 else z)
         return acts, zs
 
-    def loss_and_grads(self, x, y, m_global=None):
+    def loss_and_grads(self, x, y, m_global=None, masks=None):
+        """masks (optional): per hidden layer boolean arrays to use INSTEAD of (z >= 0) — lets a float32 device
+        run be checked exactly where ReLU's derivative is discontinuous (a pre-activation within float32
+        rounding of zero legitimately lands on the other side)."""
         y = np.asarray(y, dtype=np.float64)
         acts, zs = self.forward(x)
         out = acts[-1]
@@ -52,7 +55,9 @@ class ClosedFormMLP(object):
             gW[l] = acts[l].T @ dz
             gb[l] = dz.sum(0, keepdims=True)
             if l > 0:
-                dz = (dz @ self.W[l].T) * (zs[l - 1] >= 0)
+                mask = (zs[l - 1] >= 0) if masks is None else masks[l - 1]
+                dz = (dz @ self.W[l].T) * mask
+        self.last_pre_activations = zs
         return loss, out, gW, gb
 
     def step(self, x, y):
