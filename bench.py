@@ -14,6 +14,7 @@ backward -> [RCCL all-reduce] -> Adam update (examples/mnist/run.py:79-83).  Inp
                           the MFMA roofline run (one GPU)
   --path fused (default)  whole-step trainer (tnn_mlp_*), hipGraph replay at N=1
   --path ops              the drop-in Tensor/ops/Model path (same maths, one launch per op)
+  --path opsgraph         the same op-level loop body captured into a hipGraph and replayed
 
 Extra objects on the line:
   roofline      the dominant kernel of the step (the fp32 MFMA GEMM family): algorithmic FLOPs of the
@@ -194,7 +195,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="A", choices=["A", "C"])
-    ap.add_argument("--path", default="fused", choices=["fused", "ops"])
+    ap.add_argument("--path", default="fused", choices=["fused", "ops", "opsgraph"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -264,6 +265,26 @@ def main():
             out.backward()
             model.step()
             return out.values
+
+        if args.path == "opsgraph":
+            # the same reference-style loop body, captured once into a hipGraph (tinynn_autograd_amd.graph) and
+            # replayed; each batch is copied into two staging tensors at fixed addresses first
+            x_stage, y_stage = Tensor(batches[0][0].copy()), Tensor(batches[0][1].copy())
+
+            def body():
+                model.zero_grad()
+                out = loss_layer.loss(model.forward(x_stage), y_stage)
+                out.backward()
+                model.step()
+                return out
+
+            captured = tn.capture(body, warmup=2)
+
+            def step(i):                                     # noqa: F811
+                xb, yb = batches[i % n_batches]
+                x_stage.values[...] = xb
+                y_stage.values[...] = yb
+                return captured().values
 
     def fence():
         if comm is not None:

@@ -181,6 +181,44 @@ def trainer_A_adam_multi_step_graph():
     assert again[0] < losses[0]                      # it kept training, it did not replay step 0's state
 
 
+def op_level_step_captured_in_graph():
+    """The reference-style loop body captured once and replayed from a hipGraph must follow the same trajectory
+    as the eager op-level path (staging tensors at fixed addresses, device-side Adam state)."""
+    cfg, gold = H.load_traj("A_adam")
+    w = cfg["widths"]
+    model, loss_layer = H.build_model(cfg)
+    data = H.batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])
+    x_stage, y_stage = Tensor(data[0][0]), Tensor(data[0][1])
+    state = {}
+
+    def step():
+        model.zero_grad()
+        pred = model.forward(x_stage)
+        loss = loss_layer.loss(pred, y_stage)
+        loss.backward()
+        model.step()
+        state["loss"], state["pred"] = loss, pred
+        return loss
+
+    losses = []
+    # warm-up steps are REAL steps: feed them batches 0 and 1, then replay batches 2..19
+    x_stage.values[...] = tn.asarray(data[0][0]); y_stage.values[...] = tn.asarray(data[0][1])
+    step(); losses.append(float(state["loss"].values))
+    x_stage.values[...] = tn.asarray(data[1][0]); y_stage.values[...] = tn.asarray(data[1][1])
+    step(); losses.append(float(state["loss"].values))
+    captured = tn.capture(step, warmup=0)
+    for x, y in data[2:]:
+        x_stage.values[...] = tn.asarray(x)
+        y_stage.values[...] = tn.asarray(y)
+        loss = captured()
+        losses.append(float(loss.values))
+    np.testing.assert_allclose(losses, gold["loss"], rtol=RTOL)
+    assert np.array_equal(np.argmax(state["pred"], axis=1), gold["argmax_19"])
+    for l, layer in enumerate(H.dense_layers(model)):
+        for k in ("w", "b"):
+            H.check_summary(np.asarray(layer.params[k].values), gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * cfg["lr"])
+
+
 def trainer_A_ragged():
     _check_trainer("A_ragged", use_graph=False)
 

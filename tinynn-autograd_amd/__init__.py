@@ -22,6 +22,8 @@ from . import utils
 from .utils import data_iterator, seeder
 from . import dist
 from . import fused
+from . import graph
+from .graph import capture
 from .fused import MLPTrainer, trainer_from_net
 
 __version__ = "0.1.0"

@@ -239,8 +239,12 @@ class Graph(object):
 
     def __exit__(self, exc_type, exc, tb):
         h = c_void_p()
-        get().graph_capture_end(ctypes.byref(h))
-        self._h = h
+        try:
+            get().graph_capture_end(ctypes.byref(h))
+            self._h = h
+        except TnnError:
+            if exc_type is None:
+                raise
         return False
 
     def launch(self):

@@ -160,9 +160,8 @@ class DeviceArray(object):
         return self._ptr
 
     def _materialise_scalar(self):
-        host = np.asarray(self._hv, dtype=self.dtype)
         out = DeviceArray._new((), self.dtype)
-        _lib.get().memcpy_h2d(out._ptr, host.ctypes.data, host.nbytes)
+        _lib.get().fill(out._ptr, float(self._hv), 1, out._code())    # a kernel, not an H2D copy: capturable, no sync
         return out
 
     def _contig(self):
