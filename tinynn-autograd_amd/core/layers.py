@@ -1,75 +1,97 @@
-"""Layers (reference: core/layers.py:10-98): Dense with lazy shape inference, ReLU / Sigmoid / Tanh.
+"""Layers with the reference's API (reference: core/layers.py:10-98): `Dense` with lazy fan-in inference and the
+`ReLU` / `Sigmoid` / `Tanh` activations.
 
-`Dense.forward` computes `inputs @ w + b` (core/layers.py:49) as one GEMM with a bias epilogue
-(ops.dense_); `fused=False` runs the literal two-op expression.  Parameter dict order is "w" then "b"
-(core/layers.py:35) — the optimizer's flattening order depends on it.
+Device-side differences: `Dense.forward` issues ONE GEMM with a bias epilogue (ops.dense_) instead of a matmul
+node plus a broadcast-add node (`fused=False` restores the literal `inputs @ w + b`, core/layers.py:49);
+`Sigmoid` is a single fused kernel (the reference's raises on a Tensor).  The parameter dict order is
+"w" then "b" (core/layers.py:35): the optimizer's flatten order and the trainer's arena layout depend on it.
 """
 
 from . import ops
 from .initializer import XavierUniformInit
 from .initializer import ZerosInit
 
+PARAM_ORDER = ("w", "b")
+
 
 class Layer(object):
+    """Base class: a name, a parameter dict (empty for activations) and the TRAIN/TEST flag nobody reads
+    (core/layers.py:21-22)."""
 
     def __init__(self, name):
         self.name = name
-        self.params, self.grads = {}, {}
+        self.params = {}
+        self.grads = {}
         self.is_training = True
 
     def forward(self, inputs):
         raise NotImplementedError
 
     def set_phase(self, phase):
-        self.is_training = phase == "TRAIN"
+        self.is_training = (phase == "TRAIN")
 
 
 class Dense(Layer):
+    """y = x w + b with w: [num_in, num_out], b: [1, num_out].  num_in may be omitted and is then read off the
+    first batch (core/layers.py:43-57)."""
 
     def __init__(self, num_out, num_in=None, w_init=XavierUniformInit(), b_init=ZerosInit(), fused=True):
         super().__init__("Linear")
-        self.initializers = {"w": w_init, "b": b_init}
-        self.shapes = {"w": [num_in, num_out], "b": [1, num_out]}
-        self.params = {"w": None, "b": None}
         self.fused = fused
+        self.initializers = dict(zip(PARAM_ORDER, (w_init, b_init)))
+        self.shapes = {"w": [num_in, num_out], "b": [1, num_out]}
+        self.params = dict.fromkeys(PARAM_ORDER)
+        self.inputs = None
         self.is_init = False
         if num_in is not None:
             self._init_parameters(num_in)
-        self.inputs = None
-
-    def forward(self, inputs):
-        if not self.is_init:                      # lazy: first batch tells the fan-in
-            self._init_parameters(inputs.shape[1])
-        self.inputs = inputs
-        if self.fused:
-            return ops.dense_(inputs, self.params["w"], self.params["b"])
-        return inputs @ self.params["w"] + self.params["b"]
 
     def _init_parameters(self, input_size):
+        """Draw the parameters (host RNG, w before b — only w consumes random numbers) and upload them."""
         self.shapes["w"][0] = input_size
-        for key in ("w", "b"):                    # RNG draw order: w first (b draws nothing)
-            self.params[key] = self.initializers[key](shape=self.shapes[key])
-            self.params[key].zero_grad()
+        for name in PARAM_ORDER:
+            tensor = self.initializers[name](shape=self.shapes[name])
+            tensor.zero_grad()
+            self.params[name] = tensor
         self.is_init = True
+
+    def forward(self, inputs):
+        if not self.is_init:
+            self._init_parameters(inputs.shape[1])
+        self.inputs = inputs                     # kept like the reference does (core/layers.py:48)
+        w, b = (self.params[name] for name in PARAM_ORDER)
+        if not self.fused:
+            return inputs @ w + b
+        return ops.dense_(inputs, w, b)
 
 
 class Activation(Layer):
+    """Parameter-free layer applying `func` (core/layers.py:60-72)."""
 
     def __init__(self, name):
         super().__init__(name)
         self.inputs = None
 
+    def func(self, x):
+        raise NotImplementedError
+
     def forward(self, inputs):
         self.inputs = inputs
         return self.func(inputs)
 
+
+class ReLU(Activation):
+    """clip(x, 0.0): the vjp mask is x >= 0, i.e. gradient 1 AT zero (core/layers.py:97-98, core/ops.py:338)."""
+
+    def __init__(self):
+        super().__init__("ReLU")
+
     def func(self, x):
-        raise NotImplementedError
+        return ops.clip(x, 0.0)
 
 
 class Sigmoid(Activation):
-    """1 / (1 + exp(-x)).  The reference's version raises on a Tensor (core/layers.py:79-80);
-    here it is one fused kernel whose vjp is the closed form s (1 - s)."""
+    """1 / (1 + exp(-x)) as one kernel; vjp = s (1 - s)."""
 
     def __init__(self):
         super().__init__("Sigmoid")
@@ -79,21 +101,12 @@ class Sigmoid(Activation):
 
 
 class Tanh(Activation):
-    """Kept as the reference writes it, (1 - e^-x) / (1 + e^-x) = tanh(x / 2) (core/layers.py:88-89)."""
+    """The reference's formula verbatim in meaning: (1 - e^-x) / (1 + e^-x), which is tanh(x / 2), not tanh(x)
+    (core/layers.py:88-89) — reproduced, not corrected."""
 
     def __init__(self):
         super().__init__("Tanh")
 
     def func(self, x):
-        e = ops.exp(-x)
-        return (1.0 - e) / (1.0 + e)
-
-
-class ReLU(Activation):
-    """clip(x, 0.0): gradient 1 at x == 0 because the mask is x >= 0 (core/layers.py:97-98, ops.py:338)."""
-
-    def __init__(self):
-        super().__init__("ReLU")
-
-    def func(self, x):
-        return ops.clip(x, 0.0)
+        decay = ops.exp(-x)
+        return (1.0 - decay) / (1.0 + decay)

@@ -1,8 +1,9 @@
-"""Mini-batch iterator (reference: utils/data_iterator.py:8-34).
+"""Mini-batch iteration over HBM-resident data (reference protocol: utils/data_iterator.py:8-34).
 
-Same protocol: per-epoch `np.random.shuffle(idx)` on numpy's GLOBAL RNG, a full-dataset gather
-`inputs[idx]`, then contiguous row slices; the last batch may be ragged.  With device Tensors the gather
-is one tnn_gather_rows launch per array and every batch is a zero-copy view.
+One call = one epoch: a permutation from `np.random.shuffle` on numpy's GLOBAL RNG (so a seeded run shuffles like
+the reference), ONE gather of the whole dataset by that permutation, then consecutive row windows; the final
+window may be short.  On device Tensors the gather is a single tnn_gather_rows launch per array and every batch
+is a zero-copy view into the gathered buffer — the per-step host work is a Python slice.
 """
 
 from collections import namedtuple
@@ -24,12 +25,22 @@ class BatchIterator(BaseIterator):
         self.batch_size = batch_size
         self.shuffle = shuffle
 
+    def num_batches(self, n_rows):
+        return -(-int(n_rows) // self.batch_size)
+
+    def _epoch_order(self, n_rows):
+        """The epoch's row permutation (None = natural order).  Exactly one np.random.shuffle call."""
+        if not self.shuffle:
+            return None
+        order = np.arange(n_rows)
+        np.random.shuffle(order)
+        return order
+
     def __call__(self, inputs, targets):
-        n = len(inputs)
-        if self.shuffle:
-            idx = np.arange(n)
-            np.random.shuffle(idx)
-            inputs, targets = inputs[idx], targets[idx]
-        for start in range(0, n, self.batch_size):
-            end = start + self.batch_size
-            yield Batch(inputs=inputs[start:end], targets=targets[start:end])
+        n_rows = len(inputs)
+        order = self._epoch_order(n_rows)
+        if order is not None:
+            inputs, targets = inputs[order], targets[order]        # ops.getitem_ -> row-gather kernel
+        for window in range(self.num_batches(n_rows)):
+            rows = slice(window * self.batch_size, (window + 1) * self.batch_size)
+            yield Batch(inputs=inputs[rows], targets=targets[rows])
