@@ -241,6 +241,9 @@ TNN_API int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t
 TNN_API int tnn_mlp_update(void* handle);
 /* phases 1-3 back to back for the single-GPU case; loss_out = device scalar (may be NULL) */
 TNN_API int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
+/* one data-parallel step through the communicator of tnn_comm_init: forward + shard stats, all-gather + merge,
+ * loss/backward with the global batch size, all-reduce of the gradient arena (+ loss slot), update */
+TNN_API int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
 /* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
 TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
 

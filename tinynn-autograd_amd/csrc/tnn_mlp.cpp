@@ -40,6 +40,8 @@ struct Mlp {
     char *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
     void* pows = nullptr;            // Adam state, double[4]
     void* stats = nullptr;           // {M, S} of the last forward_stats
+    void* stats_all = nullptr;       // [world, 2] gathered shard stats (data-parallel step)
+    int stats_all_world = 0;
     std::vector<int64_t> w_off, b_off;
     std::vector<void*> act;          // act[l]  = output of layer l       [max_rows, w[l+1]]
     std::vector<void*> dact;         // dact[l] = dLoss/d(pre-activation) [max_rows, w[l+1]]
@@ -167,7 +169,7 @@ int tnn_mlp_destroy(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) return 0;
     tnn_free(h->params); tnn_free(h->grads); tnn_free(h->m); tnn_free(h->v);
-    tnn_free(h->pows); tnn_free(h->stats);
+    tnn_free(h->pows); tnn_free(h->stats); tnn_free(h->stats_all);
     for (void* p : h->act) tnn_free(p);
     for (void* p : h->dact) tnn_free(p);
     delete h;
@@ -262,6 +264,33 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                          L > 1 ? h->dact[L - 2] : nullptr, h->dtype));
     MLP_TRY(mlp_backward_layers(h, x, rows, L - 2));
     return tnn_mlp_update(handle);
+}
+
+int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t rows, void* loss_out) {
+    // One data-parallel step, every phase enqueued from here on the library stream (no host work in between):
+    //   forward + shard {max, sum-exp}  ->  C2 all-gather + log-sum-exp merge  ->  loss + backward with the GLOBAL
+    //   batch size  ->  C1 in-place all-reduce of grads[0 : n_params + 1] (the loss rides along)  ->  update
+    Mlp* h = (Mlp*)handle;
+    MLP_TRY(check_rows(h, rows, "tnn_mlp_step_sharded"));
+    int rank = 0, world = 1;
+    MLP_TRY(tnn_comm_world(&rank, &world));
+    if (h->stats_all_world != world) {
+        tnn_free(h->stats_all);
+        h->stats_all = nullptr;
+        MLP_TRY(tnn_malloc((size_t)world * 2 * 8, &h->stats_all));
+        h->stats_all_world = world;
+    }
+    MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+    const void* stats = h->stats;
+    if (h->loss_kind == 0) {
+        MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
+        MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
+    }
+    MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, stats, nullptr));
+    MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->dtype, TNN_RSUM));
+    MLP_TRY(tnn_mlp_update(handle));
+    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, at(h->grads, h->n_params, h->esz), h->esz));
+    return 0;
 }
 
 int tnn_mlp_activation(void* handle, int layer, void** ptr) {

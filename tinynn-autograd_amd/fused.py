@@ -132,6 +132,10 @@ class MLPTrainer(object):
 
     def _step_dp(self, x, y, rows):
         lib = self._lib
+        from .dist import RcclCommunicator
+        if isinstance(self.comm, RcclCommunicator):
+            lib.mlp_step_sharded(self._h, x._ptr, y._ptr, rows, None)      # all phases + both RCCL calls in C
+            return self.loss_slot
         lib.mlp_forward_stats(self._h, x._ptr, rows, self._stats._ptr)
         stats = self.comm.merge_softmax_stats(self._stats)
         lib.mlp_backward(self._h, x._ptr, y._ptr, rows, rows * self.comm.world, stats._ptr, None)
