@@ -242,10 +242,18 @@ def main():
     if args.path == "fused":
         trainer = tn.trainer_from_net(net, max_rows=rows, loss=loss, optimizer="adam", lr=1e-3, comm=comm,
                                       use_graph=not args.no_graph, force_dp=force_dp)
-        if comm is None and not args.no_graph:
+        if not args.no_graph and (comm is None or os.environ.get("TNN_DP_GRAPH", "1") != "0"):
             # every batch is resident at a fixed HBM address: capture one step per batch into ONE hipGraph
-            # and replay it (n_batches steps per hipGraphLaunch, no staging copies)
-            chunk = trainer.capture_steps(batches)
+            # and replay it (n_batches steps per hipGraphLaunch, no staging copies).  With a communicator the two
+            # RCCL collectives of every step are captured too (RCCL supports stream capture); if the capture is
+            # refused the run falls back to eager data-parallel steps.  TNN_DP_GRAPH=0 forces the eager form.
+            try:
+                chunk = trainer.capture_steps(batches)
+            except Exception as exc:                          # noqa: BLE001
+                if comm is None:
+                    raise
+                sys.stderr.write("bench: data-parallel graph capture unavailable (%s); eager steps\n" % exc)
+                chunk = None
 
         def step(i):
             return trainer.step(*batches[i % n_batches])

@@ -51,3 +51,18 @@ def test_sharded_paths_with_rccl_world1(comm):
         np.testing.assert_allclose(float(loss.values), gold["loss"][s], rtol=1e-5)
         tl = float(trainer.step(tn.asarray(x), tn.asarray(y)))
         np.testing.assert_allclose(tl, gold["loss"][s], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_sharded_steps_captured_with_rccl_in_graph(comm):
+    """The data-parallel step including its two RCCL collectives replayed from ONE hipGraph."""
+    cfg, gold = H.load_traj("A_adam")
+    w = cfg["widths"]
+    model, _ = H.build_model(cfg)
+    trainer = tn.trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"], comm=comm, force_dp=True)
+    data = H.batches(cfg["data_seed"], cfg["steps"], cfg["m"], w[0], w[-1], cfg["loss"])
+    graph = trainer.capture_steps([(tn.asarray(x), tn.asarray(y)) for x, y in data])
+    losses = np.asarray(graph.launch())
+    np.testing.assert_allclose(losses, gold["loss"], rtol=1e-5)
+    for l in range(trainer.n_layers):
+        H.check_summary(np.asarray(trainer.param_view(l, "w")), gold, "final_%dw" % l, rtol=0, atol=0.1 * cfg["lr"])

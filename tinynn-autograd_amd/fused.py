@@ -173,8 +173,11 @@ class StepGraph(object):
     step i lands in `losses[i]` (the loss_list of examples/mnist/run.py:84, kept in HBM)."""
 
     def __init__(self, trainer, batches):
-        if trainer.comm is not None:
-            raise ValueError("StepGraph is the single-GPU path (collectives are not captured)")
+        sharded = trainer.comm is not None
+        if sharded:
+            from .dist import RcclCommunicator
+            if not isinstance(trainer.comm, RcclCommunicator):
+                raise ValueError("only RCCL collectives can be captured into a hipGraph")
         self.trainer = trainer
         self.batches = [trainer._prep(x, y) for x, y in batches]      # keeps the buffers alive
         self.losses = da.empty((len(self.batches),), trainer.dtype)
@@ -182,7 +185,10 @@ class StepGraph(object):
         self._graph = _lib.Graph()
         with self._graph:
             for i, (x, y, rows) in enumerate(self.batches):
-                lib.mlp_step(trainer._h, x._ptr, y._ptr, rows, self.losses._ptr + i * esz)
+                if sharded:   # forward | all-gather + merge | backward | all-reduce | update, RCCL calls captured too
+                    lib.mlp_step_sharded(trainer._h, x._ptr, y._ptr, rows, self.losses._ptr + i * esz)
+                else:
+                    lib.mlp_step(trainer._h, x._ptr, y._ptr, rows, self.losses._ptr + i * esz)
 
     def __len__(self):
         return len(self.batches)
