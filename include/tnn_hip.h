@@ -28,7 +28,7 @@ extern "C" {
 
 #define TNN_API __attribute__((visibility("default")))
 
-enum { TNN_F32 = 0, TNN_F64 = 1, TNN_I64 = 2, TNN_U8 = 3 };
+enum { TNN_F32 = 0, TNN_F64 = 1, TNN_I64 = 2, TNN_U8 = 3, TNN_BF16 = 4 /* storage type of the bf16 path only */ };
 
 /* binary elementwise ops — reference core/ops.py:33 (add), :66 (mul), :94 (div), :122 (pow),
  * :167 (maximum), :192 (minimum) and the arithmetic inside their vjp bodies */
@@ -216,6 +216,25 @@ TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);
  * the step is written there and p is left untouched (the reference's _compute_step contract). */
 TNN_API int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
                      double b2, double eps, void* pows_f64, void* step_out, int dtype);
+
+/* ------------------------------------------------------------------ bf16 path (configs[4]) ---- */
+/* bf16 storage, fp32 accumulation (v_mfma_f32_32x32x16_bf16), fp32 master weights + Adam state.  One GEMM
+ * form: C[M,N] = A[M,K] * B[N,K]^T with BOTH operands K-contiguous — the bf16 trainer keeps a transposed weight
+ * copy (forward), uses W itself for dX, and transposed activation copies for dW, so ops.dot_'s three products
+ * (core/ops.py:151,157,160) all take this form.  K % 64 == 0, lda/ldb % 8 == 0, 16-B aligned bases.
+ * Epilogue (exclusive): bias_f32[N] (+ReLU, optional sign-bit mask) or mask_y (bf16 [M,N], zero where its sign
+ * bit is set).  c_dtype = TNN_BF16 or TNN_F32. */
+TNN_API int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                             int64_t ldb, void* C, int64_t ldc, int c_dtype, const void* bias_f32, int act,
+                             int relu_sign, const void* mask_y, int64_t ldy);
+TNN_API int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols);     /* [R,C] -> [C,R] */
+TNN_API int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16);              /* f32 <-> bf16 (RNE) */
+TNN_API int tnn_colsum_bf16(const void* in, void* out_f32, int64_t rows, int64_t cols);    /* bias gradient */
+TNN_API int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32,
+                         void* dpred);
+/* Adam on the fp32 master parameters (same maths as tnn_adam) that also refreshes the bf16 working copy */
+TNN_API int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* w_bf16, int64_t n,
+                                 double lr, double b1, double b2, double eps, void* pows_f64);
 
 /* ------------------------------------------------------------------ whole-step MLP trainer ---- */
 /* One object = Dense/ReLU stack + whole-batch softmax NLL (loss_kind 0) or sum-of-squares/m

@@ -639,6 +639,18 @@ int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, dou
     return 0;
 }
 
+// ---- bf16 path: GPU only (the twin covers the f32/f64 host logic); same symbols, explicit refusal ----
+#define NO_BF16(name) do { tnn::set_error(name ": the bf16 path has no CPU twin"); return 2; } while (0)
+int tnn_gemm_bf16_nt(int64_t, int64_t, int64_t, const void*, int64_t, const void*, int64_t, void*, int64_t, int,
+                     const void*, int, int, const void*, int64_t) { NO_BF16("tnn_gemm_bf16_nt"); }
+int tnn_transpose_bf16(const void*, void*, int64_t, int64_t) { NO_BF16("tnn_transpose_bf16"); }
+int tnn_cast_bf16(const void*, void*, int64_t, int) { NO_BF16("tnn_cast_bf16"); }
+int tnn_colsum_bf16(const void*, void*, int64_t, int64_t) { NO_BF16("tnn_colsum_bf16"); }
+int tnn_mse_bf16(const void*, const void*, int64_t, int64_t, void*, void*) { NO_BF16("tnn_mse_bf16"); }
+int tnn_adam_master_bf16(void*, const void*, void*, void*, void*, int64_t, double, double, double, double, void*) {
+    NO_BF16("tnn_adam_master_bf16");
+}
+
 // ---- comm: single-process identity (multi-process CPU tests use gloo at the Python layer) ----
 static int g_comm = 0;
 int tnn_comm_unique_id(void* id) { memset(id, 0, 128); return 0; }

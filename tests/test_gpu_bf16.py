@@ -1,0 +1,69 @@
+"""bf16 path on the MI355X: K-contiguous MFMA GEMM (fp32 accumulate) against float64 numpy on bf16-rounded
+operands, epilogues, transpose/cast/colsum, and the master-weight Adam."""
+
+import numpy as np
+import pytest
+
+import tinynn_autograd_amd as tn
+from tinynn_autograd_amd import bf16
+
+
+@pytest.mark.gpu
+def test_bf16_gemm_nt_and_epilogues():
+    rs = np.random.RandomState(41)
+    for (M, N, K) in ((512, 1024, 2048), (128, 128, 64), (200, 330, 192), (1000, 77, 512)):
+        a = bf16.round_to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+        b = bf16.round_to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+        ref = a.astype(np.float64) @ b.astype(np.float64).T
+        bound = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64).T
+        A, B = bf16.to_bf16(a), bf16.to_bf16(b)
+        assert np.array_equal(np.asarray(bf16.to_f32(A)), a)                # bf16 values survive the round trip
+        c = np.asarray(bf16.gemm_nt(A, B), dtype=np.float64)
+        assert (np.abs(c - ref) <= 2e-6 * bound + 1e-30).all(), (M, N, K, np.abs(c - ref).max())   # fp32 accumulation
+        # bf16 output: one extra rounding (2^-9 relative)
+        c16 = np.asarray(bf16.to_f32(bf16.gemm_nt(A, B, out_dtype=np.uint16)), dtype=np.float64)
+        assert (np.abs(c16 - ref) <= 4e-3 * np.abs(ref) + 2e-6 * bound).all()
+        # bias + ReLU with the mask kept in the sign bit, then the mask epilogue of the next product
+        bias = rs.randn(N).astype(np.float32)
+        y16 = bf16.gemm_nt(A, B, out_dtype=np.uint16, bias=tn.asarray(bias), relu=True, relu_sign=True)
+        y = np.asarray(bf16.to_f32(y16))
+        z = ref + bias
+        assert (np.abs(y - np.maximum(z, 0)) <= 4e-3 * np.abs(z) + 1e-5 * bound + 1e-6).all()
+        raw = np.asarray(y16)
+        clearly_neg, clearly_pos = z < -1e-3 * bound - 1e-6, z > 1e-3 * bound + 1e-6
+        assert ((raw[clearly_neg] & 0x8000) != 0).all() and ((raw[clearly_pos] & 0x8000) == 0).all()
+        masked = np.asarray(bf16.gemm_nt(A, B, mask=y16), dtype=np.float64)
+        expect = np.where((raw & 0x8000) != 0, 0.0, ref)
+        assert (np.abs(masked - expect) <= 2e-6 * bound + 1e-30).all()
+
+
+@pytest.mark.gpu
+def test_bf16_transpose_colsum_mse_adam():
+    from tinynn_autograd_amd import _lib
+    rs = np.random.RandomState(42)
+    x = bf16.round_to_bf16(rs.randn(300, 130).astype(np.float32))
+    X = bf16.to_bf16(x)
+    assert np.array_equal(np.asarray(bf16.to_f32(bf16.transpose(X))), x.T)
+    cs = tn.empty((130,))
+    _lib.get().colsum_bf16(X._ptr, cs._ptr, 300, 130)
+    np.testing.assert_allclose(np.asarray(cs), x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
+    big = bf16.round_to_bf16(rs.randn(2048, 256).astype(np.float32))
+    cs2 = tn.empty((256,))
+    _lib.get().colsum_bf16(bf16.to_bf16(big)._ptr, cs2._ptr, 2048, 256)
+    np.testing.assert_allclose(np.asarray(cs2), big.astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    y = bf16.round_to_bf16(rs.randn(300, 130).astype(np.float32))
+    loss, d = tn.empty(()), tn.empty((300, 130), np.uint16)
+    _lib.get().mse_bf16(X._ptr, bf16.to_bf16(y)._ptr, 300 * 130, 300, loss._ptr, d._ptr)
+    e = x.astype(np.float64) - y
+    np.testing.assert_allclose(float(loss), (e ** 2).sum() / 300, rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(bf16.to_f32(d)), 2 * e / 300, rtol=8e-3, atol=1e-7)
+    n = 10007
+    p0 = rs.randn(n).astype(np.float32); g = (rs.randn(n) * 1e-2).astype(np.float32)
+    P, G, M_, V_ = tn.asarray(p0), tn.asarray(g), tn.zeros((n,)), tn.zeros((n,))
+    W16 = tn.empty((n,), np.uint16)
+    pows = tn.asarray(np.array([1.0, 1.0, 0, 0]), dtype=np.float64)
+    _lib.get().adam_master_bf16(P._ptr, G._ptr, M_._ptr, V_._ptr, W16._ptr, n, 1e-3, 0.9, 0.999, 1e-8, pows._ptr)
+    m = 0.1 * g.astype(np.float64); v = 0.001 * g.astype(np.float64) ** 2
+    ref = p0 - 1e-3 * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
+    np.testing.assert_allclose(np.asarray(P), ref, rtol=0, atol=2e-6)
+    assert np.array_equal(np.asarray(bf16.to_f32(W16)), bf16.round_to_bf16(np.asarray(P)))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtnn_hip.so")
 
 # dtype / op codes (must mirror include/tnn_hip.h)
-F32, F64, I64, U8 = 0, 1, 2, 3
+F32, F64, I64, U8, BF16 = 0, 1, 2, 3, 4
 ADD, SUB, MUL, DIV, POW, MAX, MIN = range(7)
 GT, GE, LT, LE, EQ, NE = range(6)
 NEG, EXP, LOG, SQRT, SQUARE, ABS, RECIP, SIGMOID, TANH, COPY = range(10)
@@ -82,6 +82,13 @@ _SIGNATURES = {
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],
+    "tnn_gemm_bf16_nt": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, c_int, _p, c_int, c_int,
+                         _p, c_int64],
+    "tnn_transpose_bf16": [_p, _p, c_int64, c_int64],
+    "tnn_cast_bf16": [_p, _p, c_int64, c_int],
+    "tnn_colsum_bf16": [_p, _p, c_int64, c_int64],
+    "tnn_mse_bf16": [_p, _p, c_int64, c_int64, _p, _p],
+    "tnn_adam_master_bf16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
     "tnn_mlp_create": [c_int, _i64p, c_int64, c_int, c_int, c_double, c_double, c_double, c_double,
                        c_int, POINTER(c_void_p)],
     "tnn_mlp_destroy": [_p],

@@ -1,0 +1,465 @@
+// K1 (bf16 variant, BASELINE.json configs[4]): C = A * B^T with bf16 operands and fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16.  ONE layout is implemented — both operands K-contiguous (A stored [M,K], B stored
+// [N,K]) — because the bf16 trainer keeps every operand in that form:
+//     forward  z  = a  W        ->  A = a [m,in],        B = W^T [out,in]   (transposed weight copy, refreshed
+//                                                                            after every optimizer update)
+//     dX       da = dz W^T      ->  A = dz [m,out],      B = W [in,out]
+//     dW       dW = a^T dz      ->  A = a^T [in,m],      B = dz^T [out,m]   (transposed activation copies made by
+//                                                                            the LDS-tiled bf16 transpose below)
+// so no fragment ever needs a transposing LDS read.  Tile 128x128x64, 4 waves of 64x64 (2x2 MFMA tiles), LDS rows
+// padded to 144 B (conflict-free ds_read_b128, same argument as the fp32 kernel), and the fp32 kernel's software
+// pipeline: fragment slots filled two 16-deep chunks ahead, next tile's LDS store + global loads of tile kt+2 in
+// chunk 0, one barrier per K-tile after chunk 1.  Epilogues: plain (f32 or bf16 out), bias + ReLU with the mask
+// in the sign bit of zero (bf16 out), or multiply by the mask of a previous ReLU output (bf16 out).
+// Shape contract of the fast path: K % 64 == 0, lda/ldb % 8 == 0, 16-B aligned bases; M, N arbitrary (rows
+// beyond the edge read a clamped address and are never stored).
+#include <math.h>
+#include <stdlib.h>
+
+#include "tnn_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint16_t bf16_t;
+
+enum { BEPI_PLAIN = 0, BEPI_BIAS_ACT = 1, BEPI_MASK = 2 };
+
+struct BfArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    int c_bf16;            // output element type: 1 = bf16, 0 = f32
+    int epi;
+    const float* bias;
+    int act, relu_sign;
+    const bf16_t* Y;
+    int64_t ldy;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ bf16_t f2bf(float f) {       // round to nearest even (finite inputs)
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+__device__ __forceinline__ int xcd_remap16(int b, int nb) {
+    const int nx = 8;
+    if (nb < 2 * nx) return b;
+    int q = nb / nx, r = nb % nx;
+    int xcd = b % nx, local = b / nx;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+constexpr int BM = 128, BN = 128, BK = 64, WM = 2, WN = 2, NT = 256;
+constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+constexpr int SROW = BK + 8;                 // LDS row stride in bf16 elements (144 B)
+constexpr int A_ELEMS = BM * SROW, B_ELEMS = BN * SROW;
+constexpr int A_V = BM * BK / 8 / NT;        // 16-B vectors per thread per tile (4)
+constexpr int B_V = BN * BK / 8 / NT;
+constexpr int KK = BK / 16;                  // MFMA k-steps per tile (4)
+
+__global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (A_ELEMS + B_ELEMS)];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int nb = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap16((int)blockIdx.x, nb);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int first_m = (t / per_group) * GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, GROUP_M);
+    const int64_t m0 = (int64_t)(first_m + (t % per_group) % gsz) * BM;
+    const int64_t n0 = (int64_t)((t % per_group) / gsz) * BN;
+    const int nk = (int)(g.K / BK);
+
+    // staging geometry: vector f -> row f / 8, 16-B column f % 8
+    const bf16_t* a_src[A_V];
+    const bf16_t* b_src[B_V];
+    int a_dst[A_V], b_dst[B_V];
+#pragma unroll
+    for (int i = 0; i < A_V; ++i) {
+        const int f = tid + i * NT, row = f / (BK / 8), c8 = f % (BK / 8);
+        const int64_t gm = m0 + row;
+        a_src[i] = g.A + (gm < g.M ? gm : 0) * g.lda + c8 * 8;
+        a_dst[i] = row * SROW + c8 * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_V; ++i) {
+        const int f = tid + i * NT, row = f / (BK / 8), c8 = f % (BK / 8);
+        const int64_t gn = n0 + row;
+        b_src[i] = g.B + (gn < g.N ? gn : 0) * g.ldb + c8 * 8;
+        b_dst[i] = row * SROW + c8 * 8;
+    }
+    uint4 ra[A_V], rb[B_V];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_V; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (int64_t)kt * BK);
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_src[i] + (int64_t)kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+        bf16_t* As = lds + buf * (A_ELEMS + B_ELEMS);
+        bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < A_V; ++i) *reinterpret_cast<uint4*>(As + a_dst[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_V; ++i) *reinterpret_cast<uint4*>(Bs + b_dst[i]) = rb[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment: lane (row l31, k-group lhi) holds 8 consecutive k: elements [kk*16 + lhi*8, +8)
+    const int a_frag = (wm * TM + l31) * SROW + lhi * 8;
+    const int b_frag = (wn * TN + l31) * SROW + lhi * 8;
+    bf16x8 af[KK][MI], bfr[KK][NI];
+    auto read_frag = [&](int buf, int kk) {
+        const bf16_t* As = lds + buf * (A_ELEMS + B_ELEMS);
+        const bf16_t* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            uint4 v = *reinterpret_cast<const uint4*>(As + a_frag + i * 32 * SROW + kk * 16);
+            af[kk][i] = *reinterpret_cast<bf16x8*>(&v);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            uint4 v = *reinterpret_cast<const uint4*>(Bs + b_frag + i * 32 * SROW + kk * 16);
+            bfr[kk][i] = *reinterpret_cast<bf16x8*>(&v);
+        }
+    };
+    auto mfma_chunk = [&](int kk) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][mi], bfr[kk][ni], acc[mi][ni], 0, 0, 0);
+    };
+
+    static_assert(KK == 4, "pipeline written for four 16-deep chunks per K-tile");
+    if (nk > 0) {
+        load_tile(0);
+        store_tile(0);
+        if (nk > 1) load_tile(1);
+    }
+    __syncthreads();
+    if (nk > 0) {
+        read_frag(0, 0);
+        read_frag(0, 1);
+    }
+    constexpr int NMF = MI * NI;
+    int kt = 0;
+    for (; kt < nk - 2; ++kt) {                     // steady state: tiles kt+1 and kt+2 exist, no branches
+        const int cur = kt & 1;
+        store_tile(cur ^ 1);
+        load_tile(kt + 2);
+        read_frag(cur, 2);
+        mfma_chunk(0);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(cur, 3);
+        mfma_chunk(1);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(cur ^ 1, 0);
+        mfma_chunk(2);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(cur ^ 1, 1);
+        mfma_chunk(3);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; kt < nk; ++kt) {                         // last two tiles
+        const int cur = kt & 1;
+        const bool has1 = kt + 1 < nk;
+        if (has1) store_tile(cur ^ 1);
+        read_frag(cur, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(cur, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has1) read_frag(cur ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has1) read_frag(cur ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // epilogue (32x32 C/D layout: col = l31, row = (r&3) + 8*(r>>2) + 4*lhi)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int64_t col = n0 + wn * TN + ni * 32 + l31;
+            if (col >= g.N) continue;
+            const float bias = (g.epi == BEPI_BIAS_ACT && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= g.M) continue;
+                float v = acc[mi][ni][r];
+                if (g.epi == BEPI_BIAS_ACT) {
+                    v += bias;
+                    if (g.act == TNN_ACT_RELU) v = v < 0.f ? (g.relu_sign ? -0.0f : 0.f) : fabsf(v);
+                } else if (g.epi == BEPI_MASK) {
+                    if (g.Y[row * g.ldy + col] & 0x8000u) v = 0.f;
+                }
+                if (g.c_bf16) reinterpret_cast<bf16_t*>(g.C)[row * g.ldc + col] = f2bf(v);
+                else reinterpret_cast<float*>(g.C)[row * g.ldc + col] = v;
+            }
+        }
+}
+
+// bf16 [R, C] -> [C, R] through a 64x64 LDS tile (+2 padding: 2-byte elements, odd dword stride)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in,
+                                                             bf16_t* __restrict__ out, int64_t R, int64_t C) {
+    __shared__ bf16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+        const int64_t r = r0 + j, c = c0 + tx;
+        if (r < R && c < C) tile[j][tx] = in[r * C + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int64_t c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) out[c * R + r] = tile[tx][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = f2bf(in[i]);
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out,
+                                                            int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = bf2f(in[i]);
+}
+
+// column sums of a bf16 [R, C] matrix into f32 (bias gradient); block = 64 columns x 4 row lanes, f32 accumulate
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, float* __restrict__ out,
+                                                          int64_t R, int64_t C, int64_t rows_per_slice) {
+    __shared__ float lds[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
+    int64_t r1 = r0 + rows_per_slice;
+    if (r1 > R) r1 = R;
+    float acc = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + ty; r < r1; r += 4) acc += bf2f(in[r * C + c]);
+    lds[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && c < C) out[(int64_t)blockIdx.y * C + c] = (lds[0][tx] + lds[1][tx]) + (lds[2][tx] + lds[3][tx]);
+}
+
+// sum((pred - y)^2) / m and dpred = 2 (pred - y) / m on bf16 tensors (f32 math, f64 block partials)
+__global__ __launch_bounds__(256) void mse_bf16_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ y,
+                                                       int64_t n, double inv_m, double* __restrict__ partial,
+                                                       bf16_t* __restrict__ dpred) {
+    __shared__ double lds[4];
+    double local = 0.0;
+    const float two_inv_m = (float)(2.0 * inv_m);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float e = bf2f(pred[i]) - bf2f(y[i]);
+        local += (double)e * (double)e;
+        if (dpred) dpred[i] = f2bf(two_inv_m * e);
+    }
+    local = tnn::wave_sum(local);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((lds[0] + lds[1]) + (lds[2] + lds[3])) * inv_m;
+}
+__global__ __launch_bounds__(64) void sum_partials_f32_kernel(const double* __restrict__ partial, int n,
+                                                              float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = tnn::wave_sum(s);
+    if (threadIdx.x == 0) out[0] = (float)s;
+}
+
+// Adam on the fp32 master copy + refresh of the bf16 working copy (28 B + 2 B per parameter)
+__global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                               float* __restrict__ m, float* __restrict__ v,
+                                                               bf16_t* __restrict__ w16, int64_t n, float lr, float b1,
+                                                               float b2, float eps, const double* __restrict__ state) {
+    const double p1 = state[0], p2 = state[1];
+    const float ic1 = (float)(1.0 / (1.0 - p1)), ic2 = (float)(1.0 / (1.0 - p2));
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + omb1 * (gi - mi);
+        vi = vi + omb2 * (gi * gi - vi);
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] + (-lr * (mi * ic1) / (sqrtf(vi * ic2) + eps));
+        p[i] = pi;
+        w16[i] = f2bf(pi);
+    }
+}
+__global__ void adam_advance16_kernel(double* __restrict__ state, double b1, double b2) {
+    state[0] *= b1;
+    state[1] *= b2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                     void* C, int64_t ldc, int c_dtype, const void* bias_f32, int act, int relu_sign,
+                     const void* mask_y, int64_t ldy) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(M > 0 && N > 0 && K > 0, "tnn_gemm_bf16_nt: empty problem");
+    TNN_REQUIRE(K % BK == 0, "tnn_gemm_bf16_nt: K (%lld) must be a multiple of %d", (long long)K, BK);
+    TNN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "tnn_gemm_bf16_nt: lda/ldb must be >= K and multiples of 8");
+    TNN_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0,
+                "tnn_gemm_bf16_nt: operands must be 16-byte aligned");
+    TNN_REQUIRE(c_dtype == TNN_F32 || c_dtype == TNN_BF16, "tnn_gemm_bf16_nt: output dtype %d", c_dtype);
+    TNN_REQUIRE(ldc >= N, "tnn_gemm_bf16_nt: ldc too small");
+    TNN_REQUIRE(!(bias_f32 || act) || !mask_y, "tnn_gemm_bf16_nt: bias/activation and mask epilogues are exclusive");
+    BfArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.c_bf16 = c_dtype == TNN_BF16;
+    g.epi = mask_y ? BEPI_MASK : (bias_f32 || act) ? BEPI_BIAS_ACT : BEPI_PLAIN;
+    g.bias = (const float*)bias_f32; g.act = act; g.relu_sign = relu_sign;
+    g.Y = (const bf16_t*)mask_y; g.ldy = ldy;
+    g.tiles_m = (int)((M + BM - 1) / BM);
+    g.tiles_n = (int)((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), NT, 0, tnn::stream(), g);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols) {
+    TNN_NEED_INIT();
+    if (rows * cols <= 0) return 0;
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    TNN_REQUIRE(grid.y <= 65535, "tnn_transpose_bf16: too many rows");
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, 256, 0, tnn::stream(), (const bf16_t*)in, (bf16_t*)out, rows, cols);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    unsigned grid = tnn::stream_grid(n, 256);
+    if (to_bf16)
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, grid, 256, 0, tnn::stream(), (const float*)in, (bf16_t*)out, n);
+    else
+        hipLaunchKernelGGL(cast_bf16_f32_kernel, grid, 256, 0, tnn::stream(), (const bf16_t*)in, (float*)out, n);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_colsum_bf16(const void* in, void* out_f32, int64_t rows, int64_t cols) {
+    TNN_NEED_INIT();
+    if (cols <= 0) return 0;
+    const int64_t strips = (cols + 63) / 64;
+    int64_t slices = 1;
+    const int64_t cap = (int64_t)tnn::num_cus() * 4;
+    if (strips < cap && rows >= 256) {
+        slices = cap / strips;
+        if (slices > rows / 64) slices = rows / 64;
+        if (slices > 64) slices = 64;
+        if (slices < 1) slices = 1;
+    }
+    const int64_t rps = (rows + slices - 1) / slices;
+    slices = (rows + rps - 1) / rps;
+    if (slices == 1) {
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)strips, 1), 256, 0, tnn::stream(), (const bf16_t*)in,
+                           (float*)out_f32, rows, cols, rps);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
+    void* ws = nullptr;
+    if (tnn_malloc((size_t)(slices * cols) * sizeof(float), &ws)) return 1;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)strips, (unsigned)slices), 256, 0, tnn::stream(),
+                       (const bf16_t*)in, (float*)ws, rows, cols, rps);
+    int rc = tnn_reduce(TNN_RSUM, ws, out_f32, 1, slices, cols, TNN_F32);
+    tnn_free(ws);
+    if (rc) return rc;
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32, void* dpred) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(n > 0 && m_global > 0, "tnn_mse_bf16: empty batch");
+    int64_t nb = tnn::stream_grid(n, 256);
+    if (nb > 1024) nb = 1024;
+    void* ws = nullptr;
+    if (tnn_malloc((size_t)nb * sizeof(double), &ws)) return 1;
+    hipLaunchKernelGGL(mse_bf16_kernel, (unsigned)nb, 256, 0, tnn::stream(), (const bf16_t*)pred, (const bf16_t*)y, n,
+                       1.0 / (double)m_global, (double*)ws, (bf16_t*)dpred);
+    if (loss_out_f32)
+        hipLaunchKernelGGL(sum_partials_f32_kernel, 1, 64, 0, tnn::stream(), (const double*)ws, (int)nb,
+                           (float*)loss_out_f32);
+    tnn_free(ws);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* w_bf16, int64_t n, double lr,
+                         double b1, double b2, double eps, void* pows_f64) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_master_bf16: pows state is NULL");
+    hipStream_t s = tnn::stream();
+    hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
+    hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid(n, 256), 256, 0, s, (float*)p_master, (const float*)g,
+                       (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2, (float)eps,
+                       (const double*)pows_f64);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+}  // extern "C"

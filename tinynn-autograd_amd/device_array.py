@@ -27,7 +27,8 @@ from . import _lib
 from ._lib import F32, F64, I64, U8
 
 _CODE = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int64): I64,
-         np.dtype(np.bool_): U8}
+         np.dtype(np.bool_): U8,
+         np.dtype(np.uint16): _lib.BF16}     # raw bf16 bit patterns: storage only (tinynn_autograd_amd.bf16)
 _default_float = np.dtype(np.float32)
 MAX_NDIM = 6
 
