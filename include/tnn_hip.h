@@ -241,7 +241,9 @@ TNN_API int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v
  * (loss_kind 1, the (err**2).sum()/m of test/test_autograd.py:119-121) + SGD (opt 0) / Adam (opt 1),
  * i.e. the loop body of examples/mnist/run.py:79-83 as ~10 launches on device-resident state:
  * params | grads | m | v live in one flat arena each, ordered layer by layer, "w" then "b"
- * (core/layers.py:35, core/optimizer.py:14-15). */
+ * (core/layers.py:35, core/optimizer.py:14-15).
+ * dtype TNN_BF16 (configs[4]): x, y, activations are bf16; the arenas stay fp32 (master weights, gradients,
+ * Adam state); loss_kind 1 + Adam only; call tnn_mlp_sync_params after writing the parameter arena. */
 TNN_API int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int loss_kind,
                            int opt_kind, double lr, double b1, double b2, double eps, int dtype,
                            void** handle);
@@ -263,6 +265,9 @@ TNN_API int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t row
 /* one data-parallel step through the communicator of tnn_comm_init: forward + shard stats, all-gather + merge,
  * loss/backward with the global batch size, all-reduce of the gradient arena (+ loss slot), update */
 TNN_API int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
+/* after the parameter arena was written from outside (initial weights): refresh derived copies — the bf16
+ * working copies W, W^T of a TNN_BF16 trainer; no-op for f32 / f64 */
+TNN_API int tnn_mlp_sync_params(void* handle);
 /* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
 TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
 

@@ -67,3 +67,43 @@ def test_bf16_transpose_colsum_mse_adam():
     ref = p0 - 1e-3 * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
     np.testing.assert_allclose(np.asarray(P), ref, rtol=0, atol=2e-6)
     assert np.array_equal(np.asarray(bf16.to_f32(W16)), bf16.round_to_bf16(np.asarray(P)))
+
+
+@pytest.mark.gpu
+def test_bf16_trainer_tracks_float64_oracle():
+    """4-layer 512-wide ReLU MLP, sum-of-squares loss, Adam, bf16 storage / fp32 master weights: loss and
+    gradients against the float64 closed form evaluated on the SAME bf16-rounded weights and inputs; bf16
+    activations and dz add ~2^-9 relative noise per tensor, hence the 2e-2 bars."""
+    from oracle.closed_form import ClosedFormMLP
+    from tinynn_autograd_amd.fused import MLPTrainer
+    rs = np.random.RandomState(43)
+    widths, m = [512, 512, 512, 512, 512], 128
+    a = np.sqrt(6.0 / 1024)
+    W = [bf16.round_to_bf16(rs.uniform(-a, a, (512, 512)).astype(np.float32)) for _ in range(4)]
+    B = [np.zeros((1, 512), np.float32) for _ in range(4)]
+    x = bf16.round_to_bf16(rs.rand(m, 512).astype(np.float32))
+    trainer = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16")
+    trainer.set_parameters([{"w": W[i], "b": B[i]} for i in range(4)])
+    oracle = ClosedFormMLP(W, B, loss="mse", optimizer="adam", lr=1e-3)
+    x16 = bf16.to_bf16(x)
+    pred = np.asarray(trainer.forward(x16), dtype=np.float64)
+    acts, _ = oracle.forward(x)
+    assert np.abs(pred - acts[-1]).max() <= 2e-2 * np.abs(acts[-1]).max()
+    losses, ref_losses = [], []
+    for step in range(3):
+        ref_loss, _, gW, gb = oracle.loss_and_grads(x, x)
+        loss = float(trainer.step(x16, x16))
+        losses.append(loss); ref_losses.append(ref_loss)
+        if step == 0:
+            for l in range(4):
+                g = np.asarray(trainer.grad_view(l, "w"), dtype=np.float64)
+                rel = np.linalg.norm(g - gW[l]) / np.linalg.norm(gW[l])
+                assert rel <= 3e-2, ("dW%d relative L2 error" % l, rel)
+                gb_d = np.asarray(trainer.grad_view(l, "b"), dtype=np.float64)
+                assert np.linalg.norm(gb_d - gb[l]) / np.linalg.norm(gb[l]) <= 3e-2
+        oracle.step(x, x)
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-2)
+    assert losses[2] < losses[0]                              # it trains
+    # the fp32 master copy moved by Adam, and the bf16 working copy is its rounding
+    p = np.asarray(trainer.param_view(0, "w"))
+    assert np.abs(p - W[0]).max() > 1e-4

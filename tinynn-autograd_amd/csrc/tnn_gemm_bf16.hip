@@ -23,6 +23,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint16_t bf16_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native 16-B vector (HIP's uint4 struct ended up in scratch)
 
 enum { BEPI_PLAIN = 0, BEPI_BIAS_ACT = 1, BEPI_MASK = 2 };
 
@@ -98,20 +99,20 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
         b_src[i] = g.B + (gn < g.N ? gn : 0) * g.ldb + c8 * 8;
         b_dst[i] = row * SROW + c8 * 8;
     }
-    uint4 ra[A_V], rb[B_V];
+    u32x4 ra[A_V], rb[B_V];
     auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < A_V; ++i) ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (int64_t)kt * BK);
+        for (int i = 0; i < A_V; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + (int64_t)kt * BK);
 #pragma unroll
-        for (int i = 0; i < B_V; ++i) rb[i] = *reinterpret_cast<const uint4*>(b_src[i] + (int64_t)kt * BK);
+        for (int i = 0; i < B_V; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + (int64_t)kt * BK);
     };
     auto store_tile = [&](int buf) {
         bf16_t* As = lds + buf * (A_ELEMS + B_ELEMS);
         bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
-        for (int i = 0; i < A_V; ++i) *reinterpret_cast<uint4*>(As + a_dst[i]) = ra[i];
+        for (int i = 0; i < A_V; ++i) *reinterpret_cast<u32x4*>(As + a_dst[i]) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_V; ++i) *reinterpret_cast<uint4*>(Bs + b_dst[i]) = rb[i];
+        for (int i = 0; i < B_V; ++i) *reinterpret_cast<u32x4*>(Bs + b_dst[i]) = rb[i];
     };
 
     f32x16 acc[MI][NI];
@@ -131,13 +132,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
         const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            uint4 v = *reinterpret_cast<const uint4*>(As + a_frag + i * 32 * SROW + kk * 16);
-            af[kk][i] = *reinterpret_cast<bf16x8*>(&v);
+            af[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(As + a_frag + i * 32 * SROW + kk * 16));
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            uint4 v = *reinterpret_cast<const uint4*>(Bs + b_frag + i * 32 * SROW + kk * 16);
-            bfr[kk][i] = *reinterpret_cast<bf16x8*>(&v);
+            bfr[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Bs + b_frag + i * 32 * SROW + kk * 16));
         }
     };
     auto mfma_chunk = [&](int kk) {

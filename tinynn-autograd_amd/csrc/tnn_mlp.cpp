@@ -45,6 +45,14 @@ struct Mlp {
     std::vector<int64_t> w_off, b_off;
     std::vector<void*> act;          // act[l]  = output of layer l       [max_rows, w[l+1]]
     std::vector<void*> dact;         // dact[l] = dLoss/d(pre-activation) [max_rows, w[l+1]]
+    // bf16 mode (dtype == TNN_BF16): the four arenas above stay fp32 (master weights, gradients, Adam state);
+    // the GEMMs consume bf16 working copies, every operand K-contiguous (see tnn_gemm_bf16.hip)
+    bool bf16 = false;
+    char* w16 = nullptr;             // bf16 copy of the whole parameter arena (W_l at w_off[l], [in,out])
+    std::vector<void*> wT16;         // W_l^T [out,in]  (forward operand)
+    std::vector<void*> actT16;       // act[l]^T [w[l+1], max_rows]   (dW operand of layer l+1)
+    std::vector<void*> dactT16;      // dact[l]^T [w[l+1], max_rows]  (dW operand of layer l)
+    void* xT16 = nullptr;            // x^T [w[0], max_rows]
 };
 
 #define MLP_TRY(call)            \
@@ -83,6 +91,69 @@ int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1
     return 0;
 }
 
+// ---------------------------------------------------------------- bf16 mode
+inline void* at16(char* base, int64_t elem_off) { return base + elem_off * 2; }
+
+int mlp16_sync(Mlp* h) {      // refresh the bf16 working copies from the fp32 master parameters
+    MLP_TRY(tnn_cast_bf16(h->params, h->w16, h->n_params, 1));
+    for (int l = 0; l < h->L; ++l)
+        MLP_TRY(tnn_transpose_bf16(at16(h->w16, h->w_off[l]), h->wT16[l], h->w[l], h->w[l + 1]));
+    return 0;
+}
+
+int mlp16_forward(Mlp* h, const void* x16, int64_t rows) {
+    const void* in = x16;
+    for (int l = 0; l < h->L; ++l) {
+        const bool hidden = l < h->L - 1;
+        // z_l = a_{l-1} W_l + b_l : A = a [rows, in] (K = in), B = W_l^T [out, in]
+        MLP_TRY(tnn_gemm_bf16_nt(rows, h->w[l + 1], h->w[l], in, h->w[l], h->wT16[l], h->w[l], h->act[l],
+                                 h->w[l + 1], TNN_BF16, at(h->params, h->b_off[l], 4),
+                                 hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, nullptr, 0));
+        in = h->act[l];
+    }
+    return 0;
+}
+
+int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64_t m_global, void* loss_out) {
+    const int L = h->L;
+    void* loss_slot = at(h->grads, h->n_params, 4);
+    if (h->loss_kind != 1) {
+        tnn::set_error("bf16 trainer: only the sum-of-squares loss is implemented");
+        return 2;
+    }
+    MLP_TRY(tnn_mse_bf16(h->act[L - 1], y16, rows * h->w[L], m_global, loss_slot, h->dact[L - 1]));
+    for (int l = L - 1; l >= 0; --l) {
+        const void* in = l == 0 ? x16 : h->act[l - 1];
+        void* inT = l == 0 ? h->xT16 : h->actT16[l - 1];
+        // K-contiguous operands of dW_l = in^T dz: in^T [w[l], rows] and dz^T [w[l+1], rows]
+        MLP_TRY(tnn_transpose_bf16(in, inT, rows, h->w[l]));
+        MLP_TRY(tnn_transpose_bf16(h->dact[l], h->dactT16[l], rows, h->w[l + 1]));
+        MLP_TRY(tnn_gemm_bf16_nt(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows,
+                                 at(h->grads, h->w_off[l], 4), h->w[l + 1], TNN_F32, nullptr, TNN_ACT_NONE, 0,
+                                 nullptr, 0));
+        MLP_TRY(tnn_colsum_bf16(h->dact[l], at(h->grads, h->b_off[l], 4), rows, h->w[l + 1]));
+        // dz_{l-1} = (dz_l W_l^T) * mask : A = dz_l [rows, out] (K = out), B = W_l [in, out]
+        if (l > 0)
+            MLP_TRY(tnn_gemm_bf16_nt(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, h->w_off[l]),
+                                     h->w[l + 1], h->dact[l - 1], h->w[l], TNN_BF16, nullptr, TNN_ACT_NONE, 0,
+                                     h->act[l - 1], h->w[l]));
+    }
+    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, 4));
+    return 0;
+}
+
+int mlp16_update(Mlp* h) {
+    if (h->opt_kind != 1) {
+        tnn::set_error("bf16 trainer: only Adam is implemented");
+        return 2;
+    }
+    MLP_TRY(tnn_adam_master_bf16(h->params, h->grads, h->m, h->v, h->w16, h->n_params, h->lr, h->b1, h->b2, h->eps,
+                                 h->pows));
+    for (int l = 0; l < h->L; ++l)
+        MLP_TRY(tnn_transpose_bf16(at16(h->w16, h->w_off[l]), h->wT16[l], h->w[l], h->w[l + 1]));
+    return 0;
+}
+
 int check_rows(Mlp* h, int64_t rows, const char* fn) {
     if (!h) { tnn::set_error("%s: NULL handle", fn); return 2; }
     if (rows <= 0 || rows > h->max_rows) {
@@ -103,7 +174,7 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
         tnn::set_error("tnn_mlp_create: bad arguments");
         return 2;
     }
-    if (dtype != TNN_F32 && dtype != TNN_F64) {
+    if (dtype != TNN_F32 && dtype != TNN_F64 && dtype != TNN_BF16) {
         tnn::set_error("tnn_mlp_create: dtype %d is not a float type", dtype);
         return 2;
     }
@@ -119,7 +190,8 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     h->opt_kind = opt_kind;
     h->dtype = dtype;
     h->lr = lr; h->b1 = b1; h->b2 = b2; h->eps = eps;
-    h->esz = dtype == TNN_F32 ? 4 : 8;
+    h->bf16 = dtype == TNN_BF16;
+    h->esz = dtype == TNN_F64 ? 8 : 4;            // element size of the four arenas (fp32 in bf16 mode)
     int64_t off = 0;
     for (int l = 0; l < n_layers; ++l) {
         if (widths[l] < 1 || widths[l + 1] < 1) {
@@ -142,12 +214,26 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     rc |= tnn_malloc(bytes, (void**)&h->v);
     rc |= tnn_malloc(4 * sizeof(double), &h->pows);
     rc |= tnn_malloc(2 * 8, &h->stats);
+    const size_t act_esz = h->bf16 ? 2 : h->esz;
     for (int l = 0; l < n_layers && !rc; ++l) {
         void *a = nullptr, *d = nullptr;
-        rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * h->esz, &a);
-        rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * h->esz, &d);
+        rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * act_esz, &a);
+        rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * act_esz, &d);
         h->act.push_back(a);
         h->dact.push_back(d);
+        if (h->bf16) {
+            void *wt = nullptr, *at_ = nullptr, *dt = nullptr;
+            rc |= tnn_malloc((size_t)(widths[l] * widths[l + 1]) * 2, &wt);
+            rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * 2, &at_);
+            rc |= tnn_malloc((size_t)(max_rows * widths[l + 1]) * 2, &dt);
+            h->wT16.push_back(wt);
+            h->actT16.push_back(at_);
+            h->dactT16.push_back(dt);
+        }
+    }
+    if (h->bf16 && !rc) {
+        rc |= tnn_malloc((size_t)h->arena * 2, (void**)&h->w16);
+        rc |= tnn_malloc((size_t)(max_rows * widths[0]) * 2, &h->xT16);
     }
     if (!rc) {
         rc |= tnn_memset(h->params, 0, bytes);
@@ -172,6 +258,10 @@ int tnn_mlp_destroy(void* handle) {
     tnn_free(h->pows); tnn_free(h->stats); tnn_free(h->stats_all);
     for (void* p : h->act) tnn_free(p);
     for (void* p : h->dact) tnn_free(p);
+    for (void* p : h->wT16) tnn_free(p);
+    for (void* p : h->actT16) tnn_free(p);
+    for (void* p : h->dactT16) tnn_free(p);
+    tnn_free(h->w16); tnn_free(h->xT16);
     delete h;
     return 0;
 }
@@ -201,6 +291,11 @@ int tnn_mlp_param_offset(void* handle, int layer, int which, int64_t* offset, in
 int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits) {
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_forward"));
+    if (h->bf16) {
+        MLP_TRY(mlp16_forward(h, x, rows));
+        if (logits) MLP_TRY(tnn_memcpy_d2d(logits, h->act[h->L - 1], (size_t)(rows * h->w[h->L]) * 2));
+        return 0;
+    }
     MLP_TRY(mlp_forward(h, x, rows));
     if (logits)
         MLP_TRY(tnn_memcpy_d2d(logits, h->act[h->L - 1], (size_t)(rows * h->w[h->L]) * h->esz));
@@ -210,6 +305,7 @@ int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits) {
 int tnn_mlp_forward_stats(void* handle, const void* x, int64_t rows, void* stats) {
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_forward_stats"));
+    if (h->bf16) return mlp16_forward(h, x, rows);
     MLP_TRY(mlp_forward(h, x, rows));
     if (h->loss_kind == 0)
         MLP_TRY(tnn_softmax_nll_stats(h->act[h->L - 1], rows, h->w[h->L], stats ? stats : h->stats,
@@ -221,6 +317,7 @@ int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, i
                      const void* stats, void* loss_out) {
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_backward"));
+    if (h->bf16) return mlp16_backward(h, x, y, rows, m_global, loss_out);
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
     if (h->loss_kind == 0)
@@ -237,6 +334,7 @@ int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, i
 int tnn_mlp_update(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) { tnn::set_error("tnn_mlp_update: NULL handle"); return 2; }
+    if (h->bf16) return mlp16_update(h);
     if (h->opt_kind == 0) return tnn_sgd(h->params, h->grads, h->n_params, h->lr, h->dtype);
     return tnn_adam(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps,
                     h->pows, nullptr, h->dtype);
@@ -291,6 +389,12 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
     MLP_TRY(tnn_mlp_update(handle));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, at(h->grads, h->n_params, h->esz), h->esz));
     return 0;
+}
+
+int tnn_mlp_sync_params(void* handle) {
+    Mlp* h = (Mlp*)handle;
+    if (!h) { tnn::set_error("tnn_mlp_sync_params: NULL handle"); return 2; }
+    return h->bf16 ? mlp16_sync(h) : 0;
 }
 
 int tnn_mlp_activation(void* handle, int layer, void** ptr) {

@@ -30,14 +30,17 @@ class MLPTrainer(object):
         self.widths = [int(w) for w in widths]
         self.n_layers = len(self.widths) - 1
         self.max_rows = int(max_rows)
-        self.dtype = np.dtype(dtype)
+        # dtype "bfloat16": bf16 inputs / activations / working weights, fp32 master weights + gradients + Adam
+        # state (BASELINE.json configs[4]).  The arenas exposed below are then the fp32 ones.
+        self.bf16 = isinstance(dtype, str) and dtype in ("bfloat16", "bf16")
+        self.dtype = np.dtype(np.float32) if self.bf16 else np.dtype(dtype)
         # force_dp keeps the sharded code path (stats exchange, arena all-reduce) even at world size 1, which
         # is how the RCCL path is exercised on a single-GPU box
         self.comm = comm if (comm is not None and (comm.world > 1 or force_dp)) else None
         self.use_graph = bool(use_graph) and self.comm is None
         self._lib = _lib.get()
         self._h = ctypes.c_void_p()
-        code = da._CODE[self.dtype]
+        code = _lib.BF16 if self.bf16 else da._CODE[self.dtype]
         self._lib.mlp_create(self.n_layers, da._i64arr(self.widths), self.max_rows, _LOSS[loss],
                              _OPT[optimizer], float(lr), float(beta1), float(beta2), float(epsilon),
                              code, ctypes.byref(self._h))
@@ -89,6 +92,7 @@ class MLPTrainer(object):
                 src = src.values if hasattr(src, "values") and not isinstance(src, np.ndarray) else src
                 view = self.param_view(i, key)
                 view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
+        self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies W, W^T
 
     def get_parameters(self):
         return [{"w": self.param_view(i, "w"), "b": self.param_view(i, "b")} for i in range(self.n_layers)]
@@ -96,10 +100,30 @@ class MLPTrainer(object):
     def activation(self, layer, rows):
         p = ctypes.c_void_p()
         self._lib.mlp_activation(self._h, layer, ctypes.byref(p))
-        return da.from_ptr(p.value, (rows, self.widths[layer + 1]), self.dtype, self)
+        return da.from_ptr(p.value, (rows, self.widths[layer + 1]), np.uint16 if self.bf16 else self.dtype, self)
 
     # ------------------------------------------------------------------ compute
+    def _prep16(self, x, y=None):
+        from . import bf16 as _bf16
+
+        def as16(a):
+            a = da.asarray(a)
+            return a._contig() if a.dtype == np.uint16 else _bf16.to_bf16(a)     # pre-cast data is used as is
+        x = as16(x)
+        rows = x.shape[0]
+        if x.ndim != 2 or x.shape[1] != self.widths[0] or not 0 < rows <= self.max_rows:
+            raise ValueError("inputs %s do not fit a [<=%d, %d] batch" % (x.shape, self.max_rows, self.widths[0]))
+        if rows % 64:
+            raise ValueError("the bf16 path needs a batch that is a multiple of 64 rows (K of the dW GEMM)")
+        if y is not None:
+            y = as16(y)
+            if y.shape != (rows, self.widths[-1]):
+                raise ValueError("targets %s must be [%d, %d]" % (y.shape, rows, self.widths[-1]))
+        return x, y, rows
+
     def _prep(self, x, y=None):
+        if self.bf16:
+            return self._prep16(x, y)
         x = da.asarray(x, dtype=self.dtype)._contig()
         rows = x.shape[0]
         if x.ndim != 2 or x.shape[1] != self.widths[0] or not 0 < rows <= self.max_rows:
@@ -112,6 +136,11 @@ class MLPTrainer(object):
 
     def forward(self, x):
         x, _, rows = self._prep(x)
+        if self.bf16:
+            from . import bf16 as _bf16
+            out16 = da.empty((rows, self.widths[-1]), np.uint16)
+            self._lib.mlp_forward(self._h, x._ptr, rows, out16._ptr)
+            return _bf16.to_f32(out16)
         out = da.empty((rows, self.widths[-1]), self.dtype)
         self._lib.mlp_forward(self._h, x._ptr, rows, out._ptr)
         return out
