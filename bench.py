@@ -12,6 +12,9 @@ backward -> [RCCL all-reduce] -> Adam update (examples/mnist/run.py:79-83).  Inp
   --workload A (default)  configs[1]/[3] of BASELINE.json: 128 rows per GPU (N=8 -> global batch 1024)
   --workload C            configs[2]: Dense 4096->4096->4096 autoencoder, bs 512, sum-of-squares loss —
                           the MFMA roofline run (one GPU)
+  --workload E            configs[4] per GPU: 8192-wide 4-layer MLP, bf16 storage / fp32 accumulate / fp32 master
+                          weights + Adam state, bs 512, sum-of-squares loss (no cpu_baseline: one float64 step of
+                          the 268 M-parameter net takes minutes on the host)
   --path fused (default)  whole-step trainer (tnn_mlp_*), hipGraph replay at N=1
   --path ops              the drop-in Tensor/ops/Model path (same maths, one launch per op)
   --path opsgraph         the same op-level loop body captured into a hipGraph and replayed
@@ -43,8 +46,10 @@ from tinynn_autograd_amd import _lib                  # noqa: E402
 from tinynn_autograd_amd import device_array as da    # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense (AMD's 5 PF headline includes 2:1 sparsity)
 WIDTHS_A = [784, 256, 128, 10]
 WIDTHS_C = [4096, 4096, 4096]
+WIDTHS_E = [8192, 8192, 8192, 8192, 8192]
 
 
 def synth_batches(n_batches, rows, widths, kind, rank, world, seed=1234):
@@ -126,6 +131,48 @@ def time_gemms(widths, rows, reps=20):
             "gemm_us_per_step": round(tot_ms * 1e3, 2), "per_gemm": results}
 
 
+def time_gemms_bf16(widths, rows, reps=10):
+    """The bf16 step's GEMMs, all in the K-contiguous form the bf16 trainer uses (tnn_gemm_bf16_nt):
+    forward [rows,out] <- a[rows,in] W^T[out,in]; dX [rows,in] <- dz[rows,out] W[in,out]; dW [in,out] (f32) <-
+    a^T[in,rows] dz^T[out,rows]."""
+    from tinynn_autograd_amd import bf16
+    rs = np.random.RandomState(7)
+    results, tot_flops, tot_ms = [], 0.0, 0.0
+    shapes = []
+    for l in range(len(widths) - 1):
+        shapes.append(("fwd%d" % l, rows, widths[l + 1], widths[l], np.uint16))
+    for l in reversed(range(len(widths) - 1)):
+        shapes.append(("dW%d" % l, widths[l], widths[l + 1], rows, np.float32))
+        if l > 0:
+            shapes.append(("dX%d" % l, rows, widths[l], widths[l + 1], np.uint16))
+    cache = {}
+    for name, M, N, K, out in shapes:
+        key = (M, N, K, out)
+        if key not in cache:
+            A = bf16.to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+            B = bf16.to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+            for _ in range(2):
+                bf16.gemm_nt(A, B, out_dtype=out)
+            e0, e1 = _lib.Event(), _lib.Event()
+            e0.record()
+            for _ in range(reps):
+                bf16.gemm_nt(A, B, out_dtype=out)
+            e1.record()
+            cache[key] = e0.elapsed_ms(e1) / reps
+        ms = cache[key]
+        flops = 2.0 * M * N * K
+        results.append({"gemm": name, "layout": "NT(bf16)", "M": M, "N": N, "K": K, "us": round(ms * 1e3, 2),
+                        "tflops": round(flops / (ms * 1e-3) / 1e12, 1)})
+        tot_flops += flops
+        tot_ms += ms
+    achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_bf16_nt_kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+            "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "gemm_us_per_step": round(tot_ms * 1e3, 1),
+            "per_gemm": results}
+
+
 def attach_traffic(roof, tag):
     """roofline.traffic = HBM-side bytes per step of the GEMM launches, from the PMC passes committed under
     profiles/ (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; collected with rocprofv3 --pmc on this same
@@ -194,7 +241,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="A", choices=["A", "C"])
+    ap.add_argument("--workload", default="A", choices=["A", "C", "E"])
     ap.add_argument("--path", default="fused", choices=["fused", "ops", "opsgraph"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -227,19 +274,42 @@ def main():
         steps = args.steps if args.steps is not None else 2000
         warmup = args.warmup if args.warmup is not None else 64
         n_batches = 64
-    else:
+    elif args.workload == "C":
         widths, rows, kind, loss = WIDTHS_C, 512, "mse", "mse"
         steps = args.steps if args.steps is not None else 50
         warmup = args.warmup if args.warmup is not None else 5
+        n_batches = 2
+    else:
+        widths, rows, kind, loss = WIDTHS_E, 512, "mse", "mse"
+        steps = args.steps if args.steps is not None else 20
+        warmup = args.warmup if args.warmup is not None else 3
         n_batches = 2
 
     x_host, y_host = synth_batches(n_batches, rows, widths, kind, rank, world)
     X, Y = da.asarray(x_host), da.asarray(y_host)      # resident in HBM before the timed region
     batches = [(X[i * rows:(i + 1) * rows], Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
 
-    net = build_net(widths)
     chunk = None
-    if args.path == "fused":
+    if args.workload == "E":
+        # bf16 storage / fp32 master weights (configs[4]); 268 M parameters: initialise layer by layer on the host
+        from tinynn_autograd_amd import bf16
+        from tinynn_autograd_amd.fused import MLPTrainer
+        args.path = "fused"
+        trainer = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16", comm=comm,
+                             force_dp=force_dp)
+        np.random.seed(0)
+        for l in range(len(widths) - 1):
+            a = np.sqrt(6.0 / (widths[l] + widths[l + 1]))
+            trainer.param_view(l, "w")[...] = da.asarray(
+                np.random.uniform(-a, a, (widths[l], widths[l + 1])).astype(np.float32))
+        lib.mlp_sync_params(trainer._h)
+        X16 = bf16.to_bf16(X)
+        batches = [(X16[i * rows:(i + 1) * rows], X16[i * rows:(i + 1) * rows]) for i in range(n_batches)]
+
+        def step(i):
+            return trainer.step(*batches[i % n_batches])
+    elif args.path == "fused":
+        net = build_net(widths)
         trainer = tn.trainer_from_net(net, max_rows=rows, loss=loss, optimizer="adam", lr=1e-3, comm=comm,
                                       use_graph=not args.no_graph, force_dp=force_dp)
         if not args.no_graph and (comm is None or os.environ.get("TNN_DP_GRAPH", "1") != "0"):
@@ -258,6 +328,7 @@ def main():
         def step(i):
             return trainer.step(*batches[i % n_batches])
     else:
+        net = build_net(widths)
         from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss, SquaredErrorLoss
         from tinynn_autograd_amd.core.model import Model
         from tinynn_autograd_amd.core.optimizer import Adam
@@ -328,14 +399,16 @@ def main():
     if rank == 0:
         value = steps * rows * world / elapsed
         line = {
-            "metric": "training samples/sec, MNIST 3-layer MLP (784-256-128-10), bs=128, at 1/2/4/8 GPUs"
-                      if args.workload == "A" else "training samples/sec, Dense 4096-4096-4096 autoencoder, bs=512",
+            "metric": {"A": "training samples/sec, MNIST 3-layer MLP (784-256-128-10), bs=128, at 1/2/4/8 GPUs",
+                       "C": "training samples/sec, Dense 4096-4096-4096 autoencoder, bs=512",
+                       "E": "training samples/sec, 8192-wide 4-layer MLP bf16, bs=512 per GPU"}[args.workload],
             "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16 (fp32 accumulate, fp32 master weights)" if args.workload == "E" else "f32",
+            "data": "synthetic",
             "config": {"workload": "%s: Dense/ReLU MLP %s, %d rows per GPU (global batch %d), whole-batch "
                                    "softmax NLL%s, Adam lr=1e-3" % (
-                                       "configs[1]" if args.workload == "A" else "configs[2]",
+                                       {"A": "configs[1]", "C": "configs[2]", "E": "configs[4]"}[args.workload],
                                        "-".join(map(str, widths)), rows, rows * world,
                                        "" if kind == "softmax_nll" else " replaced by sum-of-squares/m"),
                        "path": args.path + ("+hipGraph(%d steps/launch)" % n_batches if chunk is not None else "")
@@ -345,12 +418,15 @@ def main():
             "final_loss": round(final_loss, 6),
             "device": _lib.device_props()["name"],
         }
-        line["roofline"] = time_gemms(widths, rows, reps=200 if args.workload == "A" else 20)
-        attach_traffic(line["roofline"], args.workload)
+        if args.workload == "E":
+            line["roofline"] = time_gemms_bf16(widths, rows)
+        else:
+            line["roofline"] = time_gemms(widths, rows, reps=200 if args.workload == "A" else 20)
+            attach_traffic(line["roofline"], args.workload)
         if args.workload == "A":
             line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
             attach_traffic(line["roofline_gemm4096"], "C")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "E":
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=12.0 if args.workload == "A" else 20.0)
         print(json.dumps(line))
     if comm is not None:
