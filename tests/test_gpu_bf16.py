@@ -44,6 +44,9 @@ def test_bf16_transpose_colsum_mse_adam():
     x = bf16.round_to_bf16(rs.randn(300, 130).astype(np.float32))
     X = bf16.to_bf16(x)
     assert np.array_equal(np.asarray(bf16.to_f32(bf16.transpose(X))), x.T)
+    for shape in ((512, 8192), (64, 64), (132, 260), (36, 8), (129, 70)):            # fast (x4) and fallback shapes
+        z = bf16.round_to_bf16(rs.randn(*shape).astype(np.float32))
+        assert np.array_equal(np.asarray(bf16.to_f32(bf16.transpose(bf16.to_bf16(z)))), z.T), shape
     cs = tn.empty((130,))
     _lib.get().colsum_bf16(X._ptr, cs._ptr, 300, 130)
     np.testing.assert_allclose(np.asarray(cs), x.astype(np.float64).sum(0), rtol=1e-5, atol=1e-5)
