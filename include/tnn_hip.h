@@ -235,6 +235,12 @@ TNN_API int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_g
 /* Adam on the fp32 master parameters (same maths as tnn_adam) that also refreshes the bf16 working copy */
 TNN_API int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* w_bf16, int64_t n,
                                  double lr, double b1, double b2, double eps, void* pows_f64);
+/* The same update on one [rows, cols] weight matrix that ALSO writes the transposed bf16 copy wT_bf16
+ * [cols, rows] the forward GEMM reads (NULL = skip it), so the refreshed weights are not re-read by a
+ * separate transpose.  advance != 0 advances the beta powers first (do it once per optimizer step). */
+TNN_API int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, void* w_bf16, void* wT_bf16,
+                                    int64_t rows, int64_t cols, double lr, double b1, double b2, double eps,
+                                    void* pows_f64, int advance);
 
 /* ------------------------------------------------------------------ whole-step MLP trainer ---- */
 /* One object = Dense/ReLU stack + whole-batch softmax NLL (loss_kind 0) or sum-of-squares/m

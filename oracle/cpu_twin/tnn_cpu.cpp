@@ -650,6 +650,10 @@ int tnn_mse_bf16(const void*, const void*, int64_t, int64_t, void*, void*) { NO_
 int tnn_adam_master_bf16(void*, const void*, void*, void*, void*, int64_t, double, double, double, double, void*) {
     NO_BF16("tnn_adam_master_bf16");
 }
+int tnn_adam_master_bf16_2d(void*, const void*, void*, void*, void*, void*, int64_t, int64_t, double, double, double,
+                            double, void*, int) {
+    NO_BF16("tnn_adam_master_bf16_2d");
+}
 
 // ---- comm: single-process identity (multi-process CPU tests use gloo at the Python layer) ----
 static int g_comm = 0;

@@ -70,6 +70,26 @@ def test_bf16_transpose_colsum_mse_adam():
     ref = p0 - 1e-3 * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
     np.testing.assert_allclose(np.asarray(P), ref, rtol=0, atol=2e-6)
     assert np.array_equal(np.asarray(bf16.to_f32(W16)), bf16.round_to_bf16(np.asarray(P)))
+    # the tiled variant that also emits the transposed working copy: bit-identical to the flat kernel
+    for (R, C) in ((192, 136), (64, 64), (100, 36), (1, 40), (30, 10)):
+        p0 = rs.randn(R, C).astype(np.float32); g = (rs.randn(R, C) * 1e-2).astype(np.float32)
+        out = []
+        for tiled in (False, True):
+            P, G, M_, V_ = tn.asarray(p0), tn.asarray(g), tn.zeros((R, C)), tn.zeros((R, C))
+            W16, WT16 = tn.empty((R, C), np.uint16), tn.empty((C, R), np.uint16)
+            pows = tn.asarray(np.array([1.0, 1.0, 0, 0]), dtype=np.float64)
+            for _ in range(2):
+                if tiled:
+                    _lib.get().adam_master_bf16_2d(P._ptr, G._ptr, M_._ptr, V_._ptr, W16._ptr, WT16._ptr, R, C,
+                                                   1e-3, 0.9, 0.999, 1e-8, pows._ptr, 1)
+                else:
+                    _lib.get().adam_master_bf16(P._ptr, G._ptr, M_._ptr, V_._ptr, W16._ptr, R * C,
+                                                1e-3, 0.9, 0.999, 1e-8, pows._ptr)
+            out.append([np.asarray(t) for t in (P, M_, V_, W16)] + [np.asarray(pows)])
+            if tiled:
+                assert np.array_equal(np.asarray(WT16), np.asarray(W16).T), (R, C)
+        for a, b in zip(*out):
+            assert np.array_equal(a, b), (R, C)
 
 
 @pytest.mark.gpu

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "tnn_colsum_bf16": [_p, _p, c_int64, c_int64],
     "tnn_mse_bf16": [_p, _p, c_int64, c_int64, _p, _p],
     "tnn_adam_master_bf16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
+    "tnn_adam_master_bf16_2d": [_p, _p, _p, _p, _p, _p, c_int64, c_int64, c_double, c_double, c_double, c_double, _p, c_int],
     "tnn_mlp_create": [c_int, _i64p, c_int64, c_int, c_int, c_double, c_double, c_double, c_double,
                        c_int, POINTER(c_void_p)],
     "tnn_mlp_destroy": [_p],

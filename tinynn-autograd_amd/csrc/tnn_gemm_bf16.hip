@@ -256,6 +256,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
 // 8-B rows into an LDS image of the OUTPUT tile, and after the barrier the tile leaves with 16-B stores, eight
 // lanes per 128-B output row.  Requires R % 4 == 0 and C % 4 == 0 (else the element-wise fallback below).
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in,
                                                              bf16_t* __restrict__ out, int64_t R, int64_t C) {
@@ -388,6 +389,99 @@ __global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict
         w16[i] = f2bf(pi);
     }
 }
+// Adam on one [R, C] weight matrix in 64x64 tiles: float4 traffic on p/g/m/v, 8-B stores to the bf16 copy, and the
+// transposed bf16 copy leaves through the same LDS image as transpose_bf16_kernel.  R % 4 == C % 4 == 0.
+template <bool WT>
+__global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                                  float* __restrict__ m, float* __restrict__ v,
+                                                                  bf16_t* __restrict__ w16, bf16_t* __restrict__ wT16,
+                                                                  int64_t R, int64_t C, float lr, float b1, float b2,
+                                                                  float eps, const double* __restrict__ state) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[WT ? 64 : 1][64 + 8];
+    const double p1 = state[0], p2 = state[1];
+    const float ic1 = (float)(1.0 / (1.0 - p1)), ic2 = (float)(1.0 / (1.0 - p2));
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t c = c0 + 4 * tx;
+    u32x2 row[4];
+    auto update = [&](f32x4 gi, f32x4& mi, f32x4& vi, f32x4& pi) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mi[k] = mi[k] + omb1 * (gi[k] - mi[k]);
+            vi[k] = vi[k] + omb2 * (gi[k] * gi[k] - vi[k]);
+            pi[k] = pi[k] + (-lr * (mi[k] * ic1) / (sqrtf(vi[k] * ic2) + eps));
+        }
+        return u32x2{(uint32_t)f2bf(pi[0]) | ((uint32_t)f2bf(pi[1]) << 16),
+                     (uint32_t)f2bf(pi[2]) | ((uint32_t)f2bf(pi[3]) << 16)};
+    };
+    if (r0 + 64 <= R && c0 + 64 <= C) {
+        // interior tile: all sixteen 16-B loads in flight before the first use
+        const int64_t o0 = (r0 + 4 * ty) * C + c;
+        f32x4 gi[4], mi[4], vi[4], pi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            gi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o0 + i * C));
+            mi[i] = *reinterpret_cast<const f32x4*>(m + o0 + i * C);
+            vi[i] = *reinterpret_cast<const f32x4*>(v + o0 + i * C);
+            pi[i] = *reinterpret_cast<const f32x4*>(p + o0 + i * C);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            row[i] = update(gi[i], mi[i], vi[i], pi[i]);
+            *reinterpret_cast<f32x4*>(m + o0 + i * C) = mi[i];
+            *reinterpret_cast<f32x4*>(v + o0 + i * C) = vi[i];
+            *reinterpret_cast<f32x4*>(p + o0 + i * C) = pi[i];
+            *reinterpret_cast<u32x2*>(w16 + o0 + i * C) = row[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t r = r0 + 4 * ty + i;
+            row[i] = u32x2{0u, 0u};
+            if (r < R && c < C) {
+                const int64_t o = r * C + c;
+                const f32x4 gi = *reinterpret_cast<const f32x4*>(g + o);
+                f32x4 mi = *reinterpret_cast<const f32x4*>(m + o);
+                f32x4 vi = *reinterpret_cast<const f32x4*>(v + o);
+                f32x4 pi = *reinterpret_cast<const f32x4*>(p + o);
+                row[i] = update(gi, mi, vi, pi);
+                *reinterpret_cast<f32x4*>(m + o) = mi;
+                *reinterpret_cast<f32x4*>(v + o) = vi;
+                *reinterpret_cast<f32x4*>(p + o) = pi;
+                *reinterpret_cast<u32x2*>(w16 + o) = row[i];
+            }
+        }
+    }
+    if (!WT) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int w = j >> 1;
+        u32x2 col;
+        if (j & 1) {
+            col.x = (row[0][w] >> 16) | (row[1][w] & 0xffff0000u);
+            col.y = (row[2][w] >> 16) | (row[3][w] & 0xffff0000u);
+        } else {
+            col.x = (row[0][w] & 0xffffu) | (row[1][w] << 16);
+            col.y = (row[2][w] & 0xffffu) | (row[3][w] << 16);
+        }
+        *reinterpret_cast<u32x2*>(&tile[4 * tx + j][4 * ty]) = col;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int cc = (threadIdx.x >> 3) + 32 * i, seg = threadIdx.x & 7;
+        const int64_t oc = c0 + cc, orow = r0 + seg * 8;
+        if (oc < C && orow < R) {
+            const u32x4 val = *reinterpret_cast<const u32x4*>(&tile[cc][seg * 8]);
+            if (orow + 8 <= R) {
+                *reinterpret_cast<u32x4*>(wT16 + oc * R + orow) = val;
+            } else {
+                *reinterpret_cast<u32x2*>(wT16 + oc * R + orow) = u32x2{val.x, val.y};
+            }
+        }
+    }
+}
 __global__ void adam_advance16_kernel(double* __restrict__ state, double b1, double b2) {
     state[0] *= b1;
     state[1] *= b2;
@@ -509,6 +603,42 @@ int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* 
                        (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2, (float)eps,
                        (const double*)pows_f64);
     TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, void* w_bf16, void* wT_bf16,
+                            int64_t rows, int64_t cols, double lr, double b1, double b2, double eps, void* pows_f64,
+                            int advance) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_master_bf16_2d: pows state is NULL");
+    hipStream_t s = tnn::stream();
+    if (advance) hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
+    if (rows <= 0 || cols <= 0) {
+        TNN_LAUNCH_OK();
+        return 0;
+    }
+    const uintptr_t align = reinterpret_cast<uintptr_t>(p_master) | reinterpret_cast<uintptr_t>(g) |
+                            reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                            reinterpret_cast<uintptr_t>(wT_bf16) | (reinterpret_cast<uintptr_t>(w_bf16) << 1);
+    if (rows % 4 == 0 && cols % 4 == 0 && (align & 15) == 0) {
+        dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+        if (wT_bf16)
+            hipLaunchKernelGGL(adam_master_bf16_2d_kernel<true>, grid, 256, 0, s, (float*)p_master, (const float*)g,
+                               (float*)m, (float*)v, (bf16_t*)w_bf16, (bf16_t*)wT_bf16, rows, cols, (float)lr,
+                               (float)b1, (float)b2, (float)eps, (const double*)pows_f64);
+        else
+            hipLaunchKernelGGL(adam_master_bf16_2d_kernel<false>, grid, 256, 0, s, (float*)p_master, (const float*)g,
+                               (float*)m, (float*)v, (bf16_t*)w_bf16, (bf16_t*)nullptr, rows, cols, (float)lr,
+                               (float)b1, (float)b2, (float)eps, (const double*)pows_f64);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
+    const int64_t n = rows * cols;
+    hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid(n, 256), 256, 0, s, (float*)p_master, (const float*)g,
+                       (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2, (float)eps,
+                       (const double*)pows_f64);
+    TNN_LAUNCH_OK();
+    if (wT_bf16) return tnn_transpose_bf16(w_bf16, wT_bf16, rows, cols);
     return 0;
 }
 

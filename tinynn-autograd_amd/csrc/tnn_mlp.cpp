@@ -147,10 +147,17 @@ int mlp16_update(Mlp* h) {
         tnn::set_error("bf16 trainer: only Adam is implemented");
         return 2;
     }
-    MLP_TRY(tnn_adam_master_bf16(h->params, h->grads, h->m, h->v, h->w16, h->n_params, h->lr, h->b1, h->b2, h->eps,
-                                 h->pows));
-    for (int l = 0; l < h->L; ++l)
-        MLP_TRY(tnn_transpose_bf16(at16(h->w16, h->w_off[l]), h->wT16[l], h->w[l], h->w[l + 1]));
+    // per layer: W (also refreshing W^T for the forward GEMM) then b; the beta powers advance once, up front
+    auto f32 = [](void* base, int64_t off) { return (void*)((float*)base + off); };
+    for (int l = 0; l < h->L; ++l) {
+        const int64_t wo = h->w_off[l], bo = h->b_off[l];
+        MLP_TRY(tnn_adam_master_bf16_2d(f32(h->params, wo), f32(h->grads, wo), f32(h->m, wo), f32(h->v, wo),
+                                        at16(h->w16, wo), h->wT16[l], h->w[l], h->w[l + 1], h->lr, h->b1, h->b2,
+                                        h->eps, h->pows, l == 0));
+        MLP_TRY(tnn_adam_master_bf16_2d(f32(h->params, bo), f32(h->grads, bo), f32(h->m, bo), f32(h->v, bo),
+                                        at16(h->w16, bo), nullptr, 1, h->w[l + 1], h->lr, h->b1, h->b2, h->eps,
+                                        h->pows, 0));
+    }
     return 0;
 }
 
