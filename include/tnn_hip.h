@@ -287,6 +287,20 @@ TNN_API int tnn_comm_world(int* rank, int* world);
 TNN_API int tnn_allreduce(void* buf, int64_t n, int dtype, int rop);
 TNN_API int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype);
 
+/* ------------------------------------------------ xGMI peer-to-peer transport under C1 / C2 --- */
+/* Latency path for small messages (the 0.94 MB MNIST gradient arena, the {max, sum-exp} pairs): every rank
+ * creates one uncached region and exports it (64-byte hipIpcMemHandle), the host side exchanges the handles
+ * (torch.distributed/gloo in dist.py), every rank maps all peers.  From then on tnn_allreduce (f32 SUM, up to
+ * max_bytes) and tnn_allgather (<= 256 B per rank) are single kernels of posted peer stores and flag barriers on
+ * the library stream, hipGraph-capturable, bit-identical on every rank; anything else still goes to RCCL.
+ * rank/world here also serve tnn_comm_world when no RCCL communicator exists. */
+TNN_API int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64_out);
+TNN_API int tnn_p2p_connect(const void* handles /* world x 64 bytes, rank order */);
+TNN_API int tnn_p2p_enable(int on);                         /* route eligible collectives here (default after connect) */
+/* dead != 0: a barrier timed out (TNN_P2P_TIMEOUT_MS, default 20000) - results since then are invalid; synchronises */
+TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);
+TNN_API int tnn_p2p_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

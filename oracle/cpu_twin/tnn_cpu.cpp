@@ -672,6 +672,17 @@ int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
     return 0;
 }
 
+// the peer-to-peer transport needs device IPC: the twin only knows the one-rank group
+int tnn_p2p_create(int rank, int world, int64_t, void* h) {
+    REQ(world == 1 && rank == 0, "cpu twin: tnn_p2p supports world size 1 only");
+    memset(h, 0, 64);
+    return 0;
+}
+int tnn_p2p_connect(const void*) { g_comm = 1; return 0; }
+int tnn_p2p_enable(int) { return 0; }
+int tnn_p2p_status(int* c, int* e, int* d) { if (c) *c = g_comm; if (e) *e = g_comm; if (d) *d = 0; return 0; }
+int tnn_p2p_destroy(void) { g_comm = 0; return 0; }
+
 }  // extern "C"
 
 // the product's own trainer host code on top of the primitives above

@@ -1,0 +1,77 @@
+"""xGMI peer-to-peer transport (csrc/tnn_p2p.hip) on the GPU box: a one-rank group in-process (kernels, hipGraph
+replay, routing under tnn_allreduce / tnn_allgather) and a real two-process group sharing the box's single GPU
+(IPC mapping, flag barriers, sharded training against the reference's bs=1024 fixture) — see tests/p2p_worker.py."""
+
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import tinynn_autograd_amd as tn
+from conftest import ROOT
+
+
+@pytest.mark.gpu
+def test_p2p_world1_collectives_and_graph():
+    from tinynn_autograd_amd.dist import XgmiCommunicator
+    from tinynn_autograd_amd import _lib
+    comm = XgmiCommunicator(0, 1, p2p_bytes=1 << 20)
+    try:
+        assert comm.p2p_status() == {"connected": True, "enabled": True, "dead": False}
+        assert comm.p2p_selftest(sizes=(1, 3, 1000, 235147), rounds=2)
+        rs = np.random.RandomState(5)
+        for n in (1, 2, 7, 64, 4099, 262144):                    # ragged tails, up to the mapped capacity
+            x = rs.randn(n).astype(np.float32)
+            d = tn.asarray(x)
+            comm.allreduce(d)
+            assert np.array_equal(np.asarray(d), x), n
+        big = tn.asarray(np.ones(300000, np.float32))              # over capacity and no RCCL communicator: loud
+        with pytest.raises(RuntimeError):
+            comm.allreduce(big)
+        g = comm.allgather(tn.asarray(np.array([1.5, -2.5], np.float32)))
+        assert np.array_equal(np.asarray(g), [[1.5, -2.5]])
+        d = tn.asarray(np.arange(1000, dtype=np.float32))
+        graph = _lib.Graph()
+        with graph:
+            for _ in range(4):
+                comm.allreduce(d)
+                d *= 2.0
+        for _ in range(3):
+            graph.launch()
+        assert np.array_equal(np.asarray(d), np.arange(1000, dtype=np.float32) * 2.0 ** 12)
+        assert not comm.p2p_status()["dead"]
+    finally:
+        comm.close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_p2p_two_processes_share_the_gpu():
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), TNN_DEVICE="0", WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNN_P2P_TIMEOUT_MS="15000",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
+        assert "p2p_worker rank %d/2 ok" % rank in out

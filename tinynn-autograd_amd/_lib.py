@@ -110,6 +110,11 @@ _SIGNATURES = {
     "tnn_comm_world": [POINTER(c_int), POINTER(c_int)],
     "tnn_allreduce": [_p, c_int64, c_int, c_int],
     "tnn_allgather": [_p, _p, c_int64, c_int],
+    "tnn_p2p_create": [c_int, c_int, c_int64, _p],
+    "tnn_p2p_connect": [_p],
+    "tnn_p2p_enable": [c_int],
+    "tnn_p2p_status": [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+    "tnn_p2p_destroy": [],
 }
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["tnn_last_error"])
@@ -161,7 +166,9 @@ def get():
     global _lib
     if _lib is None:
         lib = _Lib(LIB_PATH)
-        device = int(os.environ.get("LOCAL_RANK", "0"))
+        # one process per GPU: torchrun's LOCAL_RANK picks the device; TNN_DEVICE overrides (e.g. several ranks
+        # sharing one GPU in the peer-to-peer transport test)
+        device = int(os.environ.get("TNN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         lib.init(device)              # raises TnnError when no HIP device is visible
         _lib = lib
     return _lib

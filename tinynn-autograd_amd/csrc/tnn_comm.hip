@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "tnn_internal.h"
+#include "tnn_p2p.h"
 
 namespace {
 
@@ -108,6 +109,7 @@ int tnn_comm_destroy(void) {
 }
 
 int tnn_comm_world(int* rank, int* world) {
+    if (!R.comm && tnn::p2p_world(rank, world)) return 0;     // peer-to-peer group without an RCCL communicator
     if (rank) *rank = R.rank;
     if (world) *world = R.world;
     return 0;
@@ -115,8 +117,10 @@ int tnn_comm_world(int* rank, int* world) {
 
 int tnn_allreduce(void* buf, int64_t n, int dtype, int rop) {
     TNN_NEED_INIT();
-    TNN_REQUIRE(R.comm != nullptr, "tnn_allreduce: tnn_comm_init() has not been called");
     if (n <= 0) return 0;
+    // small f32 sums take the xGMI peer-to-peer path when the peers are mapped (tnn_p2p_connect)
+    if (tnn::p2p_can_allreduce(n, dtype, rop)) return tnn::p2p_allreduce((float*)buf, n);
+    TNN_REQUIRE(R.comm != nullptr, "tnn_allreduce: tnn_comm_init() has not been called");
     ncclDataType_t t;
     if (int rc = nccl_type(dtype, &t)) return rc;
     ncclRedOp_t op;
@@ -132,8 +136,9 @@ int tnn_allreduce(void* buf, int64_t n, int dtype, int rop) {
 
 int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
     TNN_NEED_INIT();
-    TNN_REQUIRE(R.comm != nullptr, "tnn_allgather: tnn_comm_init() has not been called");
     if (n_per_rank <= 0) return 0;
+    if (tnn::p2p_can_allgather(n_per_rank, dtype)) return tnn::p2p_allgather(send, recv, n_per_rank, dtype);
+    TNN_REQUIRE(R.comm != nullptr, "tnn_allgather: tnn_comm_init() has not been called");
     ncclDataType_t t;
     if (int rc = nccl_type(dtype, &t)) return rc;
     TNN_CHECK_NCCL(R.AllGather(send, recv, (size_t)n_per_rank, t, R.comm, tnn::stream()));

@@ -1,0 +1,320 @@
+// C1/C2 over xGMI peer-to-peer stores: a low-latency transport under tnn_allreduce / tnn_allgather for the
+// messages the MNIST-size data-parallel step exchanges (a 0.94 MB gradient arena and one {max, sum-exp} pair
+// per rank; examples/mnist/run.py:82-83 is where the exchange sits, core/losses.py:26-27 is why the second one
+// exists).  At 35 us per training step the two RCCL calls ARE the multi-GPU cost, so this path is latency-first:
+//
+//   * every rank owns one UNCACHED device region (hipDeviceMallocUncached: remote stores and local reads bypass
+//     L2, so data written by a peer inside a running kernel is visible without a kernel boundary), exported
+//     once with hipIpcGetMemHandle and mapped by every peer;
+//   * all cross-GPU traffic is PUSHED (posted xGMI writes; nothing waits for a remote read round trip);
+//   * all-reduce = ONE kernel, two-stage: (A) rank r stores its copy of slice p into peer p's recv[r];
+//     barrier; (B) rank r sums recv[0..W) of its own slice IN RANK ORDER and stores the result slice into every
+//     peer's out[]; barrier; (C) out[] -> the caller's buffer.  Each slice is reduced by exactly one rank and
+//     broadcast, so all ranks end up with bit-identical sums (replicas cannot drift apart);
+//     per link and direction: 2 x n/W elements;
+//   * barriers are per-workgroup flag exchanges (block b of every rank works on the same sub-range of every
+//     slice, so only the W "block b"s have to meet): system-scope release store into each peer's flag word,
+//     acquire spin on the local words.  Flag values grow monotonically from a per-block epoch kept in DEVICE
+//     memory, so the kernel is replayable from a hipGraph with fixed arguments and never needs a reset;
+//   * spins are bounded by the constant 100 MHz clock: on timeout the kernel sets a sticky `dead` word, stops
+//     waiting (this and every later launch) and the host sees it through tnn_p2p_status() — a lost peer is an
+//     error, not a hung GPU.
+//
+// Buffer reuse is safe without extra barriers: a rank enters stage A of call k+1 only after barrier 2 of call k,
+// which every peer signals after its last read of recv[]; out[] of call k+1 is written after barrier 1 of call
+// k+1, which a peer signals only after its kernel k (stage C included) has finished in stream order.
+// The small all-gather double-buffers its slots on epoch parity for the same reason.
+#include <string.h>
+
+#include "tnn_internal.h"
+#include "tnn_p2p.h"
+
+namespace {
+
+constexpr int MAXW = 16;          // ranks
+constexpr int MAXB = 64;          // workgroups of the all-reduce kernel
+constexpr int AG_BYTES = 256;     // per-rank payload limit of the small all-gather
+constexpr int THREADS = 512;
+
+struct Header {                                   // start of every rank's uncached region
+    uint32_t flag[2][MAXB][MAXW];                 // [barrier][block][source rank]
+    uint32_t ag_flag[MAXW];                       // [source rank]
+    uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
+};
+constexpr size_t HEADER_BYTES = (sizeof(Header) + 4095) / 4096 * 4096;
+
+struct Peers {
+    char* base[MAXW];                             // every rank's region in THIS process' address space
+    int rank, world;
+    int64_t slice_cap;                            // floats per slice the regions were sized for
+};
+
+struct State {
+    bool open = false, enabled = false;
+    Peers p = {};
+    char* own = nullptr;
+    void* mapped[MAXW] = {};                      // hipIpcOpenMemHandle results (NULL for self)
+    uint32_t* epoch = nullptr;                    // [MAXB + 1] per-block epochs + the all-gather epoch (local, cached)
+    int* dead = nullptr;                          // sticky timeout word (local)
+    int64_t max_floats = 0;
+    int64_t timeout_ticks = 0;
+    int blocks_override = 0;
+} S;
+
+__device__ __forceinline__ float* recv_of(const Peers& p, int who) {
+    return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES);
+}
+__device__ __forceinline__ float* out_of(const Peers& p, int who) {
+    return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES) + (int64_t)p.world * p.slice_cap;
+}
+
+// signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine
+__device__ __forceinline__ void exchange_flags(const Peers& p, size_t word_offset_bytes, uint32_t val, int* dead,
+                                               int64_t timeout_ticks) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // my remote stores first (system scope)
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < p.world) {
+        uint32_t* theirs = reinterpret_cast<uint32_t*>(p.base[t] + word_offset_bytes) + p.rank;
+        __hip_atomic_store(theirs, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        uint32_t* mine = reinterpret_cast<uint32_t*>(p.base[p.rank] + word_offset_bytes) + t;
+        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            const uint64_t t0 = wall_clock64();
+            while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - val) < 0) {
+                if ((int64_t)(wall_clock64() - t0) > timeout_ticks) {
+                    __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
+    if (i + 4 <= n) return *reinterpret_cast<const f32x4*>(buf + i);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) v[k] = buf[i + k];
+    return v;
+}
+__device__ __forceinline__ void store_guarded(float* buf, int64_t i, int64_t n, f32x4 v) {
+    if (i + 4 <= n) {
+        *reinterpret_cast<f32x4*>(buf + i) = v;
+        return;
+    }
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) buf[i + k] = v[k];
+}
+
+// buf[0:n] <- sum over ranks, in place.  slice = floats per rank slice (multiple of 4, W*slice >= n).
+__global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* __restrict__ buf, int64_t n,
+                                                                int64_t slice, uint32_t* __restrict__ epoch,
+                                                                int* dead, int64_t timeout_ticks) {
+    const int b = blockIdx.x, W = p.world, r = p.rank;
+    const uint32_t e = epoch[b];
+    const int64_t s4 = slice / 4;
+    const int64_t per = (s4 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = min((int64_t)b * per, s4), hi = min(lo + per, s4);
+    const int64_t cap = p.slice_cap;
+
+    // (A) my copy of slice q -> rank q's recv[r]; start with my right-hand neighbour so the links fill evenly
+    for (int k = 0; k < W; ++k) {
+        const int q = (r + 1 + k) % W;
+        float* dst = recv_of(p, q) + (int64_t)r * cap;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS)
+            *reinterpret_cast<f32x4*>(dst + 4 * i) = load_guarded(buf, (int64_t)q * slice + 4 * i, n);
+    }
+    exchange_flags(p, offsetof(Header, flag) + ((size_t)(0 * MAXB + b) * MAXW) * 4, 2 * e + 1, dead, timeout_ticks);
+
+    // (B) reduce my slice in rank order, broadcast the result slice
+    const float* mine = recv_of(p, r);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(mine + 4 * i);
+        for (int q = 1; q < W; ++q) acc += *reinterpret_cast<const f32x4*>(mine + (int64_t)q * cap + 4 * i);
+        for (int k = 0; k < W; ++k) {
+            const int q = (r + 1 + k) % W;
+            *reinterpret_cast<f32x4*>(out_of(p, q) + (int64_t)r * cap + 4 * i) = acc;
+        }
+    }
+    exchange_flags(p, offsetof(Header, flag) + ((size_t)(1 * MAXB + b) * MAXW) * 4, 2 * e + 2, dead, timeout_ticks);
+
+    // (C) gathered result -> caller's buffer
+    const float* res = out_of(p, r);
+    for (int q = 0; q < W; ++q)
+        for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS)
+            store_guarded(buf, (int64_t)q * slice + 4 * i, n,
+                          *reinterpret_cast<const f32x4*>(res + (int64_t)q * cap + 4 * i));
+    if (threadIdx.x == 0) epoch[b] = e + 1;
+}
+
+// recv[q][0:words] <- rank q's send[0:words]  (words <= 64), one workgroup
+__global__ __launch_bounds__(THREADS) void p2p_allgather_kernel(Peers p, const uint32_t* __restrict__ send,
+                                                                uint32_t* __restrict__ recv, int words,
+                                                                uint32_t* __restrict__ epoch, int* dead,
+                                                                int64_t timeout_ticks) {
+    const int W = p.world, r = p.rank;
+    const uint32_t e = *epoch;
+    const int par = e & 1;
+    const size_t slots = offsetof(Header, ag_slot) + (size_t)par * MAXW * AG_BYTES;
+    for (int t = threadIdx.x; t < W * words; t += THREADS) {
+        const int q = t / words, w = t % words;
+        reinterpret_cast<uint32_t*>(p.base[q] + slots + (size_t)r * AG_BYTES)[w] = send[w];
+    }
+    exchange_flags(p, offsetof(Header, ag_flag), e + 1, dead, timeout_ticks);
+    for (int t = threadIdx.x; t < W * words; t += THREADS) {
+        const int q = t / words, w = t % words;
+        recv[t] = reinterpret_cast<const uint32_t*>(p.base[r] + slots + (size_t)q * AG_BYTES)[w];
+    }
+    if (threadIdx.x == 0) *epoch = e + 1;
+}
+
+int esize(int dtype) {
+    switch (dtype) {
+        case TNN_F32: return 4;
+        case TNN_F64: case TNN_I64: return 8;
+        case TNN_U8: return 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+namespace tnn {
+
+bool p2p_world(int* rank, int* world) {
+    if (!S.open) return false;
+    if (rank) *rank = S.p.rank;
+    if (world) *world = S.p.world;
+    return true;
+}
+
+bool p2p_can_allreduce(int64_t n, int dtype, int rop) {
+    return S.enabled && dtype == TNN_F32 && rop == TNN_RSUM && n > 0 && n <= S.max_floats;
+}
+
+int p2p_allreduce(float* buf, int64_t n) {
+    const int W = S.p.world;
+    int64_t slice = (n + W - 1) / W;
+    slice = (slice + 3) / 4 * 4;
+    // one workgroup per ~256 float4 of a slice: the message is small, barrier fan-in grows with the block count
+    int64_t blocks = S.blocks_override > 0 ? S.blocks_override : (slice / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 32 && S.blocks_override <= 0) blocks = 32;
+    if (blocks > MAXB) blocks = MAXB;
+    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, tnn::stream(), S.p, buf, n, slice,
+                       S.epoch, S.dead, S.timeout_ticks);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+bool p2p_can_allgather(int64_t n_per_rank, int dtype) {
+    const int64_t bytes = n_per_rank * esize(dtype);
+    return S.enabled && bytes > 0 && bytes <= AG_BYTES && bytes % 4 == 0;
+}
+
+int p2p_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
+    const int words = (int)(n_per_rank * esize(dtype) / 4);
+    hipLaunchKernelGGL(p2p_allgather_kernel, dim3(1), dim3(THREADS), 0, tnn::stream(), S.p, (const uint32_t*)send,
+                       (uint32_t*)recv, words, S.epoch + MAXB, S.dead, S.timeout_ticks);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace tnn
+
+extern "C" {
+
+int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
+    TNN_NEED_INIT();
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+    TNN_REQUIRE(!S.open, "tnn_p2p_create: already created");
+    TNN_REQUIRE(world >= 1 && world <= MAXW && rank >= 0 && rank < world, "tnn_p2p_create: rank %d / world %d (max %d)",
+                rank, world, MAXW);
+    TNN_REQUIRE(max_bytes >= 16 && handle64, "tnn_p2p_create: bad arguments");
+    const int64_t max_floats = max_bytes / 4;
+    int64_t cap = (max_floats + world - 1) / world;
+    cap = (cap + 3) / 4 * 4;
+    const size_t bytes = HEADER_BYTES + (size_t)2 * world * cap * 4;
+    void* region = nullptr;
+    TNN_CHECK_HIP(hipExtMallocWithFlags(&region, bytes, hipDeviceMallocUncached));
+    TNN_CHECK_HIP(hipMemset(region, 0, bytes));
+    void* local = nullptr;
+    TNN_CHECK_HIP(hipMalloc(&local, (MAXB + 1) * sizeof(uint32_t) + 64));
+    TNN_CHECK_HIP(hipMemset(local, 0, (MAXB + 1) * sizeof(uint32_t) + 64));
+    TNN_CHECK_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    TNN_CHECK_HIP(hipIpcGetMemHandle(&h, region));
+    memcpy(handle64, &h, sizeof(h));
+    S = State();
+    S.own = (char*)region;
+    S.epoch = (uint32_t*)local;
+    S.dead = (int*)((char*)local + (MAXB + 1) * sizeof(uint32_t) + 28);
+    S.p.rank = rank;
+    S.p.world = world;
+    S.p.slice_cap = cap;
+    S.max_floats = max_floats;
+    const char* to = getenv("TNN_P2P_TIMEOUT_MS");
+    const double ms = to ? atof(to) : 20000.0;
+    S.timeout_ticks = (int64_t)(ms * 1e5);                      // wall_clock64(): 100 MHz
+    const char* nb = getenv("TNN_P2P_BLOCKS");
+    S.blocks_override = nb ? atoi(nb) : 0;
+    S.open = true;
+    return 0;
+}
+
+int tnn_p2p_connect(const void* handles) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(S.open && !S.enabled, "tnn_p2p_connect: create first (and connect once)");
+    TNN_REQUIRE(handles != nullptr, "tnn_p2p_connect: handles is NULL");
+    for (int q = 0; q < S.p.world; ++q) {
+        if (q == S.p.rank) {
+            S.p.base[q] = S.own;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + (size_t)q * 64, sizeof(h));
+        void* ptr = nullptr;
+        TNN_CHECK_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+        S.mapped[q] = ptr;
+        S.p.base[q] = (char*)ptr;
+    }
+    S.enabled = true;
+    return 0;
+}
+
+int tnn_p2p_enable(int on) {
+    TNN_REQUIRE(S.open && S.p.base[S.p.rank] != nullptr, "tnn_p2p_enable: not connected");
+    S.enabled = on != 0;
+    return 0;
+}
+
+int tnn_p2p_status(int* connected, int* enabled, int* dead) {
+    if (connected) *connected = S.open && S.p.base[S.p.rank] != nullptr;
+    if (enabled) *enabled = S.enabled;
+    if (dead) {
+        *dead = 0;
+        if (S.open) {
+            TNN_CHECK_HIP(hipStreamSynchronize(tnn::stream()));
+            TNN_CHECK_HIP(hipMemcpy(dead, S.dead, sizeof(int), hipMemcpyDeviceToHost));
+        }
+    }
+    return 0;
+}
+
+int tnn_p2p_destroy(void) {
+    if (!S.open) return 0;
+    if (tnn::initialised()) (void)hipStreamSynchronize(tnn::stream());
+    for (int q = 0; q < S.p.world; ++q)
+        if (S.mapped[q]) (void)hipIpcCloseMemHandle(S.mapped[q]);
+    (void)hipFree(S.own);
+    (void)hipFree(S.epoch);
+    S = State();
+    return 0;
+}
+
+}  // extern "C"

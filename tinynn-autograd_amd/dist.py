@@ -45,24 +45,107 @@ class Communicator(object):
         return merged
 
 
-class RcclCommunicator(Communicator):
-    """RCCL through the C-ABI (tnn_comm_*), collectives enqueued on the library's own stream."""
+def _control_plane():
+    dist = sys.modules.get("torch.distributed")
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist
+    return None
 
-    def __init__(self, rank, world, unique_id):
+
+class DeviceCommunicator(Communicator):
+    """Collectives through the C-ABI (tnn_allreduce / tnn_allgather) on the library's own stream.  Two transports
+    sit under those entry points: RCCL (any size / dtype) and the xGMI peer-to-peer path of csrc/tnn_p2p.hip (f32
+    sums up to `p2p_bytes`, all-gathers up to 256 B per rank) which the library prefers whenever it is mapped."""
+
+    def __init__(self, rank, world):
         self.rank, self.world = int(rank), int(world)
-        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
-        _lib.get().comm_init(self.rank, self.world, buf)
+        self._rccl = False
+        self._p2p = False
         self._open = True
-        # RCCL must be torn down before the HIP runtime's own exit handlers run (otherwise the process aborts
-        # with "double free or corruption" at interpreter exit)
+        # tear the transports down before the HIP runtime's own exit handlers run (RCCL otherwise aborts the
+        # process with "double free or corruption" at interpreter exit)
         atexit.register(self.close)
 
-    @staticmethod
-    def new_unique_id():
-        buf = ctypes.create_string_buffer(128)
-        _lib.get().comm_unique_id(buf)
-        return buf.raw
+    # ---- transports
+    def enable_rccl(self, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _lib.get().comm_init(self.rank, self.world, buf)
+        self._rccl = True
+        return self
 
+    def enable_p2p(self, max_bytes=8 << 20, exchange=None):
+        """Create this rank's region, swap the 64-byte IPC handles (`exchange(bytes) -> [bytes] * world`, default:
+        torch.distributed.all_gather_object on the gloo control plane) and map every peer."""
+        lib = _lib.get()
+        mine = ctypes.create_string_buffer(64)
+        created, failure = False, None
+        try:
+            lib.p2p_create(self.rank, self.world, int(max_bytes), mine)
+            created = True
+        except Exception as e:                  # noqa: BLE001 - still take part in the exchange below
+            failure = e
+        token = mine.raw if created else None
+        # every rank takes part in the exchange even if its own create failed, so nobody waits forever
+        if exchange is not None:
+            handles = exchange(token)
+        elif self.world == 1:
+            handles = [token]
+        else:
+            dist = _control_plane()
+            if dist is None:
+                if created:
+                    lib.p2p_destroy()
+                raise RuntimeError("enable_p2p: torch.distributed is not initialised and no exchange() was given")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, token)
+        try:
+            if failure is not None:
+                raise failure
+            if any(h is None for h in handles):
+                raise RuntimeError("enable_p2p: a peer could not create its region")
+            blob = ctypes.create_string_buffer(b"".join(bytes(h) for h in handles), 64 * self.world)
+            lib.p2p_connect(blob)
+        except Exception:
+            if created:
+                lib.p2p_destroy()
+            raise
+        self._p2p = True
+        return self
+
+    def set_p2p(self, on):
+        if self._p2p:
+            _lib.get().p2p_enable(1 if on else 0)
+
+    def p2p_status(self):
+        """{'connected', 'enabled', 'dead'}; dead = a peer barrier timed out (synchronises the stream)."""
+        c, e, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        _lib.get().p2p_status(ctypes.byref(c), ctypes.byref(e), ctypes.byref(d))
+        return {"connected": bool(c.value), "enabled": bool(e.value), "dead": bool(d.value)}
+
+    def p2p_selftest(self, sizes=(1, 1000, 235147, 65536), rounds=3):
+        """All-reduce inputs every rank can reproduce locally (x_r[i] is a function of r and i), so the expected
+        sum — float32 adds in rank order, exactly what the kernel does — needs no second transport: the comparison is
+        bit-exact.  Also runs the small all-gather.  Returns True when every round matched and no barrier timed out."""
+        ok = True
+        for n in sizes:
+            i = np.arange(n, dtype=np.int64)
+            contrib = [(((i * 7 + r * 13 + n) % 101).astype(np.float32) / np.float32(101.0)) - np.float32(0.5 * (r % 2))
+                       for r in range(self.world)]
+            want = contrib[0].copy()
+            for r in range(1, self.world):
+                want = want + contrib[r]
+            for _ in range(rounds):
+                buf = da.asarray(contrib[self.rank])
+                self.allreduce(buf)
+                ok = ok and np.array_equal(np.asarray(buf), want)
+        for k in range(rounds):
+            mine = da.asarray(np.array([self.rank + 0.25 * k, -1.0 - self.rank], np.float32))
+            got = np.asarray(self.allgather(mine))
+            want = np.array([[r + 0.25 * k, -1.0 - r] for r in range(self.world)], np.float32)
+            ok = ok and np.array_equal(got, want)
+        return bool(ok and not self.p2p_status()["dead"])
+
+    # ---- collectives
     def allreduce(self, arr, op="sum"):
         code = {"sum": _lib.RSUM, "max": _lib.RMAX, "min": _lib.RMIN}[op]
         _lib.get().allreduce(arr._ptr, arr.size, arr._code(), code)
@@ -76,15 +159,51 @@ class RcclCommunicator(Communicator):
 
     def barrier(self):
         _lib.synchronize()
-        dist = sys.modules.get("torch.distributed")
-        if dist is not None and dist.is_available() and dist.is_initialized():
+        dist = _control_plane()
+        if dist is not None:
             dist.barrier()
 
     def close(self):
         if getattr(self, "_open", False):
             self._open = False
             _lib.synchronize()
-            _lib.get().comm_destroy()
+            if self._p2p:
+                # nobody may unmap while a peer can still store into the region
+                try:
+                    dist = _control_plane()
+                    if dist is not None and self.world > 1:
+                        dist.barrier()
+                except Exception:
+                    pass
+                _lib.get().p2p_destroy()
+                self._p2p = False
+            if self._rccl:
+                _lib.get().comm_destroy()
+                self._rccl = False
+
+
+class RcclCommunicator(DeviceCommunicator):
+    """RCCL communicator (tnn_comm_*); `p2p=True` additionally maps the peers for the xGMI latency path."""
+
+    def __init__(self, rank, world, unique_id, p2p=False, p2p_bytes=8 << 20):
+        DeviceCommunicator.__init__(self, rank, world)
+        self.enable_rccl(unique_id)
+        if p2p:
+            self.enable_p2p(p2p_bytes)
+
+    @staticmethod
+    def new_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.get().comm_unique_id(buf)
+        return buf.raw
+
+
+class XgmiCommunicator(DeviceCommunicator):
+    """Peer-to-peer transport only (no RCCL communicator): f32 sums up to `p2p_bytes` and small all-gathers."""
+
+    def __init__(self, rank, world, p2p_bytes=8 << 20, exchange=None):
+        DeviceCommunicator.__init__(self, rank, world)
+        self.enable_p2p(p2p_bytes, exchange)
 
 
 class GlooCommunicator(Communicator):
@@ -115,13 +234,52 @@ class GlooCommunicator(Communicator):
         self._dist.barrier()
 
 
-def init_from_env(backend="rccl"):
-    """Build the communicator for this rank from the torchrun environment (None when world == 1)."""
+def _want_p2p(p2p):
+    if p2p is None:
+        return os.environ.get("TNN_P2P", "1") != "0"
+    return bool(p2p)
+
+
+def _try_p2p(comm, dist):
+    """Map the peers and prove the path before trusting it: any failure — IPC refused, a wrong sum, a barrier
+    timeout — on ANY rank leaves every rank on RCCL.  Returns True when the peer-to-peer path is live."""
+    import torch
+    ok = 1
+    try:
+        comm.enable_p2p(int(os.environ.get("TNN_P2P_BYTES", str(8 << 20))))
+    except Exception as e:                      # noqa: BLE001 - every failure means "stay on RCCL"
+        sys.stderr.write("[tinynn_autograd_amd] xGMI peer-to-peer path unavailable on rank %d: %s\n" % (comm.rank, e))
+        ok = 0
+    flag = torch.tensor([ok])
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag) == 0:
+        if comm._p2p:
+            comm.set_p2p(False)
+        return False
+    good = 1 if comm.p2p_selftest() else 0
+    flag = torch.tensor([good])
+    if dist is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag) == 0:
+        sys.stderr.write("[tinynn_autograd_amd] xGMI peer-to-peer self-test failed on rank %d; using RCCL\n" % comm.rank)
+        comm.set_p2p(False)
+        return False
+    return True
+
+
+def init_from_env(backend="rccl", p2p=None):
+    """Build the communicator for this rank from the torchrun environment (None when world == 1).
+    backend "rccl": RCCL plus, unless p2p=False / TNN_P2P=0, the self-tested xGMI peer-to-peer latency path."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         if backend == "rccl" and os.environ.get("TNN_FORCE_COMM") == "1":
             # single-GPU boxes: a 1-rank RCCL communicator, so the collectives' code path can be run and timed
-            return RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
+            comm = RcclCommunicator(0, 1, RcclCommunicator.new_unique_id())
+            if _want_p2p(p2p):
+                import torch  # noqa: F401
+                _try_p2p(comm, None)
+            return comm
         return None
     if backend == "rccl" and _lib.is_loaded() and "torch" not in sys.modules:
         # torch preloads its bundled libamdhip64 / librccl by absolute path: importing it AFTER libtnn_hip.so
@@ -138,4 +296,7 @@ def init_from_env(backend="rccl"):
         return GlooCommunicator()
     box = [RcclCommunicator.new_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    return RcclCommunicator(rank, world, box[0])
+    comm = RcclCommunicator(rank, world, box[0])
+    if _want_p2p(p2p):
+        _try_p2p(comm, dist)
+    return comm

@@ -161,9 +161,9 @@ class MLPTrainer(object):
 
     def _step_dp(self, x, y, rows):
         lib = self._lib
-        from .dist import RcclCommunicator
-        if isinstance(self.comm, RcclCommunicator):
-            lib.mlp_step_sharded(self._h, x._ptr, y._ptr, rows, None)      # all phases + both RCCL calls in C
+        from .dist import DeviceCommunicator
+        if isinstance(self.comm, DeviceCommunicator):
+            lib.mlp_step_sharded(self._h, x._ptr, y._ptr, rows, None)      # all phases + both collectives in C
             return self.loss_slot
         lib.mlp_forward_stats(self._h, x._ptr, rows, self._stats._ptr)
         stats = self.comm.merge_softmax_stats(self._stats)
@@ -204,9 +204,9 @@ class StepGraph(object):
     def __init__(self, trainer, batches):
         sharded = trainer.comm is not None
         if sharded:
-            from .dist import RcclCommunicator
-            if not isinstance(trainer.comm, RcclCommunicator):
-                raise ValueError("only RCCL collectives can be captured into a hipGraph")
+            from .dist import DeviceCommunicator
+            if not isinstance(trainer.comm, DeviceCommunicator):
+                raise ValueError("only device-side collectives (RCCL / xGMI peer-to-peer) can be captured into a hipGraph")
         self.trainer = trainer
         self.batches = [trainer._prep(x, y) for x, y in batches]      # keeps the buffers alive
         self.losses = da.empty((len(self.batches),), trainer.dtype)
@@ -214,7 +214,7 @@ class StepGraph(object):
         self._graph = _lib.Graph()
         with self._graph:
             for i, (x, y, rows) in enumerate(self.batches):
-                if sharded:   # forward | all-gather + merge | backward | all-reduce | update, RCCL calls captured too
+                if sharded:   # forward | all-gather + merge | backward | all-reduce | update, collectives captured too
                     lib.mlp_step_sharded(trainer._h, x._ptr, y._ptr, rows, self.losses._ptr + i * esz)
                 else:
                     lib.mlp_step(trainer._h, x._ptr, y._ptr, rows, self.losses._ptr + i * esz)
