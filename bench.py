@@ -312,18 +312,22 @@ def main():
         net = build_net(widths)
         trainer = tn.trainer_from_net(net, max_rows=rows, loss=loss, optimizer="adam", lr=1e-3, comm=comm,
                                       use_graph=not args.no_graph, force_dp=force_dp)
-        if not args.no_graph and (comm is None or os.environ.get("TNN_DP_GRAPH", "1") != "0"):
+        def build_chunk():
             # every batch is resident at a fixed HBM address: capture one step per batch into ONE hipGraph
             # and replay it (n_batches steps per hipGraphLaunch, no staging copies).  With a communicator the two
-            # RCCL collectives of every step are captured too (RCCL supports stream capture); if the capture is
-            # refused the run falls back to eager data-parallel steps.  TNN_DP_GRAPH=0 forces the eager form.
+            # collectives of every step are captured too (peer-to-peer kernels, or RCCL which supports stream
+            # capture); if the capture is refused the run falls back to eager data-parallel steps.
+            # TNN_DP_GRAPH=0 forces the eager form.
+            if args.no_graph or not (comm is None or os.environ.get("TNN_DP_GRAPH", "1") != "0"):
+                return None
             try:
-                chunk = trainer.capture_steps(batches)
+                return trainer.capture_steps(batches)
             except Exception as exc:                          # noqa: BLE001
                 if comm is None:
                     raise
                 sys.stderr.write("bench: data-parallel graph capture unavailable (%s); eager steps\n" % exc)
-                chunk = None
+                return None
+        chunk = build_chunk()
 
         def step(i):
             return trainer.step(*batches[i % n_batches])
@@ -383,17 +387,68 @@ def main():
                 i, count = i + 1, count - 1
         return last
 
-    run(0, warmup)
-    fence()
-    t0 = time.perf_counter()
-    last = run(warmup, steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def measure(first):
+        run(first, warmup)
+        fence()
+        t0 = time.perf_counter()
+        last_loss = run(first + warmup, steps)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, last_loss
+
+    def p2p_alive():
+        """True when the xGMI peer-to-peer path is live and no rank saw a barrier time out (collective check)."""
+        st = comm.p2p_status() if comm is not None and hasattr(comm, "p2p_status") else None
+        bad = 0 if (st and st["enabled"] and not st["dead"]) else 1
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([bad])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bad = int(t.item())
+        return bad == 0
+
+    transports = None
+    if comm is not None and args.path == "fused" and args.workload != "E":
+        # Data-parallel run: the peer-to-peer transport was mapped and self-tested by init_from_env(); time the K
+        # steps on it, make sure no barrier timed out, then time the same K steps over RCCL for comparison.  `value`
+        # comes from the peer-to-peer run when it is alive, else from RCCL.
+        transports = {}
+        second = (warmup + steps + n_batches - 1) // n_batches * n_batches      # chunk-aligned start of a second run
+        used_p2p = p2p_alive()
+        elapsed, last = measure(0)
+        if used_p2p and not p2p_alive():
+            sys.stderr.write("bench: xGMI peer-to-peer barrier timed out during the run; measuring on RCCL\n")
+            used_p2p = False
+            elapsed = None
+        if used_p2p:
+            transports["xgmi_p2p_ms_per_step"] = round(elapsed / steps * 1e3, 5)
+            comm.set_p2p(False)
+            chunk = build_chunk()
+            dt_rccl, _ = measure(second)
+            transports["rccl_ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
+        else:
+            if elapsed is None:
+                comm.set_p2p(False)
+                chunk = build_chunk()
+                elapsed, last = measure(second)
+            transports["rccl_ms_per_step"] = round(elapsed / steps * 1e3, 5)
+        transports["used"] = "xgmi-p2p" if used_p2p else "rccl"
+        # replicas must still hold bit-identical parameters
+        crc = int(np.frombuffer(np.asarray(trainer.params).tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
+        if world > 1:
+            import torch.distributed as dist
+            box = [None] * world
+            dist.all_gather_object(box, crc)
+            transports["replicas_identical"] = bool(all(c == box[0] for c in box))
+        else:
+            transports["replicas_identical"] = True
+    else:
+        elapsed, last = measure(0)
     final_loss = float(last)
 
     if rank == 0:
@@ -412,9 +467,10 @@ def main():
                                        "-".join(map(str, widths)), rows, rows * world,
                                        "" if kind == "softmax_nll" else " replaced by sum-of-squares/m"),
                        "path": args.path + ("+hipGraph(%d steps/launch)" % n_batches if chunk is not None else "")
-                               + ("+rccl(world=1, forced)" if force_dp else ""),
+                               + ("+comm(world=1, forced)" if force_dp else ""),
                        "parallelism": "dp%d" % world, "global_batch": rows * world,
-                       "data_resident_in_hbm": True},
+                       "data_resident_in_hbm": True,
+                       **({"collectives": transports} if transports else {})},
             "final_loss": round(final_loss, 6),
             "device": _lib.device_props()["name"],
         }

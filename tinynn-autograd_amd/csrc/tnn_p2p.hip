@@ -32,12 +32,16 @@
 namespace {
 
 constexpr int MAXW = 16;          // ranks
-constexpr int MAXB = 64;          // workgroups of the all-reduce kernel
+constexpr int MAXB = 128;         // workgroups of the all-reduce kernel
 constexpr int AG_BYTES = 256;     // per-rank payload limit of the small all-gather
 constexpr int THREADS = 512;
 
+// Flag words are polled straight from DRAM (uncached).  With every workgroup's words packed into one 4 KB page all
+// pollers hit one HBM channel and the flag stores queue behind them (measured: 64 workgroups cost +7 us per
+// all-reduce over one); each workgroup's words therefore get a row of their own, FLAG_ROW bytes apart.
+constexpr int FLAG_ROW = 4096;
 struct Header {                                   // start of every rank's uncached region
-    uint32_t flag[2][MAXB][MAXW];                 // [barrier][block][source rank]
+    uint8_t flag[2][MAXB][FLAG_ROW];              // [barrier][block] -> uint32_t[MAXW] indexed by source rank
     uint32_t ag_flag[MAXW];                       // [source rank]
     uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
 };
@@ -68,32 +72,60 @@ __device__ __forceinline__ float* out_of(const Peers& p, int who) {
     return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES) + (int64_t)p.world * p.slice_cap;
 }
 
-// signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine
+// Signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine.
+// Everything that crosses a device boundary lives in UNCACHED memory (stores go straight to the fabric, loads come
+// from memory), so no L2 write-back / invalidate is needed — and none is issued: a system-scope release fence is a
+// whole-L2 `buffer_wbl2` per workgroup (measured: 64 workgroups -> +12 us per all-reduce).  What IS needed is
+// order: each thread waits until its own stores were acknowledged (s_waitcnt vmcnt(0)), the workgroup meets, and only
+// then the flag words go out as relaxed system-scope stores; the poll is a relaxed system-scope load (cache-bypassing).
+// An agent-scope acquire after the meeting (`buffer_inv sc1`) was measured too: +6 us per all-reduce at 64
+// workgroups.  Instead every load of peer-written data carries sc0 sc1 itself (load_sys below), so it cannot be served
+// from a vector-L1 or L2 line whatever the page's cache policy turns out to be.
 __device__ __forceinline__ void exchange_flags(const Peers& p, size_t word_offset_bytes, uint32_t val, int* dead,
                                                int64_t timeout_ticks) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // my remote stores first (system scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int t = threadIdx.x;
     if (t < p.world) {
         uint32_t* theirs = reinterpret_cast<uint32_t*>(p.base[t] + word_offset_bytes) + p.rank;
-        __hip_atomic_store(theirs, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(theirs, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         uint32_t* mine = reinterpret_cast<uint32_t*>(p.base[p.rank] + word_offset_bytes) + t;
         if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            const uint64_t t0 = wall_clock64();
-            while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - val) < 0) {
-                if ((int64_t)(wall_clock64() - t0) > timeout_ticks) {
-                    __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+            uint64_t t0 = 0;
+            uint32_t polls = 0;
+            while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - val) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 63u) == 0) {                       // look at the clock now and then
+                    const uint64_t now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if ((int64_t)(now - t0) > timeout_ticks) {
+                        __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
-                __builtin_amdgcn_s_sleep(2);
             }
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-B load that bypasses the vector L1 and L2 (system-scope bits on the instruction).  The compiler does not see
+// the outstanding load: issue a batch, then loads_landed() on the batch before the first use.
+__device__ __forceinline__ void load_sys(f32x4& v, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void load_sys(uint32_t& v, const uint32_t* ptr) {
+    asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
+}
+template <typename T, int N>
+__device__ __forceinline__ void loads_landed(T (&v)[N]) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));      // uses of v[k] stay behind the wait
+}
 
 __device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
     if (i + 4 <= n) return *reinterpret_cast<const f32x4*>(buf + i);
@@ -111,6 +143,8 @@ __device__ __forceinline__ void store_guarded(float* buf, int64_t i, int64_t n, 
         if (i + k < n) buf[i + k] = v[k];
 }
 
+constexpr int UNROLL = 4;          // independent 16-B accesses in flight per thread and loop trip
+
 // buf[0:n] <- sum over ranks, in place.  slice = floats per rank slice (multiple of 4, W*slice >= n).
 __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* __restrict__ buf, int64_t n,
                                                                 int64_t slice, uint32_t* __restrict__ epoch,
@@ -120,35 +154,67 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
     const int64_t s4 = slice / 4;
     const int64_t per = (s4 + gridDim.x - 1) / gridDim.x;
     const int64_t lo = min((int64_t)b * per, s4), hi = min(lo + per, s4);
-    const int64_t cap = p.slice_cap;
+    const int64_t len = hi - lo, cap = p.slice_cap;
+    const int64_t items = len * W;                        // (slice k, element i) pairs of this workgroup
 
-    // (A) my copy of slice q -> rank q's recv[r]; start with my right-hand neighbour so the links fill evenly
-    for (int k = 0; k < W; ++k) {
-        const int q = (r + 1 + k) % W;
-        float* dst = recv_of(p, q) + (int64_t)r * cap;
-        for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS)
-            *reinterpret_cast<f32x4*>(dst + 4 * i) = load_guarded(buf, (int64_t)q * slice + 4 * i, n);
+    // (A) my copy of slice q -> rank q's recv[r]; slice order starts at my right-hand neighbour so the links
+    // fill evenly.  Loads first (L2 hits: the gradients were just written), then the posted stores.
+    for (int64_t j0 = threadIdx.x; j0 < items; j0 += (int64_t)THREADS * UNROLL) {
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t j = j0 + (int64_t)u * THREADS;
+            if (j < items) {
+                const int q = (r + 1 + (int)(j / len)) % W;
+                v[u] = load_guarded(buf, (int64_t)q * slice + 4 * (lo + j % len), n);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t j = j0 + (int64_t)u * THREADS;
+            if (j < items) {
+                const int q = (r + 1 + (int)(j / len)) % W;
+                *reinterpret_cast<f32x4*>(recv_of(p, q) + (int64_t)r * cap + 4 * (lo + j % len)) = v[u];
+            }
+        }
     }
-    exchange_flags(p, offsetof(Header, flag) + ((size_t)(0 * MAXB + b) * MAXW) * 4, 2 * e + 1, dead, timeout_ticks);
+    exchange_flags(p, offsetof(Header, flag) + (size_t)(0 * MAXB + b) * FLAG_ROW, 2 * e + 1, dead, timeout_ticks);
 
-    // (B) reduce my slice in rank order, broadcast the result slice
+    // (B) reduce my slice in rank order (all W loads in flight, then a fixed-order sum), broadcast the result slice
     const float* mine = recv_of(p, r);
     for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS) {
-        f32x4 acc = *reinterpret_cast<const f32x4*>(mine + 4 * i);
-        for (int q = 1; q < W; ++q) acc += *reinterpret_cast<const f32x4*>(mine + (int64_t)q * cap + 4 * i);
+        f32x4 part[MAXW] = {};
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+            if (q < W) load_sys(part[q], mine + (int64_t)q * cap + 4 * i);
+        loads_landed(part);
+        f32x4 acc = part[0];
+#pragma unroll
+        for (int q = 1; q < MAXW; ++q)
+            if (q < W) acc += part[q];
         for (int k = 0; k < W; ++k) {
             const int q = (r + 1 + k) % W;
             *reinterpret_cast<f32x4*>(out_of(p, q) + (int64_t)r * cap + 4 * i) = acc;
         }
     }
-    exchange_flags(p, offsetof(Header, flag) + ((size_t)(1 * MAXB + b) * MAXW) * 4, 2 * e + 2, dead, timeout_ticks);
+    exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
 
     // (C) gathered result -> caller's buffer
     const float* res = out_of(p, r);
-    for (int q = 0; q < W; ++q)
-        for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS)
-            store_guarded(buf, (int64_t)q * slice + 4 * i, n,
-                          *reinterpret_cast<const f32x4*>(res + (int64_t)q * cap + 4 * i));
+    for (int64_t j0 = threadIdx.x; j0 < items; j0 += (int64_t)THREADS * UNROLL) {
+        f32x4 v[UNROLL] = {};
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t j = j0 + (int64_t)u * THREADS;
+            if (j < items) load_sys(v[u], res + (j / len) * cap + 4 * (lo + j % len));
+        }
+        loads_landed(v);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t j = j0 + (int64_t)u * THREADS;
+            if (j < items) store_guarded(buf, (j / len) * slice + 4 * (lo + j % len), n, v[u]);
+        }
+    }
     if (threadIdx.x == 0) epoch[b] = e + 1;
 }
 
@@ -168,7 +234,10 @@ __global__ __launch_bounds__(THREADS) void p2p_allgather_kernel(Peers p, const u
     exchange_flags(p, offsetof(Header, ag_flag), e + 1, dead, timeout_ticks);
     for (int t = threadIdx.x; t < W * words; t += THREADS) {
         const int q = t / words, w = t % words;
-        recv[t] = reinterpret_cast<const uint32_t*>(p.base[r] + slots + (size_t)q * AG_BYTES)[w];
+        uint32_t v[1] = {0u};
+        load_sys(v[0], reinterpret_cast<const uint32_t*>(p.base[r] + slots + (size_t)q * AG_BYTES) + w);
+        loads_landed(v);
+        recv[t] = v[0];
     }
     if (threadIdx.x == 0) *epoch = e + 1;
 }
@@ -201,10 +270,9 @@ int p2p_allreduce(float* buf, int64_t n) {
     const int W = S.p.world;
     int64_t slice = (n + W - 1) / W;
     slice = (slice + 3) / 4 * 4;
-    // one workgroup per ~256 float4 of a slice: the message is small, barrier fan-in grows with the block count
-    int64_t blocks = S.blocks_override > 0 ? S.blocks_override : (slice / 4 + 255) / 256;
+    // one workgroup per 512 float4 of the whole message (measured, 0.94 MB: 16 -> 19.8, 32 -> 12.1, 64 -> 8.4 us)
+    int64_t blocks = S.blocks_override > 0 ? S.blocks_override : (n / 4 + 511) / 512;
     if (blocks < 1) blocks = 1;
-    if (blocks > 32 && S.blocks_override <= 0) blocks = 32;
     if (blocks > MAXB) blocks = MAXB;
     hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, tnn::stream(), S.p, buf, n, slice,
                        S.epoch, S.dead, S.timeout_ticks);

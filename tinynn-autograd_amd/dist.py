@@ -129,12 +129,12 @@ class DeviceCommunicator(Communicator):
         ok = True
         for n in sizes:
             i = np.arange(n, dtype=np.int64)
-            contrib = [(((i * 7 + r * 13 + n) % 101).astype(np.float32) / np.float32(101.0)) - np.float32(0.5 * (r % 2))
-                       for r in range(self.world)]
-            want = contrib[0].copy()
-            for r in range(1, self.world):
-                want = want + contrib[r]
-            for _ in range(rounds):
+            for k in range(rounds):                 # fresh values every round: a stale read cannot pass
+                contrib = [(((i * 7 + r * 13 + n + 31 * k) % 101).astype(np.float32) / np.float32(101.0))
+                           - np.float32(0.5 * (r % 2)) for r in range(self.world)]
+                want = contrib[0].copy()
+                for r in range(1, self.world):
+                    want = want + contrib[r]
                 buf = da.asarray(contrib[self.rank])
                 self.allreduce(buf)
                 ok = ok and np.array_equal(np.asarray(buf), want)
