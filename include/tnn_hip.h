@@ -189,6 +189,12 @@ TNN_API int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int
  * three-kernel sequence otherwise); stats_out (device [2], may be NULL) receives {M, S}. */
 TNN_API int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, void* stats_out,
                                   void* loss_out, void* dz, int dtype);
+/* Data-parallel form of the same single launch (f32, shard fits one workgroup, peer-to-peer transport enabled):
+ * m = this rank's rows, the softmax spans all m_global rows of all ranks; the kernel exchanges the shards'
+ * {max, sum-exp} over xGMI itself (C2).  stats_out = GLOBAL {M, S}; loss_out = this rank's share of the loss
+ * (the shares sum to the whole-batch loss, core/losses.py:30-32); dz uses 1/m_global. */
+TNN_API int tnn_softmax_nll_fused_sharded(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global,
+                                          void* stats_out, void* loss_out, void* dz, int dtype);
 
 /* Classifier head of an unsharded step in one launch (MNIST-size heads: n_classes <= 16, n_hidden % 16 == 0,
  * the activations fit in LDS; anything else runs as gemm_bias_act + softmax_nll_fused + dense_bwd):
@@ -216,6 +222,11 @@ TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);
  * the step is written there and p is left untouched (the reference's _compute_step contract). */
 TNN_API int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
                      double b2, double eps, void* pows_f64, void* step_out, int dtype);
+/* tnn_adam that also copies one scalar of `dtype` from scalar_src to scalar_dst (both NULL = plain tnn_adam) in the
+ * same one-thread launch that advances pows — e.g. the loss of this step into a loss history (run.py:84). */
+TNN_API int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
+                        double b2, double eps, void* pows_f64, void* step_out, int dtype,
+                        const void* scalar_src, void* scalar_dst);
 
 /* ------------------------------------------------------------------ bf16 path (configs[4]) ---- */
 /* bf16 storage, fp32 accumulation (v_mfma_f32_32x32x16_bf16), fp32 master weights + Adam state.  One GEMM

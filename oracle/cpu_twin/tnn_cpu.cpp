@@ -615,9 +615,14 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
 }
 int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2, double eps,
              void* pows, void* step_out, int dtype) {
+    return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, nullptr, nullptr);
+}
+int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2, double eps,
+                void* pows, void* step_out, int dtype, const void* scalar_src, void* scalar_dst) {
     NEED_INIT();
     REQ(pows, "tnn_adam: pows state is NULL");
-    RECORD(tnn_adam(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype));
+    RECORD(tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, scalar_src, scalar_dst));
+    if (scalar_dst) memcpy(scalar_dst, scalar_src, dtype == TNN_F64 ? 8 : 4);
     double* st = (double*)pows;
     double p1 = st[0] * b1, p2 = st[1] * b2;
     FLOAT_SWITCH(dtype, "tnn_adam", {
@@ -672,6 +677,11 @@ int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
     return 0;
 }
 
+int tnn_softmax_nll_fused_sharded(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global, void* stats_out,
+                                  void* loss_out, void* dz, int dtype) {
+    REQ(m_global == m, "cpu twin: one-rank group only");
+    return tnn_softmax_nll_fused(z, y, m, c, stats_out, loss_out, dz, dtype);
+}
 // the peer-to-peer transport needs device IPC: the twin only knows the one-rank group
 int tnn_p2p_create(int rank, int world, int64_t, void* h) {
     REQ(world == 1 && rank == 0, "cpu twin: tnn_p2p supports world size 1 only");

@@ -56,6 +56,19 @@ def main():
     want = np.float32(sum(1.0 + r for r in range(world))) / np.float32(world)
     np.testing.assert_allclose(np.asarray(buf), want, rtol=1e-5)
     comm.barrier()
+    # a peer that never shows up must not hang the GPU: rank 0 alone enters one more all-reduce, its barrier times
+    # out (TNN_P2P_TIMEOUT_MS), the kernel finishes and the sticky `dead` word reports it
+    if os.environ.get("TNN_P2P_TEST_TIMEOUT") == "1":
+        if rank == 0:
+            import time
+            t0 = time.time()
+            comm.allreduce(buf)
+            st = comm.p2p_status()
+            assert st["dead"], "timeout was not reported"
+            assert time.time() - t0 < 10.0
+            comm.allreduce(buf)                      # later launches no longer wait at all
+            assert comm.p2p_status()["dead"]
+        comm.barrier()
     comm.close()
     print("p2p_worker rank %d/%d ok" % (rank, world))
 

@@ -78,10 +78,12 @@ _SIGNATURES = {
     "tnn_lse_merge": [_p, c_int, _p, c_int],
     "tnn_softmax_nll_fwd_bwd": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
     "tnn_softmax_nll_fused": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int],
+    "tnn_softmax_nll_fused_sharded": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
     "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],
+    "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, _p, _p],
     "tnn_gemm_bf16_nt": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, c_int, _p, c_int, c_int,
                          _p, c_int64],
     "tnn_transpose_bf16": [_p, _p, c_int64, c_int64],

@@ -3,6 +3,7 @@
 #include <math.h>
 
 #include "tnn_internal.h"
+#include "tnn_p2p.h"
 
 namespace {
 
@@ -219,10 +220,19 @@ __device__ __forceinline__ double block_reduce_fast(R v, R* slots) {
 
 // z and y are fetched ONCE, up front and coalesced, into LDS; every later phase touches only LDS, so the
 // kernel has a single global-memory round trip before its final store.
-template <typename T>
+//
+// SHARDED (data parallel, f32): m is this rank's row count and the softmax still spans the GLOBAL batch
+// (core/losses.py:26-27).  After the local {M_r, S_r} the workgroup pushes the pair into every peer's all-gather
+// slot over xGMI (csrc/tnn_p2p.h), meets the peers' workgroups at a flag barrier and merges
+// M = max_r M_r, S = sum_r S_r exp(M_r - M).  Nothing else is recomputed: with f = exp(M_r - M) the global
+// probabilities are e_local * f / S, the term (e*y)/q is invariant under the common factor f, and
+// log q_global = log q_local + (M_r - M) — so only two scalars change.  loss_out receives this rank's SHARE
+// (rows_local/m_global * log-normaliser - sum(log q)/m_global): the all-reduce of the gradient arena sums it.
+template <typename T, bool SHARDED>
 __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z, const T* __restrict__ y,
                                                          int m, int c, T* __restrict__ stats_out,
-                                                         T* __restrict__ loss_out, T* __restrict__ dz) {
+                                                         T* __restrict__ loss_out, T* __restrict__ dz,
+                                                         double inv_m_global, tnn::p2p::LaunchCtx ctx) {
     constexpr int kMax = NllCap<T>::elems;
     __shared__ T e_lds[kMax];              // z -> exp(z - M)
     __shared__ T y_lds[kMax];              // y -> e * y
@@ -246,9 +256,42 @@ __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z
         s += e;
     }
     const double S = block_reduce_fast<false, T>((T)s, red_sum);    // its barrier also publishes e/y_lds
-    __shared__ double scal[2];
-    if (tid == 0) { scal[0] = log(S); scal[1] = 1.0 / S; }           // once, not once per wave
-    const double inv_m = 1.0 / (double)m;
+    __shared__ double scal[4];
+    if constexpr (SHARDED) {
+        using namespace tnn::p2p;
+        __shared__ float peer_stats[MAXW][2];
+        const Peers& P = ctx.peers;
+        const int W = P.world;
+        const uint32_t ep = *ctx.ag_epoch;
+        const size_t slots = offsetof(Header, ag_slot) + (size_t)(ep & 1) * MAXW * AG_BYTES;
+        if (tid < 2 * W) {                                            // {M_r, S_r} -> slot [rank] of every peer
+            const float mine = (tid & 1) ? (float)S : (float)M;
+            store_sys(reinterpret_cast<uint32_t*>(P.base[tid >> 1] + slots + (size_t)P.rank * AG_BYTES) + (tid & 1),
+                      __float_as_uint(mine));
+        }
+        exchange_flags(P, offsetof(Header, ag_flag), ep + 1, ctx.dead, ctx.timeout_ticks);
+        if (tid < 2 * W) {
+            uint32_t w[1] = {0u};
+            load_sys(w[0], reinterpret_cast<const uint32_t*>(P.base[P.rank] + slots + (size_t)(tid >> 1) * AG_BYTES) + (tid & 1));
+            loads_landed(w);
+            peer_stats[tid >> 1][tid & 1] = __uint_as_float(w[0]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double gm = -INFINITY, gs = 0.0;
+            for (int q = 0; q < W; ++q) gm = fmax(gm, (double)peer_stats[q][0]);
+            for (int q = 0; q < W; ++q) gs += (double)peer_stats[q][1] * exp((double)peer_stats[q][0] - gm);
+            const double shift = M - gm;                               // <= 0
+            scal[0] = log(gs) - shift;                                 // per-row log-normaliser for LOCAL q
+            scal[1] = exp(shift) / gs;                                 // e_local -> global probability
+            scal[2] = gm;
+            scal[3] = gs;
+            *ctx.ag_epoch = ep + 1;
+        }
+    } else {
+        if (tid == 0) { scal[0] = log(S); scal[1] = 1.0 / S; scal[2] = M; scal[3] = S; }   // once, not once per wave
+    }
+    const double inv_m = SHARDED ? inv_m_global : 1.0 / (double)m;
     double local = 0.0;
     for (int r = tid; r < m; r += blockDim.x) {
         double q = 0.0;
@@ -265,7 +308,8 @@ __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z
         local -= nll_log((T)q);
     }
     const double sum_log_q = block_reduce_fast<false, T>((T)local, red_loss);   // barrier publishes q_lds, scal
-    const double loss = scal[0] + sum_log_q * inv_m;                          // log S - mean(log q)
+    // log S - mean(log q); a shard contributes its rows' share of the log-normaliser
+    const double loss = (SHARDED ? scal[0] * (double)m * inv_m : scal[0]) + sum_log_q * inv_m;
     const double inv_s = scal[1];
     if (dz) {
         if (sizeof(T) == 4) {
@@ -279,7 +323,7 @@ __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z
     }
     if (tid == 0) {
         if (loss_out) loss_out[0] = (T)loss;
-        if (stats_out) { stats_out[0] = (T)M; stats_out[1] = (T)S; }
+        if (stats_out) { stats_out[0] = (T)scal[2]; stats_out[1] = (T)scal[3]; }
     }
 }
 
@@ -334,9 +378,16 @@ __global__ __launch_bounds__(kThreads) void sgd_kernel(T* __restrict__ p, const 
 // adam_advance_kernel (one thread) right before this kernel, so that a captured hipGraph replays the right
 // bias correction without any host-side step counter.  (A first version advanced the state inside this
 // kernel with an atomic ticket per block: 230 same-address atomics cost ~3 us, more than the whole update.)
-__global__ void adam_advance_kernel(double* __restrict__ state, double b1, double b2) {
+// The same single thread can carry one scalar along (esz bytes, 4 or 8): the data-parallel trainer files the
+// all-reduced loss into its loss history this way instead of paying a separate copy launch per step.
+__global__ void adam_advance_kernel(double* __restrict__ state, double b1, double b2, const void* __restrict__ src,
+                                    void* __restrict__ dst, int esz) {
     state[0] *= b1;
     state[1] *= b2;
+    if (dst) {
+        if (esz == 8) *(double*)dst = *(const double*)src;
+        else *(float*)dst = *(const float*)src;
+    }
 }
 
 template <typename T, int VEC>
@@ -494,11 +545,28 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
     }
     int threads = m * c >= 512 ? 1024 : 256;
     if (dtype == TNN_F32)
-        hipLaunchKernelGGL((nll_fused_kernel<float>), 1, threads, 0, tnn::stream(), (const float*)z,
-                           (const float*)y, (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz);
+        hipLaunchKernelGGL((nll_fused_kernel<float, false>), 1, threads, 0, tnn::stream(), (const float*)z,
+                           (const float*)y, (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz, 0.0,
+                           tnn::p2p::LaunchCtx{});
     else
-        hipLaunchKernelGGL((nll_fused_kernel<double>), 1, threads, 0, tnn::stream(), (const double*)z,
-                           (const double*)y, (int)m, (int)c, (double*)stats_out, (double*)loss_out, (double*)dz);
+        hipLaunchKernelGGL((nll_fused_kernel<double, false>), 1, threads, 0, tnn::stream(), (const double*)z,
+                           (const double*)y, (int)m, (int)c, (double*)stats_out, (double*)loss_out, (double*)dz, 0.0,
+                           tnn::p2p::LaunchCtx{});
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_softmax_nll_fused_sharded(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global,
+                                  void* stats_out, void* loss_out, void* dz, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(dtype == TNN_F32, "tnn_softmax_nll_fused_sharded: f32 only (dtype %d)", dtype);
+    TNN_REQUIRE(m > 0 && c > 0 && m_global >= m, "tnn_softmax_nll_fused_sharded: bad batch sizes");
+    TNN_REQUIRE(m * c <= NllCap<float>::elems && m <= kNllMaxRows,
+                "tnn_softmax_nll_fused_sharded: %lld x %lld does not fit one workgroup", (long long)m, (long long)c);
+    tnn::p2p::LaunchCtx ctx;
+    TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_softmax_nll_fused_sharded: the peer-to-peer transport is not enabled");
+    hipLaunchKernelGGL((nll_fused_kernel<float, true>), 1, 1024, 0, tnn::stream(), (const float*)z, (const float*)y,
+                       (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz, 1.0 / (double)m_global, ctx);
     TNN_LAUNCH_OK();
     return 0;
 }
@@ -545,11 +613,18 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
 
 int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2,
              double eps, void* pows_f64, void* step_out, int dtype) {
+    return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows_f64, step_out, dtype, nullptr, nullptr);
+}
+
+int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2,
+                double eps, void* pows_f64, void* step_out, int dtype, const void* scalar_src, void* scalar_dst) {
     TNN_NEED_INIT();
     if (n <= 0) return 0;
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam: pows state is NULL");
+    TNN_REQUIRE((scalar_src == nullptr) == (scalar_dst == nullptr), "tnn_adam_ex: scalar_src / scalar_dst go together");
     hipStream_t s = tnn::stream();
-    hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
+    hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2, scalar_src, scalar_dst,
+                       dtype == TNN_F64 ? 8 : 4);
     if (dtype == TNN_F32) {
         bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                      reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |

@@ -385,16 +385,31 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
         MLP_TRY(tnn_malloc((size_t)world * 2 * 8, &h->stats_all));
         h->stats_all_world = world;
     }
-    MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
-    const void* stats = h->stats;
-    if (h->loss_kind == 0) {
-        MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
-        MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
+    int p2p_on = 0;
+    MLP_TRY(tnn_p2p_status(nullptr, &p2p_on, nullptr));
+    const int L = h->L;
+    void* loss_slot = at(h->grads, h->n_params, h->esz);
+    if (p2p_on && !h->bf16 && h->loss_kind == 0 && h->dtype == TNN_F32 && rows * h->w[L] <= 4096 && rows <= 1024) {
+        // xGMI peer-to-peer transport and a head that fits one workgroup: the softmax statistics are exchanged
+        // INSIDE the loss kernel (stats + C2 + merge + loss + dz = one launch instead of five)
+        MLP_TRY(mlp_forward(h, x, rows));
+        MLP_TRY(tnn_softmax_nll_fused_sharded(h->act[L - 1], y, rows, h->w[L], rows * world, h->stats, loss_slot,
+                                              h->dact[L - 1], h->dtype));
+        MLP_TRY(mlp_backward_layers(h, x, rows));
+    } else {
+        MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+        if (h->loss_kind == 0) {
+            MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
+            MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
+        }
+        MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr));
     }
-    MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, stats, nullptr));
     MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->dtype, TNN_RSUM));
+    if (!h->bf16 && h->opt_kind == 1 && loss_out)      // the loss of this step rides in Adam's one-thread prologue
+        return tnn_adam_ex(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps, h->pows,
+                           nullptr, h->dtype, loss_slot, loss_out);
     MLP_TRY(tnn_mlp_update(handle));
-    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, at(h->grads, h->n_params, h->esz), h->esz));
+    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;
 }
 

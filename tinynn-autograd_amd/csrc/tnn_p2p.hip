@@ -31,27 +31,7 @@
 
 namespace {
 
-constexpr int MAXW = 16;          // ranks
-constexpr int MAXB = 128;         // workgroups of the all-reduce kernel
-constexpr int AG_BYTES = 256;     // per-rank payload limit of the small all-gather
-constexpr int THREADS = 512;
-
-// Flag words are polled straight from DRAM (uncached).  With every workgroup's words packed into one 4 KB page all
-// pollers hit one HBM channel and the flag stores queue behind them (measured: 64 workgroups cost +7 us per
-// all-reduce over one); each workgroup's words therefore get a row of their own, FLAG_ROW bytes apart.
-constexpr int FLAG_ROW = 4096;
-struct Header {                                   // start of every rank's uncached region
-    uint8_t flag[2][MAXB][FLAG_ROW];              // [barrier][block] -> uint32_t[MAXW] indexed by source rank
-    uint32_t ag_flag[MAXW];                       // [source rank]
-    uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
-};
-constexpr size_t HEADER_BYTES = (sizeof(Header) + 4095) / 4096 * 4096;
-
-struct Peers {
-    char* base[MAXW];                             // every rank's region in THIS process' address space
-    int rank, world;
-    int64_t slice_cap;                            // floats per slice the regions were sized for
-};
+using namespace tnn::p2p;
 
 struct State {
     bool open = false, enabled = false;
@@ -64,68 +44,6 @@ struct State {
     int64_t timeout_ticks = 0;
     int blocks_override = 0;
 } S;
-
-__device__ __forceinline__ float* recv_of(const Peers& p, int who) {
-    return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES);
-}
-__device__ __forceinline__ float* out_of(const Peers& p, int who) {
-    return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES) + (int64_t)p.world * p.slice_cap;
-}
-
-// Signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine.
-// Everything that crosses a device boundary lives in UNCACHED memory (stores go straight to the fabric, loads come
-// from memory), so no L2 write-back / invalidate is needed — and none is issued: a system-scope release fence is a
-// whole-L2 `buffer_wbl2` per workgroup (measured: 64 workgroups -> +12 us per all-reduce).  What IS needed is
-// order: each thread waits until its own stores were acknowledged (s_waitcnt vmcnt(0)), the workgroup meets, and only
-// then the flag words go out as relaxed system-scope stores; the poll is a relaxed system-scope load (cache-bypassing).
-// An agent-scope acquire after the meeting (`buffer_inv sc1`) was measured too: +6 us per all-reduce at 64
-// workgroups.  Instead every load of peer-written data carries sc0 sc1 itself (load_sys below), so it cannot be served
-// from a vector-L1 or L2 line whatever the page's cache policy turns out to be.
-__device__ __forceinline__ void exchange_flags(const Peers& p, size_t word_offset_bytes, uint32_t val, int* dead,
-                                               int64_t timeout_ticks) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t < p.world) {
-        uint32_t* theirs = reinterpret_cast<uint32_t*>(p.base[t] + word_offset_bytes) + p.rank;
-        __hip_atomic_store(theirs, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        uint32_t* mine = reinterpret_cast<uint32_t*>(p.base[p.rank] + word_offset_bytes) + t;
-        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            uint64_t t0 = 0;
-            uint32_t polls = 0;
-            while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - val) < 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++polls & 63u) == 0) {                       // look at the clock now and then
-                    const uint64_t now = wall_clock64();
-                    if (t0 == 0) t0 = now;
-                    if ((int64_t)(now - t0) > timeout_ticks) {
-                        __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// 16-B load that bypasses the vector L1 and L2 (system-scope bits on the instruction).  The compiler does not see
-// the outstanding load: issue a batch, then loads_landed() on the batch before the first use.
-__device__ __forceinline__ void load_sys(f32x4& v, const float* ptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
-}
-__device__ __forceinline__ void load_sys(uint32_t& v, const uint32_t* ptr) {
-    asm volatile("global_load_dword %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
-}
-template <typename T, int N>
-__device__ __forceinline__ void loads_landed(T (&v)[N]) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));      // uses of v[k] stay behind the wait
-}
 
 __device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
     if (i + 4 <= n) return *reinterpret_cast<const f32x4*>(buf + i);
@@ -174,7 +92,7 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             const int64_t j = j0 + (int64_t)u * THREADS;
             if (j < items) {
                 const int q = (r + 1 + (int)(j / len)) % W;
-                *reinterpret_cast<f32x4*>(recv_of(p, q) + (int64_t)r * cap + 4 * (lo + j % len)) = v[u];
+                store_sys(recv_of(p, q) + (int64_t)r * cap + 4 * (lo + j % len), v[u]);
             }
         }
     }
@@ -194,7 +112,7 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             if (q < W) acc += part[q];
         for (int k = 0; k < W; ++k) {
             const int q = (r + 1 + k) % W;
-            *reinterpret_cast<f32x4*>(out_of(p, q) + (int64_t)r * cap + 4 * i) = acc;
+            store_sys(out_of(p, q) + (int64_t)r * cap + 4 * i, acc);
         }
     }
     exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
@@ -229,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void p2p_allgather_kernel(Peers p, const u
     const size_t slots = offsetof(Header, ag_slot) + (size_t)par * MAXW * AG_BYTES;
     for (int t = threadIdx.x; t < W * words; t += THREADS) {
         const int q = t / words, w = t % words;
-        reinterpret_cast<uint32_t*>(p.base[q] + slots + (size_t)r * AG_BYTES)[w] = send[w];
+        store_sys(reinterpret_cast<uint32_t*>(p.base[q] + slots + (size_t)r * AG_BYTES) + w, send[w]);
     }
     exchange_flags(p, offsetof(Header, ag_flag), e + 1, dead, timeout_ticks);
     for (int t = threadIdx.x; t < W * words; t += THREADS) {
@@ -278,6 +196,15 @@ int p2p_allreduce(float* buf, int64_t n) {
                        S.epoch, S.dead, S.timeout_ticks);
     TNN_LAUNCH_OK();
     return 0;
+}
+
+bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
+    if (!S.enabled) return false;
+    ctx->peers = S.p;
+    ctx->ag_epoch = S.epoch + MAXB;
+    ctx->dead = S.dead;
+    ctx->timeout_ticks = S.timeout_ticks;
+    return true;
 }
 
 bool p2p_can_allgather(int64_t n_per_rank, int dtype) {
