@@ -195,6 +195,13 @@ TNN_API int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64
  * (the shares sum to the whole-batch loss, core/losses.py:30-32); dz uses 1/m_global. */
 TNN_API int tnn_softmax_nll_fused_sharded(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global,
                                           void* stats_out, void* loss_out, void* dz, int dtype);
+/* The single-launch loss with everything a whole-step trainer hangs on it: sharded != 0 = the data-parallel form
+ * above (f32), else m_global must equal m; adam_pows_f64 != NULL: thread 0 also advances Adam's {b1^t, b2^t}
+ * (pows[0] *= b1, pows[1] *= b2) so the optimizer needs no prologue launch.  Requires m*c <= 4096 (f32) /
+ * 2048 (f64) and m <= 1024 — it is an error otherwise (callers pick the multi-launch sequence themselves). */
+TNN_API int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global,
+                                       int sharded, void* stats_out, void* loss_out, void* dz, int dtype,
+                                       void* adam_pows_f64, double b1, double b2);
 
 /* Classifier head of an unsharded step in one launch (MNIST-size heads: n_classes <= 16, n_hidden % 16 == 0,
  * the activations fit in LDS; anything else runs as gemm_bias_act + softmax_nll_fused + dense_bwd):
@@ -222,10 +229,12 @@ TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);
  * the step is written there and p is left untouched (the reference's _compute_step contract). */
 TNN_API int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
                      double b2, double eps, void* pows_f64, void* step_out, int dtype);
-/* tnn_adam that also copies one scalar of `dtype` from scalar_src to scalar_dst (both NULL = plain tnn_adam) in the
- * same one-thread launch that advances pows — e.g. the loss of this step into a loss history (run.py:84). */
+/* tnn_adam with its one-thread prologue under the caller's control: advance = 0 when pows was already advanced for
+ * this step (tnn_softmax_nll_fused_tick does it inside the loss kernel); scalar_src/scalar_dst (both or neither) copy
+ * one scalar of `dtype` in that prologue — e.g. the loss of this step into a loss history (run.py:84).  With
+ * advance = 0 and no scalar the prologue launch disappears. */
 TNN_API int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1,
-                        double b2, double eps, void* pows_f64, void* step_out, int dtype,
+                        double b2, double eps, void* pows_f64, void* step_out, int dtype, int advance,
                         const void* scalar_src, void* scalar_dst);
 
 /* ------------------------------------------------------------------ bf16 path (configs[4]) ---- */
@@ -297,6 +306,13 @@ TNN_API int tnn_comm_world(int* rank, int* world);
 /* in-place all-reduce on the library stream; rop = TNN_RSUM / TNN_RMAX */
 TNN_API int tnn_allreduce(void* buf, int64_t n, int dtype, int rop);
 TNN_API int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype);
+/* C1 and the optimizer in one call (run.py:82-83 with the exchange in between): grads[0:n_reduce] <- SUM over ranks,
+ * then tnn_adam_ex(p, grads, m, v, n_params <= n_reduce, ..., advance, scalar_src = grads + scalar_index, scalar_dst).
+ * On the peer-to-peer transport (f32, advance == 0) the update is applied by the all-reduce kernel's last stage, so
+ * the reduced gradient is consumed from registers and no optimizer launch follows. */
+TNN_API int tnn_allreduce_adam(void* grads, int64_t n_reduce, void* p, void* m, void* v, int64_t n_params, double lr,
+                               double b1, double b2, double eps, void* pows_f64, int advance, int dtype,
+                               int64_t scalar_index, void* scalar_dst);
 
 /* ------------------------------------------------ xGMI peer-to-peer transport under C1 / C2 --- */
 /* Latency path for small messages (the 0.94 MB MNIST gradient arena, the {max, sum-exp} pairs): every rank

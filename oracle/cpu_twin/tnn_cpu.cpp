@@ -615,16 +615,16 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
 }
 int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2, double eps,
              void* pows, void* step_out, int dtype) {
-    return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, nullptr, nullptr);
+    return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, 1, nullptr, nullptr);
 }
 int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2, double eps,
-                void* pows, void* step_out, int dtype, const void* scalar_src, void* scalar_dst) {
+                void* pows, void* step_out, int dtype, int advance, const void* scalar_src, void* scalar_dst) {
     NEED_INIT();
     REQ(pows, "tnn_adam: pows state is NULL");
-    RECORD(tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, scalar_src, scalar_dst));
+    RECORD(tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, advance, scalar_src, scalar_dst));
     if (scalar_dst) memcpy(scalar_dst, scalar_src, dtype == TNN_F64 ? 8 : 4);
     double* st = (double*)pows;
-    double p1 = st[0] * b1, p2 = st[1] * b2;
+    double p1 = advance ? st[0] * b1 : st[0], p2 = advance ? st[1] * b2 : st[1];
     FLOAT_SWITCH(dtype, "tnn_adam", {
         T ic1 = (T)(1.0 / (1.0 - p1)), ic2 = (T)(1.0 / (1.0 - p2));
         for (int64_t i = 0; i < n; ++i) {
@@ -677,10 +677,26 @@ int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
     return 0;
 }
 
+int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global, int sharded,
+                               void* stats_out, void* loss_out, void* dz, int dtype, void* pows, double b1, double b2) {
+    NEED_INIT();
+    REQ(m_global == m, "cpu twin: one-rank group only");
+    REQ(m * c <= (dtype == TNN_F32 ? 4096 : 2048) && m <= 1024, "tnn_softmax_nll_fused_tick: does not fit one workgroup");
+    RECORD(tnn_softmax_nll_fused_tick(z, y, m, c, m_global, sharded, stats_out, loss_out, dz, dtype, pows, b1, b2));
+    if (pows) { ((double*)pows)[0] *= b1; ((double*)pows)[1] *= b2; }
+    return tnn_softmax_nll_fused(z, y, m, c, stats_out, loss_out, dz, dtype);
+}
 int tnn_softmax_nll_fused_sharded(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global, void* stats_out,
                                   void* loss_out, void* dz, int dtype) {
-    REQ(m_global == m, "cpu twin: one-rank group only");
-    return tnn_softmax_nll_fused(z, y, m, c, stats_out, loss_out, dz, dtype);
+    return tnn_softmax_nll_fused_tick(z, y, m, c, m_global, 1, stats_out, loss_out, dz, dtype, nullptr, 0.0, 0.0);
+}
+int tnn_allreduce_adam(void* grads, int64_t n_reduce, void* p, void* m, void* v, int64_t n_params, double lr, double b1,
+                       double b2, double eps, void* pows, int advance, int dtype, int64_t scalar_index, void* scalar_dst) {
+    REQ(n_params > 0 && n_reduce >= n_params, "tnn_allreduce_adam: n_reduce < n_params");
+    if (int rc = tnn_allreduce(grads, n_reduce, dtype, TNN_RSUM)) return rc;
+    const size_t esz = dtype == TNN_F64 ? 8 : 4;
+    return tnn_adam_ex(p, grads, m, v, n_params, lr, b1, b2, eps, pows, nullptr, dtype, advance,
+                       scalar_dst ? (const char*)grads + (size_t)scalar_index * esz : nullptr, scalar_dst);
 }
 // the peer-to-peer transport needs device IPC: the twin only knows the one-rank group
 int tnn_p2p_create(int rank, int world, int64_t, void* h) {

@@ -79,11 +79,12 @@ _SIGNATURES = {
     "tnn_softmax_nll_fwd_bwd": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
     "tnn_softmax_nll_fused": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int],
     "tnn_softmax_nll_fused_sharded": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
+    "tnn_softmax_nll_fused_tick": [_p, _p, c_int64, c_int64, c_int64, c_int, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],
-    "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, _p, _p],
+    "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, c_int, _p, _p],
     "tnn_gemm_bf16_nt": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, c_int, _p, c_int, c_int,
                          _p, c_int64],
     "tnn_transpose_bf16": [_p, _p, c_int64, c_int64],
@@ -112,6 +113,8 @@ _SIGNATURES = {
     "tnn_comm_world": [POINTER(c_int), POINTER(c_int)],
     "tnn_allreduce": [_p, c_int64, c_int, c_int],
     "tnn_allgather": [_p, _p, c_int64, c_int],
+    "tnn_allreduce_adam": [_p, c_int64, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, c_int, c_int,
+                           c_int64, _p],
     "tnn_p2p_create": [c_int, c_int, c_int64, _p],
     "tnn_p2p_connect": [_p],
     "tnn_p2p_enable": [c_int],

@@ -134,6 +134,28 @@ int tnn_allreduce(void* buf, int64_t n, int dtype, int rop) {
     return 0;
 }
 
+int tnn_allreduce_adam(void* grads, int64_t n_reduce, void* p, void* m, void* v, int64_t n_params, double lr,
+                       double b1, double b2, double eps, void* pows_f64, int advance, int dtype,
+                       int64_t scalar_index, void* scalar_dst) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(n_params > 0 && n_reduce >= n_params, "tnn_allreduce_adam: n_reduce (%lld) < n_params (%lld)",
+                (long long)n_reduce, (long long)n_params);
+    TNN_REQUIRE(pows_f64 != nullptr, "tnn_allreduce_adam: pows state is NULL");
+    TNN_REQUIRE(!scalar_dst || (scalar_index >= 0 && scalar_index < n_reduce), "tnn_allreduce_adam: scalar_index");
+    const bool aligned = ((reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(p) |
+                           reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    // scalar_index inside the vectorised interior is not supported by the fused tail; the trainer's loss slot is
+    // the element right behind the parameters
+    if (!advance && aligned && (!scalar_dst || scalar_index >= n_params) &&
+        tnn::p2p_can_allreduce(n_reduce, dtype, TNN_RSUM))
+        return tnn::p2p_allreduce_adam((float*)grads, n_reduce, (float*)p, (float*)m, (float*)v, n_params, lr, b1, b2,
+                                       eps, (const double*)pows_f64, scalar_index, (float*)scalar_dst);
+    if (int rc = tnn_allreduce(grads, n_reduce, dtype, TNN_RSUM)) return rc;
+    const size_t esz = dtype == TNN_F64 ? 8 : 4;
+    return tnn_adam_ex(p, grads, m, v, n_params, lr, b1, b2, eps, pows_f64, nullptr, dtype, advance,
+                       scalar_dst ? (const char*)grads + (size_t)scalar_index * esz : nullptr, scalar_dst);
+}
+
 int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
     TNN_NEED_INIT();
     if (n_per_rank <= 0) return 0;

@@ -232,13 +232,20 @@ template <typename T, bool SHARDED>
 __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z, const T* __restrict__ y,
                                                          int m, int c, T* __restrict__ stats_out,
                                                          T* __restrict__ loss_out, T* __restrict__ dz,
-                                                         double inv_m_global, tnn::p2p::LaunchCtx ctx) {
+                                                         double inv_m_global, tnn::p2p::LaunchCtx ctx,
+                                                         double* __restrict__ tick, double b1, double b2) {
     constexpr int kMax = NllCap<T>::elems;
     __shared__ T e_lds[kMax];              // z -> exp(z - M)
     __shared__ T y_lds[kMax];              // y -> e * y
     __shared__ double q_lds[kNllMaxRows];
     __shared__ T red_max[16], red_sum[16], red_loss[16];
     const int tid = threadIdx.x, n = m * c;
+    // the loss kernel is the one single-workgroup launch of a training step: its thread 0 can also advance Adam's
+    // {b1^t, b2^t} (tick != NULL), which otherwise costs a launch of its own (adam_advance_kernel, ~1.6 us)
+    if (tick != nullptr && tid == 0) {
+        tick[0] *= b1;
+        tick[1] *= b2;
+    }
     T mx = -INFINITY;
     for (int i = tid; i < n; i += blockDim.x) {
         const T zi = z[i];
@@ -547,26 +554,49 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
     if (dtype == TNN_F32)
         hipLaunchKernelGGL((nll_fused_kernel<float, false>), 1, threads, 0, tnn::stream(), (const float*)z,
                            (const float*)y, (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz, 0.0,
-                           tnn::p2p::LaunchCtx{});
+                           tnn::p2p::LaunchCtx{}, (double*)nullptr, 0.0, 0.0);
     else
         hipLaunchKernelGGL((nll_fused_kernel<double, false>), 1, threads, 0, tnn::stream(), (const double*)z,
                            (const double*)y, (int)m, (int)c, (double*)stats_out, (double*)loss_out, (double*)dz, 0.0,
-                           tnn::p2p::LaunchCtx{});
+                           tnn::p2p::LaunchCtx{}, (double*)nullptr, 0.0, 0.0);
     TNN_LAUNCH_OK();
     return 0;
 }
 
 int tnn_softmax_nll_fused_sharded(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global,
                                   void* stats_out, void* loss_out, void* dz, int dtype) {
+    return tnn_softmax_nll_fused_tick(z, y, m, c, m_global, 1, stats_out, loss_out, dz, dtype, nullptr, 0.0, 0.0);
+}
+
+int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t c, int64_t m_global, int sharded,
+                               void* stats_out, void* loss_out, void* dz, int dtype, void* adam_pows_f64, double b1,
+                               double b2) {
     TNN_NEED_INIT();
-    TNN_REQUIRE(dtype == TNN_F32, "tnn_softmax_nll_fused_sharded: f32 only (dtype %d)", dtype);
-    TNN_REQUIRE(m > 0 && c > 0 && m_global >= m, "tnn_softmax_nll_fused_sharded: bad batch sizes");
-    TNN_REQUIRE(m * c <= NllCap<float>::elems && m <= kNllMaxRows,
-                "tnn_softmax_nll_fused_sharded: %lld x %lld does not fit one workgroup", (long long)m, (long long)c);
-    tnn::p2p::LaunchCtx ctx;
-    TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_softmax_nll_fused_sharded: the peer-to-peer transport is not enabled");
-    hipLaunchKernelGGL((nll_fused_kernel<float, true>), 1, 1024, 0, tnn::stream(), (const float*)z, (const float*)y,
-                       (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz, 1.0 / (double)m_global, ctx);
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fused_tick: dtype %d", dtype);
+    TNN_REQUIRE(m > 0 && c > 0, "tnn_softmax_nll_fused_tick: empty batch");
+    TNN_REQUIRE(m * c <= (dtype == TNN_F32 ? NllCap<float>::elems : NllCap<double>::elems) && m <= kNllMaxRows,
+                "tnn_softmax_nll_fused_tick: %lld x %lld does not fit one workgroup", (long long)m, (long long)c);
+    double* tick = (double*)adam_pows_f64;
+    if (sharded) {
+        TNN_REQUIRE(dtype == TNN_F32, "tnn_softmax_nll_fused_tick: the sharded form is f32 only (dtype %d)", dtype);
+        TNN_REQUIRE(m_global >= m, "tnn_softmax_nll_fused_tick: m_global < m");
+        tnn::p2p::LaunchCtx ctx;
+        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_softmax_nll_fused_tick: the peer-to-peer transport is not enabled");
+        hipLaunchKernelGGL((nll_fused_kernel<float, true>), 1, 1024, 0, tnn::stream(), (const float*)z, (const float*)y,
+                           (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz, 1.0 / (double)m_global, ctx,
+                           tick, b1, b2);
+    } else {
+        TNN_REQUIRE(m_global == m, "tnn_softmax_nll_fused_tick: unsharded call with m_global != m");
+        const int threads = m * c >= 512 ? 1024 : 256;
+        if (dtype == TNN_F32)
+            hipLaunchKernelGGL((nll_fused_kernel<float, false>), 1, threads, 0, tnn::stream(), (const float*)z,
+                               (const float*)y, (int)m, (int)c, (float*)stats_out, (float*)loss_out, (float*)dz, 0.0,
+                               tnn::p2p::LaunchCtx{}, tick, b1, b2);
+        else
+            hipLaunchKernelGGL((nll_fused_kernel<double, false>), 1, threads, 0, tnn::stream(), (const double*)z,
+                               (const double*)y, (int)m, (int)c, (double*)stats_out, (double*)loss_out, (double*)dz,
+                               0.0, tnn::p2p::LaunchCtx{}, tick, b1, b2);
+    }
     TNN_LAUNCH_OK();
     return 0;
 }
@@ -613,18 +643,20 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
 
 int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2,
              double eps, void* pows_f64, void* step_out, int dtype) {
-    return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows_f64, step_out, dtype, nullptr, nullptr);
+    return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows_f64, step_out, dtype, 1, nullptr, nullptr);
 }
 
 int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2,
-                double eps, void* pows_f64, void* step_out, int dtype, const void* scalar_src, void* scalar_dst) {
+                double eps, void* pows_f64, void* step_out, int dtype, int advance, const void* scalar_src,
+                void* scalar_dst) {
     TNN_NEED_INIT();
     if (n <= 0) return 0;
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam: pows state is NULL");
     TNN_REQUIRE((scalar_src == nullptr) == (scalar_dst == nullptr), "tnn_adam_ex: scalar_src / scalar_dst go together");
     hipStream_t s = tnn::stream();
-    hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2, scalar_src, scalar_dst,
-                       dtype == TNN_F64 ? 8 : 4);
+    if (advance || scalar_dst)
+        hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, advance ? b1 : 1.0, advance ? b2 : 1.0,
+                           scalar_src, scalar_dst, dtype == TNN_F64 ? 8 : 4);
     if (dtype == TNN_F32) {
         bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                      reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |

@@ -21,6 +21,8 @@
 
 #include <vector>
 
+#include <stdlib.h>
+
 #include "tnn_hip.h"
 
 namespace tnn {
@@ -159,6 +161,11 @@ int mlp16_update(Mlp* h) {
                                         h->pows, 0));
     }
     return 0;
+}
+
+// limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
+bool head_fits_one_workgroup(const Mlp* h, int64_t rows) {
+    return !h->bf16 && h->loss_kind == 0 && rows <= 1024 && rows * h->w[h->L] <= (h->dtype == TNN_F32 ? 4096 : 2048);
 }
 
 int check_rows(Mlp* h, int64_t rows, const char* fn) {
@@ -359,8 +366,19 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     // (e.g. one slot of a per-step loss history) or, by default, to the slot behind the gradient arena
     const int L = h->L;
     void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
-    // hidden layers forward; then the classifier head (last Dense forward + loss + its backward) in one
-    // launch; then one launch per remaining layer backward; then the optimizer
+    static const bool head_fusion = getenv("TNN_HEAD_FUSION") != nullptr;
+    if (!head_fusion && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
+        // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward | Adam without a prologue:
+        // 8 launches for the 3-layer net
+        MLP_TRY(mlp_forward(h, x, rows));
+        MLP_TRY(tnn_softmax_nll_fused_tick(h->act[L - 1], y, rows, h->w[L], rows, 0, h->stats, loss_dst,
+                                           h->dact[L - 1], h->dtype, h->pows, h->b1, h->b2));
+        MLP_TRY(mlp_backward_layers(h, x, rows));
+        return tnn_adam_ex(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps, h->pows,
+                           nullptr, h->dtype, 0, nullptr, nullptr);
+    }
+    // hidden layers forward; then the classifier head (last Dense forward + loss + its backward, one launch when
+    // TNN_HEAD_FUSION is set); then one launch per remaining layer backward; then the optimizer
     MLP_TRY(mlp_forward(h, x, rows, L - 1));
     MLP_TRY(tnn_mlp_head(rows, h->w[L - 1], h->w[L], L > 1 ? h->act[L - 2] : x,
                          at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
@@ -389,25 +407,27 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
     MLP_TRY(tnn_p2p_status(nullptr, &p2p_on, nullptr));
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
-    if (p2p_on && !h->bf16 && h->loss_kind == 0 && h->dtype == TNN_F32 && rows * h->w[L] <= 4096 && rows <= 1024) {
-        // xGMI peer-to-peer transport and a head that fits one workgroup: the softmax statistics are exchanged
-        // INSIDE the loss kernel (stats + C2 + merge + loss + dz = one launch instead of five)
+    if (p2p_on && h->dtype == TNN_F32 && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
+        // xGMI peer-to-peer transport and a head that fits one workgroup — 8 launches, like the single-GPU step:
+        //   forward | loss kernel that exchanges the shards' {max, sum-exp} itself (stats + C2 + merge + loss + dz)
+        //   and advances Adam's beta powers | backward | all-reduce whose last stage applies Adam and files the loss
         MLP_TRY(mlp_forward(h, x, rows));
-        MLP_TRY(tnn_softmax_nll_fused_sharded(h->act[L - 1], y, rows, h->w[L], rows * world, h->stats, loss_slot,
-                                              h->dact[L - 1], h->dtype));
+        MLP_TRY(tnn_softmax_nll_fused_tick(h->act[L - 1], y, rows, h->w[L], rows * world, 1, h->stats, loss_slot,
+                                           h->dact[L - 1], h->dtype, h->pows, h->b1, h->b2));
         MLP_TRY(mlp_backward_layers(h, x, rows));
-    } else {
-        MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
-        if (h->loss_kind == 0) {
-            MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
-            MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
-        }
-        MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr));
+        return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
+                                  h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);
     }
+    MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+    if (h->loss_kind == 0) {
+        MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
+        MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
+    }
+    MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr));
+    if (!h->bf16 && h->opt_kind == 1)
+        return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
+                                  h->eps, h->pows, 1, h->dtype, h->n_params, loss_out);
     MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->dtype, TNN_RSUM));
-    if (!h->bf16 && h->opt_kind == 1 && loss_out)      // the loss of this step rides in Adam's one-thread prologue
-        return tnn_adam_ex(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps, h->pows,
-                           nullptr, h->dtype, loss_slot, loss_out);
     MLP_TRY(tnn_mlp_update(handle));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;

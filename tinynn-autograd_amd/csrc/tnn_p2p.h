@@ -114,6 +114,9 @@ __device__ __forceinline__ void loads_landed(T (&v)[N]) {
 bool p2p_world(int* rank, int* world);                       // false when no peer group exists
 bool p2p_can_allreduce(int64_t n, int dtype, int rop);       // enabled, f32 SUM, fits the mapped regions
 int p2p_allreduce(float* buf, int64_t n);
+// all-reduce with Adam applied in the kernel's last stage (pows already advanced); buf[scalar_index] -> *scalar_dst
+int p2p_allreduce_adam(float* buf, int64_t n, float* p, float* m, float* v, int64_t n_params, double lr, double b1,
+                       double b2, double eps, const double* pows, int64_t scalar_index, float* scalar_dst);
 bool p2p_can_allgather(int64_t n_per_rank, int dtype);       // enabled, <= 256 B per rank
 int p2p_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype);
 bool p2p_launch_ctx(p2p::LaunchCtx* ctx);                    // false when the transport is not enabled

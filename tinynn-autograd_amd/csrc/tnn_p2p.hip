@@ -63,10 +63,25 @@ __device__ __forceinline__ void store_guarded(float* buf, int64_t i, int64_t n, 
 
 constexpr int UNROLL = 4;          // independent 16-B accesses in flight per thread and loop trip
 
+// Optional optimizer tail: stage (C) holds the reduced gradient in registers anyway, so Adam
+// (core/optimizer.py:67-79, the maths of adam_kernel in tnn_fused.hip) is applied right there — no second launch and
+// no second pass over the gradient.  pows must already hold b1^t, b2^t of THIS step.
+struct AdamTail {
+    float* p;
+    float* m;
+    float* v;
+    int64_t n_params;              // elements [0, n_params) of buf are gradients of p; the rest is only reduced
+    float lr, b1, b2, eps;
+    const double* pows;
+    int64_t scalar_index;          // buf[scalar_index] is also written to *scalar_dst (e.g. the loss); -1 = none
+    float* scalar_dst;
+};
+
 // buf[0:n] <- sum over ranks, in place.  slice = floats per rank slice (multiple of 4, W*slice >= n).
+template <bool ADAM>
 __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* __restrict__ buf, int64_t n,
                                                                 int64_t slice, uint32_t* __restrict__ epoch,
-                                                                int* dead, int64_t timeout_ticks) {
+                                                                int* dead, int64_t timeout_ticks, AdamTail t) {
     const int b = blockIdx.x, W = p.world, r = p.rank;
     const uint32_t e = epoch[b];
     const int64_t s4 = slice / 4;
@@ -117,20 +132,79 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
     }
     exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
 
-    // (C) gathered result -> caller's buffer
+    // (C) gathered result -> caller's buffer (+ the optimizer update when ADAM)
     const float* res = out_of(p, r);
+    float ic1 = 0.f, ic2 = 0.f, omb1 = 0.f, omb2 = 0.f;
+    if constexpr (ADAM) {
+        ic1 = (float)(1.0 / (1.0 - t.pows[0]));
+        ic2 = (float)(1.0 / (1.0 - t.pows[1]));
+        omb1 = 1.f - t.b1;
+        omb2 = 1.f - t.b2;
+    }
+    auto adam1 = [&](float g, float& mi, float& vi, float& pi) {
+        mi = mi + omb1 * (g - mi);
+        vi = vi + omb2 * (g * g - vi);
+        const float mh = mi * ic1, vh = vi * ic2;
+        pi = pi + (-t.lr * mh / (sqrtf(vh) + t.eps));
+    };
     for (int64_t j0 = threadIdx.x; j0 < items; j0 += (int64_t)THREADS * UNROLL) {
-        f32x4 v[UNROLL] = {};
+        f32x4 g[UNROLL] = {};
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t j = j0 + (int64_t)u * THREADS;
-            if (j < items) load_sys(v[u], res + (j / len) * cap + 4 * (lo + j % len));
+            if (j < items) load_sys(g[u], res + (j / len) * cap + 4 * (lo + j % len));
         }
-        loads_landed(v);
+        if constexpr (ADAM) {
+            // the parameter / moment loads do not depend on the peers: issue them under the same wait
+            f32x4 pm[UNROLL] = {}, mm[UNROLL] = {}, vm[UNROLL] = {};
+            int64_t at[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int64_t j = j0 + (int64_t)u * THREADS;
-            if (j < items) store_guarded(buf, (j / len) * slice + 4 * (lo + j % len), n, v[u]);
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t j = j0 + (int64_t)u * THREADS;
+                at[u] = j < items ? (j / len) * slice + 4 * (lo + j % len) : n;
+                if (at[u] + 4 <= t.n_params) {
+                    pm[u] = *reinterpret_cast<const f32x4*>(t.p + at[u]);
+                    mm[u] = *reinterpret_cast<const f32x4*>(t.m + at[u]);
+                    vm[u] = *reinterpret_cast<const f32x4*>(t.v + at[u]);
+                }
+            }
+            loads_landed(g);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t i0 = at[u];
+                if (i0 >= n) continue;
+                if (i0 + 4 <= t.n_params) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float mi = mm[u][k], vi = vm[u][k], pi = pm[u][k];
+                        adam1(g[u][k], mi, vi, pi);
+                        mm[u][k] = mi; vm[u][k] = vi; pm[u][k] = pi;
+                    }
+                    *reinterpret_cast<f32x4*>(t.m + i0) = mm[u];
+                    *reinterpret_cast<f32x4*>(t.v + i0) = vm[u];
+                    *reinterpret_cast<f32x4*>(t.p + i0) = pm[u];
+                    *reinterpret_cast<f32x4*>(buf + i0) = g[u];
+                } else {                                         // the arena's ragged end and the slots behind it
+                    for (int k = 0; k < 4; ++k) {
+                        const int64_t i = i0 + k;
+                        if (i >= n) break;
+                        if (i < t.n_params) {
+                            float mi = t.m[i], vi = t.v[i], pi = t.p[i];
+                            adam1(g[u][k], mi, vi, pi);
+                            t.m[i] = mi; t.v[i] = vi; t.p[i] = pi;
+                        }
+                        buf[i] = g[u][k];
+                        if (i == t.scalar_index) *t.scalar_dst = g[u][k];
+                    }
+                }
+            }
+        } else {
+            loads_landed(g);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int64_t j = j0 + (int64_t)u * THREADS;
+                if (j < items) store_guarded(buf, (j / len) * slice + 4 * (lo + j % len), n, g[u]);
+            }
         }
     }
     if (threadIdx.x == 0) epoch[b] = e + 1;
@@ -184,7 +258,7 @@ bool p2p_can_allreduce(int64_t n, int dtype, int rop) {
     return S.enabled && dtype == TNN_F32 && rop == TNN_RSUM && n > 0 && n <= S.max_floats;
 }
 
-int p2p_allreduce(float* buf, int64_t n) {
+static int launch_allreduce(float* buf, int64_t n, const AdamTail* tail) {
     const int W = S.p.world;
     int64_t slice = (n + W - 1) / W;
     slice = (slice + 3) / 4 * 4;
@@ -192,10 +266,27 @@ int p2p_allreduce(float* buf, int64_t n) {
     int64_t blocks = S.blocks_override > 0 ? S.blocks_override : (n / 4 + 511) / 512;
     if (blocks < 1) blocks = 1;
     if (blocks > MAXB) blocks = MAXB;
-    hipLaunchKernelGGL(p2p_allreduce_kernel, dim3((unsigned)blocks), dim3(THREADS), 0, tnn::stream(), S.p, buf, n, slice,
-                       S.epoch, S.dead, S.timeout_ticks);
+    if (tail)
+        hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, tnn::stream(), S.p, buf,
+                           n, slice, S.epoch, S.dead, S.timeout_ticks, *tail);
+    else
+        hipLaunchKernelGGL(p2p_allreduce_kernel<false>, dim3((unsigned)blocks), dim3(THREADS), 0, tnn::stream(), S.p, buf,
+                           n, slice, S.epoch, S.dead, S.timeout_ticks, AdamTail{});
     TNN_LAUNCH_OK();
     return 0;
+}
+
+int p2p_allreduce(float* buf, int64_t n) { return launch_allreduce(buf, n, nullptr); }
+
+int p2p_allreduce_adam(float* buf, int64_t n, float* p, float* m, float* v, int64_t n_params, double lr, double b1,
+                       double b2, double eps, const double* pows, int64_t scalar_index, float* scalar_dst) {
+    AdamTail t;
+    t.p = p; t.m = m; t.v = v; t.n_params = n_params;
+    t.lr = (float)lr; t.b1 = (float)b1; t.b2 = (float)b2; t.eps = (float)eps;
+    t.pows = pows;
+    t.scalar_index = scalar_dst ? scalar_index : -1;
+    t.scalar_dst = scalar_dst;
+    return launch_allreduce(buf, n, &t);
 }
 
 bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
