@@ -41,6 +41,8 @@ enum { TNN_NEG = 0, TNN_EXP = 1, TNN_LOG = 2, TNN_SQRT = 3, TNN_SQUARE = 4, TNN_
        TNN_RECIP = 6, TNN_SIGMOID = 7, TNN_TANH = 8, TNN_COPY = 9 };
 /* reductions — core/ops.py:42,46,51,54 (un-broadcast sums), :226 (max), :235 (min), :253 (sum) */
 enum { TNN_RSUM = 0, TNN_RMAX = 1, TNN_RMIN = 2 };
+/* the other optimizers of core/optimizer.py:82-164 (tnn_optim_step) */
+enum { TNN_OPT_MOMENTUM = 0, TNN_OPT_RMSPROP = 1, TNN_OPT_ADAGRAD = 2, TNN_OPT_ADADELTA = 3 };
 /* activation codes for fused epilogues — core/layers.py:97-98 (ReLU = clip(x, 0.0)) */
 enum { TNN_ACT_NONE = 0, TNN_ACT_RELU = 1 };
 
@@ -220,6 +222,13 @@ TNN_API int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t 
 
 /* SGD: p += -lr * g — core/optimizer.py:46-47 + core/model.py:59-61 */
 TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);
+/* Momentum / RMSProp / Adagrad / Adadelta `_compute_step` (core/optimizer.py:102-107, :121-123, :138-141,
+ * :157-163) as one pass over the flat arena.  s1, s2 = the optimizer's state vectors, zero-initialised by the caller
+ * (Momentum: acc, -; RMSProp: mean square, momentum; Adagrad: G, -; Adadelta: E[g^2], E[delta^2]); a, b =
+ * (momentum, -), (decay, momentum), (-, -), (decay, -).  step_out (may be NULL) receives the step; p (may be NULL)
+ * is updated in place, p += step (core/model.py:59-61). */
+TNN_API int tnn_optim_step(int kind, void* p, const void* g, void* s1, void* s2, void* step_out, int64_t n,
+                           double lr, double a, double b, double eps, int dtype);
 /* Fused Adam on the flat arena, core/optimizer.py:67-79 + core/model.py:59-61:
  *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); p += -lr*(m/(1-b1^t))/(sqrt(v/(1-b2^t))+eps)
  * pows = device double[4] {b1^(t-1), b2^(t-1), reserved, reserved}; initialise to {1, 1, 0, 0}.  The call

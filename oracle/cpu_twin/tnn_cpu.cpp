@@ -613,6 +613,40 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
     });
     return 0;
 }
+int tnn_optim_step(int kind, void* p, const void* g, void* s1, void* s2, void* step_out, int64_t n, double lr, double a,
+                   double b, double eps, int dtype) {
+    NEED_INIT();
+    REQ(kind >= TNN_OPT_MOMENTUM && kind <= TNN_OPT_ADADELTA, "tnn_optim_step: unknown optimizer");
+    REQ(g && s1 && (p || step_out), "tnn_optim_step: g, s1 and one of p / step_out are required");
+    REQ(s2 || kind == TNN_OPT_MOMENTUM || kind == TNN_OPT_ADAGRAD, "tnn_optim_step: this optimizer needs s2");
+    RECORD(tnn_optim_step(kind, p, g, s1, s2, step_out, n, lr, a, b, eps, dtype));
+    FLOAT_SWITCH(dtype, "tnn_optim_step", {
+        T* S1 = (T*)s1; T* S2 = (T*)s2;
+        for (int64_t i = 0; i < n; ++i) {
+            const T gi = ((const T*)g)[i];
+            T step;
+            if (kind == TNN_OPT_MOMENTUM) {
+                S1[i] = (T)a * S1[i] + gi;
+                step = -(T)lr * S1[i];
+            } else if (kind == TNN_OPT_RMSPROP) {
+                S1[i] = S1[i] + ((T)1 - (T)a) * (gi * gi - S1[i]);
+                S2[i] = (T)b * S2[i] + (T)lr * gi / (T)sqrt((double)(S1[i] + (T)eps));
+                step = -S2[i];
+            } else if (kind == TNN_OPT_ADAGRAD) {
+                S1[i] = S1[i] + gi * gi;
+                step = -((T)lr / (T)sqrt((double)(S1[i] + (T)eps))) * gi;
+            } else {
+                S1[i] = S1[i] + ((T)1 - (T)a) * (gi * gi - S1[i]);
+                const T delta = gi * ((T)sqrt((double)(S2[i] + (T)eps)) / (T)sqrt((double)(S1[i] + (T)eps)));
+                step = -(T)lr * delta;
+                S2[i] = S2[i] + ((T)1 - (T)a) * (delta * delta - S2[i]);
+            }
+            if (step_out) ((T*)step_out)[i] = step;
+            if (p) ((T*)p)[i] = ((T*)p)[i] + step;
+        }
+    });
+    return 0;
+}
 int tnn_adam(void* p, const void* g, void* m, void* v, int64_t n, double lr, double b1, double b2, double eps,
              void* pows, void* step_out, int dtype) {
     return tnn_adam_ex(p, g, m, v, n, lr, b1, b2, eps, pows, step_out, dtype, 1, nullptr, nullptr);

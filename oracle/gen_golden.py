@@ -253,6 +253,30 @@ def eval_fixture(ref):
     print("  eval: %s" % res)
 
 
+OPTIMIZERS = {                   # name -> (reference class name, constructor kwargs)
+    "momentum": ("Momentum", dict(lr=0.05, momentum=0.9)),
+    "rmsprop": ("RMSProp", dict(lr=0.01, decay=0.99, momentum=0.0)),
+    "rmsprop_mom": ("RMSProp", dict(lr=0.01, decay=0.9, momentum=0.5)),
+    "adagrad": ("Adagrad", dict(lr=0.1)),
+    "adadelta": ("Adadelta", dict(lr=1.0, decay=0.9)),
+}
+
+
+def optimizer_fixture(ref):
+    """The four optimizers SURVEY §8(f)-4 names, straight from the reference's `_compute_step` (core/optimizer.py:
+    82-164): six consecutive steps on a fixed gradient sequence (float64, like the reference's flat vector)."""
+    ropt = ref[4]
+    rs = np.random.RandomState(77)
+    grads = rs.randn(6, 257) * np.array([1.0, 0.1, 3.0, 1e-3, 1.0, 0.5])[:, None]
+    grads[2, ::17] = 0.0                                  # exact zeros: sqrt(eps) denominators
+    out = {"grads": grads}
+    for name, (cls, kw) in OPTIMIZERS.items():
+        opt = getattr(ropt, cls)(**kw)
+        out[name] = np.stack([np.asarray(opt._compute_step(g.copy()), dtype=np.float64) for g in grads])
+    np.savez_compressed(os.path.join(GOLDEN, "optim_steps.npz"), **out)
+    print("  optimizers: %s" % ", ".join(OPTIMIZERS))
+
+
 def reference_own_tests():
     """The reference's own unit tests must pass in this container (pins the import itself)."""
     import subprocess
@@ -269,9 +293,13 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     ref = import_reference()
     print("generating golden fixtures from %s (numpy %s)" % (REF, np.__version__))
+    only = sys.argv[1:]
+    if only == ["optim"]:                                   # just the optimizer-step fixture
+        optimizer_fixture(ref)
+        return
     reference_own_tests()
     op_case_fixture(ref)
-    only = sys.argv[1:]
+    optimizer_fixture(ref)
     for name, cfg in CONFIGS.items():
         if only and name not in only:
             continue

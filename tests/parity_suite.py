@@ -592,5 +592,36 @@ def model_save_load_roundtrip():
             assert np.array_equal(np.asarray(a.params[k].values), np.asarray(b.params[k].values))
 
 
+def other_optimizers_match_reference_steps():
+    """Momentum / RMSProp / Adagrad / Adadelta: six consecutive `_compute_step` results against the
+    reference's own (tests/golden/optim_steps.npz, generated from core/optimizer.py:82-164), fused kernel and
+    array-expression path, f32 and f64."""
+    from tinynn_autograd_amd.core import optimizer as O
+    gold = dict(np.load(H.GOLDEN + "/optim_steps.npz"))
+    make = {"momentum": lambda f: O.Momentum(lr=0.05, momentum=0.9, fused=f),
+            "rmsprop": lambda f: O.RMSProp(lr=0.01, decay=0.99, momentum=0.0, fused=f),
+            "rmsprop_mom": lambda f: O.RMSProp(lr=0.01, decay=0.9, momentum=0.5, fused=f),
+            "adagrad": lambda f: O.Adagrad(lr=0.1, fused=f),
+            "adadelta": lambda f: O.Adadelta(lr=1.0, decay=0.9, fused=f)}
+    for name, ctor in make.items():
+        # f32: 1e-5 of the step vector's max-norm (a momentum sum cancels to ~1e-4 of its terms in places)
+        for dtype, rtol, atol in ((np.float64, 1e-12, 1e-15), (np.float32, 2e-5, 1e-5 * np.abs(gold[name]).max())):
+            for fused in (True, False):
+                opt = ctor(fused)
+                for k, g in enumerate(gold["grads"]):
+                    step = opt._compute_step(tn.asarray(g, dtype=dtype))
+                    assert step.dtype == dtype
+                    np.testing.assert_allclose(np.asarray(step, dtype=np.float64), gold[name][k], rtol=rtol, atol=atol,
+                                               err_msg="%s %s fused=%s step %d" % (name, dtype.__name__, fused, k))
+    # in-place form used by whole-arena updates: p += step in the same pass
+    from tinynn_autograd_amd import _lib
+    g = gold["grads"][0].astype(np.float32)
+    p0 = np.linspace(-1, 1, g.size).astype(np.float32)
+    p, s1, gd = tn.asarray(p0), tn.zeros(g.shape), tn.asarray(g)
+    _lib.get().optim_step(_lib.OPT_ADAGRAD, p._ptr, gd._ptr, s1._ptr, None, None, g.size, 0.1, 0.0, 0.0,
+                          1e-8, _lib.F32)
+    np.testing.assert_allclose(np.asarray(p), p0 + gold["adagrad"][0], rtol=1e-5, atol=1e-7)
+
+
 SUITE = {name: fn for name, fn in list(globals().items())
          if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", None) == __name__}

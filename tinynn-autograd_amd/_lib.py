@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtnn_hip.so")
 
 # dtype / op codes (must mirror include/tnn_hip.h)
 F32, F64, I64, U8, BF16 = 0, 1, 2, 3, 4
+OPT_MOMENTUM, OPT_RMSPROP, OPT_ADAGRAD, OPT_ADADELTA = 0, 1, 2, 3
 ADD, SUB, MUL, DIV, POW, MAX, MIN = range(7)
 GT, GE, LT, LE, EQ, NE = range(6)
 NEG, EXP, LOG, SQRT, SQUARE, ABS, RECIP, SIGMOID, TANH, COPY = range(10)
@@ -83,6 +84,7 @@ _SIGNATURES = {
     "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
+    "tnn_optim_step": [c_int, _p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, c_int],
     "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],
     "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, c_int, _p, _p],
     "tnn_gemm_bf16_nt": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, c_int, _p, c_int, c_int,

@@ -89,57 +89,107 @@ class Adam(BaseOptimizer):
         return step
 
 
-class Momentum(BaseOptimizer):
-    """acc = momentum * acc + g; step = -lr * acc (core/optimizer.py:111-124)"""
+class _FusedStateOptimizer(BaseOptimizer):
+    """Momentum / RMSProp / Adagrad / Adadelta: the state vectors live in HBM next to the flat gradient and one
+    kernel (tnn_optim_step) reads g + state, writes state + step.  `fused=False`, or a gradient that is not a float
+    DeviceArray, takes the reference's array expressions instead (same maths through DeviceArray arithmetic)."""
+    _kind = None
+    _n_state = 1
 
-    def __init__(self, lr, momentum=0.9, weight_decay=0.0):
+    def __init__(self, lr, weight_decay=0.0, fused=True):
         super().__init__(lr, weight_decay)
+        self.fused = fused
+        self._state = None
+
+    def _hyper(self):               # (a, b, eps) of tnn_optim_step
+        raise NotImplementedError
+
+    def _array_step(self, grad):
+        raise NotImplementedError
+
+    def _compute_step(self, grad):
+        if not (self.fused and isinstance(grad, da.DeviceArray) and grad.dtype.kind == "f"):
+            return self._array_step(grad)
+        grad = grad._contig()
+        if self._state is None:
+            self._state = [da.zeros(grad.shape, grad.dtype) for _ in range(self._n_state)]
+        a, b, eps = self._hyper()
+        step = da.empty(grad.shape, grad.dtype)
+        s2 = self._state[1]._ptr if self._n_state > 1 else None
+        _lib.get().optim_step(self._kind, None, grad._ptr, self._state[0]._ptr, s2, step._ptr, grad.size, self.lr,
+                              a, b, eps, grad._code())
+        return step
+
+
+class Momentum(_FusedStateOptimizer):
+    """acc = momentum * acc + g; step = -lr * acc (core/optimizer.py:111-124)"""
+    _kind = _lib.OPT_MOMENTUM
+
+    def __init__(self, lr, momentum=0.9, weight_decay=0.0, fused=True):
+        super().__init__(lr, weight_decay, fused)
         self._momentum = momentum
         self._acc = 0
 
-    def _compute_step(self, grad):
+    def _hyper(self):
+        return self._momentum, 0.0, 0.0
+
+    def _array_step(self, grad):
         self._acc = self._momentum * self._acc + grad
         return -self.lr * self._acc
 
 
-class RMSProp(BaseOptimizer):
+class RMSProp(_FusedStateOptimizer):
     """reference: core/optimizer.py:82-108"""
+    _kind = _lib.OPT_RMSPROP
+    _n_state = 2
 
-    def __init__(self, lr=0.01, decay=0.99, momentum=0.0, epsilon=1e-8, weight_decay=0.0):
-        super().__init__(lr, weight_decay)
+    def __init__(self, lr=0.01, decay=0.99, momentum=0.0, epsilon=1e-8, weight_decay=0.0, fused=True):
+        super().__init__(lr, weight_decay, fused)
         self._decay, self._momentum, self._eps = decay, momentum, epsilon
         self._ms = 0
         self._mom = 0
 
-    def _compute_step(self, grad):
+    def _hyper(self):
+        return self._decay, self._momentum, self._eps
+
+    def _array_step(self, grad):
         self._ms += (1 - self._decay) * (grad ** 2 - self._ms)
         self._mom = self._momentum * self._mom + self.lr * grad / (self._ms + self._eps) ** 0.5
         return -self._mom
 
 
-class Adagrad(BaseOptimizer):
+class Adagrad(_FusedStateOptimizer):
     """reference: core/optimizer.py:127-142"""
+    _kind = _lib.OPT_ADAGRAD
 
-    def __init__(self, lr, weight_decay=0.0, epsilon=1e-8):
-        super().__init__(lr, weight_decay)
+    def __init__(self, lr, weight_decay=0.0, epsilon=1e-8, fused=True):
+        super().__init__(lr, weight_decay, fused)
         self._G = 0
         self._eps = epsilon
 
-    def _compute_step(self, grad):
+    def _hyper(self):
+        return 0.0, 0.0, self._eps
+
+    def _array_step(self, grad):
         self._G += grad ** 2
         return -(self.lr / (self._G + self._eps) ** 0.5) * grad
 
 
-class Adadelta(BaseOptimizer):
+class Adadelta(_FusedStateOptimizer):
     """reference: core/optimizer.py:145-164"""
+    _kind = _lib.OPT_ADADELTA
+    _n_state = 2
 
-    def __init__(self, lr=1.0, weight_decay=0.0, decay=0.9, epsilon=1e-8):
-        super().__init__(lr, weight_decay)
+    def __init__(self, lr=1.0, weight_decay=0.0, decay=0.9, epsilon=1e-8, fused=True):
+        super().__init__(lr, weight_decay, fused)
         self._eps, self._decay = epsilon, decay
         self._Eg = 0
         self._delta = 0
 
-    def _compute_step(self, grad):
+    def _hyper(self):
+        return self._decay, 0.0, self._eps
+
+    def _array_step(self, grad):
         self._Eg += (1 - self._decay) * (grad ** 2 - self._Eg)
         std = (self._delta + self._eps) ** 0.5
         delta = grad * (std / (self._Eg + self._eps) ** 0.5)

@@ -380,6 +380,46 @@ __global__ __launch_bounds__(kThreads) void sgd_kernel(T* __restrict__ p, const 
         p[i] = p[i] + (-lr * g[i]);
 }
 
+// Momentum / RMSProp / Adagrad / Adadelta (core/optimizer.py:82-164), one pass each over the flat arena: read g and
+// the optimizer's one or two state vectors, write the state and the step (and p += step when p is given).
+// The expressions keep the reference's operation order (e.g. lr * g / sqrt(ms + eps), not g * (lr / sqrt(..))).
+template <typename T, int KIND>
+__global__ __launch_bounds__(kThreads) void optim_kernel(T* __restrict__ p, const T* __restrict__ g,
+                                                         T* __restrict__ s1, T* __restrict__ s2,
+                                                         T* __restrict__ step_out, int64_t n, T lr, T a, T b, T eps) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const T gi = g[i];
+        T step;
+        if constexpr (KIND == TNN_OPT_MOMENTUM) {            // acc = momentum * acc + g; step = -lr * acc
+            const T acc = a * s1[i] + gi;
+            s1[i] = acc;
+            step = -lr * acc;
+        } else if constexpr (KIND == TNN_OPT_RMSPROP) {      // ms += (1-decay)(g^2 - ms); mom = momentum*mom + lr*g/sqrt(ms+eps)
+            T ms = s1[i];
+            ms = ms + (T(1) - a) * (gi * gi - ms);
+            s1[i] = ms;
+            const T mom = b * s2[i] + lr * gi / sqrt(ms + eps);
+            s2[i] = mom;
+            step = -mom;
+        } else if constexpr (KIND == TNN_OPT_ADAGRAD) {      // G += g^2; step = -(lr / sqrt(G + eps)) * g
+            const T G = s1[i] + gi * gi;
+            s1[i] = G;
+            step = -(lr / sqrt(G + eps)) * gi;
+        } else {                                             // Adadelta
+            T Eg = s1[i];
+            Eg = Eg + (T(1) - a) * (gi * gi - Eg);
+            s1[i] = Eg;
+            T d = s2[i];
+            const T delta = gi * (sqrt(d + eps) / sqrt(Eg + eps));
+            step = -lr * delta;
+            s2[i] = d + (T(1) - a) * (delta * delta - d);
+        }
+        if (step_out) step_out[i] = step;
+        if (p) p[i] = p[i] + step;
+    }
+}
+
 // Adam, core/optimizer.py:67-79, one pass: read p,g,m,v / write p,m,v = 28 B per fp32 parameter.
 // state (device, f64): [0] = b1^t, [1] = b2^t of the CURRENT step, advanced on the device by
 // adam_advance_kernel (one thread) right before this kernel, so that a captured hipGraph replays the right
@@ -637,6 +677,33 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
         case TNN_F64: hipLaunchKernelGGL((sgd_kernel<double>), grid, kThreads, 0, tnn::stream(), (double*)p, (const double*)g, n, lr); break;
         default: tnn::set_error("tnn_sgd: dtype %d is not a float type", dtype); return 2;
     }
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_optim_step(int kind, void* p, const void* g, void* s1, void* s2, void* step_out, int64_t n, double lr,
+                   double a, double b, double eps, int dtype) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    TNN_REQUIRE(kind >= TNN_OPT_MOMENTUM && kind <= TNN_OPT_ADADELTA, "tnn_optim_step: unknown optimizer %d", kind);
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_optim_step: dtype %d is not a float type", dtype);
+    TNN_REQUIRE(g && s1 && (p || step_out), "tnn_optim_step: g, s1 and one of p / step_out are required");
+    TNN_REQUIRE(s2 || kind == TNN_OPT_MOMENTUM || kind == TNN_OPT_ADAGRAD, "tnn_optim_step: this optimizer needs s2");
+    const unsigned grid = tnn::stream_grid(n, kThreads);
+    hipStream_t st = tnn::stream();
+#define TNN_OPT_LAUNCH(T, K)                                                                                      \
+    hipLaunchKernelGGL((optim_kernel<T, K>), grid, kThreads, 0, st, (T*)p, (const T*)g, (T*)s1, (T*)s2, (T*)step_out, \
+                       n, (T)lr, (T)a, (T)b, (T)eps)
+#define TNN_OPT_KINDS(T)                                             \
+    switch (kind) {                                                  \
+        case TNN_OPT_MOMENTUM: TNN_OPT_LAUNCH(T, TNN_OPT_MOMENTUM); break; \
+        case TNN_OPT_RMSPROP: TNN_OPT_LAUNCH(T, TNN_OPT_RMSPROP); break;   \
+        case TNN_OPT_ADAGRAD: TNN_OPT_LAUNCH(T, TNN_OPT_ADAGRAD); break;   \
+        default: TNN_OPT_LAUNCH(T, TNN_OPT_ADADELTA); break;               \
+    }
+    if (dtype == TNN_F32) { TNN_OPT_KINDS(float) } else { TNN_OPT_KINDS(double) }
+#undef TNN_OPT_KINDS
+#undef TNN_OPT_LAUNCH
     TNN_LAUNCH_OK();
     return 0;
 }
