@@ -4,6 +4,9 @@
 // and :83), and the whole-batch softmax (core/losses.py:26-27) exchanges one {max, sum-exp} pair per
 // rank.  librccl is dlopen()ed on first use so that single-GPU users, the CPU container and the
 // symbol test never need it, and so that a process which already loaded torch's copy reuses it.
+// tnn_allreduce / tnn_allgather are the front for TWO transports: messages the xGMI peer-to-peer path of
+// tnn_p2p.hip accepts (f32 sums up to its mapped capacity, all-gathers up to 256 B per rank) go there when it
+// is enabled; everything else goes to RCCL.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>

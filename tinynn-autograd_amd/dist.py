@@ -1,13 +1,17 @@
-"""Data-parallel plumbing: one process per GPU, RCCL over xGMI for the data plane.
+"""Data-parallel plumbing: one process per GPU; data plane = RCCL plus an xGMI peer-to-peer latency path.
 
 New relative to the reference (no communication there).  Two collectives exist on the path:
   C1  in-place SUM all-reduce of the flat gradient arena between backward() and the optimizer step;
   C2  an all-gather of one {max, sum-exp} pair per rank inside the whole-batch softmax loss
       (core/losses.py:26-27 couples the shards), merged with a log-sum-exp kernel.
 
+Both go through tnn_allreduce / tnn_allgather: small f32 sums and tiny all-gathers take the peer-to-peer transport
+(csrc/tnn_p2p.hip: IPC-mapped uncached regions, pushed stores, flag barriers — self-tested at start-up, see
+`_try_p2p`), everything else RCCL.
+
 `torch.distributed` (gloo) is used only as the control plane: rendezvous from the RANK / WORLD_SIZE /
-MASTER_* environment that `python -m torch.distributed.run` provides, broadcast of the RCCL unique id,
-barriers and the max-over-ranks of bench timings.  Import torch BEFORE the first device call of this package
+MASTER_* environment that `python -m torch.distributed.run` provides, broadcast of the RCCL unique id, exchange
+of the IPC handles, barriers and the max-over-ranks of bench timings.  Import torch BEFORE the first device call of this package
 (single HIP runtime per process, see init_from_env).  `GlooCommunicator` moves the same two collectives over
 gloo through host memory; it exists for the world_size-2 CPU tests.
 """
