@@ -429,6 +429,15 @@ def main():
             chunk = build_chunk()
             elapsed, last = measure(second)
         transports["xgmi_p2p_ms_per_step" if used_p2p else "rccl_ms_per_step"] = round(elapsed / steps * 1e3, 5)
+        if used_p2p:
+            # the transport again after the run, bit-exact against locally reproducible sums (all ranks must agree)
+            ok = 1 if comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6) else 0
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([ok])
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                ok = int(t.item())
+            transports["xgmi_p2p_verified_after_run"] = bool(ok)
         transports["used"] = "xgmi-p2p" if used_p2p else "rccl"
         compare_rccl = used_p2p and os.environ.get("TNN_BENCH_COMPARE_RCCL", "1") != "0"
         # replicas must still hold bit-identical parameters
