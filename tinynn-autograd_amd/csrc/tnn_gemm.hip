@@ -120,8 +120,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
 
     // ---- per-thread staging geometry, fixed for the whole K loop
     // element (row, c4) of the tile: KC operand -> row = m/n index, c4 = k/4;  MN-contig -> row = k, c4 = m/4
-    const float* a_src[A_F4];
-    const float* b_src[B_F4];
+    // fast loader addressing = wave-uniform base (advances by a scalar add per K-tile) + a per-thread 32-bit byte
+    // offset that never changes (the host takes this kernel's VEC variant only for operands below 4 GiB)
+    uint32_t a_off[A_F4], b_off[B_F4];
     int a_dst[A_F4], b_dst[B_F4];
     int a_row[A_F4], a_c4[A_F4], b_row[B_F4], b_c4[B_F4];
 #pragma unroll
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         a_dst[i] = a_row[i] * SA + a_c4[i] * 4;
         if constexpr (AKC) {
             const int64_t gm = m0 + a_row[i];
-            a_src[i] = g.A + (gm < g.M ? gm : 0) * g.lda + kbeg + a_c4[i] * 4;
+            a_off[i] = (uint32_t)(((gm < g.M ? gm : 0) * g.lda + a_c4[i] * 4) * 4);
         } else {
             const int64_t gm = m0 + a_c4[i] * 4;       // VEC: M % 4 == 0, a float4 is wholly in or out of range
-            a_src[i] = g.A + (kbeg + a_row[i]) * g.lda + (gm < g.M ? gm : 0);
+            a_off[i] = (uint32_t)((a_row[i] * g.lda + (gm < g.M ? gm : 0)) * 4);
         }
     }
 #pragma unroll
@@ -146,14 +147,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         b_dst[i] = b_row[i] * SB + b_c4[i] * 4;
         if constexpr (BKC) {
             const int64_t gn = n0 + b_row[i];
-            b_src[i] = g.B + (gn < g.N ? gn : 0) * g.ldb + kbeg + b_c4[i] * 4;
+            b_off[i] = (uint32_t)(((gn < g.N ? gn : 0) * g.ldb + b_c4[i] * 4) * 4);
         } else {
             const int64_t gn = n0 + b_c4[i] * 4;
-            b_src[i] = g.B + (kbeg + b_row[i]) * g.ldb + (gn < g.N ? gn : 0);
+            b_off[i] = (uint32_t)((b_row[i] * g.ldb + (gn < g.N ? gn : 0)) * 4);
         }
     }
-    const int64_t a_step = AKC ? (int64_t)BK : (int64_t)BK * g.lda;   // pointer advance per K-tile
-    const int64_t b_step = BKC ? (int64_t)BK : (int64_t)BK * g.ldb;
+    const int64_t a_step = (AKC ? (int64_t)BK : (int64_t)BK * g.lda) * 4;   // bytes per K-tile
+    const int64_t b_step = (BKC ? (int64_t)BK : (int64_t)BK * g.ldb) * 4;
+    const char* const a_base = reinterpret_cast<const char*>(g.A) + (AKC ? kbeg : kbeg * g.lda) * 4;
+    const char* const b_base = reinterpret_cast<const char*>(g.B) + (BKC ? kbeg : kbeg * g.ldb) * 4;
 
     float4 ra[A_F4], rb[B_F4];
 
@@ -162,12 +165,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // columns beyond M / N read a clamped, valid address: what they load only ever reaches accumulator rows /
     // columns >= M / N, which the epilogue never stores (an output row depends on its own A row only).
     auto load_full = [&](int kt) {
+        const char* at = a_base + (int64_t)kt * a_step;       // wave-uniform
+        const char* bt = b_base + (int64_t)kt * b_step;
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i)
-            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (int64_t)kt * a_step);
+        for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(at + a_off[i]);
 #pragma unroll
-        for (int i = 0; i < B_F4; ++i)
-            rb[i] = *reinterpret_cast<const float4*>(b_src[i] + (int64_t)kt * b_step);
+        for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const float4*>(bt + b_off[i]);
     };
     // guarded loader: element-wise bounds on every axis (K tail, odd shapes, unaligned operands)
     auto load_guarded = [&](int kt) {
@@ -282,11 +285,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // chunks later (sched_barrier(0) pins "memory ops first, then the chunk's MFMAs": left alone hipcc sinks
     // the reads below the MFMAs and then drains them in front of the barrier):
     //   chunk 0 : write tile kt+1 to the other buffer (its global loads were issued a whole tile ago),
-    //             issue the global loads of tile kt+2, read F(kt,2)                       | MFMA F(kt,0)
-    //   chunk 1 : read F(kt,3) (right behind the chunk's first MFMA)                      | MFMA F(kt,1)
-    //   ---- s_barrier ---- every LDS op issued so far is several MFMAs old: (almost) nothing to drain
-    //   chunk 2 : read F(kt+1,0) from the other buffer                                    | MFMA F(kt,2)
-    //   chunk 3 : read F(kt+1,1)                                                          | MFMA F(kt,3)
+    //             issue the global loads of tile kt+2, read F(kt,2) and F(kt,3)           | MFMA F(kt,0)
+    //   chunk 1 :                                                                         | MFMA F(kt,1)
+    //   ---- s_barrier ---- (pinned, see pinned_barrier)
+    //   chunk 2 : read F(kt+1,0), F(kt+1,1) from the other buffer                         | MFMA F(kt,2)
+    //   chunk 3 :                                                                         | MFMA F(kt,3)
+    // (the tail loop keeps the older placement: F(kt,3) in chunk 1, F(kt+1,1) in chunk 3 — same register slots)
     // Hazards: the buffer written in chunk 0 of tile kt was last read in chunks 0-1 of tile kt-1, i.e. before
     // the barrier of tile kt-1 that every wave has passed; it is first read after the barrier of tile kt,
     // which every wave reaches after its own writes.
@@ -320,36 +324,52 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 \
     }
 
-    // steady state: tiles kt+1 and kt+2 exist and tile kt+2 is a full, vector-loadable tile -> no branches
+    // The barrier as the compiler must see it: hipcc hoists the register-only MFMAs of chunks 2-3 above a plain
+    // __syncthreads() (nothing orders them against it), which leaves the post-barrier LDS reads with no MFMAs to hide
+    // behind.  Empty asm statements that "redefine" the fragments of chunks 2-3 right after the barrier tie those
+    // MFMAs to it (volatile asm statements keep their order).  lgkmcnt(0): this wave's tile stores have landed.
+    auto pinned_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int kk = 2; kk < 4; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(af[kk][i][j]));
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bf[kk][i][j]));
+            }
+        }
+    };
+    // steady state: tiles kt+1 and kt+2 exist and tile kt+2 is a full, vector-loadable tile -> no branches.
+    // Two tiles per trip with the buffer index a compile-time constant: every LDS address is then a loop-invariant
+    // register plus an immediate offset (no per-tile address arithmetic next to the MFMAs).
     int kt = 0;
     const int n_steady = VEC ? (nk_full - 2 < nk - 2 ? nk_full - 2 : nk - 2) : 0;
-    for (; kt < n_steady; ++kt) {
-        const int cur = kt & 1;
-        store_tile(cur ^ 1);
-        load_full(kt + 2);
-        read_frag(cur, 2);
-        mfma_chunk(0);
-        TNN_INTERLEAVE_HEAVY();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frag(cur, 3);
-        mfma_chunk(1);
-        TNN_INTERLEAVE_LIGHT();
-        __builtin_amdgcn_sched_barrier(0);
-
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frag(cur ^ 1, 0);
-        mfma_chunk(2);
-        TNN_INTERLEAVE_LIGHT();
-        __builtin_amdgcn_sched_barrier(0);
-
-        read_frag(cur ^ 1, 1);
-        mfma_chunk(3);
-        TNN_INTERLEAVE_LIGHT();
-        __builtin_amdgcn_sched_barrier(0);
+#define TNN_STEADY_TILE(CUR, KT)                                           \
+    store_tile((CUR) ^ 1);                                                 \
+    load_full((KT) + 2);                                                   \
+    read_frag((CUR), 2);                                                   \
+    read_frag((CUR), 3);                                                   \
+    mfma_chunk(0);                                                         \
+    TNN_INTERLEAVE_HEAVY();                                                \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    mfma_chunk(1);                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    pinned_barrier();                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    read_frag((CUR) ^ 1, 0);                                               \
+    read_frag((CUR) ^ 1, 1);                                               \
+    mfma_chunk(2);                                                         \
+    TNN_INTERLEAVE_LIGHT();                                                \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    mfma_chunk(3);                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    for (; kt + 1 < n_steady; kt += 2) {
+        TNN_STEADY_TILE(0, kt)
+        TNN_STEADY_TILE(1, kt + 1)
     }
+#undef TNN_STEADY_TILE
 #undef TNN_INTERLEAVE_LIGHT
 #undef TNN_INTERLEAVE_HEAVY
 
@@ -667,8 +687,10 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
 int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     // 16-B loads need: contiguous extent and leading dimension multiples of 4, base 16-B aligned
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    g.vecA = al(g.A) && g.lda % 4 == 0 && ((transA ? g.M : g.K) % 4 == 0);
-    g.vecB = al(g.B) && g.ldb % 4 == 0 && ((transB ? g.K : g.N) % 4 == 0);
+    // ... and, for the 32-bit per-thread offsets of the fast loader, an operand below 4 GiB
+    const int64_t a_bytes = (transA ? g.K : g.M) * g.lda * 4, b_bytes = (transB ? g.N : g.K) * g.ldb * 4;
+    g.vecA = al(g.A) && g.lda % 4 == 0 && ((transA ? g.M : g.K) % 4 == 0) && a_bytes < (int64_t(1) << 32);
+    g.vecB = al(g.B) && g.ldb % 4 == 0 && ((transB ? g.K : g.N) % 4 == 0) && b_bytes < (int64_t(1) << 32);
     if (use_small_path(g)) return gemm_small(g, transA, transB, colsum);
     if (colsum != nullptr) {   // large shapes: the column sum is a separate (HBM-bound, <1 % of the time) pass
         if (int rc = tnn_reduce(TNN_RSUM, g.B, colsum, 1, g.K, g.N, TNN_F32)) return rc;
