@@ -164,13 +164,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // put an s_waitcnt right behind the loads and expose the whole global latency before the MFMAs).  Rows /
     // columns beyond M / N read a clamped, valid address: what they load only ever reaches accumulator rows /
     // columns >= M / N, which the epilogue never stores (an output row depends on its own A row only).
+    // buffer loads: resource (4 SGPRs) + constant per-thread VGPR offset + a scalar offset that advances per K-tile —
+    // no vector address arithmetic at all in the loop, and a single address VGPR per load
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(a_base), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(b_base), 0, 0xffffffffu, 0x00020000);
     auto load_full = [&](int kt) {
-        const char* at = a_base + (int64_t)kt * a_step;       // wave-uniform
-        const char* bt = b_base + (int64_t)kt * b_step;
+        const uint32_t at = (uint32_t)kt * (uint32_t)a_step, bt = (uint32_t)kt * (uint32_t)b_step;   // wave-uniform
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const float4*>(at + a_off[i]);
+        for (int i = 0; i < A_F4; ++i)
+            ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], at, 0));
 #pragma unroll
-        for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const float4*>(bt + b_off[i]);
+        for (int i = 0; i < B_F4; ++i)
+            rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], bt, 0));
     };
     // guarded loader: element-wise bounds on every axis (K tail, odd shapes, unaligned operands)
     auto load_guarded = [&](int kt) {
