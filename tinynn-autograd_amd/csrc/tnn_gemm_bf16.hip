@@ -82,29 +82,34 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
     const int nk = (int)(g.K / BK);
 
     // staging geometry: vector f -> row f / 8, 16-B column f % 8
-    const bf16_t* a_src[A_V];
-    const bf16_t* b_src[B_V];
+    uint32_t a_off[A_V], b_off[B_V];      // constant per-thread byte offsets (operands below 4 GiB, checked on the host)
     int a_dst[A_V], b_dst[B_V];
 #pragma unroll
     for (int i = 0; i < A_V; ++i) {
         const int f = tid + i * NT, row = f / (BK / 8), c8 = f % (BK / 8);
         const int64_t gm = m0 + row;
-        a_src[i] = g.A + (gm < g.M ? gm : 0) * g.lda + c8 * 8;
+        a_off[i] = (uint32_t)(((gm < g.M ? gm : 0) * g.lda + c8 * 8) * 2);
         a_dst[i] = row * SROW + c8 * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_V; ++i) {
         const int f = tid + i * NT, row = f / (BK / 8), c8 = f % (BK / 8);
         const int64_t gn = n0 + row;
-        b_src[i] = g.B + (gn < g.N ? gn : 0) * g.ldb + c8 * 8;
+        b_off[i] = (uint32_t)(((gn < g.N ? gn : 0) * g.ldb + c8 * 8) * 2);
         b_dst[i] = row * SROW + c8 * 8;
     }
     u32x4 ra[A_V], rb[B_V];
+    // buffer loads: SGPR resource + constant VGPR offset + scalar K offset (no vector address arithmetic in the loop)
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(g.A), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(g.B), 0, 0xffffffffu, 0x00020000);
     auto load_tile = [&](int kt) {
+        const uint32_t koff = (uint32_t)kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < A_V; ++i) ra[i] = *reinterpret_cast<const u32x4*>(a_src[i] + (int64_t)kt * BK);
+        for (int i = 0; i < A_V; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, a_off[i], koff, 0);
 #pragma unroll
-        for (int i = 0; i < B_V; ++i) rb[i] = *reinterpret_cast<const u32x4*>(b_src[i] + (int64_t)kt * BK);
+        for (int i = 0; i < B_V; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, b_off[i], koff, 0);
     };
     auto store_tile = [&](int buf) {
         bf16_t* As = lds + buf * (A_ELEMS + B_ELEMS);
@@ -159,53 +164,54 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
         read_frag(0, 1);
     }
     constexpr int NMF = MI * NI;
+    // the barrier with the MFMAs of chunks 2-3 tied behind it (see tnn_gemm.hip: hipcc otherwise hoists them above
+    // the barrier and the post-barrier fragment reads have nothing to hide behind)
+    auto pinned_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int kk = 2; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" : "+v"(af[kk][i]));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(bfr[kk][i]));
+        }
+    };
+#define TNN_BF16_TILE(CUR, KT)                                                 \
+    store_tile((CUR) ^ 1);                                                     \
+    load_tile((KT) + 2);                                                       \
+    read_frag((CUR), 2);                                                       \
+    read_frag((CUR), 3);                                                       \
+    mfma_chunk(0);                                                             \
+    mfma_chunk(1);                                                             \
+    _Pragma("unroll") for (int q = 0; q < 2 * NMF; ++q) {                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    pinned_barrier();                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    read_frag((CUR) ^ 1, 0);                                                   \
+    read_frag((CUR) ^ 1, 1);                                                   \
+    mfma_chunk(2);                                                             \
+    mfma_chunk(3);                                                             \
+    _Pragma("unroll") for (int q = 0; q < 2 * NMF; ++q) {                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     \
+    }                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
     int kt = 0;
-    for (; kt < nk - 2; ++kt) {                     // steady state: tiles kt+1 and kt+2 exist, no branches
-        const int cur = kt & 1;
-        store_tile(cur ^ 1);
-        load_tile(kt + 2);
-        read_frag(cur, 2);
-        mfma_chunk(0);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(cur, 3);
-        mfma_chunk(1);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(cur ^ 1, 0);
-        mfma_chunk(2);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(cur ^ 1, 1);
-        mfma_chunk(3);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (; kt + 1 < nk - 2; kt += 2) {              // steady state: tiles kt+1 and kt+2 exist, no branches
+        TNN_BF16_TILE(0, kt)
+        TNN_BF16_TILE(1, kt + 1)
     }
-    for (; kt < nk; ++kt) {                         // last two tiles
+#undef TNN_BF16_TILE
+    for (; kt < nk; ++kt) {                         // last two or three tiles
         const int cur = kt & 1;
         const bool has1 = kt + 1 < nk;
         if (has1) store_tile(cur ^ 1);
+        if (kt + 2 < nk) load_tile(kt + 2);
         read_frag(cur, 2);
         __builtin_amdgcn_sched_barrier(0);
         mfma_chunk(0);
@@ -500,6 +506,8 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     TNN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "tnn_gemm_bf16_nt: lda/ldb must be >= K and multiples of 8");
     TNN_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0,
                 "tnn_gemm_bf16_nt: operands must be 16-byte aligned");
+    TNN_REQUIRE(M * lda * 2 < (int64_t(1) << 32) && N * ldb * 2 < (int64_t(1) << 32),
+                "tnn_gemm_bf16_nt: operands of 4 GiB or more are not supported (32-bit buffer offsets)");
     TNN_REQUIRE(c_dtype == TNN_F32 || c_dtype == TNN_BF16, "tnn_gemm_bf16_nt: output dtype %d", c_dtype);
     TNN_REQUIRE(ldc >= N, "tnn_gemm_bf16_nt: ldc too small");
     TNN_REQUIRE(!(bias_f32 || act) || !mask_y, "tnn_gemm_bf16_nt: bias/activation and mask epilogues are exclusive");
