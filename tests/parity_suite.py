@@ -592,6 +592,41 @@ def model_save_load_roundtrip():
             assert np.array_equal(np.asarray(a.params[k].values), np.asarray(b.params[k].values))
 
 
+def dense_vjp_writes_arena_views_and_survives_weight_sharing():
+    """ops.dense_'s fused vjp (dW + db in one launch, written straight into the parameters' arena views) — single use
+    and the same layer applied twice (the second contribution must not clobber the first)."""
+    rs = np.random.RandomState(11)
+    m, k = 6, 8
+    xh, wh, bh = rs.randn(m, k), rs.randn(k, k) * 0.3, rs.randn(1, k)
+    for uses in (1, 2):
+        x = Tensor(xh.astype(np.float32))
+        w = Tensor(wh.astype(np.float32), requires_grad=True)
+        b = Tensor(bh.astype(np.float32), requires_grad=True)
+        arena = tn.zeros((k * k + k,))
+        w._grad_home, b._grad_home = arena[:k * k].reshape((k, k)), arena[k * k:].reshape((1, k))
+        w.zero_grad(); b.zero_grad()
+        h = ops.dense_(x, w, b)
+        y = ops.dense_(h, w, b) if uses == 2 else h
+        (y * y).sum().backward()
+        hh = xh @ wh + bh
+        if uses == 1:
+            dy = 2 * hh
+            dw, db = xh.T @ dy, dy.sum(0, keepdims=True)
+        else:
+            yy = hh @ wh + bh
+            dy = 2 * yy
+            dh = dy @ wh.T
+            dw, db = hh.T @ dy + xh.T @ dh, dy.sum(0, keepdims=True) + dh.sum(0, keepdims=True)
+        np.testing.assert_allclose(np.asarray(w.grad), dw, rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(np.asarray(b.grad), db, rtol=2e-5, atol=1e-5)
+        flat = np.asarray(arena)                                  # the gradients live in the arena itself
+        np.testing.assert_allclose(flat[:k * k].reshape(k, k), dw, rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(flat[k * k:].reshape(1, k), db, rtol=2e-5, atol=1e-5)
+        (y * y).sum().backward()                                  # accumulates on top (core/tensor.py:163)
+        np.testing.assert_allclose(np.asarray(w.grad), 2 * dw, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(np.asarray(b.grad), 2 * db, rtol=2e-5, atol=2e-5)
+
+
 def other_optimizers_match_reference_steps():
     """Momentum / RMSProp / Adagrad / Adadelta: six consecutive `_compute_step` results against the
     reference's own (tests/golden/optim_steps.npz, generated from core/optimizer.py:82-164), fused kernel and

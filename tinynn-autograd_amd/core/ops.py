@@ -260,11 +260,53 @@ def dense_(x, w, b):
     if out.size:
         _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_NONE, 0,
                                  out._ptr, n, out._code())
-    parents = [
-        (x, lambda g: da.asarray(g) @ wv.T),
-        (w, lambda g: xv.T @ da.asarray(g)),
-        (b, lambda g: _unbroadcast(g, b.shape)),
-    ]
+    # vjps.  dW and db come out of ONE launch (tnn_gemm_tn_colsum: the bias gradient is the column sum of the B
+    # fragments the dW GEMM already holds); `into` lets the backward scheduler hand over the parameter's own
+    # gradient buffer (a view of the flat arena) so nothing is copied afterwards.
+    shared = []                       # [(g object, db)] computed together with dW, waiting for the bias vjp
+
+    def d_x(g):
+        return da.asarray(g) @ wv.T
+
+    def _dw_db(g_in, out):
+        g = da.asarray(g_in)
+        if g.shape != (m, n) or g.dtype != dt or g._hv is not None or not g.size:
+            return None
+        g = g._contig()
+        dw = out if out is not None else da.empty((k, n), dt)
+        db = None
+        if b.requires_grad:
+            home = getattr(b, "_grad_home", None)
+            if (home is not None and b._grad is None and b._grad_zero and not getattr(b, "_home_lent", False)
+                    and home.size == n and home.dtype == dt):
+                db = home                            # the bias' own arena view: lent out once per backward
+                b._home_lent = True
+            else:
+                db = da.empty(tuple(b.shape), dt)
+        _lib.get().gemm_tn_colsum(k, n, m, xv._ptr, k, g._ptr, n, dw._ptr, n, db._ptr if db is not None else None,
+                                  dw._code())
+        if db is not None:
+            del shared[:]
+            shared.append((g_in, db))
+        return dw
+
+    def d_w(g):
+        dw = _dw_db(g, None)
+        return dw if dw is not None else xv.T @ da.asarray(g)
+
+    def d_w_into(g, dest):
+        if dest.shape != (k, n) or dest.dtype != dt or dest._t or dest._hv is not None:
+            return d_w(g)
+        dw = _dw_db(g, dest)
+        return dw if dw is not None else d_w(g)
+    d_w.into = d_w_into
+
+    def d_b(g):
+        if shared and shared[0][0] is g:
+            return shared.pop()[1]
+        return _unbroadcast(g, b.shape)
+
+    parents = [(x, d_x), (w, d_w), (b, d_b)]
     return _make_node(x.__class__, out, parents)
 
 
@@ -288,14 +330,15 @@ def softmax_nll_(logits, labels, comm=None):
     m, c = z.shape
     lib = _lib.get()
     stats = da.empty((2,), dt)
-    lib.softmax_nll_stats(z._ptr, m, c, stats._ptr, stats._code())
-    m_global = m
-    if comm is not None and comm.world > 1:
-        stats = comm.merge_softmax_stats(stats)
-        m_global = m * comm.world
     loss = da.empty((), dt)
     dz = da.empty((m, c), dt)
-    lib.softmax_nll_fwd_bwd(z._ptr, y._ptr, m, c, m_global, stats._ptr, loss._ptr, dz._ptr, z._code())
+    if comm is None or comm.world == 1:
+        # one launch (stats + loss + dz); batches that do not fit one workgroup take the multi-launch form inside
+        lib.softmax_nll_fused(z._ptr, y._ptr, m, c, stats._ptr, loss._ptr, dz._ptr, z._code())
+    else:
+        lib.softmax_nll_stats(z._ptr, m, c, stats._ptr, stats._code())
+        stats = comm.merge_softmax_stats(stats)
+        lib.softmax_nll_fwd_bwd(z._ptr, y._ptr, m, c, m * comm.world, stats._ptr, loss._ptr, dz._ptr, z._code())
     return build_unary_ops_tensor(logits, lambda g: g * dz, loss)
 
 

@@ -249,6 +249,7 @@ class Tensor(object):
         self._grad = None
         self._grad_zero = True
         self._grad_shared = False
+        self._home_lent = False
 
     def _accumulate(self, g):
         """self.grad += g (core/tensor.py:163) with broadcasting of g to self.shape."""
@@ -256,6 +257,7 @@ class Tensor(object):
             raise TypeError("unsupported operand type(s) for +=: 'NoneType' and 'DeviceArray' "
                             "(the gradient was dropped by a value assignment; call zero_grad())")
         g = da.asarray(g)
+        self._home_lent = False                      # see ops.dense_: the arena view may be lent to a fused vjp
         if g.shape != self.shape or g.dtype != self._float_dtype() or g.is_host_scalar:
             if len(g.shape) > len(self.shape) or np.broadcast_shapes(g.shape, self.shape) != self.shape:
                 raise ValueError("non-broadcastable output operand with shape %s doesn't match the "
@@ -263,7 +265,8 @@ class Tensor(object):
             g = g.astype(self._float_dtype())._broadcast_to(self.shape)
         if self._grad is None:                       # lazily zero: adopt instead of memset + add
             if self._grad_home is not None:
-                self._grad_home[...] = g
+                if g is not self._grad_home:         # a vjp with `into` already wrote the arena view itself
+                    self._grad_home[...] = g
                 self._grad, self._grad_shared = self._grad_home, False
             else:
                 self._grad, self._grad_shared = g, True
@@ -297,8 +300,15 @@ class Tensor(object):
                 continue
             node._accumulate(g)
             for dep in node.dependency:
-                contrib = dep["grad_fn"](g)
-                key = id(dep["tensor"])
+                child, fn = dep["tensor"], dep["grad_fn"]
+                key = id(child)
+                into = getattr(fn, "into", None)
+                home = getattr(child, "_grad_home", None)
+                if (into is not None and home is not None and key not in pending and not child.dependency
+                        and child._grad is None and child._grad_zero):
+                    contrib = into(g, home)          # first contribution of a lazily-zero, arena-backed leaf
+                else:
+                    contrib = fn(g)
                 if key in pending:
                     pending[key] = pending[key] + contrib
                 else:
