@@ -114,6 +114,15 @@ class Model(object):
                     for g in layer.values():
                         self.comm.allreduce(g)
 
+        if (self._param_arena is not None and self._grad_arena is not None
+                and all(t._grad is t._grad_home for t in self._arena_tensors)
+                and getattr(self.optimizer, "apply_flat", lambda *_: False)(self._param_arena, self._grad_arena)):
+            # every gradient already sits in the flat arena: the optimizer updated the parameter arena in place,
+            # one pass (core/optimizer.py `_compute_step` + core/model.py:59-61 `param += step`)
+            for t in self._arena_tensors:
+                t.values = t._values_home                # same post-state as `param += step`: grad dropped
+            return
+
         steps = self.optimizer.compute_step(all_grads, params)
 
         flat = getattr(self.optimizer, "_last_flat_step", None)

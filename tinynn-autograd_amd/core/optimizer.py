@@ -44,6 +44,12 @@ class BaseOptimizer(object):
     def _compute_step(self, grad):
         raise NotImplementedError
 
+    def apply_flat(self, params, grads):
+        """Optional fast path for `Model.step` when parameters and gradients live in flat arenas: update `params`
+        in place from `grads` in ONE pass (same maths as compute_step followed by `param += step`,
+        core/model.py:56-61) and return True; return False to take the compute_step route."""
+        return False
+
 
 class SGD(BaseOptimizer):
     """step = -lr * g (core/optimizer.py:46-47)"""
@@ -53,6 +59,18 @@ class SGD(BaseOptimizer):
 
     def _compute_step(self, grad):
         return -self.lr * grad
+
+    def apply_flat(self, params, grads):
+        if not _flat_pair_ok(params, grads):
+            return False
+        _lib.get().sgd(params._ptr, grads._ptr, grads.size, self.lr, grads._code())
+        return True
+
+
+def _flat_pair_ok(params, grads):
+    return (isinstance(params, da.DeviceArray) and isinstance(grads, da.DeviceArray) and params.shape == grads.shape
+            and params.dtype == grads.dtype and params.dtype.kind == "f" and params.ndim == 1
+            and not params._t and not grads._t and params._hv is None and grads._hv is None)
 
 
 class Adam(BaseOptimizer):
@@ -77,12 +95,24 @@ class Adam(BaseOptimizer):
         v_hat = self._v / (1 - self._b2 ** self._t)
         return -self.lr * m_hat / (v_hat ** 0.5 + self._eps)
 
-    def _fused_step(self, grad):
-        lib = _lib.get()
+    def apply_flat(self, params, grads):
+        if not (self.fused and _flat_pair_ok(params, grads)):
+            return False
+        self._t += 1
+        self._ensure_state(grads)
+        _lib.get().adam(params._ptr, grads._ptr, self._m._ptr, self._v._ptr, grads.size, self.lr, self._b1, self._b2,
+                        self._eps, self._pows._ptr, None, grads._code())
+        return True
+
+    def _ensure_state(self, grad):
         if self._pows is None:
             self._m = da.zeros(grad.shape, grad.dtype)
             self._v = da.zeros(grad.shape, grad.dtype)
             self._pows = da.asarray(np.array([1.0, 1.0, 0.0, 0.0]), dtype=np.float64)
+
+    def _fused_step(self, grad):
+        lib = _lib.get()
+        self._ensure_state(grad)
         step = da.empty(grad.shape, grad.dtype)
         lib.adam(None, grad._ptr, self._m._ptr, self._v._ptr, grad.size, self.lr, self._b1, self._b2,
                  self._eps, self._pows._ptr, step._ptr, grad._code())
@@ -111,14 +141,24 @@ class _FusedStateOptimizer(BaseOptimizer):
         if not (self.fused and isinstance(grad, da.DeviceArray) and grad.dtype.kind == "f"):
             return self._array_step(grad)
         grad = grad._contig()
+        step = da.empty(grad.shape, grad.dtype)
+        self._launch(None, grad, step)
+        return step
+
+    def _launch(self, params, grad, step):
         if self._state is None:
             self._state = [da.zeros(grad.shape, grad.dtype) for _ in range(self._n_state)]
         a, b, eps = self._hyper()
-        step = da.empty(grad.shape, grad.dtype)
         s2 = self._state[1]._ptr if self._n_state > 1 else None
-        _lib.get().optim_step(self._kind, None, grad._ptr, self._state[0]._ptr, s2, step._ptr, grad.size, self.lr,
+        _lib.get().optim_step(self._kind, params._ptr if params is not None else None, grad._ptr,
+                              self._state[0]._ptr, s2, step._ptr if step is not None else None, grad.size, self.lr,
                               a, b, eps, grad._code())
-        return step
+
+    def apply_flat(self, params, grads):
+        if not (self.fused and _flat_pair_ok(params, grads)):
+            return False
+        self._launch(params, grads, None)
+        return True
 
 
 class Momentum(_FusedStateOptimizer):
