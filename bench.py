@@ -247,6 +247,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON result: native libraries print there too (RCCL writes a version /
+    # hostname banner to stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the
+    # whole run and the result goes to a saved duplicate of the original stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
@@ -500,7 +510,7 @@ def main():
             if line is not None:
                 line["config"]["collectives"]["rccl_ms_per_step"] = None
                 line["config"]["collectives"]["rccl_comparison"] = "did not finish in %d s" % limit
-                print(json.dumps(line), flush=True)
+                emit(line)
             os._exit(0)
         limit = int(os.environ.get("TNN_BENCH_COMPARE_TIMEOUT_S", "90"))
         dog = threading.Timer(limit, give_up)
@@ -513,7 +523,7 @@ def main():
         if line is not None:
             line["config"]["collectives"]["rccl_ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
     if line is not None:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if comm is not None:
         comm.barrier()
         if hasattr(comm, "close"):
