@@ -383,14 +383,14 @@ __global__ __launch_bounds__(1024) void nll_rows_kernel(const T* __restrict__ z,
     }
     // one combined reduction: waves first (shuffles), then <= 16 wave triples through LDS
     double wm = tnn::wave_max(mi);
-    double ws = tnn::wave_sum(live ? si * exp(mi - wm) : 0.0);
+    double ws = tnn::wave_sum(live ? si * nll_exp((T)(mi - wm)) : 0.0);
     double wl = tnn::wave_sum(li);
     if (lane == 0) { wave_m[wid] = wm; wave_s[wid] = ws; wave_l[wid] = wl; }
     __syncthreads();
     double M = -INFINITY, S = 0.0, L = 0.0;
     for (int w = 0; w < nw; ++w) M = fmax(M, wave_m[w]);
     for (int w = 0; w < nw; ++w) {
-        if (wave_m[w] > -INFINITY) S += wave_s[w] * exp(wave_m[w] - M);
+        if (wave_m[w] > -INFINITY) S += wave_s[w] * nll_exp((T)(wave_m[w] - M));
         L += wave_l[w];
     }
     double inv_m = 1.0 / (double)m;
@@ -417,16 +417,16 @@ __global__ __launch_bounds__(1024) void nll_rows_kernel(const T* __restrict__ z,
         __syncthreads();
         double gm = -INFINITY, gs = 0.0;
         for (int q = 0; q < W; ++q) gm = fmax(gm, (double)peer_stats[q][0]);
-        for (int q = 0; q < W; ++q) gs += (double)peer_stats[q][1] * exp((double)peer_stats[q][0] - gm);
+        for (int q = 0; q < W; ++q) gs += (double)peer_stats[q][1] * nll_exp((T)((double)peer_stats[q][0] - gm));
         if (tid == 0) *ctx.ag_epoch = ep + 1;
         M = gm; S = gs;
         inv_m = inv_m_global;
-        loss = ((log(S) + M) * (double)m - L) * inv_m;          // this rank's share
+        loss = ((nll_log((T)S) + M) * (double)m - L) * inv_m;   // this rank's share
     } else {
-        loss = log(S) + M - L * inv_m;
+        loss = nll_log((T)S) + M - L * inv_m;
     }
     if (live && dz) {
-        const double scale = exp(mi - M) / S, inv_u = inv_m / ui;
+        const double scale = nll_exp((T)(mi - M)) / S, inv_u = inv_m / ui;
         if (sizeof(T) == 4) {
             const float sf = (float)scale, uf = (float)inv_u;
 #pragma unroll
