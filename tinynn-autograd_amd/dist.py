@@ -261,7 +261,11 @@ def _try_p2p(comm, dist):
         if comm._p2p:
             comm.set_p2p(False)
         return False
-    good = 1 if comm.p2p_selftest() else 0
+    try:
+        good = 1 if comm.p2p_selftest() else 0
+    except Exception as e:                      # noqa: BLE001 - keep every rank in the vote below
+        sys.stderr.write("[tinynn_autograd_amd] xGMI peer-to-peer self-test raised on rank %d: %s\n" % (comm.rank, e))
+        good = 0
     flag = torch.tensor([good])
     if dist is not None:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
