@@ -441,7 +441,11 @@ def main():
         transports["xgmi_p2p_ms_per_step" if used_p2p else "rccl_ms_per_step"] = round(elapsed / steps * 1e3, 5)
         if used_p2p:
             # the transport again after the run, bit-exact against locally reproducible sums (all ranks must agree)
-            ok = 1 if comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6) else 0
+            try:
+                ok = 1 if comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6) else 0
+            except Exception as exc:                          # noqa: BLE001 - every rank must reach the vote below
+                sys.stderr.write("bench: post-run peer-to-peer check raised: %s\n" % exc)
+                ok = 0
             if world > 1:
                 import torch.distributed as dist
                 t = torch.tensor([ok])
