@@ -395,20 +395,22 @@ __global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict
         w16[i] = f2bf(pi);
     }
 }
-// Adam on one [R, C] weight matrix in 64x64 tiles: float4 traffic on p/g/m/v, 8-B stores to the bf16 copy, and the
-// transposed bf16 copy leaves through the same LDS image as transpose_bf16_kernel.  R % 4 == C % 4 == 0.
-template <bool WT>
+// Adam on one [R, C] weight matrix in TR x TC tiles (TR * TC = 4096, 16 elements per thread): float4 traffic on
+// p/g/m/v, 8-B stores to the bf16 copy, and the transposed bf16 copy leaves through an LDS image of the output tile
+// like transpose_bf16_kernel.  R % 4 == C % 4 == 0.
+template <bool WT, int TC>
 __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                   float* __restrict__ m, float* __restrict__ v,
                                                                   bf16_t* __restrict__ w16, bf16_t* __restrict__ wT16,
                                                                   int64_t R, int64_t C, float lr, float b1, float b2,
                                                                   float eps, const double* __restrict__ state) {
-    __shared__ __attribute__((aligned(16))) bf16_t tile[WT ? 64 : 1][64 + 8];
+    constexpr int TXN = TC / 4, TR = 4 * (256 / TXN);
+    __shared__ __attribute__((aligned(16))) bf16_t tile[WT ? TC : 1][TR + 8];
     const double p1 = state[0], p2 = state[1];
     const float ic1 = (float)(1.0 / (1.0 - p1)), ic2 = (float)(1.0 / (1.0 - p2));
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t r0 = (int64_t)blockIdx.y * TR, c0 = (int64_t)blockIdx.x * TC;
+    const int tx = threadIdx.x % TXN, ty = threadIdx.x / TXN;
     const int64_t c = c0 + 4 * tx;
     u32x2 row[4];
     auto update = [&](f32x4 gi, f32x4& mi, f32x4& vi, f32x4& pi) {
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
         return u32x2{(uint32_t)f2bf(pi[0]) | ((uint32_t)f2bf(pi[1]) << 16),
                      (uint32_t)f2bf(pi[2]) | ((uint32_t)f2bf(pi[3]) << 16)};
     };
-    if (r0 + 64 <= R && c0 + 64 <= C) {
+    if (r0 + TR <= R && c0 + TC <= C) {
         // interior tile: all sixteen 16-B loads in flight before the first use
         const int64_t o0 = (r0 + 4 * ty) * C + c;
         f32x4 gi[4], mi[4], vi[4], pi[4];
@@ -474,9 +476,11 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
         *reinterpret_cast<u32x2*>(&tile[4 * tx + j][4 * ty]) = col;
     }
     __syncthreads();
+    constexpr int SEGS = TR / 8;                     // 16-B segments per transposed row
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int cc = (threadIdx.x >> 3) + 32 * i, seg = threadIdx.x & 7;
+        const int sidx = (int)threadIdx.x + 256 * i;
+        const int cc = sidx / SEGS, seg = sidx % SEGS;
         const int64_t oc = c0 + cc, orow = r0 + seg * 8;
         if (oc < C && orow < R) {
             const u32x4 val = *reinterpret_cast<const u32x4*>(&tile[cc][seg * 8]);
@@ -629,13 +633,14 @@ int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, voi
                             reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
                             reinterpret_cast<uintptr_t>(wT_bf16) | (reinterpret_cast<uintptr_t>(w_bf16) << 1);
     if (rows % 4 == 0 && cols % 4 == 0 && (align & 15) == 0) {
-        dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+        constexpr int TC = 64, TR = 64;      // measured on 8192x8192: 64x64 3.15 ms/step, 32x128 (wider rows) 3.31
+        dim3 grid((unsigned)((cols + TC - 1) / TC), (unsigned)((rows + TR - 1) / TR));
         if (wT_bf16)
-            hipLaunchKernelGGL(adam_master_bf16_2d_kernel<true>, grid, 256, 0, s, (float*)p_master, (const float*)g,
+            hipLaunchKernelGGL((adam_master_bf16_2d_kernel<true, TC>), grid, 256, 0, s, (float*)p_master, (const float*)g,
                                (float*)m, (float*)v, (bf16_t*)w_bf16, (bf16_t*)wT_bf16, rows, cols, (float)lr,
                                (float)b1, (float)b2, (float)eps, (const double*)pows_f64);
         else
-            hipLaunchKernelGGL(adam_master_bf16_2d_kernel<false>, grid, 256, 0, s, (float*)p_master, (const float*)g,
+            hipLaunchKernelGGL((adam_master_bf16_2d_kernel<false, TC>), grid, 256, 0, s, (float*)p_master, (const float*)g,
                                (float*)m, (float*)v, (bf16_t*)w_bf16, (bf16_t*)nullptr, rows, cols, (float)lr,
                                (float)b1, (float)b2, (float)eps, (const double*)pows_f64);
         TNN_LAUNCH_OK();
