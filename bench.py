@@ -503,6 +503,38 @@ def main():
     else:
         line = None
 
+    def graph_latency_us(fn, reps=100, launches=3):
+        g = _lib.Graph()
+        with g:
+            for _ in range(reps):
+                fn()
+        g.launch()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            g.launch()
+        fence()
+        return round((time.perf_counter() - t0) / (reps * launches) * 1e6, 2)
+
+    def p2p_latency_table():
+        """Per-call latency of the peer-to-peer all-reduce on the gradient-arena size for several workgroup counts, and
+        of the small all-gather — replayed from hipGraphs, every rank in lockstep.  Tuning data for the next round:
+        the development boxes have one GPU, real xGMI hops are only ever seen by this run."""
+        table = {}
+        n_arena = int(trainer.params.size) + 1
+        scratch = da.zeros((n_arena,), np.float32)
+        pair, out = da.zeros((2,), np.float32), da.zeros((world, 2), np.float32)
+        for blocks in (0, 16, 32, 64, 128):
+            lib.p2p_tune(blocks)
+            table["allreduce_us_blocks_%s" % (blocks or "auto")] = graph_latency_us(lambda: comm.allreduce(scratch))
+        lib.p2p_tune(0)
+        table["allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
+        comm.set_p2p(False)                                   # the same two calls over RCCL
+        table["rccl_allreduce_us"] = graph_latency_us(lambda: comm.allreduce(scratch))
+        table["rccl_allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
+        comm.set_p2p(True)
+        return table
+
     if compare_rccl:
         # Secondary measurement, never allowed to cost the primary one: the same K steps with both collectives on
         # RCCL (captured into the step graph like the primary run).  A watchdog prints the line as it stands and ends
@@ -520,6 +552,12 @@ def main():
         dog = threading.Timer(limit, give_up)
         dog.daemon = True
         dog.start()
+        try:
+            lat = p2p_latency_table()
+            if line is not None:
+                line["config"]["collectives"]["xgmi_p2p_latency"] = lat
+        except Exception as exc:                              # noqa: BLE001
+            sys.stderr.write("bench: peer-to-peer latency table skipped: %s\n" % exc)
         comm.set_p2p(False)
         chunk = build_chunk()
         dt_rccl, _ = measure(second)

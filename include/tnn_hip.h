@@ -332,6 +332,9 @@ TNN_API int tnn_allreduce_adam(void* grads, int64_t n_reduce, void* p, void* m, 
  * rank/world here also serve tnn_comm_world when no RCCL communicator exists. */
 TNN_API int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64_out);
 TNN_API int tnn_p2p_connect(const void* handles /* world x 64 bytes, rank order */);
+/* workgroups of the all-reduce kernel (0 = pick from the message size; TNN_P2P_BLOCKS sets the initial value).
+ * Collective: every rank must set the same value before the next all-reduce. */
+TNN_API int tnn_p2p_tune(int allreduce_blocks);
 TNN_API int tnn_p2p_enable(int on);                         /* route eligible collectives here (default after connect) */
 /* dead != 0: a barrier timed out (TNN_P2P_TIMEOUT_MS, default 20000) - results since then are invalid; synchronises */
 TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);

@@ -740,6 +740,7 @@ int tnn_p2p_create(int rank, int world, int64_t, void* h) {
 }
 int tnn_p2p_connect(const void*) { g_comm = 1; return 0; }
 int tnn_p2p_enable(int) { return 0; }
+int tnn_p2p_tune(int) { return 0; }
 int tnn_p2p_status(int* c, int* e, int* d) { if (c) *c = g_comm; if (e) *e = g_comm; if (d) *d = 0; return 0; }
 int tnn_p2p_destroy(void) { g_comm = 0; return 0; }
 

@@ -120,6 +120,7 @@ _SIGNATURES = {
     "tnn_p2p_create": [c_int, c_int, c_int64, _p],
     "tnn_p2p_connect": [_p],
     "tnn_p2p_enable": [c_int],
+    "tnn_p2p_tune": [c_int],
     "tnn_p2p_status": [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
     "tnn_p2p_destroy": [],
 }

@@ -379,6 +379,13 @@ int tnn_p2p_enable(int on) {
     return 0;
 }
 
+int tnn_p2p_tune(int allreduce_blocks) {
+    TNN_REQUIRE(S.open, "tnn_p2p_tune: no peer group");
+    TNN_REQUIRE(allreduce_blocks >= 0 && allreduce_blocks <= MAXB, "tnn_p2p_tune: blocks must be in [0, %d]", MAXB);
+    S.blocks_override = allreduce_blocks;          // every rank must use the same value (block b meets block b)
+    return 0;
+}
+
 int tnn_p2p_status(int* connected, int* enabled, int* dead) {
     if (connected) *connected = S.open && S.p.base[S.p.rank] != nullptr;
     if (enabled) *enabled = S.enabled;
