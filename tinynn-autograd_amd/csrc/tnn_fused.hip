@@ -76,9 +76,10 @@ int bias_act_typed(const void* x, const void* bias, void* y, int64_t M, int64_t 
 // ------------------------------------------------------------------------------ softmax NLL (F5)
 // core/losses.py:24-32 normalises over the WHOLE [m, c] batch:  M = max z,  S = sum exp(z - M).
 // Stage 1: per-block (M_b, S_b); stage 2 merges with S = sum S_b * exp(M_b - M).  Both in f64.
+// final != NULL (single-block launches): the block's pair IS the result and goes straight out as T.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void nll_stats_kernel(const T* __restrict__ z, int64_t n,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, T* __restrict__ final) {
     __shared__ double lds_m[kThreads / 64], lds_s[kThreads / 64];
     double mx = -INFINITY;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -106,8 +107,13 @@ __global__ __launch_bounds__(kThreads) void nll_stats_kernel(const T* __restrict
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < kThreads / 64; ++i) t += lds_s[i];
-        partial[2 * blockIdx.x] = bm;
-        partial[2 * blockIdx.x + 1] = t;
+        if (final) {
+            final[0] = (T)bm;
+            final[1] = (T)t;
+        } else {
+            partial[2 * blockIdx.x] = bm;
+            partial[2 * blockIdx.x + 1] = t;
+        }
     }
 }
 
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restri
                                                                int64_t c, double inv_m_global,
                                                                const T* __restrict__ stats,
                                                                double* __restrict__ partial,
-                                                               T* __restrict__ dz) {
+                                                               T* __restrict__ dz, T* __restrict__ final_loss) {
     __shared__ double lds[kThreads / 64];
     const double M = (double)stats[0], S = (double)stats[1];
     const double log_s = log(S), inv_s = 1.0 / S;
@@ -171,7 +177,8 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restri
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < kThreads / 64; ++i) t += lds[i];
-        partial[blockIdx.x] = t;
+        if (final_loss) final_loss[0] = (T)t;        // single-block launch: the partial is the loss
+        else if (partial) partial[blockIdx.x] = t;
     }
 }
 
@@ -628,14 +635,22 @@ int tnn_softmax_nll_stats(const void* z, int64_t m, int64_t c, void* stats, int 
     TNN_REQUIRE(n > 0, "tnn_softmax_nll_stats: empty logits");
     int64_t nb = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
     if (nb > 1024) nb = 1024;
+    hipStream_t s = tnn::stream();
+    if (nb == 1) {                                   // classifier-size logits: one block, one launch
+        if (dtype == TNN_F32)
+            hipLaunchKernelGGL((nll_stats_kernel<float>), 1, kThreads, 0, s, (const float*)z, n, (double*)nullptr, (float*)stats);
+        else
+            hipLaunchKernelGGL((nll_stats_kernel<double>), 1, kThreads, 0, s, (const double*)z, n, (double*)nullptr, (double*)stats);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
     void* ws = nullptr;
     if (tnn_malloc((size_t)nb * 2 * sizeof(double), &ws)) return 1;
-    hipStream_t s = tnn::stream();
     if (dtype == TNN_F32) {
-        hipLaunchKernelGGL((nll_stats_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)z, n, (double*)ws);
+        hipLaunchKernelGGL((nll_stats_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)z, n, (double*)ws, (float*)nullptr);
         hipLaunchKernelGGL((lse_merge_kernel<double, float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)stats);
     } else {
-        hipLaunchKernelGGL((nll_stats_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)z, n, (double*)ws);
+        hipLaunchKernelGGL((nll_stats_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)z, n, (double*)ws, (double*)nullptr);
         hipLaunchKernelGGL((lse_merge_kernel<double, double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)stats);
     }
     tnn_free(ws);
@@ -663,18 +678,28 @@ int tnn_softmax_nll_fwd_bwd(const void* z, const void* y, int64_t m, int64_t c, 
     TNN_REQUIRE(m > 0 && c > 0 && m_global > 0, "tnn_softmax_nll_fwd_bwd: empty batch");
     int64_t nb = (m + kThreads - 1) / kThreads;
     if (nb > 1024) nb = 1024;
-    void* ws = nullptr;
-    if (tnn_malloc((size_t)nb * sizeof(double), &ws)) return 1;
     hipStream_t s = tnn::stream();
     double inv_m = 1.0 / (double)m_global;
+    if (nb == 1) {                                   // up to 256 rows: one block writes dz and the loss, one launch
+        if (dtype == TNN_F32)
+            hipLaunchKernelGGL((nll_fwd_bwd_kernel<float>), 1, kThreads, 0, s, (const float*)z, (const float*)y, m, c,
+                               inv_m, (const float*)stats, (double*)nullptr, (float*)dz, (float*)loss_out);
+        else
+            hipLaunchKernelGGL((nll_fwd_bwd_kernel<double>), 1, kThreads, 0, s, (const double*)z, (const double*)y, m,
+                               c, inv_m, (const double*)stats, (double*)nullptr, (double*)dz, (double*)loss_out);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
+    void* ws = nullptr;
+    if (tnn_malloc((size_t)nb * sizeof(double), &ws)) return 1;
     if (dtype == TNN_F32) {
         hipLaunchKernelGGL((nll_fwd_bwd_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)z,
-                           (const float*)y, m, c, inv_m, (const float*)stats, (double*)ws, (float*)dz);
+                           (const float*)y, m, c, inv_m, (const float*)stats, (double*)ws, (float*)dz, (float*)nullptr);
         if (loss_out)
             hipLaunchKernelGGL((sum_partials_kernel<float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)loss_out);
     } else {
         hipLaunchKernelGGL((nll_fwd_bwd_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)z,
-                           (const double*)y, m, c, inv_m, (const double*)stats, (double*)ws, (double*)dz);
+                           (const double*)y, m, c, inv_m, (const double*)stats, (double*)ws, (double*)dz, (double*)nullptr);
         if (loss_out)
             hipLaunchKernelGGL((sum_partials_kernel<double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)loss_out);
     }
