@@ -47,6 +47,30 @@ def test_p2p_world1_collectives_and_graph():
         comm.close()
 
 
+@pytest.mark.gpu
+def test_sharded_trainer_on_p2p_world1_matches_reference_fixture():
+    """The 8-launch data-parallel step (exchange inside the loss kernel, Adam inside the all-reduce kernel) on a
+    one-rank group: every collective is the identity, so the reference's single-process trajectory must come out —
+    eagerly and replayed from a hipGraph."""
+    import helpers as H
+    from tinynn_autograd_amd.dist import XgmiCommunicator
+    comm = XgmiCommunicator(0, 1, p2p_bytes=2 << 20)
+    try:
+        cfg, gold = H.load_traj("A_adam")
+        w = cfg["widths"]
+        model, _ = H.build_model(cfg)
+        trainer = tn.trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"], comm=comm, force_dp=True)
+        data = list(H.batches(cfg["data_seed"], 8, cfg["m"], w[0], w[-1], cfg["loss"]))
+        for s in range(4):
+            x, y = data[s]
+            np.testing.assert_allclose(float(trainer.step(tn.asarray(x), tn.asarray(y))), gold["loss"][s], rtol=1e-5)
+        graph = trainer.capture_steps([(tn.asarray(x), tn.asarray(y)) for x, y in data[4:8]])
+        np.testing.assert_allclose(np.asarray(graph.launch()), gold["loss"][4:8], rtol=1e-5)
+        assert not comm.p2p_status()["dead"]
+    finally:
+        comm.close()
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
