@@ -627,6 +627,36 @@ def dense_vjp_writes_arena_views_and_survives_weight_sharing():
         np.testing.assert_allclose(np.asarray(b.grad), 2 * db, rtol=2e-5, atol=2e-5)
 
 
+def trainer_with_other_optimizers_matches_op_level_model():
+    """The whole-step trainer driving Momentum / RMSProp / Adagrad / Adadelta (tnn_optim_step on the arenas) against
+    the op-level Model with the same optimizer class (itself pinned to the reference's steps): three training
+    steps from the same initial parameters must end in the same parameters."""
+    from tinynn_autograd_amd.core import optimizer as O
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    cases = {"momentum": (lambda: O.Momentum(lr=0.05, momentum=0.9), dict(lr=0.05, beta1=0.9)),
+             "rmsprop": (lambda: O.RMSProp(lr=0.01, decay=0.9, momentum=0.5), dict(lr=0.01, beta1=0.9, beta2=0.5)),
+             "adagrad": (lambda: O.Adagrad(lr=0.1), dict(lr=0.1)),
+             "adadelta": (lambda: O.Adadelta(lr=1.0, decay=0.9), dict(lr=1.0, beta1=0.9))}
+    cfg = dict(widths=[20, 16, 12, 5], seed=3, opt="sgd", lr=0.1, loss="softmax_nll")
+    rs = np.random.RandomState(8)
+    data = [(rs.rand(24, 20).astype(np.float32), np.eye(5, dtype=np.float32)[rs.randint(0, 5, 24)]) for _ in range(3)]
+    for name, (make, kw) in cases.items():
+        ref_model, _ = H.build_model(cfg)
+        loss_layer = SoftmaxCrossEntropyLoss()
+        model = Model(net=ref_model.net, loss=loss_layer, optimizer=make())
+        trainer = trainer_from_net(ref_model.net, max_rows=24, loss="softmax_nll", optimizer=name, **kw)
+        for x, y in data:
+            model.zero_grad()
+            out = loss_layer.loss(model.forward(Tensor(x)), Tensor(y))
+            out.backward()
+            model.step()
+            tl = float(trainer.step(tn.asarray(x), tn.asarray(y)))
+            np.testing.assert_allclose(tl, float(out.values), rtol=2e-5, err_msg=name)
+        flat = np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
+        np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=5e-5 * np.abs(flat).max(), err_msg=name)
+
+
 def other_optimizers_match_reference_steps():
     """Momentum / RMSProp / Adagrad / Adadelta: six consecutive `_compute_step` results against the
     reference's own (tests/golden/optim_steps.npz, generated from core/optimizer.py:82-164), fused kernel and

@@ -192,7 +192,7 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
         tnn::set_error("tnn_mlp_create: dtype %d is not a float type", dtype);
         return 2;
     }
-    if (loss_kind < 0 || loss_kind > 1 || opt_kind < 0 || opt_kind > 1) {
+    if (loss_kind < 0 || loss_kind > 1 || opt_kind < 0 || opt_kind > 5) {
         tnn::set_error("tnn_mlp_create: loss_kind %d / opt_kind %d unknown", loss_kind, opt_kind);
         return 2;
     }
@@ -350,6 +350,9 @@ int tnn_mlp_update(void* handle) {
     if (!h) { tnn::set_error("tnn_mlp_update: NULL handle"); return 2; }
     if (h->bf16) return mlp16_update(h);
     if (h->opt_kind == 0) return tnn_sgd(h->params, h->grads, h->n_params, h->lr, h->dtype);
+    if (h->opt_kind >= 2)   // Momentum / RMSProp / Adagrad / Adadelta: m, v are the two state vectors; b1, b2 = a, b
+        return tnn_optim_step(h->opt_kind - 2, h->params, h->grads, h->m, h->v, nullptr, h->n_params, h->lr, h->b1,
+                              h->b2, h->eps, h->dtype);
     return tnn_adam(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps,
                     h->pows, nullptr, h->dtype);
 }

@@ -20,13 +20,16 @@ from . import _lib
 from . import device_array as da
 
 _LOSS = {"softmax_nll": 0, "mse": 1}
-_OPT = {"sgd": 0, "adam": 1}
+_OPT = {"sgd": 0, "adam": 1, "momentum": 2, "rmsprop": 3, "adagrad": 4, "adadelta": 5}
 
 
 class MLPTrainer(object):
 
     def __init__(self, widths, max_rows, loss="softmax_nll", optimizer="adam", lr=1e-3, beta1=0.9,
                  beta2=0.999, epsilon=1e-8, dtype=np.float32, comm=None, use_graph=False, force_dp=False):
+        """optimizer: "sgd", "adam" (beta1, beta2, epsilon) or the reference's other four with their hyper-parameters
+        in the same slots — "momentum" (beta1 = momentum), "rmsprop" (beta1 = decay, beta2 = momentum, epsilon),
+        "adagrad" (epsilon), "adadelta" (beta1 = decay, epsilon)."""
         self.widths = [int(w) for w in widths]
         self.n_layers = len(self.widths) - 1
         self.max_rows = int(max_rows)
