@@ -424,13 +424,16 @@ def main():
 
     transports = None
     compare_rccl = False
-    if comm is not None and args.path == "fused" and args.workload != "E":
+    if comm is not None and args.path == "fused":
         # Data-parallel run: the peer-to-peer transport was mapped and self-tested by init_from_env(); time the K
         # steps on it and make sure no barrier timed out (else: re-measure on RCCL).  `value` comes from this run.
         # The same K steps are timed over RCCL afterwards for comparison (see below).
         transports = {}
         second = (warmup + steps + n_batches - 1) // n_batches * n_batches      # chunk-aligned start of a second run
-        used_p2p = p2p_alive()
+        # the latency path carries f32 sums up to its mapped capacity: config A's 0.94 MB arena, not C's 134 MB or E's
+        # 1 GB — those go to RCCL whatever the transport's state
+        arena_bytes = (int(trainer.params.size) + 1) * 4
+        used_p2p = p2p_alive() and arena_bytes <= getattr(comm, "p2p_bytes", 0)
         elapsed, last = measure(0)
         if used_p2p and not p2p_alive():
             sys.stderr.write("bench: xGMI peer-to-peer barrier timed out during the run; measuring on RCCL\n")

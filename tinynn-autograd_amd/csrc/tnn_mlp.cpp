@@ -430,7 +430,8 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
     if (!h->bf16 && h->opt_kind == 1)
         return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
                                   h->eps, h->pows, 1, h->dtype, h->n_params, loss_out);
-    MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->dtype, TNN_RSUM));
+    // the arenas of a bf16 trainer are fp32 (master weights, gradients, optimizer state)
+    MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->bf16 ? TNN_F32 : h->dtype, TNN_RSUM));
     MLP_TRY(tnn_mlp_update(handle));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;

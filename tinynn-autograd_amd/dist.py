@@ -65,6 +65,7 @@ class DeviceCommunicator(Communicator):
         self.rank, self.world = int(rank), int(world)
         self._rccl = False
         self._p2p = False
+        self.p2p_bytes = 0                # capacity of the mapped peer regions (largest f32 sum they carry)
         self._open = True
         # tear the transports down before the HIP runtime's own exit handlers run (RCCL otherwise aborts the
         # process with "double free or corruption" at interpreter exit)
@@ -114,6 +115,7 @@ class DeviceCommunicator(Communicator):
                 lib.p2p_destroy()
             raise
         self._p2p = True
+        self.p2p_bytes = int(max_bytes)
         return self
 
     def set_p2p(self, on):
