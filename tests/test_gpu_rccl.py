@@ -66,3 +66,27 @@ def test_sharded_steps_captured_with_rccl_in_graph(comm):
     np.testing.assert_allclose(losses, gold["loss"], rtol=1e-5)
     for l in range(trainer.n_layers):
         H.check_summary(np.asarray(trainer.param_view(l, "w")), gold, "final_%dw" % l, rtol=0, atol=0.1 * cfg["lr"])
+
+
+@pytest.mark.gpu
+def test_bf16_trainer_sharded_step_world1(comm):
+    """bf16 storage / fp32 arenas: the sharded step (fp32 gradient arena all-reduced as f32) at world 1 must equal the
+    unsharded step bit for bit."""
+    from tinynn_autograd_amd import bf16
+    from tinynn_autograd_amd.fused import MLPTrainer
+    rs = np.random.RandomState(5)
+    widths, m = [256, 256, 256], 128
+    a = np.sqrt(6.0 / 512)
+    layers = [{"w": rs.uniform(-a, a, (256, 256)).astype(np.float32), "b": np.zeros((1, 256), np.float32)}
+              for _ in range(2)]
+    x16 = bf16.to_bf16(rs.rand(m, 256).astype(np.float32))
+    losses = []
+    for c in (None, comm):
+        t = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16", comm=c, force_dp=c is not None)
+        t.set_parameters(layers)
+        losses.append([float(t.step(x16, x16)) for _ in range(3)])
+        params = np.asarray(t.params)
+        if c is None:
+            ref_params = params
+    assert losses[0] == losses[1]
+    assert np.array_equal(params, ref_params)
