@@ -90,3 +90,20 @@ def test_bf16_trainer_sharded_step_world1(comm):
             ref_params = params
     assert losses[0] == losses[1]
     assert np.array_equal(params, ref_params)
+
+
+@pytest.mark.gpu
+def test_float64_trainer_sharded_step_world1(comm):
+    """float64 arenas through the sharded step (RCCL carries f64; the f32-only peer-to-peer path must step aside)."""
+    cfg, gold = H.load_traj("A_adam")
+    w = cfg["widths"]
+    tn.set_default_float(np.float64)
+    try:
+        model, _ = H.build_model(cfg)
+        trainer = tn.trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"], comm=comm, force_dp=True,
+                                      dtype=np.float64)
+        for s, (x, y) in enumerate(H.batches(cfg["data_seed"], 5, cfg["m"], w[0], w[-1], cfg["loss"])):
+            tl = float(trainer.step(tn.asarray(x, dtype=np.float64), tn.asarray(y, dtype=np.float64)))
+            np.testing.assert_allclose(tl, gold["loss"][s], rtol=1e-9)
+    finally:
+        tn.set_default_float(np.float32)
