@@ -573,24 +573,26 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(T* __restrict__ p, const
     };
     if constexpr (VEC == 4) {
         int64_t nv = n / 4;
+        typedef float f4 __attribute__((ext_vector_type(4)));
         for (int64_t i = tid; i < nv; i += nth) {
-            float4 g4 = reinterpret_cast<const float4*>(g)[i];
-            float4 m4 = reinterpret_cast<float4*>(m)[i];
-            float4 v4 = reinterpret_cast<float4*>(v)[i];
-            float4 s4;
-            s4.x = upd(g4.x, m4.x, v4.x);
-            s4.y = upd(g4.y, m4.y, v4.y);
-            s4.z = upd(g4.z, m4.z, v4.z);
-            s4.w = upd(g4.w, m4.w, v4.w);
-            reinterpret_cast<float4*>(m)[i] = m4;
-            reinterpret_cast<float4*>(v)[i] = v4;
-            if (step_out) {
-                reinterpret_cast<float4*>(step_out)[i] = s4;
-            } else {
-                float4 p4 = reinterpret_cast<float4*>(p)[i];
-                p4.x += s4.x; p4.y += s4.y; p4.z += s4.z; p4.w += s4.w;
-                reinterpret_cast<float4*>(p)[i] = p4;
+            // all four streams requested before the first use (p used to be fetched after the arithmetic); g, m, v
+            // are touched once per step: non-temporal, so they do not evict the parameters the next forward re-reads
+            const f4 g4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g) + i);
+            f4 m4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m) + i);
+            f4 v4 = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v) + i);
+            f4 p4 = {0.f, 0.f, 0.f, 0.f};
+            if (!step_out) p4 = reinterpret_cast<const f4*>(p)[i];
+            f4 s4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float mk = m4[k], vk = v4[k];
+                s4[k] = upd(g4[k], mk, vk);
+                m4[k] = mk; v4[k] = vk;
             }
+            __builtin_nontemporal_store(m4, reinterpret_cast<f4*>(m) + i);
+            __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(v) + i);
+            if (step_out) reinterpret_cast<f4*>(step_out)[i] = s4;
+            else reinterpret_cast<f4*>(p)[i] = p4 + s4;
         }
         for (int64_t i = nv * 4 + tid; i < n; i += nth) {
             T mi = m[i], vi = v[i];

@@ -383,7 +383,30 @@ __global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict
     const double p1 = state[0], p2 = state[1];
     const float ic1 = (float)(1.0 / (1.0 - p1)), ic2 = (float)(1.0 / (1.0 - p2));
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // 16-B non-temporal streams for everything only the optimizer touches (g, m, v, fp32 master weights); the bf16
+    // copy is re-read by the next GEMMs and takes ordinary 8-B stores.  n4 = vectorisable prefix (arenas 16-B aligned).
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (reinterpret_cast<uintptr_t>(w16) & 7) == 0;
+    const int64_t n4 = aligned ? n / 4 : 0;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < n4; i += nth) {
+        const f32x4 gi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        f32x4 mi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
+        f32x4 vi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
+        f32x4 pi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mi[k] = mi[k] + omb1 * (gi[k] - mi[k]);
+            vi[k] = vi[k] + omb2 * (gi[k] * gi[k] - vi[k]);
+            pi[k] = pi[k] + (-lr * (mi[k] * ic1) / (sqrtf(vi[k] * ic2) + eps));
+        }
+        __builtin_nontemporal_store(mi, reinterpret_cast<f32x4*>(m) + i);
+        __builtin_nontemporal_store(vi, reinterpret_cast<f32x4*>(v) + i);
+        __builtin_nontemporal_store(pi, reinterpret_cast<f32x4*>(p) + i);
+        reinterpret_cast<u32x2*>(w16)[i] = u32x2{(uint32_t)f2bf(pi[0]) | ((uint32_t)f2bf(pi[1]) << 16),
+                                                 (uint32_t)f2bf(pi[2]) | ((uint32_t)f2bf(pi[3]) << 16)};
+    }
+    for (int64_t i = n4 * 4 + tid; i < n; i += nth) {
         const float gi = g[i];
         float mi = m[i], vi = v[i];
         mi = mi + omb1 * (gi - mi);
@@ -429,17 +452,19 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
         f32x4 gi[4], mi[4], vi[4], pi[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // g, m, v and the fp32 master weights are touched once per step: non-temporal on both sides; only the bf16
+            // copies are re-read (by the next forward / backward)
             gi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + o0 + i * C));
-            mi[i] = *reinterpret_cast<const f32x4*>(m + o0 + i * C);
-            vi[i] = *reinterpret_cast<const f32x4*>(v + o0 + i * C);
-            pi[i] = *reinterpret_cast<const f32x4*>(p + o0 + i * C);
+            mi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m + o0 + i * C));
+            vi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v + o0 + i * C));
+            pi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + o0 + i * C));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             row[i] = update(gi[i], mi[i], vi[i], pi[i]);
-            *reinterpret_cast<f32x4*>(m + o0 + i * C) = mi[i];
-            *reinterpret_cast<f32x4*>(v + o0 + i * C) = vi[i];
-            *reinterpret_cast<f32x4*>(p + o0 + i * C) = pi[i];
+            __builtin_nontemporal_store(mi[i], reinterpret_cast<f32x4*>(m + o0 + i * C));
+            __builtin_nontemporal_store(vi[i], reinterpret_cast<f32x4*>(v + o0 + i * C));
+            __builtin_nontemporal_store(pi[i], reinterpret_cast<f32x4*>(p + o0 + i * C));
             *reinterpret_cast<u32x2*>(w16 + o0 + i * C) = row[i];
         }
     } else {
@@ -611,9 +636,9 @@ int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* 
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_master_bf16: pows state is NULL");
     hipStream_t s = tnn::stream();
     hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
-    hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid(n, 256), 256, 0, s, (float*)p_master, (const float*)g,
-                       (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2, (float)eps,
-                       (const double*)pows_f64);
+    hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid((n + 3) / 4, 256), 256, 0, s, (float*)p_master,
+                       (const float*)g, (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2,
+                       (float)eps, (const double*)pows_f64);
     TNN_LAUNCH_OK();
     return 0;
 }
