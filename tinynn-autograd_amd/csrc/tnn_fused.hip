@@ -507,6 +507,7 @@ __global__ __launch_bounds__(kThreads) void optim_kernel(T* __restrict__ p, cons
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const T gi = g[i];
+        const T pi = p ? p[i] : T(0);                        // requested with the other streams, not after the maths
         T step;
         if constexpr (KIND == TNN_OPT_MOMENTUM) {            // acc = momentum * acc + g; step = -lr * acc
             const T acc = a * s1[i] + gi;
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void optim_kernel(T* __restrict__ p, cons
             s2[i] = d + (T(1) - a) * (delta * delta - d);
         }
         if (step_out) step_out[i] = step;
-        if (p) p[i] = p[i] + step;
+        if (p) p[i] = pi + step;
     }
 }
 
