@@ -310,7 +310,8 @@ def dense_backward_one_launch_vs_numpy():
 def gemm_shapes_and_transposes():
     rs = np.random.RandomState(11)
     shapes = [(128, 256, 784), (80, 10, 128), (128, 10, 128), (33, 17, 5), (1, 1, 1), (64, 64, 32),
-              (130, 70, 100), (256, 128, 1), (7, 300, 9), (200, 129, 257)]
+              (130, 70, 100), (256, 128, 1), (7, 300, 9), (200, 129, 257),
+              (50, 30, 36), (17, 40, 20), (128, 256, 52), (16, 16, 1040)]      # K % 4 == 0 with ragged last chunk / tiles
     for (M, N, K) in shapes:
         a = rs.randn(M, K).astype(np.float32)
         b = rs.randn(K, N).astype(np.float32)
