@@ -4,6 +4,7 @@
 
 #include "tnn_internal.h"
 #include "tnn_p2p.h"
+#include "tnn_nll_rows.h"
 
 namespace {
 
@@ -189,10 +190,8 @@ __global__ __launch_bounds__(kThreads) void nll_fwd_bwd_kernel(const T* __restri
 constexpr int kNllMaxRows = 1024;
 // transcendental in the array's own precision (f32: hardware v_exp/v_log based expf/logf, <= 1 ulp; the sums
 // they feed are still accumulated in f64); f64 arrays keep f64 throughout (exact-mode parity)
-__device__ __forceinline__ double nll_exp(float x) { return (double)expf(x); }
-__device__ __forceinline__ double nll_exp(double x) { return exp(x); }
-__device__ __forceinline__ double nll_log(float x) { return (double)logf(x); }
-__device__ __forceinline__ double nll_log(double x) { return log(x); }
+using tnn::nll_exp;   // tnn_nll_rows.h
+using tnn::nll_log;
 template <typename T> struct NllCap { static constexpr int elems = sizeof(T) == 4 ? 4096 : 2048; };
 
 // Block reduction tuned for latency (measured on MI355X: a 64-bit __shfl_xor is two ds_bpermute round trips
@@ -341,114 +340,13 @@ __global__ __launch_bounds__(1024) void nll_fused_kernel(const T* __restrict__ z
     }
 }
 
-// Classifier heads (c <= 16 classes, m <= 1024 rows): ONE THREAD PER ROW and a single block reduction.
-// Each row is normalised against its OWN maximum first (m_i, e_ik = exp(z_ik - m_i), s_i = sum_k e_ik, u_i = sum_k e_ik y_ik),
-// which needs no communication; the whole-batch quantities then follow from one combined reduction of
-// {M = max m_i, S = sum s_i exp(m_i - M), L = sum (log u_i + m_i)}:
-//     loss = log S + M - L / m,      dz_ik = e_ik exp(m_i - M) / S - (e_ik y_ik / u_i) / m
-// The element-parallel kernel above needs three dependent block reductions (max, sum-exp, loss) with 16 waves; this one
-// has one, over m / 64 waves — 4.5 -> ~3.3 us for the 128 x 10 MNIST head, whose cost is all dependent latency.
-// SHARDED as above: the {M, S} pair is exchanged with the peers between the reduction and the dz pass.
 template <typename T, bool SHARDED>
 __global__ __launch_bounds__(1024) void nll_rows_kernel(const T* __restrict__ z, const T* __restrict__ y, int m, int c,
                                                         T* __restrict__ stats_out, T* __restrict__ loss_out,
                                                         T* __restrict__ dz, double inv_m_global,
                                                         tnn::p2p::LaunchCtx ctx, double* __restrict__ tick, double b1,
                                                         double b2) {
-    constexpr int CMAX = 16;
-    __shared__ double wave_m[16], wave_s[16], wave_l[16];
-    __shared__ double scal[4];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = (blockDim.x + 63) >> 6;
-    if (tick != nullptr && tid == 0) {
-        tick[0] *= b1;
-        tick[1] *= b2;
-    }
-    T e[CMAX], ey[CMAX];
-    double mi = -INFINITY, si = 0.0, li = 0.0, ui = 1.0;
-    const bool live = tid < m;
-    if (live) {
-        T zr[CMAX], yr[CMAX];
-#pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            zr[k] = k < c ? z[(int64_t)tid * c + k] : (T)-INFINITY;
-            yr[k] = k < c ? y[(int64_t)tid * c + k] : (T)0;
-        }
-        T mx = zr[0];
-#pragma unroll
-        for (int k = 1; k < CMAX; ++k) mx = zr[k] > mx ? zr[k] : mx;
-        double s = 0.0, u = 0.0;
-#pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            const double ek = k < c ? nll_exp((T)(zr[k] - mx)) : 0.0;
-            e[k] = (T)ek;
-            ey[k] = (T)((double)(T)ek * (double)yr[k]);
-            s += ek;
-            u += (double)ey[k];
-        }
-        mi = (double)mx; si = s; ui = u;
-        li = nll_log((T)u) + (double)mx;
-    }
-    // one combined reduction: waves first (shuffles), then <= 16 wave triples through LDS
-    double wm = tnn::wave_max(mi);
-    double ws = tnn::wave_sum(live ? si * nll_exp((T)(mi - wm)) : 0.0);
-    double wl = tnn::wave_sum(li);
-    if (lane == 0) { wave_m[wid] = wm; wave_s[wid] = ws; wave_l[wid] = wl; }
-    __syncthreads();
-    double M = -INFINITY, S = 0.0, L = 0.0;
-    for (int w = 0; w < nw; ++w) M = fmax(M, wave_m[w]);
-    for (int w = 0; w < nw; ++w) {
-        if (wave_m[w] > -INFINITY) S += wave_s[w] * nll_exp((T)(wave_m[w] - M));
-        L += wave_l[w];
-    }
-    double inv_m = 1.0 / (double)m;
-    double loss;
-    if constexpr (SHARDED) {
-        using namespace tnn::p2p;
-        __shared__ float peer_stats[MAXW][2];
-        const Peers& P = ctx.peers;
-        const int W = P.world;
-        const uint32_t ep = *ctx.ag_epoch;
-        const size_t slots = offsetof(Header, ag_slot) + (size_t)(ep & 1) * MAXW * AG_BYTES;
-        if (tid < 2 * W) {
-            const float mine = (tid & 1) ? (float)S : (float)M;
-            store_sys(reinterpret_cast<uint32_t*>(P.base[tid >> 1] + slots + (size_t)P.rank * AG_BYTES) + (tid & 1),
-                      __float_as_uint(mine));
-        }
-        exchange_flags(P, offsetof(Header, ag_flag), ep + 1, ctx.dead, ctx.timeout_ticks);
-        if (tid < 2 * W) {
-            uint32_t w[1] = {0u};
-            load_sys(w[0], reinterpret_cast<const uint32_t*>(P.base[P.rank] + slots + (size_t)(tid >> 1) * AG_BYTES) + (tid & 1));
-            loads_landed(w);
-            peer_stats[tid >> 1][tid & 1] = __uint_as_float(w[0]);
-        }
-        __syncthreads();
-        double gm = -INFINITY, gs = 0.0;
-        for (int q = 0; q < W; ++q) gm = fmax(gm, (double)peer_stats[q][0]);
-        for (int q = 0; q < W; ++q) gs += (double)peer_stats[q][1] * nll_exp((T)((double)peer_stats[q][0] - gm));
-        if (tid == 0) *ctx.ag_epoch = ep + 1;
-        M = gm; S = gs;
-        inv_m = inv_m_global;
-        loss = ((nll_log((T)S) + M) * (double)m - L) * inv_m;   // this rank's share
-    } else {
-        loss = nll_log((T)S) + M - L * inv_m;
-    }
-    if (live && dz) {
-        const double scale = nll_exp((T)(mi - M)) / S, inv_u = inv_m / ui;
-        if (sizeof(T) == 4) {
-            const float sf = (float)scale, uf = (float)inv_u;
-#pragma unroll
-            for (int k = 0; k < CMAX; ++k)
-                if (k < c) dz[(int64_t)tid * c + k] = (T)((float)e[k] * sf - (float)ey[k] * uf);
-        } else {
-#pragma unroll
-            for (int k = 0; k < CMAX; ++k)
-                if (k < c) dz[(int64_t)tid * c + k] = (T)((double)e[k] * scale - (double)ey[k] * inv_u);
-        }
-    }
-    if (tid == 0) {
-        if (loss_out) loss_out[0] = (T)loss;
-        if (stats_out) { stats_out[0] = (T)M; stats_out[1] = (T)S; }
-    }
+    tnn::nll_rows_body<T, SHARDED, false>(z, y, m, c, stats_out, loss_out, dz, inv_m_global, ctx, tick, b1, b2);
 }
 
 template <typename TO>
