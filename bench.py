@@ -273,7 +273,7 @@ def main():
     import torch
     import torch.distributed                              # noqa: F401
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(int(os.environ.get("TNN_DEVICE", local_rank)))   # TNN_DEVICE: ranks sharing one GPU (tests)
     lib = _lib.get()                                    # binds LOCAL_RANK's GPU; raises without HIP
     assert tn.backend_name() == "hip-gfx950", "bench.py measures the HIP library only"
     comm = tn.dist.init_from_env() if (world > 1 or os.environ.get("TNN_FORCE_COMM") == "1") else None
@@ -456,7 +456,8 @@ def main():
                 ok = int(t.item())
             transports["xgmi_p2p_verified_after_run"] = bool(ok)
         transports["used"] = "xgmi-p2p" if used_p2p else "rccl"
-        compare_rccl = used_p2p and os.environ.get("TNN_BENCH_COMPARE_RCCL", "1") != "0"
+        compare_rccl = (used_p2p and getattr(comm, "_rccl", False)
+                        and os.environ.get("TNN_BENCH_COMPARE_RCCL", "1") != "0")
         # replicas must still hold bit-identical parameters
         crc = int(np.frombuffer(np.asarray(trainer.params).tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
         if world > 1:

@@ -304,6 +304,13 @@ def init_from_env(backend="rccl", p2p=None):
     rank = dist.get_rank()
     if backend == "gloo":
         return GlooCommunicator()
+    if os.environ.get("TNN_COMM") == "xgmi":
+        # peer-to-peer transport only, no RCCL communicator: RCCL refuses ranks that share a GPU, this does not —
+        # how the N > 1 code paths (bench.py included) are exercised on a one-GPU box (TNN_DEVICE=0 for every rank)
+        comm = DeviceCommunicator(rank, world)
+        if not _try_p2p(comm, dist):
+            raise RuntimeError("TNN_COMM=xgmi: the peer-to-peer transport is not available")
+        return comm
     box = [RcclCommunicator.new_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
     comm = RcclCommunicator(rank, world, box[0])
