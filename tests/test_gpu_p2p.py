@@ -100,3 +100,27 @@ def test_p2p_two_processes_share_the_gpu():
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
         assert "p2p_worker rank %d/2 ok" % rank in out
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_torchrun_share_the_gpu():
+    """bench.py's N > 1 flow exactly as the driver launches it (python -m torch.distributed.run ... bench.py --gpus 2),
+    with both ranks on the box's one GPU and the peer-to-peer-only communicator (RCCL refuses ranks that share a
+    device): rendezvous, transport self-test vote, sharded steps in hipGraphs, max-over-ranks timing, the replicas
+    check, and exactly ONE JSON line on stdout from rank 0."""
+    import json
+    env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "128",
+           "--warmup", "64"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 128 and d["warmup"] == 64 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp2"
+    coll = d["config"]["collectives"]
+    assert coll["used"] == "xgmi-p2p" and coll["replicas_identical"] and coll["xgmi_p2p_verified_after_run"]
+    assert d["value"] > 0 and "roofline" in d
