@@ -520,7 +520,7 @@ def main():
         fence()
         return round((time.perf_counter() - t0) / (reps * launches) * 1e6, 2)
 
-    def p2p_latency_table():
+    def p2p_latency_table(with_rccl):
         """Per-call latency of the peer-to-peer all-reduce on the gradient-arena size for several workgroup counts, and
         of the small all-gather — replayed from hipGraphs, every rank in lockstep.  Tuning data for the next round:
         the development boxes have one GPU, real xGMI hops are only ever seen by this run."""
@@ -533,23 +533,23 @@ def main():
             table["allreduce_us_blocks_%s" % (blocks or "auto")] = graph_latency_us(lambda: comm.allreduce(scratch))
         lib.p2p_tune(0)
         table["allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
-        comm.set_p2p(False)                                   # the same two calls over RCCL
-        table["rccl_allreduce_us"] = graph_latency_us(lambda: comm.allreduce(scratch))
-        table["rccl_allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
-        comm.set_p2p(True)
+        if with_rccl:
+            comm.set_p2p(False)                               # the same two calls over RCCL
+            table["rccl_allreduce_us"] = graph_latency_us(lambda: comm.allreduce(scratch))
+            table["rccl_allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
+            comm.set_p2p(True)
         return table
 
-    if compare_rccl:
-        # Secondary measurement, never allowed to cost the primary one: the same K steps with both collectives on
-        # RCCL (captured into the step graph like the primary run).  A watchdog prints the line as it stands and ends
-        # the process if this does not come back (RCCL inside hipGraphs at world > 1 has never run on this code's
-        # one-GPU development boxes).
+    if transports is not None and transports.get("used") == "xgmi-p2p":
+        # Secondary measurements, never allowed to cost the primary one: the per-call latency table of the transport
+        # and (when an RCCL communicator exists) the same K steps with both collectives on RCCL, captured into the
+        # step graph like the primary run.  A watchdog prints the line as it stands and ends the process if this does
+        # not come back (none of it has ever run across real xGMI links on this code's one-GPU development boxes).
         import threading
 
         def give_up():
             if line is not None:
-                line["config"]["collectives"]["rccl_ms_per_step"] = None
-                line["config"]["collectives"]["rccl_comparison"] = "did not finish in %d s" % limit
+                line["config"]["collectives"]["secondary_measurements"] = "did not finish in %d s" % limit
                 emit(line)
             os._exit(0)
         limit = int(os.environ.get("TNN_BENCH_COMPARE_TIMEOUT_S", "90"))
@@ -557,24 +557,25 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            lat = p2p_latency_table()
+            lat = p2p_latency_table(with_rccl=bool(getattr(comm, "_rccl", False)))
             if line is not None:
                 line["config"]["collectives"]["xgmi_p2p_latency"] = lat
         except Exception as exc:                              # noqa: BLE001
             sys.stderr.write("bench: peer-to-peer latency table skipped: %s\n" % exc)
-        comm.set_p2p(False)
-        chunk = build_chunk()
-        dt_rccl, last_rccl = measure(second)
+        if compare_rccl:
+            comm.set_p2p(False)
+            chunk = build_chunk()
+            dt_rccl, last_rccl = measure(second)
+            if line is not None:
+                coll = line["config"]["collectives"]
+                coll["rccl_ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
+                if dt_rccl < elapsed:
+                    # both transports ran the same K timed steps after the same warm-up: report the faster one
+                    coll["used"] = "rccl"
+                    line["value"] = round(steps * rows * world / dt_rccl, 1)
+                    line["ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
+                    line["final_loss"] = round(float(last_rccl), 6)
         dog.cancel()
-        if line is not None:
-            coll = line["config"]["collectives"]
-            coll["rccl_ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
-            if dt_rccl < elapsed:
-                # both transports ran the same K timed steps after the same warm-up: report the faster one
-                coll["used"] = "rccl"
-                line["value"] = round(steps * rows * world / dt_rccl, 1)
-                line["ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
-                line["final_loss"] = round(float(last_rccl), 6)
     if line is not None:
         emit(line)
     if comm is not None:

@@ -124,3 +124,4 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     coll = d["config"]["collectives"]
     assert coll["used"] == "xgmi-p2p" and coll["replicas_identical"] and coll["xgmi_p2p_verified_after_run"]
     assert d["value"] > 0 and "roofline" in d
+    assert coll["xgmi_p2p_latency"]["allreduce_us_blocks_auto"] > 0 and coll["xgmi_p2p_latency"]["allgather_us"] > 0
