@@ -1,7 +1,7 @@
 // C1/C2 over xGMI peer-to-peer stores: a low-latency transport under tnn_allreduce / tnn_allgather for the
 // messages the MNIST-size data-parallel step exchanges (a 0.94 MB gradient arena and one {max, sum-exp} pair
 // per rank; examples/mnist/run.py:82-83 is where the exchange sits, core/losses.py:26-27 is why the second one
-// exists).  At 35 us per training step the two RCCL calls ARE the multi-GPU cost, so this path is latency-first:
+// exists).  At 32 us per training step the two RCCL calls ARE the multi-GPU cost, so this path is latency-first:
 //
 //   * every rank owns one UNCACHED device region (hipDeviceMallocUncached: remote stores and local reads bypass
 //     L2, so data written by a peer inside a running kernel is visible without a kernel boundary), exported
@@ -13,9 +13,11 @@
 //     broadcast, so all ranks end up with bit-identical sums (replicas cannot drift apart);
 //     per link and direction: 2 x n/W elements;
 //   * barriers are per-workgroup flag exchanges (block b of every rank works on the same sub-range of every
-//     slice, so only the W "block b"s have to meet): system-scope release store into each peer's flag word,
-//     acquire spin on the local words.  Flag values grow monotonically from a per-block epoch kept in DEVICE
+//     slice, so only the W "block b"s have to meet): each thread waits for its own stores to be acknowledged, then
+//     relaxed system-scope stores into each peer's flag word and relaxed polls of the local words (tnn_p2p.h has the
+//     reasoning and the measurements).  Flag values grow monotonically from a per-block epoch kept in DEVICE
 //     memory, so the kernel is replayable from a hipGraph with fixed arguments and never needs a reset;
+//   * (C) can carry the optimizer: the reduced gradient is in registers there, so Adam is applied on the spot;
 //   * spins are bounded by the constant 100 MHz clock: on timeout the kernel sets a sticky `dead` word, stops
 //     waiting (this and every later launch) and the host sees it through tnn_p2p_status() — a lost peer is an
 //     error, not a hung GPU.
