@@ -316,6 +316,13 @@ TNN_API int tnn_comm_world(int* rank, int* world);
 /* in-place all-reduce on the library stream; rop = TNN_RSUM / TNN_RMAX */
 TNN_API int tnn_allreduce(void* buf, int64_t n, int dtype, int rop);
 TNN_API int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype);
+/* Bucketed, overlapped C1 for large arenas: the SUM all-reduce of one gradient bucket runs on a communication
+ * stream, ordered after everything enqueued so far on the library stream, while the library stream continues (e.g.
+ * with the next layer's backward).  tnn_comm_join makes the library stream wait for every outstanding bucket —
+ * call it before anything reads the buckets (the optimizer).  Small messages the peer-to-peer path carries, or a
+ * missing RCCL communicator, make it the ordinary tnn_allreduce. */
+TNN_API int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop);
+TNN_API int tnn_comm_join(void);
 /* C1 and the optimizer in one call (run.py:82-83 with the exchange in between): grads[0:n_reduce] <- SUM over ranks,
  * then tnn_adam_ex(p, grads, m, v, n_params <= n_reduce, ..., advance, scalar_src = grads + scalar_index, scalar_dst).
  * On the peer-to-peer transport (f32, advance == 0) the update is applied by the all-reduce kernel's last stage, so

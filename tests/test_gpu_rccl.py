@@ -107,3 +107,28 @@ def test_float64_trainer_sharded_step_world1(comm):
             np.testing.assert_allclose(tl, gold["loss"][s], rtol=1e-9)
     finally:
         tn.set_default_float(np.float32)
+
+
+@pytest.mark.gpu
+def test_bucketed_overlapped_allreduce_world1(comm):
+    """Large arena (8.4 MB): the sharded step all-reduces each layer's gradients on the communication stream right
+    behind that layer's backward (tnn_allreduce_async / tnn_comm_join).  At world 1 every collective is the identity,
+    so losses and parameters must equal the unsharded trainer's bit for bit — eagerly and replayed from a hipGraph
+    (the event edges become a side branch of the graph)."""
+    from tinynn_autograd_amd.fused import MLPTrainer
+    rs = np.random.RandomState(9)
+    widths, m = [1024, 1024, 1024], 256
+    a = np.sqrt(6.0 / 2048)
+    layers = [{"w": rs.uniform(-a, a, (1024, 1024)).astype(np.float32), "b": np.zeros((1, 1024), np.float32)}
+              for _ in range(2)]
+    data = [tn.asarray(rs.rand(m, 1024).astype(np.float32)) for _ in range(4)]
+    results = []
+    for c in (None, comm):
+        t = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3, comm=c, force_dp=c is not None)
+        t.set_parameters(layers)
+        losses = [float(t.step(x, x)) for x in data[:2]]
+        graph = t.capture_steps([(x, x) for x in data[2:]])
+        losses += [float(v) for v in np.asarray(graph.launch())]
+        results.append((losses, np.asarray(t.params)))
+    assert results[0][0] == results[1][0]
+    assert np.array_equal(results[0][1], results[1][1])

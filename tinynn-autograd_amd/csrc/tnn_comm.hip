@@ -11,6 +11,8 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <vector>
+
 #include "tnn_internal.h"
 #include "tnn_p2p.h"
 
@@ -30,6 +32,8 @@ struct Rccl {
     int rank = 0, world = 1;
 };
 Rccl R;
+hipStream_t g_comm_stream = nullptr;            // bucketed all-reduces run here (tnn_allreduce_async)
+std::vector<hipEvent_t>* g_pending = nullptr;       // their "bucket done" events not yet joined
 
 int load_rccl() {
     if (R.so) return 0;
@@ -101,6 +105,15 @@ int tnn_comm_init(int rank, int world, const void* id128) {
 }
 
 int tnn_comm_destroy(void) {
+    if (g_comm_stream) {
+        (void)hipStreamSynchronize(g_comm_stream);
+        if (g_pending) {
+            for (hipEvent_t e : *g_pending) (void)hipEventDestroy(e);
+            g_pending->clear();
+        }
+        (void)hipStreamDestroy(g_comm_stream);
+        g_comm_stream = nullptr;
+    }
     if (R.comm && R.CommDestroy) {
         if (tnn::initialised()) (void)hipStreamSynchronize(tnn::stream());
         R.CommDestroy(R.comm);
@@ -157,6 +170,45 @@ int tnn_allreduce_adam(void* grads, int64_t n_reduce, void* p, void* m, void* v,
     const size_t esz = dtype == TNN_F64 ? 8 : 4;
     return tnn_adam_ex(p, grads, m, v, n_params, lr, b1, b2, eps, pows_f64, nullptr, dtype, advance,
                        scalar_dst ? (const char*)grads + (size_t)scalar_index * esz : nullptr, scalar_dst);
+}
+
+// Bucketed overlap: a gradient bucket is all-reduced on a separate communication stream as soon as the backward
+// launch that produced it has been enqueued, while the library stream goes on with the next layer's backward; the
+// optimizer waits for all buckets (tnn_comm_join).  Events carry the two orderings; under hipGraph capture they turn
+// into a side branch of the graph.
+int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    // nothing to overlap with on the latency path, or no RCCL communicator: the ordinary call
+    if (R.comm == nullptr || tnn::p2p_can_allreduce(n, dtype, rop)) return tnn_allreduce(buf, n, dtype, rop);
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    TNN_REQUIRE(rop == TNN_RSUM, "tnn_allreduce_async: only sums are bucketed");
+    if (!g_comm_stream) {
+        TNN_CHECK_HIP(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+        g_pending = new std::vector<hipEvent_t>();
+    }
+    hipEvent_t produced, done;
+    TNN_CHECK_HIP(hipEventCreateWithFlags(&produced, hipEventDisableTiming));
+    TNN_CHECK_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    TNN_CHECK_HIP(hipEventRecord(produced, tnn::stream()));
+    TNN_CHECK_HIP(hipStreamWaitEvent(g_comm_stream, produced, 0));
+    TNN_CHECK_NCCL(R.AllReduce(buf, buf, (size_t)n, t, ncclSum, R.comm, g_comm_stream));
+    TNN_CHECK_HIP(hipEventRecord(done, g_comm_stream));
+    g_pending->push_back(done);
+    (void)hipEventDestroy(produced);                    // released once the recorded work has completed
+    return 0;
+}
+
+int tnn_comm_join(void) {
+    TNN_NEED_INIT();
+    if (!g_pending) return 0;
+    for (hipEvent_t e : *g_pending) {
+        TNN_CHECK_HIP(hipStreamWaitEvent(tnn::stream(), e, 0));
+        (void)hipEventDestroy(e);
+    }
+    g_pending->clear();
+    return 0;
 }
 
 int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {

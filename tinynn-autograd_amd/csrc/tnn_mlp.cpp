@@ -36,6 +36,7 @@ struct Mlp {
     std::vector<int64_t> w;          // widths, L+1
     int64_t max_rows = 0;
     int loss_kind = 0, opt_kind = 0, dtype = TNN_F32;
+    bool bucket_comm = false;        // data-parallel step of a large net: all-reduce each layer's gradients as they appear
     double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
     int64_t n_params = 0, arena = 0;
     size_t esz = 4;
@@ -80,6 +81,15 @@ int mlp_forward(Mlp* h, const void* x, int64_t rows, int n_layers = -1) {
     return 0;
 }
 
+// Layer l's gradients (W_l then b_l, contiguous in the arena; the last layer's bucket also carries the loss slot
+// behind the arena) go to the communication stream as soon as their backward launch is enqueued.
+int allreduce_layer_bucket(Mlp* h, int l) {
+    const int64_t first = h->w_off[l];
+    int64_t count = h->w[l] * h->w[l + 1] + h->w[l + 1];
+    if (l == h->L - 1) count = h->n_params + 1 - first;
+    return tnn_allreduce_async(at(h->grads, first, h->esz), count, h->bf16 ? TNN_F32 : h->dtype, TNN_RSUM);
+}
+
 // gradients of every layer from dact[L-1] (set by the loss kernel) down to layer 0
 int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1) {
     if (from_layer < 0) from_layer = h->L - 1;
@@ -89,6 +99,7 @@ int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1
         MLP_TRY(tnn_dense_bwd(rows, h->w[l], h->w[l + 1], in, h->dact[l], at(h->params, h->w_off[l], h->esz),
                               at(h->grads, h->w_off[l], h->esz), at(h->grads, h->b_off[l], h->esz),
                               l > 0 ? h->dact[l - 1] : nullptr, l > 0 ? h->act[l - 1] : nullptr, h->dtype));
+        if (h->bucket_comm) MLP_TRY(allreduce_layer_bucket(h, l));
     }
     return 0;
 }
@@ -134,6 +145,7 @@ int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64
                                  at(h->grads, h->w_off[l], 4), h->w[l + 1], TNN_F32, nullptr, TNN_ACT_NONE, 0,
                                  nullptr, 0));
         MLP_TRY(tnn_colsum_bf16(h->dact[l], at(h->grads, h->b_off[l], 4), rows, h->w[l + 1]));
+        if (h->bucket_comm) MLP_TRY(allreduce_layer_bucket(h, l));
         // dz_{l-1} = (dz_l W_l^T) * mask : A = dz_l [rows, out] (K = out), B = W_l [in, out]
         if (l > 0)
             MLP_TRY(tnn_gemm_bf16_nt(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, h->w_off[l]),
@@ -425,6 +437,21 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
     if (h->loss_kind == 0) {
         MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
         MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
+    }
+    // large arenas (config C: 134 MB, config E: 1 GB of fp32 gradients): one all-reduce per layer, issued to the
+    // communication stream right behind that layer's backward launch, overlapping the remaining backward
+    if ((size_t)(h->n_params + 1) * h->esz > ((size_t)4 << 20)) {
+        h->bucket_comm = true;
+        const int rc = tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr);
+        h->bucket_comm = false;
+        if (rc) return rc;
+        MLP_TRY(tnn_comm_join());
+        if (!h->bf16 && h->opt_kind == 1)
+            return tnn_adam_ex(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps, h->pows,
+                               nullptr, h->dtype, 1, loss_out ? loss_slot : nullptr, loss_out);
+        MLP_TRY(tnn_mlp_update(handle));
+        if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
+        return 0;
     }
     MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr));
     if (!h->bf16 && h->opt_kind == 1)
