@@ -323,6 +323,9 @@ TNN_API int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int 
  * missing RCCL communicator, make it the ordinary tnn_allreduce. */
 TNN_API int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop);
 TNN_API int tnn_comm_join(void);
+/* wait only for the OLDEST outstanding bucket (buckets complete in issue order): lets the optimizer start on the
+ * last layer's parameters while the earlier layers' buckets are still on the links */
+TNN_API int tnn_comm_wait_oldest(void);
 /* C1 and the optimizer in one call (run.py:82-83 with the exchange in between): grads[0:n_reduce] <- SUM over ranks,
  * then tnn_adam_ex(p, grads, m, v, n_params <= n_reduce, ..., advance, scalar_src = grads + scalar_index, scalar_dst).
  * On the peer-to-peer transport (f32, advance == 0) the update is applied by the all-reduce kernel's last stage, so

@@ -707,6 +707,7 @@ int tnn_comm_world(int* r, int* w) { if (r) *r = 0; if (w) *w = 1; return 0; }
 int tnn_allreduce(void*, int64_t, int, int) { REQ(g_comm, "tnn_allreduce: tnn_comm_init() has not been called"); return 0; }
 int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) { return tnn_allreduce(buf, n, dtype, rop); }
 int tnn_comm_join(void) { return 0; }
+int tnn_comm_wait_oldest(void) { return 0; }
 int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
     REQ(g_comm, "tnn_allgather: tnn_comm_init() has not been called");
     memmove(r, s, (size_t)n * dsize(dtype));

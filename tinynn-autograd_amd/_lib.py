@@ -117,6 +117,7 @@ _SIGNATURES = {
     "tnn_allgather": [_p, _p, c_int64, c_int],
     "tnn_allreduce_async": [_p, c_int64, c_int, c_int],
     "tnn_comm_join": [],
+    "tnn_comm_wait_oldest": [],
     "tnn_allreduce_adam": [_p, c_int64, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, c_int, c_int,
                            c_int64, _p],
     "tnn_p2p_create": [c_int, c_int, c_int64, _p],

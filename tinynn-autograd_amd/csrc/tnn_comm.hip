@@ -200,6 +200,16 @@ int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) {
     return 0;
 }
 
+int tnn_comm_wait_oldest(void) {
+    TNN_NEED_INIT();
+    if (!g_pending || g_pending->empty()) return 0;
+    hipEvent_t e = g_pending->front();
+    g_pending->erase(g_pending->begin());
+    TNN_CHECK_HIP(hipStreamWaitEvent(tnn::stream(), e, 0));
+    (void)hipEventDestroy(e);
+    return 0;
+}
+
 int tnn_comm_join(void) {
     TNN_NEED_INIT();
     if (!g_pending) return 0;

@@ -180,6 +180,28 @@ bool head_fits_one_workgroup(const Mlp* h, int64_t rows) {
     return !h->bf16 && h->loss_kind == 0 && rows <= 1024 && rows * h->w[h->L] <= (h->dtype == TNN_F32 ? 4096 : 2048);
 }
 
+// Adam on ONE layer's parameters (W_l and b_l are contiguous in the arenas).  advance: first call of the step
+// (advances the beta powers); loss_out: also file the (already reduced) loss.
+int adam_layer(Mlp* h, int l, bool advance, void* loss_out) {
+    const int64_t wo = h->w_off[l], bo = h->b_off[l];
+    void* loss_slot = at(h->grads, h->n_params, h->esz);
+    if (h->bf16) {
+        auto f32 = [](void* base, int64_t off) { return (void*)((float*)base + off); };
+        MLP_TRY(tnn_adam_master_bf16_2d(f32(h->params, wo), f32(h->grads, wo), f32(h->m, wo), f32(h->v, wo),
+                                        at16(h->w16, wo), h->wT16[l], h->w[l], h->w[l + 1], h->lr, h->b1, h->b2,
+                                        h->eps, h->pows, advance ? 1 : 0));
+        MLP_TRY(tnn_adam_master_bf16_2d(f32(h->params, bo), f32(h->grads, bo), f32(h->m, bo), f32(h->v, bo),
+                                        at16(h->w16, bo), nullptr, 1, h->w[l + 1], h->lr, h->b1, h->b2, h->eps,
+                                        h->pows, 0));
+        if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, 4));
+        return 0;
+    }
+    const int64_t count = h->w[l] * h->w[l + 1] + h->w[l + 1];
+    return tnn_adam_ex(at(h->params, wo, h->esz), at(h->grads, wo, h->esz), at(h->m, wo, h->esz), at(h->v, wo, h->esz),
+                       count, h->lr, h->b1, h->b2, h->eps, h->pows, nullptr, h->dtype, advance ? 1 : 0,
+                       loss_out ? loss_slot : nullptr, loss_out);
+}
+
 int check_rows(Mlp* h, int64_t rows, const char* fn) {
     if (!h) { tnn::set_error("%s: NULL handle", fn); return 2; }
     if (rows <= 0 || rows > h->max_rows) {
@@ -445,10 +467,16 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
         const int rc = tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr);
         h->bucket_comm = false;
         if (rc) return rc;
+        if (h->opt_kind == 1) {
+            // Adam layer by layer in bucket order (last layer first): layer l's update starts when ITS bucket has
+            // landed, while the earlier layers' buckets are still on the links
+            for (int l = h->L - 1; l >= 0; --l) {
+                MLP_TRY(tnn_comm_wait_oldest());
+                MLP_TRY(adam_layer(h, l, l == h->L - 1, l == h->L - 1 ? loss_out : nullptr));
+            }
+            return 0;
+        }
         MLP_TRY(tnn_comm_join());
-        if (!h->bf16 && h->opt_kind == 1)
-            return tnn_adam_ex(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps, h->pows,
-                               nullptr, h->dtype, 1, loss_out ? loss_slot : nullptr, loss_out);
         MLP_TRY(tnn_mlp_update(handle));
         if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
         return 0;
