@@ -114,6 +114,16 @@ TNN_API int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, i
  * One launch for MNIST-size layers, the three separate kernels otherwise. */
 TNN_API int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz,
                           const void* w, void* dw, void* db, void* dx, const void* mask_src, int dtype);
+/* Backward of the FIRST Dense layer (its input needs no gradient) with the whole Adam step folded in, for the
+ * single-GPU training step: dw = x^T dz, db = column-sum dz as in tnn_dense_bwd, then Adam (tnn_adam maths, pows NOT
+ * advanced here) on this layer's weights (p_w, m_w, v_w: [n_in, n_out]) and bias (p_b, m_b, v_b: [n_out]) from the
+ * gradients just produced, and on one extra flat range of flat_n elements (every other layer's parameters, whose
+ * gradients flat_g are already final).  MNIST-size layers: ONE launch — the optimizer costs no launch of its own;
+ * other shapes / f64 run the launches this replaces. */
+TNN_API int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* dw,
+                                     void* db, void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b,
+                                     void* flat_p, const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n,
+                                     double lr, double b1, double b2, double eps, const void* pows_f64, int dtype);
 
 /* ------------------------------------------------------------------ elementwise (K2,K3) ------- */
 /* out[shape] = a (op) b with numpy broadcasting expressed as element strides (0 = broadcast dim).
@@ -275,7 +285,7 @@ TNN_API int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void
 /* One object = Dense/ReLU stack + whole-batch softmax NLL (loss_kind 0) or sum-of-squares/m
  * (loss_kind 1, the (err**2).sum()/m of test/test_autograd.py:119-121) + SGD (opt 0) / Adam (opt 1) /
  * Momentum, RMSProp, Adagrad, Adadelta (opt 2 + TNN_OPT_*; their hyper-parameters a, b travel in b1, b2),
- * i.e. the loop body of examples/mnist/run.py:79-83 as 8 launches (3-layer net) on device-resident state:
+ * i.e. the loop body of examples/mnist/run.py:79-83 as 7 launches (3-layer net) on device-resident state:
  * params | grads | m | v live in one flat arena each, ordered layer by layer, "w" then "b"
  * (core/layers.py:35, core/optimizer.py:14-15).
  * dtype TNN_BF16 (configs[4]): x, y, activations are bf16; the arenas stay fp32 (master weights, gradients,

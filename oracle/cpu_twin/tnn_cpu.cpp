@@ -613,6 +613,18 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
     });
     return 0;
 }
+int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* dw, void* db,
+                             void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b, void* flat_p,
+                             const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n, double lr, double b1,
+                             double b2, double eps, const void* pows, int dtype) {
+    if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
+    void* pw = const_cast<void*>(pows);
+    if (int rc = tnn_adam_ex(p_w, dw, m_w, v_w, n_in * n_out, lr, b1, b2, eps, pw, nullptr, dtype, 0, nullptr, nullptr)) return rc;
+    if (int rc = tnn_adam_ex(p_b, db, m_b, v_b, n_out, lr, b1, b2, eps, pw, nullptr, dtype, 0, nullptr, nullptr)) return rc;
+    if (flat_n > 0)
+        return tnn_adam_ex(flat_p, flat_g, flat_m, flat_v, flat_n, lr, b1, b2, eps, pw, nullptr, dtype, 0, nullptr, nullptr);
+    return 0;
+}
 int tnn_optim_step(int kind, void* p, const void* g, void* s1, void* s2, void* step_out, int64_t n, double lr, double a,
                    double b, double eps, int dtype) {
     NEED_INIT();

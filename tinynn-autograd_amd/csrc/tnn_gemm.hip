@@ -456,9 +456,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 //   lane l: i = l & 15 (row of A / column of B), grp = l >> 4 holds k = 16c + 4 grp + j, j = 0..3
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool AKC, bool BKC, int WAVES>
+// Optional optimizer tail of a dW tile (single-GPU step): the tile's 256 gradient values are in registers when the
+// epilogue stores them, so Adam (core/optimizer.py:67-79, the maths of adam_kernel in tnn_fused.hip) is applied to
+// the matching weights on the spot, and to the bias entries by the column-sum threads; pows already holds b1^t, b2^t
+// of this step.  The parameter / moment values are requested before the K loop.
+struct AdamEpi {
+    float* pw; float* mw; float* vw;     // weight block [M, ldc] matching C
+    float* pb; float* mb; float* vb;     // bias block [N] matching colsum
+    float* fp; const float* fg; float* fm; float* fv; int64_t fn;   // extra flat range updated by the trailing blocks
+    float lr, b1, b2, eps;
+    const double* pows;
+};
+__device__ __forceinline__ float adam_apply(const AdamEpi& ad, float ic1, float ic2, float g, float& m, float& v, float p) {
+    m = m + (1.f - ad.b1) * (g - m);
+    v = v + (1.f - ad.b2) * (g * g - v);
+    return p + (-ad.lr * (m * ic1) / (sqrtf(v * ic2) + ad.eps));
+}
+
+template <bool AKC, bool BKC, int WAVES, bool ADAM = false>
 __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict__ colsum, int block,
-                                           float (*red)[4][64], float (*bsum)[64]) {
+                                           float (*red)[4][64], float (*bsum)[64], const AdamEpi* ad = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
     const int tm = block % g.tiles_m, tn = block / g.tiles_m;
@@ -468,6 +485,21 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
     const int nchunks = (int)((g.K + 15) / 16);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
+    float a_p = 0.f, a_m = 0.f, a_v = 0.f, ab_p = 0.f, ab_m = 0.f, ab_v = 0.f, ic1 = 0.f, ic2 = 0.f;
+    if constexpr (ADAM) {
+        ic1 = (float)(1.0 / (1.0 - ad->pows[0]));
+        ic2 = (float)(1.0 / (1.0 - ad->pows[1]));
+        if (tid < 256) {
+            const int64_t row = m0 + ((tid & 63) >> 4) * 4 + (tid >> 6), col = n0 + (tid & 15);
+            if (row < g.M && col < g.N) {
+                const int64_t i = row * g.ldc + col;
+                a_p = ad->pw[i]; a_m = ad->mw[i]; a_v = ad->vw[i];
+            }
+        }
+        if (tm == 0 && tid < 16 && n0 + tid < g.N) {
+            ab_p = ad->pb[n0 + tid]; ab_m = ad->mb[n0 + tid]; ab_v = ad->vb[n0 + tid];
+        }
+    }
     for (int c = wid; c < nchunks; c += WAVES) {
         const int64_t k = (int64_t)c * 16 + grp * 4;
         float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
@@ -519,13 +551,27 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += red[w][r][ln];
         const int64_t row = m0 + (ln >> 4) * 4 + r, col = n0 + (ln & 15);   // 16x16x4 C/D layout
-        if (row < g.M && col < g.N) g.C[row * g.ldc + col] = apply_epilogue(g, s, row, col);
+        if (row < g.M && col < g.N) {
+            const float gval = apply_epilogue(g, s, row, col);
+            g.C[row * g.ldc + col] = gval;
+            if constexpr (ADAM) {
+                const int64_t i = row * g.ldc + col;
+                ad->pw[i] = adam_apply(*ad, ic1, ic2, gval, a_m, a_v, a_p);
+                ad->mw[i] = a_m;
+                ad->vw[i] = a_v;
+            }
+        }
     }
     if (colsum != nullptr && tm == 0 && tid < 16 && n0 + tid < g.N) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += (bsum[w][tid] + bsum[w][16 + tid]) + (bsum[w][32 + tid] + bsum[w][48 + tid]);
         colsum[n0 + tid] = s;
+        if constexpr (ADAM) {
+            ad->pb[n0 + tid] = adam_apply(*ad, ic1, ic2, s, ab_m, ab_v, ab_p);
+            ad->mb[n0 + tid] = ab_m;
+            ad->vb[n0 + tid] = ab_v;
+        }
     }
 }
 
@@ -693,6 +739,29 @@ bool small_fast_ok(const GemmArgs& g, int transA, int transB) {
     if (bkc && !(al(g.B) && g.ldb % 4 == 0 && g.K % 4 == 0)) return false;
     const int64_t a_bytes = ((akc ? g.M : g.K) * g.lda) * 4, b_bytes = ((bkc ? g.N : g.K) * g.ldb) * 4;
     return a_bytes < (int64_t(1) << 31) && b_bytes < (int64_t(1) << 31);
+}
+
+// Backward of the FIRST Dense layer (no dX) with the whole optimizer step folded in (single-GPU training step):
+// blocks [0, n_dw): dW0 = X^T dZ0 tiles + db0, Adam applied to W0 / b0 in the epilogue; blocks >= n_dw: Adam over
+// the flat range that holds every other layer's parameters (their gradients were finished by earlier launches).
+// The step then has no optimizer launch at all.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_bwd0_adam_kernel(GemmArgs gw, float* __restrict__ db, AdamEpi ad,
+                                                                     int n_dw) {
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    if ((int)blockIdx.x < n_dw) {
+        small_tile<false, false, WAVES, true>(gw, db, (int)blockIdx.x, red, bsum, &ad);
+        return;
+    }
+    const float ic1 = (float)(1.0 / (1.0 - ad.pows[0])), ic2 = (float)(1.0 / (1.0 - ad.pows[1]));
+    const int64_t nth = (int64_t)(gridDim.x - n_dw) * blockDim.x;
+    for (int64_t i = (int64_t)(blockIdx.x - n_dw) * blockDim.x + threadIdx.x; i < ad.fn; i += nth) {
+        float m = ad.fm[i], v = ad.fv[i];
+        ad.fp[i] = adam_apply(ad, ic1, ic2, ad.fg[i], m, v, ad.fp[i]);
+        ad.fm[i] = m;
+        ad.fv[i] = v;
+    }
 }
 
 template <int WAVES>
@@ -997,6 +1066,53 @@ int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, cons
     if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
     if (dx != nullptr)
         return tnn_gemm_mask(0, 1, rows, n_in, n_out, dz, n_out, w, n_out, mask_src, n_in, dx, n_in, dtype);
+    return 0;
+}
+
+int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* dw, void* db,
+                             void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b, void* flat_p,
+                             const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n, double lr, double b1,
+                             double b2, double eps, const void* pows_f64, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(rows > 0 && n_in > 0 && n_out > 0, "tnn_dense_bwd_first_adam: empty layer");
+    TNN_REQUIRE(pows_f64 && p_w && m_w && v_w && p_b && m_b && v_b, "tnn_dense_bwd_first_adam: optimizer state is required");
+    if (dtype == TNN_F32) {
+        GemmArgs gw = {};
+        gw.A = (const float*)x; gw.B = (const float*)dz; gw.C = (float*)dw;
+        gw.M = n_in; gw.N = n_out; gw.K = rows; gw.lda = n_in; gw.ldb = n_out; gw.ldc = n_out;
+        gw.alpha = 1.f; gw.beta = 0.f; gw.epi = EPI_AXPBY;
+        if (use_small_path(gw)) {
+            gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1;
+            const int n_dw = gw.tiles_m * gw.tiles_n;
+            AdamEpi ad;
+            ad.pw = (float*)p_w; ad.mw = (float*)m_w; ad.vw = (float*)v_w;
+            ad.pb = (float*)p_b; ad.mb = (float*)m_b; ad.vb = (float*)v_b;
+            ad.fp = (float*)flat_p; ad.fg = (const float*)flat_g; ad.fm = (float*)flat_m; ad.fv = (float*)flat_v;
+            ad.fn = flat_n > 0 ? flat_n : 0;
+            ad.lr = (float)lr; ad.b1 = (float)b1; ad.b2 = (float)b2; ad.eps = (float)eps;
+            ad.pows = (const double*)pows_f64;
+            const int nchunks = (int)((gw.K + 15) / 16);
+            hipStream_t s = tnn::stream();
+#define TNN_BWD0(W)                                                                                         \
+    do {                                                                                                    \
+        const int extra = ad.fn > 0 ? (int)std::min<int64_t>((ad.fn + W * 64 - 1) / (W * 64), 64) : 0;      \
+        hipLaunchKernelGGL((dense_bwd0_adam_kernel<W>), n_dw + extra, W * 64, 0, s, gw, (float*)db, ad, n_dw); \
+    } while (0)
+            if (nchunks <= 16) TNN_BWD0(4);
+            else if (nchunks <= 48) TNN_BWD0(8);
+            else TNN_BWD0(16);
+#undef TNN_BWD0
+            TNN_LAUNCH_OK();
+            return 0;
+        }
+    }
+    // any other shape / dtype: the launches this replaces
+    if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
+    void* pows = const_cast<void*>(pows_f64);
+    if (int rc = tnn_adam_ex(p_w, dw, m_w, v_w, n_in * n_out, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr)) return rc;
+    if (int rc = tnn_adam_ex(p_b, db, m_b, v_b, n_out, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr)) return rc;
+    if (flat_n > 0)
+        return tnn_adam_ex(flat_p, flat_g, flat_m, flat_v, flat_n, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr);
     return 0;
 }
 

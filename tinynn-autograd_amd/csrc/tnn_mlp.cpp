@@ -91,9 +91,9 @@ int allreduce_layer_bucket(Mlp* h, int l) {
 }
 
 // gradients of every layer from dact[L-1] (set by the loss kernel) down to layer 0
-int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1) {
+int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1, int to_layer = 0) {
     if (from_layer < 0) from_layer = h->L - 1;
-    for (int l = from_layer; l >= 0; --l) {
+    for (int l = from_layer; l >= to_layer; --l) {
         const void* in = l == 0 ? x : h->act[l - 1];
         // dW_l = in^T d, db_l = column-sum d, dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]  — one launch per layer
         MLP_TRY(tnn_dense_bwd(rows, h->w[l], h->w[l + 1], in, h->dact[l], at(h->params, h->w_off[l], h->esz),
@@ -405,14 +405,22 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
     static const bool head_fusion = getenv("TNN_HEAD_FUSION") != nullptr;
     if (!head_fusion && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
-        // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward | Adam without a prologue:
-        // 8 launches for the 3-layer net
+        // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward, the last launch of which also
+        // carries the optimizer
         MLP_TRY(mlp_forward(h, x, rows));
         MLP_TRY(tnn_softmax_nll_fused_tick(h->act[L - 1], y, rows, h->w[L], rows, 0, h->stats, loss_dst,
                                            h->dact[L - 1], h->dtype, h->pows, h->b1, h->b2));
-        MLP_TRY(mlp_backward_layers(h, x, rows));
-        return tnn_adam_ex(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps, h->pows,
-                           nullptr, h->dtype, 0, nullptr, nullptr);
+        // backward of layers L-1 .. 1, then the first layer's backward with the whole Adam step folded into its
+        // launch (its own W / b in the dW epilogue, every other layer's parameters by trailing blocks): 7 launches
+        MLP_TRY(mlp_backward_layers(h, x, rows, -1, 1));
+        const int64_t rest = L > 1 ? h->w_off[1] : h->n_params;
+        return tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
+                                        at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
+                                        at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
+                                        at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
+                                        at(h->v, h->b_off[0], h->esz), at(h->params, rest, h->esz),
+                                        at(h->grads, rest, h->esz), at(h->m, rest, h->esz), at(h->v, rest, h->esz),
+                                        h->n_params - rest, h->lr, h->b1, h->b2, h->eps, h->pows, h->dtype);
     }
     // hidden layers forward; then the classifier head (last Dense forward + loss + its backward, one launch when
     // TNN_HEAD_FUSION is set); then one launch per remaining layer backward; then the optimizer
