@@ -556,6 +556,7 @@ def main():
         dog = threading.Timer(limit, give_up)
         dog.daemon = True
         dog.start()
+        comm.barrier()           # rank 0 has just spent seconds timing GEMMs for the roofline: enter together
         try:
             lat = p2p_latency_table(with_rccl=bool(getattr(comm, "_rccl", False)))
             if line is not None:
