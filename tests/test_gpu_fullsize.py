@@ -91,3 +91,16 @@ def test_fused_adam_33M_matches_numpy():
         p += -lr * (m / (1 - b1 ** t)) / (np.sqrt(v / (1 - b2 ** t)) + eps)
     np.testing.assert_allclose(np.asarray(P), p, rtol=0, atol=2e-6)
     np.testing.assert_allclose(np.asarray(pows)[:2], [b1 ** 2, b2 ** 2], rtol=1e-14)
+
+
+@pytest.mark.gpu
+def test_gemm_fuzz_against_numpy():
+    """tools/gemm_fuzz.py: random shapes / layouts / epilogues through every fp32 GEMM entry point, the fused Dense
+    backward and the first-layer backward with Adam folded in, against float64 numpy."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_fuzz.py"), "120", "3"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-3000:]
