@@ -104,3 +104,20 @@ def test_gemm_fuzz_against_numpy():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_fuzz.py"), "120", "3"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "cases ok" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_example_learns_the_teacher_labels():
+    """End to end: examples/mnist_run.py --trainer (resident dataset, per-epoch device shuffle, one hipGraph per epoch,
+    device argmax + AccEvaluator) on the synthetic linear-teacher data must LEARN — accuracy far above the 10 % of
+    chance after two epochs."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tinynn-autograd_amd", "examples", "mnist_run.py"), "--num_ep", "2",
+                        "--trainer", "--seed", "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    acc = [float(a) for a in re.findall(r"'accuracy': ([0-9.]+)", r.stdout)]
+    assert len(acc) == 2 and acc[-1] > 0.7, r.stdout[-2000:]

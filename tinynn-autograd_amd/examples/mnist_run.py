@@ -46,18 +46,20 @@ def prepare_dataset(data_dir, n_train=51200, n_test=10000):
         with gzip.open(path, "rb") as f:
             train_set, _, test_set = pickle.load(f, encoding="latin1")
         return train_set, test_set, "mnist.pkl.gz"
-    rs = np.random.RandomState(1234)                       # SURVEY §8d synthetic recipe
+    rs = np.random.RandomState(1234)                       # SURVEY §8d synthetic recipe (MNIST-like 19 % sparsity)
+    teacher = rs.randn(784, 10)                            # labels a network can learn: argmax of a fixed linear map
+
     def make(n):
         x = (rs.rand(n, 784) * (rs.rand(n, 784) < 0.19)).astype(np.float32)
-        return x, rs.randint(0, 10, n)
-    return make(n_train), make(n_test), "synthetic (MNIST-like sparsity)"
+        return x, np.argmax(x @ teacher, axis=1)
+    return make(n_train), make(n_test), "synthetic (MNIST-like sparsity, linear-teacher labels)"
 
 
 def main(args):
     if args.seed >= 0:
         random_seed(args.seed)
     (train_x, train_y), (test_x, test_y), source = prepare_dataset(args.data_dir)
-    print("data: %s, %d train / %d test rows; backend %s" % (source, len(train_x), len(test_x), "?"))
+    print("data: %s, %d train / %d test rows" % (source, len(train_x), len(test_x)))
     train_y = get_one_hot(train_y, 10)
     train_x, train_y = Tensor(train_x), Tensor(train_y)    # resident in HBM for the whole run
     test_x = Tensor(test_x)
