@@ -102,8 +102,11 @@ def time_gemms(widths, rows, reps=20):
     rs = np.random.RandomState(7)
     results, tot_flops, tot_ms = [], 0.0, 0.0
     for name, ta, tb, M, N, K in gemm_list(widths, rows):
-        a = da.asarray(rs.randn(*((K, M) if ta else (M, K))).astype(np.float32))
-        b = da.asarray(rs.randn(*((N, K) if tb else (K, N))).astype(np.float32))
+        # operands shaped like the step's own: activations / inputs uniform in [0, 1) (the synthetic x of SURVEY §8d),
+        # weights Xavier-uniform — the MFMA data path's power draw, and with it the sustained clock, depends on the values
+        lim = float(np.sqrt(6.0 / (K + N)))
+        a = da.asarray(rs.rand(*((K, M) if ta else (M, K))).astype(np.float32))
+        b = da.asarray(rs.uniform(-lim, lim, (N, K) if tb else (K, N)).astype(np.float32))
         c = da.empty((M, N), np.float32)
         lda, ldb = (M if ta else K), (K if tb else N)
         for _ in range(3):
