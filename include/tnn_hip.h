@@ -297,6 +297,9 @@ TNN_API int tnn_mlp_destroy(void* handle);
 TNN_API int tnn_mlp_arena(void* handle, void** params, void** grads, void** m, void** v,
                           int64_t* n_params);
 TNN_API int tnn_mlp_param_offset(void* handle, int layer, int which, int64_t* offset, int64_t* count);
+/* the rest of the optimizer state for checkpoints: device double[4] {b1^t, b2^t, -, -} of Adam (see tnn_adam);
+ * together with the params / m / v arenas it is everything a resumed run needs */
+TNN_API int tnn_mlp_optimizer_state(void* handle, void** pows_f64);
 /* logits[rows, widths[n]] = net(x[rows, widths[0]]) */
 TNN_API int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits);
 /* forward + loss stats of this shard (phase 1); stats = device [2] */

@@ -658,6 +658,29 @@ def trainer_with_other_optimizers_matches_op_level_model():
         np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=5e-5 * np.abs(flat).max(), err_msg=name)
 
 
+def trainer_checkpoint_resume_is_bit_exact():
+    """Train 3 steps, checkpoint (params + Adam state + beta powers), train 3 more; a fresh trainer restored from the
+    checkpoint must produce exactly the same 3 losses and parameters."""
+    import tempfile, os
+    cfg, _ = H.load_traj("A_adam")
+    w = cfg["widths"]
+    model, _ = H.build_model(cfg)
+    data = [(tn.asarray(x), tn.asarray(y)) for x, y in H.batches(cfg["data_seed"], 6, cfg["m"], w[0], w[-1], cfg["loss"])]
+    t1 = trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"])
+    for x, y in data[:3]:
+        t1.step(x, y)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ckpt.npz")
+        t1.save(path)
+        tail1 = [float(t1.step(x, y)) for x, y in data[3:]]
+        t2 = MLPTrainer(w, cfg["m"], lr=cfg["lr"])
+        t2.load(path)
+    tail2 = [float(t2.step(x, y)) for x, y in data[3:]]
+    assert tail1 == tail2
+    assert np.array_equal(np.asarray(t1.params), np.asarray(t2.params))
+    assert np.array_equal(np.asarray(t1.adam_m), np.asarray(t2.adam_m))
+
+
 def other_optimizers_match_reference_steps():
     """Momentum / RMSProp / Adagrad / Adadelta: six consecutive `_compute_step` results against the
     reference's own (tests/golden/optim_steps.npz, generated from core/optimizer.py:82-164), fused kernel and

@@ -102,6 +102,7 @@ _SIGNATURES = {
     "tnn_mlp_destroy": [_p],
     "tnn_mlp_arena": [_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                       POINTER(c_void_p), _i64p],
+    "tnn_mlp_optimizer_state": [_p, POINTER(ctypes.c_void_p)],
     "tnn_mlp_param_offset": [_p, c_int, c_int, _i64p, _i64p],
     "tnn_mlp_forward": [_p, _p, c_int64, _p],
     "tnn_mlp_forward_stats": [_p, _p, c_int64, _p],

@@ -325,6 +325,13 @@ int tnn_mlp_arena(void* handle, void** params, void** grads, void** m, void** v,
     return 0;
 }
 
+int tnn_mlp_optimizer_state(void* handle, void** pows_f64) {
+    Mlp* h = (Mlp*)handle;
+    if (!h || !pows_f64) { tnn::set_error("tnn_mlp_optimizer_state: bad arguments"); return 2; }
+    *pows_f64 = h->pows;
+    return 0;
+}
+
 int tnn_mlp_param_offset(void* handle, int layer, int which, int64_t* offset, int64_t* count) {
     Mlp* h = (Mlp*)handle;
     if (!h || layer < 0 || layer >= h->L || which < 0 || which > 1) {

@@ -97,6 +97,37 @@ class MLPTrainer(object):
                 view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
         self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies W, W^T
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything a resumed run needs, as host arrays: parameters, the optimizer's two state arenas and Adam's
+        beta powers (the reference's Model.save only pickles the parameters and its load is broken)."""
+        pows = ctypes.c_void_p()
+        self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
+        return {"widths": list(self.widths), "dtype": "bfloat16" if self.bf16 else self.dtype.name,
+                "params": np.asarray(self.params).copy(), "m": np.asarray(self.adam_m).copy(),
+                "v": np.asarray(self.adam_v).copy(),
+                "pows": np.asarray(da.from_ptr(pows.value, (4,), np.float64, self)).copy()}
+
+    def load_state_dict(self, state):
+        if list(state["widths"]) != list(self.widths):
+            raise ValueError("checkpoint is for widths %s, this trainer has %s" % (state["widths"], self.widths))
+        pows = ctypes.c_void_p()
+        self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
+        self.params[...] = da.asarray(np.asarray(state["params"]), dtype=self.dtype)
+        self.adam_m[...] = da.asarray(np.asarray(state["m"]), dtype=self.dtype)
+        self.adam_v[...] = da.asarray(np.asarray(state["v"]), dtype=self.dtype)
+        da.from_ptr(pows.value, (4,), np.float64, self)[...] = da.asarray(np.asarray(state["pows"]), dtype=np.float64)
+        self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies
+        self._graph = None                            # a captured single-step graph holds no state, but be safe
+
+    def save(self, path):
+        np.savez(path, **{k: np.asarray(v) for k, v in self.state_dict().items()})
+
+    def load(self, path):
+        with np.load(path, allow_pickle=False) as f:
+            self.load_state_dict({k: (f[k].tolist() if k == "widths" else (str(f[k]) if k == "dtype" else f[k]))
+                                  for k in f.files})
+
     def get_parameters(self):
         return [{"w": self.param_view(i, "w"), "b": self.param_view(i, "b")} for i in range(self.n_layers)]
 
