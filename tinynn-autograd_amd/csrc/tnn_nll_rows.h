@@ -84,19 +84,9 @@ __device__ __forceinline__ void nll_rows_body(const T* __restrict__ z, const T* 
         const Peers& P = ctx.peers;
         const int W = P.world;
         const uint32_t ep = *ctx.ag_epoch;
-        const size_t slots = offsetof(Header, ag_slot) + (size_t)(ep & 1) * MAXW * AG_BYTES;
-        if (tid < 2 * W) {
-            const float mine = (tid & 1) ? (float)S : (float)M;
-            store_sys(reinterpret_cast<uint32_t*>(P.base[tid >> 1] + slots + (size_t)P.rank * AG_BYTES) + (tid & 1),
-                      __float_as_uint(mine));
-        }
-        exchange_flags(P, offsetof(Header, ag_flag), ep + 1, ctx.dead, ctx.timeout_ticks);
-        if (tid < 2 * W) {
-            uint32_t w[1] = {0u};
-            load_sys(w[0], reinterpret_cast<const uint32_t*>(P.base[P.rank] + slots + (size_t)(tid >> 1) * AG_BYTES) + (tid & 1));
-            loads_landed(w);
-            peer_stats[tid >> 1][tid & 1] = __uint_as_float(w[0]);
-        }
+        if (tid < 2 * W)           // {M_r, S_r} to every rank and theirs back: one 8-byte tagged store per word and peer
+            peer_stats[tid >> 1][tid & 1] =
+                ll_exchange2(P, ep, (tid & 1) ? (float)S : (float)M, ctx.dead, ctx.timeout_ticks);
         __syncthreads();
         double gm = -INFINITY, gs = 0.0;
         for (int q = 0; q < W; ++q) gm = fmax(gm, (double)peer_stats[q][0]);

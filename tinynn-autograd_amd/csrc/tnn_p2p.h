@@ -23,6 +23,7 @@ struct Header {                                   // start of every rank's uncac
     uint8_t flag[2][MAXB][FLAG_ROW];              // [barrier][block] -> uint32_t[MAXW] indexed by source rank
     uint32_t ag_flag[MAXW];                       // [source rank]
     uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
+    uint64_t ll[2][MAXW][2];                      // [epoch parity][source rank][word]: (tag << 32) | payload, see ll_exchange2
 };
 constexpr size_t HEADER_BYTES = (sizeof(Header) + 4095) / 4096 * 4096;
 
@@ -102,11 +103,49 @@ __device__ __forceinline__ void store_sys(float* ptr, f32x4 v) {
 __device__ __forceinline__ void store_sys(uint32_t* ptr, uint32_t v) {
     asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
 }
+__device__ __forceinline__ void load_sys(uint64_t& v, const uint64_t* ptr) {
+    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void store_sys(uint64_t* ptr, uint64_t v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
+}
 template <typename T, int N>
 __device__ __forceinline__ void loads_landed(T (&v)[N]) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int k = 0; k < N; ++k) asm volatile("" : "+v"(v[k]));      // uses of v[k] stay behind the wait
+}
+
+// Two floats per rank to every rank, "low-latency" style: payload and a tag travel in ONE naturally aligned 8-byte
+// store (a single fabric transaction), so the receiver simply polls the word until the tag is the one it expects —
+// no acknowledgement wait on the sender, no separate flag, no second read: one link latency end to end instead of
+// three.  Threads 0 .. 2W-1 take part (thread t: peer t >> 1, word t & 1); returns this thread's received float.
+// Slots are double-buffered on the epoch's parity like the all-gather's.
+__device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, float mine, int* dead, int64_t timeout_ticks) {
+    const int t = threadIdx.x, q = t >> 1, idx = t & 1;
+    const uint32_t tag = epoch + 1;
+    const size_t base = offsetof(Header, ll) + (size_t)(epoch & 1) * MAXW * 16;
+    store_sys(reinterpret_cast<uint64_t*>(p.base[q] + base + (size_t)p.rank * 16) + idx,
+              ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(mine));
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(p.base[p.rank] + base + (size_t)q * 16) + idx;
+    uint64_t v[1] = {0};
+    if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return 0.f;
+    uint64_t t0 = 0;
+    uint32_t polls = 0;
+    for (;;) {
+        load_sys(v[0], src);
+        loads_landed(v);
+        if ((uint32_t)(v[0] >> 32) == tag) break;
+        if ((++polls & 63u) == 0) {
+            const uint64_t now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if ((int64_t)(now - t0) > timeout_ticks) {
+                __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    return __uint_as_float((uint32_t)v[0]);
 }
 
 }  // namespace p2p
