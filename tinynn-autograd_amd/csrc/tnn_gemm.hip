@@ -43,6 +43,7 @@ struct GemmArgs {
     int splits;
     float* ws;             // [splits, M, N] partial sums when splits > 1
     int tiles_m, tiles_n;
+    unsigned long long* trace;   // TNN_GEMM_TRACE builds: [grid][8] timeline words, else unused
 };
 
 __device__ __forceinline__ float apply_epilogue(const GemmArgs& g, float acc, int64_t row,
@@ -100,6 +101,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
+    // Debug build only (make trace -> libtnn_hip_trace.so, tools/gemm_block_timeline.py): thread 0 of every
+    // workgroup leaves four 100 MHz timestamps (entry, K loop start, K loop end, stores acknowledged) and its
+    // HW_ID / XCC_ID in a host-supplied buffer, 8 words per workgroup.
+#ifdef TNN_GEMM_TRACE
+#define TNN_TRACE(i) do { if (tid == 0 && g.trace) g.trace[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+    if (tid == 0 && g.trace) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g.trace[(size_t)blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+#else
+#define TNN_TRACE(i)
+#endif
+    TNN_TRACE(0);
 
     // tile order: each XCD (private 4 MB L2) gets a contiguous range of ids (xcd_remap); inside the range the
     // ids sweep N for a GROUP of 8 M-tiles at a time, so the group's A panels stay L2-resident while the B
@@ -352,6 +368,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // steady state: tiles kt+1 and kt+2 exist and tile kt+2 is a full, vector-loadable tile -> no branches.
     // Two tiles per trip with the buffer index a compile-time constant: every LDS address is then a loop-invariant
     // register plus an immediate offset (no per-tile address arithmetic next to the MFMAs).
+    TNN_TRACE(1);
     int kt = 0;
     const int n_steady = VEC ? (nk_full - 2 < nk - 2 ? nk_full - 2 : nk - 2) : 0;
 #define TNN_STEADY_TILE(CUR, KT)                                           \
@@ -412,6 +429,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    TNN_TRACE(2);
     // epilogue: lane holds col = l31, rows (r&3) + 8*(r>>2) + 4*lhi of each 32x32 block
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -430,6 +448,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
                     g.C[row * g.ldc + col] = apply_epilogue(g, a, row, col);
             }
         }
+#ifdef TNN_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TNN_TRACE(3);
+#endif
+#undef TNN_TRACE
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
@@ -880,6 +903,11 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
     g.k_per_split = tiles_per_split * BK;
     g.splits = splits;
     g.ws = nullptr;
+    g.trace = nullptr;
+#ifdef TNN_GEMM_TRACE
+    if (const char* e = getenv("TNN_GEMM_TRACE_PTR"))
+        if (splits == 1) g.trace = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
+#endif
     void* ws = nullptr;
     if (splits > 1) {
         if (tnn_malloc((size_t)splits * g.M * g.N * sizeof(float), &ws)) return 1;
