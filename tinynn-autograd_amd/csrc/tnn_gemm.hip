@@ -43,7 +43,9 @@ struct GemmArgs {
     int splits;
     float* ws;             // [splits, M, N] partial sums when splits > 1
     int tiles_m, tiles_n;
-    unsigned long long* trace;   // TNN_GEMM_TRACE builds: [grid][8] timeline words, else unused
+#ifdef TNN_GEMM_TRACE
+    unsigned long long* trace;   // debug build only: [grid][8] timeline words (nullptr = off)
+#endif
 };
 
 __device__ __forceinline__ float apply_epilogue(const GemmArgs& g, float acc, int64_t row,
@@ -903,8 +905,8 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
     g.k_per_split = tiles_per_split * BK;
     g.splits = splits;
     g.ws = nullptr;
-    g.trace = nullptr;
 #ifdef TNN_GEMM_TRACE
+    g.trace = nullptr;
     if (const char* e = getenv("TNN_GEMM_TRACE_PTR"))
         if (splits == 1) g.trace = reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0));
 #endif
