@@ -277,6 +277,47 @@ def optimizer_fixture(ref):
     print("  optimizers: %s" % ", ".join(OPTIMIZERS))
 
 
+INIT_SHAPES = [(30, 20), (1, 20), (6, 3, 3, 4)]
+INITIALIZERS = {                 # name -> (reference class name, constructor kwargs)
+    "normal": ("NormalInit", dict(mean=0.5, std=2.0)),
+    "truncated_normal": ("TruncatedNormalInit", dict(mean=0.0, std=1.0)),
+    "uniform": ("UniformInit", dict(a=-1.0, b=3.0)),
+    "constant": ("ConstantInit", dict(val=3.1)),
+    "zeros": ("ZerosInit", dict()),
+    "xavier_uniform": ("XavierUniformInit", dict()),
+    "xavier_normal": ("XavierNormalInit", dict()),
+    "he_uniform": ("HeUniformInit", dict()),
+    "he_normal": ("HeNormalInit", dict()),
+}
+
+
+def host_side_fixture():
+    """SURVEY §8 a24 / a25, the host-side callers either side of the path: every initializer of core/initializer.py
+    (`Initializer.__call__`, :17-19, on the global numpy RNG seeded with 123 before each draw) on three shapes, `get_fans`
+    (:7-14), and the index order utils/data_iterator.py:22-34 produces for two epochs of 103 rows in batches of 32
+    (shuffled, seed 7) and unshuffled."""
+    import core.initializer as rinit
+    from utils.data_iterator import BatchIterator
+    out = {}
+    for name, (cls, kw) in INITIALIZERS.items():
+        for si, shape in enumerate(INIT_SHAPES):
+            np.random.seed(123)
+            t = getattr(rinit, cls)(**kw)(shape)
+            out["%s_%d" % (name, si)] = np.asarray(t.values)
+            out["%s_%d_dtype" % (name, si)] = np.array(str(np.asarray(t.values).dtype))
+    out["fans"] = np.array([rinit.get_fans(s) for s in INIT_SHAPES + [(100, 10), (64, 5, 5, 128)]], dtype=np.int64)
+    x = np.arange(103 * 2, dtype=np.float64).reshape(103, 2)
+    y = np.arange(103, dtype=np.int64)
+    for tag, shuffle in (("shuffled", True), ("ordered", False)):
+        np.random.seed(7)
+        it = BatchIterator(batch_size=32, shuffle=shuffle)
+        order = [np.asarray(b.targets).copy() for _ in range(2) for b in it(x, y)]
+        out["iter_%s_sizes" % tag] = np.array([len(o) for o in order], dtype=np.int64)
+        out["iter_%s_targets" % tag] = np.concatenate(order)
+    np.savez_compressed(os.path.join(GOLDEN, "host_side.npz"), **out)
+    print("  initializers: %s; batch iterator orders" % ", ".join(INITIALIZERS))
+
+
 def reference_own_tests():
     """The reference's own unit tests must pass in this container (pins the import itself)."""
     import subprocess
@@ -297,9 +338,13 @@ def main():
     if only == ["optim"]:                                   # just the optimizer-step fixture
         optimizer_fixture(ref)
         return
+    if only == ["host"]:                                    # just the initializer / iterator fixture
+        host_side_fixture()
+        return
     reference_own_tests()
     op_case_fixture(ref)
     optimizer_fixture(ref)
+    host_side_fixture()
     for name, cfg in CONFIGS.items():
         if only and name not in only:
             continue

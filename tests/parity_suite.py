@@ -538,6 +538,45 @@ def batch_iterator_on_device_tensors():
     assert batches[1].inputs.values._ptr == batches[0].inputs.values._ptr + 32 * 7 * 4
 
 
+def host_side_callers_match_reference():
+    """SURVEY §8 a24 / a25 — the host code either side of the path, draw for draw against the reference itself
+    (tests/golden/host_side.npz, written by oracle/gen_golden.py from core/initializer.py and utils/data_iterator.py):
+    every initializer on the global numpy RNG (seed 123) gives the reference's float32 parameter bit for bit, `get_fans`
+    agrees on dense and conv shapes, and two epochs of BatchIterator visit the rows in the reference's order."""
+    from tinynn_autograd_amd.core import initializer as init
+    from tinynn_autograd_amd.utils.data_iterator import BatchIterator
+    gold = dict(np.load(H.GOLDEN + "/host_side.npz"))
+    shapes = [(30, 20), (1, 20), (6, 3, 3, 4)]
+    cases = {"normal": (init.NormalInit, dict(mean=0.5, std=2.0)),
+             "truncated_normal": (init.TruncatedNormalInit, dict(mean=0.0, std=1.0)),
+             "uniform": (init.UniformInit, dict(a=-1.0, b=3.0)),
+             "constant": (init.ConstantInit, dict(val=3.1)),
+             "zeros": (init.ZerosInit, dict()),
+             "xavier_uniform": (init.XavierUniformInit, dict()),
+             "xavier_normal": (init.XavierNormalInit, dict()),
+             "he_uniform": (init.HeUniformInit, dict()),
+             "he_normal": (init.HeNormalInit, dict())}
+    for name, (cls, kw) in cases.items():
+        for si, shape in enumerate(shapes):
+            np.random.seed(123)
+            t = cls(**kw)(shape)
+            assert isinstance(t, Tensor) and t.requires_grad, name
+            got, want = np.asarray(t.values), gold["%s_%d" % (name, si)]
+            assert str(got.dtype) == str(gold["%s_%d_dtype" % (name, si)]) == "float32", (name, got.dtype)
+            assert got.shape == want.shape and np.array_equal(got, want), (name, shape)
+    fans = [init.get_fans(s) for s in shapes + [(100, 10), (64, 5, 5, 128)]]
+    assert np.array_equal(np.array(fans, dtype=np.int64), gold["fans"])
+    x = np.arange(103 * 2, dtype=np.float64).reshape(103, 2)
+    y = np.arange(103, dtype=np.int64)
+    for tag, shuffle in (("shuffled", True), ("ordered", False)):
+        np.random.seed(7)
+        it = BatchIterator(batch_size=32, shuffle=shuffle)
+        tx, ty = Tensor(x), Tensor(y)
+        order = [np.asarray(b.targets.values) for _ in range(2) for b in it(tx, ty)]
+        assert [len(o) for o in order] == gold["iter_%s_sizes" % tag].tolist(), tag
+        assert np.array_equal(np.concatenate(order).astype(np.int64), gold["iter_%s_targets" % tag]), tag
+
+
 def error_behaviour():
     """Same failure modes as the reference: backward on a non-requires-grad tensor asserts
     (core/tensor.py:158), bad broadcasts raise ValueError, and native errors surface as exceptions."""
@@ -712,5 +751,9 @@ def other_optimizers_match_reference_steps():
     np.testing.assert_allclose(np.asarray(p), p0 + gold["adagrad"][0], rtol=1e-5, atol=1e-7)
 
 
-SUITE = {name: fn for name, fn in list(globals().items())
-         if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", None) == __name__}
+# host-only cases (the code either side of the path: nothing to learn from a second run on the GPU)
+HOST_ONLY = {"host_side_callers_match_reference"}
+_ALL = {name: fn for name, fn in list(globals().items())
+        if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", None) == __name__}
+SUITE = {name: fn for name, fn in _ALL.items() if name not in HOST_ONLY}
+HOST_SUITE = dict(_ALL)

@@ -7,6 +7,6 @@ import pytest
 import parity_suite
 
 
-@pytest.mark.parametrize("name", sorted(parity_suite.SUITE))
+@pytest.mark.parametrize("name", sorted(parity_suite.HOST_SUITE))
 def test_host_logic(name):
-    parity_suite.SUITE[name]()
+    parity_suite.HOST_SUITE[name]()
