@@ -575,6 +575,18 @@ def host_side_callers_match_reference():
         order = [np.asarray(b.targets.values) for _ in range(2) for b in it(tx, ty)]
         assert [len(o) for o in order] == gold["iter_%s_sizes" % tag].tolist(), tag
         assert np.array_equal(np.concatenate(order).astype(np.int64), gold["iter_%s_targets" % tag]), tag
+    # utils/seeder.py:6-11 (test/test_utils_seeder.py:9-11): out-of-range seeds raise, in-range ones seed the global RNG
+    from tinynn_autograd_amd.utils.seeder import random_seed
+    for bad in (2 ** 32 + 1, -1):
+        try:
+            random_seed(bad)
+            raise AssertionError("random_seed(%d) must raise ValueError" % bad)
+        except ValueError:
+            pass
+    random_seed(123.0)
+    a = np.random.rand(3)
+    np.random.seed(123)
+    assert np.array_equal(a, np.random.rand(3))
 
 
 def error_behaviour():
