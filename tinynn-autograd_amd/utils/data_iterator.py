@@ -14,22 +14,24 @@ Batch = namedtuple("Batch", ["inputs", "targets"])
 
 
 class BaseIterator(object):
+    """Protocol: `iterator(inputs, targets)` yields `Batch(inputs, targets)` for one epoch."""
 
     def __call__(self, inputs, targets):
-        raise NotImplementedError
+        raise NotImplementedError("%s does not implement one epoch" % type(self).__name__)
 
 
 class BatchIterator(BaseIterator):
+    """Consecutive windows of `batch_size` rows over a per-epoch permutation (`shuffle`) or the natural order."""
 
     def __init__(self, batch_size=32, shuffle=True):
-        self.batch_size = batch_size
-        self.shuffle = shuffle
+        self.batch_size, self.shuffle = batch_size, shuffle
 
     def num_batches(self, n_rows):
         return -(-int(n_rows) // self.batch_size)
 
     def _epoch_order(self, n_rows):
-        """The epoch's row permutation (None = natural order).  Exactly one np.random.shuffle call."""
+        """The epoch's row permutation (None = natural order).  Exactly one np.random.shuffle call on the global RNG,
+        like utils/data_iterator.py:25-26."""
         if not self.shuffle:
             return None
         order = np.arange(n_rows)
