@@ -10,7 +10,8 @@ closed form — and (3) writes the reference's outputs as small fixtures.  The G
 
 Trajectory configs (SURVEY §8c):  A = 784-256-128-10, bs 128, Adam 1e-3 and SGD 1e-2, 20 steps;
 D = same net, bs 1024, Adam, 5 steps;  C-small = 256-256-256 autoencoder, bs 64, sum-of-squares/m, Adam,
-5 steps;  eval = argmax + AccEvaluator on 1000 rows with forced ties.
+5 steps;  eval = argmax + AccEvaluator on 1000 rows with forced ties;  layers = Tanh / ReLU objects forward + vjp and
+a Dense-Tanh-Dense net;  epoch = the whole loop of examples/mnist/run.py (shuffle, ragged batch, 2 epochs, eval).
 """
 
 import json
@@ -318,6 +319,123 @@ def host_side_fixture():
     print("  initializers: %s; batch iterator orders" % ", ".join(INITIALIZERS))
 
 
+def layer_fixture(ref):
+    """Activation layers as objects: the reference's own `Tanh` — (1 - e^-x)/(1 + e^-x) = tanh(x/2),
+    core/layers.py:83-89 — and `ReLU` (:92-98) run forward and backward on fixed inputs, float64 and float32; plus
+    three SGD steps of a Dense-Tanh-Dense net under the softmax loss.  `Sigmoid` is absent: the reference's raises
+    (SURVEY F7).  The oracle's restatement (ref_nn.Tanh) must agree bit for bit."""
+    import synth
+    from oracle import ref_nn
+    from oracle.ref_autograd import RefTensor
+    rt, rlayers, rlosses, ropt, rmodel, rnn = ref[0], ref[2], ref[3], ref[4], ref[5], ref[6]
+    x, g = synth.layer_inputs()
+    out = {}
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        for name, cls, mine in (("tanh", rlayers.Tanh, ref_nn.Tanh), ("relu", rlayers.ReLU, ref_nn.ReLU)):
+            t = rt.Tensor(x.astype(dt), requires_grad=True)
+            y = cls().forward(t)
+            y.backward(g)
+            o = RefTensor(x.astype(dt), requires_grad=True)
+            yo = mine().forward(o)
+            yo.backward(g)
+            assert np.array_equal(np.asarray(y.values), yo.values) and np.array_equal(t.grad, o.grad), name
+            out["%s_%s_out" % (name, tag)] = np.asarray(y.values, dtype=np.float64)
+            out["%s_%s_grad" % (name, tag)] = np.asarray(t.grad, dtype=np.float64)
+    # Dense(6) - Tanh - Dense(4), softmax loss, SGD lr 0.1, three steps on one batch
+    rs = np.random.RandomState(17)
+    bx = rs.randn(12, 9).astype(np.float32)
+    by = np.eye(4)[rs.randint(0, 4, 12)]
+    np.random.seed(11)
+    net = rnn.Net([rlayers.Dense(6, num_in=9), rlayers.Tanh(), rlayers.Dense(4, num_in=6)])
+    loss_layer = rlosses.SoftmaxCrossEntropyLoss()
+    model = rmodel.Model(net=net, loss=loss_layer, optimizer=ropt.SGD(lr=0.1))
+    np.random.seed(11)
+    mine = [ref_nn.Dense(9, 6), ref_nn.Tanh(), ref_nn.Dense(6, 4)]
+    mopt = ref_nn.SGD(lr=0.1)
+    losses = []
+    for s in range(3):
+        model.zero_grad()
+        loss = loss_layer.loss(model.forward(rt.Tensor(bx)), rt.Tensor(by))
+        loss.backward()
+        if s == 0:
+            out["net_grad0_w0"] = np.array(net.layers[0].params["w"].grad)
+        model.step()
+        losses.append(float(loss.values))
+        lv, _ = ref_nn.train_step(mine, mopt, ref_nn.softmax_nll, bx, by)
+        assert float(lv) == losses[-1], "ref_nn Dense-Tanh-Dense step %d differs from the reference" % s
+    out["net_loss"] = np.array(losses)
+    out["net_final_w0"] = np.array(net.layers[0].params["w"].values, dtype=np.float64)
+    out["net_final_w1"] = np.array(net.layers[2].params["w"].values, dtype=np.float64)
+    assert np.array_equal(mine[0].params["w"].values, net.layers[0].params["w"].values)
+    np.savez_compressed(os.path.join(GOLDEN, "layers.npz"), **out)
+    print("  layers: Tanh / ReLU forward + vjp (f64, f32), Dense-Tanh-Dense 3 SGD steps, loss %.6f -> %.6f"
+          % (losses[0], losses[-1]))
+
+
+def epoch_fixture(ref):
+    """SURVEY §8 a25 end to end: the reference's own loop (examples/mnist/run.py:45-93) — random_seed, Tensors of the
+    whole dataset, a Net of lazily initialised Dense layers, BatchIterator (utils/data_iterator.py:22-34: per-epoch
+    shuffle on the global RNG, ragged last batch), zero_grad / forward / loss / backward / step per batch, then per
+    epoch `np.argmax(test_pred, axis=1)` on the Tensor and AccEvaluator — on 1000 synthetic rows (tests/synth.py),
+    bs 128 -> 7 full batches + 104 rows, 2 epochs.  Only the MNIST download and the net's widths differ from run.py
+    (784-256-128-10 = BASELINE.json's net instead of 200-100-70-30)."""
+    import synth
+    from oracle import ref_nn
+    rt, rlayers, rlosses, ropt, rmodel, rnn, reval = ref[0], ref[2], ref[3], ref[4], ref[5], ref[6], ref[7]
+    from utils.data_iterator import BatchIterator
+    from utils.seeder import random_seed
+    cfg = synth.EPOCH_CFG
+    train_x, train_lab, test_x, test_lab = synth.epoch_dataset(cfg)
+    train_y = np.eye(10)[np.array(train_lab).reshape(-1)]            # get_one_hot, run.py:27-28
+    random_seed(cfg["seed"])
+    tx, ty, sx = rt.Tensor(train_x), rt.Tensor(train_y), rt.Tensor(test_x)
+    w = cfg["widths"]
+    layers = []
+    for i in range(1, len(w)):
+        layers.append(rlayers.Dense(w[i]))                            # lazy: shapes from the first batch
+        if i < len(w) - 1:
+            layers.append(rlayers.ReLU())
+    net = rnn.Net(layers)
+    model = rmodel.Model(net=net, loss=rlosses.SoftmaxCrossEntropyLoss(), optimizer=ropt.Adam(lr=cfg["lr"]))
+    loss_layer = rlosses.SoftmaxCrossEntropyLoss()
+    iterator = BatchIterator(batch_size=cfg["batch_size"])
+    evaluator = reval.AccEvaluator()
+    loss_list, sizes, preds, results, margins = [], [], [], [], []
+    for epoch in range(cfg["num_ep"]):
+        for batch in iterator(tx, ty):
+            model.zero_grad()
+            pred = model.forward(batch.inputs)
+            loss = loss_layer.loss(pred, batch.targets)
+            loss.backward()
+            model.step()
+            loss_list.append(float(loss.values))
+            sizes.append(len(batch.inputs))
+        model.set_phase("TEST")
+        test_pred = model.forward(sx)
+        idx = np.argmax(test_pred, axis=1)                             # on the Tensor, as run.py:89 does
+        assert np.array_equal(idx, np.argmax(test_pred.values, axis=1))
+        results.append(evaluator.evaluate(idx, test_lab))
+        preds.append(np.asarray(idx, dtype=np.int64))
+        top2 = np.sort(np.asarray(test_pred.values), axis=1)[:, -2:]
+        margins.append(float((top2[:, 1] - top2[:, 0]).min()))
+        model.set_phase("TRAIN")
+    # the smallest top-2 logit gap must be far above float32 round-off, or "identical hit_num" would be luck
+    assert min(margins) > 1e-4, "pick another seed: top-2 margin %g" % min(margins)
+    # --- pin the oracle's restatement of the loop
+    random_seed(cfg["seed"])
+    o_losses, o_preds, o_results = ref_nn.train_epochs(w, train_x, train_y, test_x, test_lab, cfg["num_ep"],
+                                                       cfg["batch_size"], cfg["lr"])
+    assert o_losses == loss_list, "ref_nn.train_epochs losses differ from the reference loop"
+    assert all(np.array_equal(a, b) for a, b in zip(o_preds, preds)) and o_results == results
+    np.savez_compressed(os.path.join(GOLDEN, "epoch.npz"), loss=np.array(loss_list), batch_sizes=np.array(sizes),
+                        argmax=np.stack(preds), hit_num=np.array([r["hit_num"] for r in results], dtype=np.int64),
+                        total_num=np.array([r["total_num"] for r in results], dtype=np.int64),
+                        accuracy=np.array([r["accuracy"] for r in results]), min_top2_margin=np.array(margins),
+                        config=np.array(json.dumps(cfg)))
+    print("  epoch: %d steps (batch sizes %s), loss %.4f -> %.4f, eval %s, min top-2 margin %.2e"
+          % (len(loss_list), sorted(set(sizes)), loss_list[0], loss_list[-1], results, min(margins)))
+
+
 def reference_own_tests():
     """The reference's own unit tests must pass in this container (pins the import itself)."""
     import subprocess
@@ -341,10 +459,18 @@ def main():
     if only == ["host"]:                                    # just the initializer / iterator fixture
         host_side_fixture()
         return
+    if only == ["layers"]:
+        layer_fixture(ref)
+        return
+    if only == ["epoch"]:
+        epoch_fixture(ref)
+        return
     reference_own_tests()
     op_case_fixture(ref)
     optimizer_fixture(ref)
     host_side_fixture()
+    layer_fixture(ref)
+    epoch_fixture(ref)
     for name, cfg in CONFIGS.items():
         if only and name not in only:
             continue

@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE — numpy restatement of the reference's nn stack on top of ref_autograd.
 
-Dense (core/layers.py:25-57), ReLU (:92-98), whole-batch SoftmaxCrossEntropyLoss (core/losses.py:24-32),
-sum-of-squares loss (test/test_autograd.py:119-121), BaseOptimizer.compute_step / SGD / Adam
-(core/optimizer.py:12-35,46-47,67-79) and Model.step / zero_grad (core/model.py:45-68).  It is also the
-`cpu_baseline` ("port") that bench.py times on the GPU box's host cores.
+Dense (core/layers.py:25-57), ReLU (:92-98), Tanh (:83-89), whole-batch SoftmaxCrossEntropyLoss
+(core/losses.py:24-32), sum-of-squares loss (test/test_autograd.py:119-121), BaseOptimizer.compute_step / SGD / Adam
+(core/optimizer.py:12-35,46-47,67-79), Model.step / zero_grad (core/model.py:45-68), and the loop either side of the
+step: BatchIterator (utils/data_iterator.py:22-34), argmax + AccEvaluator (examples/mnist/run.py:87-93,
+core/evaluator.py:15-23).  It is also the `cpu_baseline` ("port") that bench.py times on the GPU box's host cores.
 """
 
 import numpy as np
@@ -32,6 +33,14 @@ class ReLU(object):
 
     def forward(self, x):
         return ra.clip(x, 0.0)                             # core/layers.py:97-98
+
+
+class Tanh(object):
+    params = {}
+
+    def forward(self, x):
+        """core/layers.py:88-89 — (1 - e^-x) / (1 + e^-x) = tanh(x / 2), with exp(-x) evaluated twice as there"""
+        return (1.0 - ra.exp(-x)) / (1.0 + ra.exp(-x))
 
 
 def build_mlp(widths):
@@ -116,3 +125,44 @@ def train_step(layers, opt, loss_fn, x, y):
     loss.backward()
     apply_step(layers, opt)
     return loss.values, pred.values
+
+
+def epoch_batches(inputs, targets, batch_size, shuffle=True):
+    """utils/data_iterator.py:22-34 — one np.random.shuffle on the GLOBAL RNG per epoch, whole-dataset gather through
+    getitem, consecutive row windows (the last one may be short)"""
+    starts = np.arange(0, len(inputs), batch_size)
+    if shuffle:
+        idx = np.arange(len(inputs))
+        np.random.shuffle(idx)
+        inputs, targets = inputs[idx], targets[idx]
+    for start in starts:
+        yield inputs[start:start + batch_size], targets[start:start + batch_size]
+
+
+def acc_evaluate(predictions, targets):
+    """core/evaluator.py:15-23"""
+    hit = int(np.sum(predictions == targets))
+    return {"total_num": len(predictions), "hit_num": hit, "accuracy": 1.0 * hit / len(predictions)}
+
+
+def train_epochs(widths, train_x, train_y_onehot, test_x, test_y, num_ep, batch_size, lr):
+    """examples/mnist/run.py:50-93 with Dense layers that initialise lazily: the RNG is consumed in the reference's
+    order — first epoch's shuffle, THEN W0, W1, ... at the first forward (core/layers.py:45-46).
+    Returns (per-step losses, per-epoch argmax vectors, per-epoch AccEvaluator dicts)."""
+    layers, opt = None, Adam(lr=lr)
+    train_x, train_y = RefTensor(train_x), RefTensor(train_y_onehot)
+    test_x = RefTensor(test_x)
+    losses, preds, results = [], [], []
+    for _ in range(num_ep):
+        for bx, by in epoch_batches(train_x, train_y, batch_size):
+            if layers is None:
+                layers = build_mlp(widths)                   # lazy init happens inside the first forward
+            zero_grad(layers)
+            loss = softmax_nll(forward(layers, bx), by)
+            loss.backward()
+            apply_step(layers, opt)
+            losses.append(float(loss.values))
+        idx = np.argmax(forward(layers, test_x).values, axis=1)
+        preds.append(idx)
+        results.append(acc_evaluate(idx, test_y))
+    return losses, preds, results

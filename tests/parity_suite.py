@@ -448,6 +448,85 @@ def sigmoid_closed_form():
     np.testing.assert_allclose(np.asarray(t2.grad), ref * (1 - ref), rtol=1e-5, atol=1e-7)
 
 
+def tanh_and_relu_layers_match_reference():
+    """the `Tanh` layer — the reference's (1 - e^-x)/(1 + e^-x) = tanh(x/2), core/layers.py:83-89 — and
+    `ReLU`, forward and vjp through the layer objects, against the reference's own outputs (tests/golden/layers.npz);
+    then three SGD steps of Dense-Tanh-Dense under the softmax loss."""
+    import synth
+    from tinynn_autograd_amd.core.layers import Dense, ReLU, Tanh
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.nn import Net
+    from tinynn_autograd_amd.core.optimizer import SGD
+    gold = dict(np.load(H.GOLDEN + "/layers.npz"))
+    x, g = synth.layer_inputs()
+    for tag, dt, tol in (("f64", np.float64, 1e-12), ("f32", np.float32, RTOL)):
+        tn.set_default_float(dt)
+        for name, cls in (("tanh", Tanh), ("relu", ReLU)):
+            t = Tensor(x.astype(dt), requires_grad=True)
+            y = cls().forward(t)
+            y.backward(g)
+            for key, val in (("out", y.values), ("grad", t.grad)):
+                ref = gold["%s_%s_%s" % (name, tag, key)]
+                np.testing.assert_allclose(np.asarray(val, dtype=np.float64), ref, rtol=tol, atol=tol * np.abs(ref).max(),
+                                           err_msg="%s %s %s" % (name, tag, key))
+        relu_grad = np.asarray(ReLU().forward(Tensor(x.astype(dt), requires_grad=True)).values)
+        assert np.array_equal(relu_grad, gold["relu_%s_out" % tag].astype(dt))          # clip is exact
+    tn.set_default_float(np.float32)
+    rs = np.random.RandomState(17)
+    bx = rs.randn(12, 9).astype(np.float32)
+    by = np.eye(4)[rs.randint(0, 4, 12)]
+    np.random.seed(11)
+    net = Net([Dense(6, num_in=9), Tanh(), Dense(4, num_in=6)])
+    loss_layer = SoftmaxCrossEntropyLoss()
+    model = Model(net=net, loss=loss_layer, optimizer=SGD(lr=0.1))
+    losses = []
+    for s in range(3):
+        model.zero_grad()
+        loss = loss_layer.loss(model.forward(Tensor(bx)), Tensor(by))
+        loss.backward()
+        if s == 0:
+            g0 = np.asarray(net.layers[0].params["w"].grad)
+            np.testing.assert_allclose(g0, gold["net_grad0_w0"], rtol=0, atol=RTOL * np.abs(gold["net_grad0_w0"]).max())
+        model.step()
+        losses.append(float(loss.values))
+    np.testing.assert_allclose(losses, gold["net_loss"], rtol=RTOL)
+    for key, layer in (("net_final_w0", net.layers[0]), ("net_final_w1", net.layers[2])):
+        np.testing.assert_allclose(np.asarray(layer.params["w"].values), gold[key], rtol=0, atol=RTOL * np.abs(gold[key]).max())
+
+
+def _check_epoch_loop(trainer):
+    """SURVEY §8 a25 end to end against the reference's own loop (tests/golden/epoch.npz, written by
+    oracle/gen_golden.py from examples/mnist/run.py:45-93 + utils/data_iterator.py:22-34): seed -> per-epoch shuffle
+    -> lazy init -> 7 batches of 128 + a ragged 104 -> Adam, two epochs, then argmax -> AccEvaluator.  Per-step loss
+    to 1e-5, argmax vectors and hit_num IDENTICAL."""
+    import json
+    import synth
+    from tinynn_autograd_amd.examples import mnist_run
+    from tinynn_autograd_amd.utils.seeder import random_seed
+    gold = dict(np.load(H.GOLDEN + "/epoch.npz"))
+    cfg = json.loads(str(gold["config"]))
+    assert cfg == synth.EPOCH_CFG
+    train_x, train_y, test_x, test_y = synth.epoch_dataset(cfg)
+    random_seed(cfg["seed"])
+    losses, preds, results = mnist_run.train(train_x, train_y, test_x, test_y, cfg["widths"][1:-1], cfg["num_ep"],
+                                             cfg["batch_size"], cfg["lr"], trainer=trainer)
+    assert len(losses) == len(gold["loss"]) == 16 and gold["batch_sizes"].tolist() == ([128] * 7 + [104]) * 2
+    np.testing.assert_allclose(losses, gold["loss"], rtol=RTOL)
+    for ep in range(cfg["num_ep"]):
+        assert preds[ep].dtype == np.int64 and np.array_equal(preds[ep], gold["argmax"][ep]), "epoch %d argmax" % ep
+        assert results[ep]["hit_num"] == int(gold["hit_num"][ep]) and results[ep]["total_num"] == int(gold["total_num"][ep])
+        assert results[ep]["accuracy"] == float(gold["accuracy"][ep])
+
+
+def epoch_loop_ops_path_matches_reference():
+    _check_epoch_loop(trainer=False)
+
+
+def epoch_loop_trainer_path_matches_reference():
+    _check_epoch_loop(trainer=True)
+
+
 def fused_ops_match_generic_chain():
     """softmax_nll_ / dense_ / fused Adam against the literal op chains on the same device."""
     from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss

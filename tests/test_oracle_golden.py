@@ -61,3 +61,27 @@ def test_closed_form_matches_reference_trajectory():
         np.testing.assert_allclose(loss, gold["loss"][s], rtol=1e-6)
         if s == 0:
             H.check_summary(gW[2], gold, "grad0_2w", rtol=0, atol=2e-5 * np.abs(gold["grad0_2w"]).max())
+
+
+def test_layers_and_epoch_loop_bit_exact():
+    """ref_nn.Tanh and ref_nn.train_epochs against the reference's outputs (layers.npz, epoch.npz)."""
+    import json
+    import synth
+    gold = dict(np.load(H.GOLDEN + "/layers.npz"))
+    x, g = synth.layer_inputs()
+    for tag, dt in (("f64", np.float64), ("f32", np.float32)):
+        t = RefTensor(x.astype(dt), requires_grad=True)
+        y = ref_nn.Tanh().forward(t)
+        y.backward(g)
+        assert np.array_equal(np.asarray(y.values, dtype=np.float64), gold["tanh_%s_out" % tag])
+        assert np.array_equal(t.grad, gold["tanh_%s_grad" % tag])
+    # the formula is tanh(x / 2), not tanh(x) (SURVEY F7)
+    np.testing.assert_allclose(gold["tanh_f64_out"], np.tanh(x / 2), rtol=1e-12, atol=1e-15)
+    ep = dict(np.load(H.GOLDEN + "/epoch.npz"))
+    cfg = json.loads(str(ep["config"]))
+    train_x, train_y, test_x, test_y = synth.epoch_dataset(cfg)
+    np.random.seed(cfg["seed"])
+    losses, preds, results = ref_nn.train_epochs(cfg["widths"], train_x, np.eye(10)[train_y], test_x, test_y, 1,
+                                                 cfg["batch_size"], cfg["lr"])
+    assert np.array_equal(np.array(losses), ep["loss"][:8])
+    assert np.array_equal(preds[0], ep["argmax"][0]) and results[0]["hit_num"] == int(ep["hit_num"][0])

@@ -55,60 +55,76 @@ def prepare_dataset(data_dir, n_train=51200, n_test=10000):
     return make(n_train), make(n_test), "synthetic (MNIST-like sparsity, linear-teacher labels)"
 
 
-def main(args):
-    if args.seed >= 0:
-        random_seed(args.seed)
-    (train_x, train_y), (test_x, test_y), source = prepare_dataset(args.data_dir)
-    print("data: %s, %d train / %d test rows" % (source, len(train_x), len(test_x)))
+def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trainer=False, log=None):
+    """The loop of examples/mnist/run.py:50-93 on device Tensors.  `train_y` / `test_y` are integer labels.  Returns
+    (loss_list as floats, per-epoch argmax vectors, per-epoch AccEvaluator dicts).
+
+    RNG order is the reference's: the first epoch's shuffle is drawn BEFORE the lazily initialised Dense layers draw
+    their weights at the first forward (core/layers.py:45-46) — also on the trainer path."""
     train_y = get_one_hot(train_y, 10)
     train_x, train_y = Tensor(train_x), Tensor(train_y)    # resident in HBM for the whole run
     test_x = Tensor(test_x)
-
-    widths = [int(w) for w in args.widths.split(",")]
     layers = []
     for w in widths:
         layers += [Dense(w), ReLU()]
     layers.append(Dense(10))
     net = Net(layers)
-    model = Model(net=net, loss=SoftmaxCrossEntropyLoss(), optimizer=Adam(lr=args.lr))
+    model = Model(net=net, loss=SoftmaxCrossEntropyLoss(), optimizer=Adam(lr=lr))
     loss_layer = SoftmaxCrossEntropyLoss()
-    iterator = BatchIterator(batch_size=args.batch_size)
+    iterator = BatchIterator(batch_size=batch_size)
     evaluator = AccEvaluator()
-    print("backend:", tn.backend_name())
-
-    trainer = None
-    loss_list = []
-    for epoch in range(args.num_ep):
+    step_trainer = None
+    loss_list, preds, results = [], [], []
+    for epoch in range(num_ep):
         t_start = time.time()
-        if args.trainer and trainer is None:
-            model.forward(train_x[:1])                     # lazy Dense init from the first batch's width
-            trainer = tn.trainer_from_net(net, max_rows=args.batch_size, lr=args.lr)
-        if trainer is not None:
-            batches = [(b.inputs.values, b.targets.values) for b in iterator(train_x, train_y)]
-            full = [b for b in batches if b[0].shape[0] == args.batch_size]
-            graph = trainer.capture_steps(full)            # the epoch's steps as ONE hipGraph launch
-            loss_list.extend(list(np.asarray(graph.launch())))
+        if trainer:
+            batches = [(b.inputs.values, b.targets.values) for b in iterator(train_x, train_y)]   # shuffle drawn here
+            if step_trainer is None:
+                model.forward(Tensor(batches[0][0][:1]))   # lazy Dense init from the first batch's width
+                step_trainer = tn.trainer_from_net(net, max_rows=batch_size, lr=lr)
+            full = [b for b in batches if b[0].shape[0] == batch_size]
+            graph = step_trainer.capture_steps(full)       # the epoch's full batches as ONE hipGraph launch
+            loss_list.extend(float(v) for v in np.asarray(graph.launch()))
             for x, y in batches[len(full):]:               # ragged last batch
-                loss_list.append(float(trainer.step(x, y)))
+                loss_list.append(float(step_trainer.step(x, y)))
             for i, layer in enumerate(l for l in net.layers if isinstance(l, Dense)):
-                layer.params["w"].values = trainer.param_view(i, "w")
-                layer.params["b"].values = trainer.param_view(i, "b")
+                layer.params["w"].values = step_trainer.param_view(i, "w")
+                layer.params["b"].values = step_trainer.param_view(i, "b")
         else:
+            device_losses = []
             for batch in iterator(train_x, train_y):
                 model.zero_grad()
                 pred = model.forward(batch.inputs)
                 loss = loss_layer.loss(pred, batch.targets)
                 loss.backward()
                 model.step()
-                loss_list.append(loss.values)              # a 0-d DeviceArray: no host sync inside the loop
+                device_losses.append(loss.values)          # a 0-d DeviceArray: no host sync inside the loop
+            loss_list.extend(float(v) for v in device_losses)
         tn.synchronize()
-        print("Epoch %d tim cost: %.4f" % (epoch, time.time() - t_start))
+        if log:
+            log("Epoch %d tim cost: %.4f" % (epoch, time.time() - t_start))
         model.set_phase("TEST")
         test_pred = model.forward(test_x)
         test_pred_idx = np.argmax(test_pred, axis=1)
-        print(evaluator.evaluate(test_pred_idx, np.asarray(test_y)))
+        res = evaluator.evaluate(test_pred_idx, np.asarray(test_y))
+        preds.append(test_pred_idx)
+        results.append(res)
+        if log:
+            log(res)
         model.set_phase("TRAIN")
-    print("last loss: %.6f" % float(loss_list[-1]))
+    return loss_list, preds, results
+
+
+def main(args):
+    if args.seed >= 0:
+        random_seed(args.seed)
+    (train_x, train_y), (test_x, test_y), source = prepare_dataset(args.data_dir)
+    print("data: %s, %d train / %d test rows" % (source, len(train_x), len(test_x)))
+    print("backend:", tn.backend_name())
+    widths = [int(w) for w in args.widths.split(",")]
+    loss_list, _, _ = train(train_x, train_y, test_x, test_y, widths, args.num_ep, args.batch_size, args.lr,
+                            trainer=args.trainer, log=print)
+    print("last loss: %.6f" % loss_list[-1])
 
 
 if __name__ == "__main__":
