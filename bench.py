@@ -1,38 +1,50 @@
 #!/usr/bin/env python3
-"""bench.py — training samples/sec of the MNIST-shape MLP (784-256-128-10, bs=128 per GPU, Adam 1e-3),
-the metric BASELINE.json names, on N GPUs of one node.
+"""bench.py — training samples/sec of the MNIST-shape MLP (784-256-128-10, Adam 1e-3), the metric BASELINE.json
+names, on N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload A|C] [--path fused|ops]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload A|C|E] [--path fused|ops|opsgraph] [--rows R]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: zero_grad -> forward -> whole-batch softmax NLL ->
-backward -> [RCCL all-reduce] -> Adam update (examples/mnist/run.py:79-83).  Inputs are synthetic
-(MNIST-like sparsity), resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch: zero_grad -> forward -> whole-batch softmax NLL -> backward ->
+[all-reduce] -> Adam update (examples/mnist/run.py:79-83).  Inputs are synthetic (MNIST-like sparsity),
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-  --workload A (default)  configs[1]/[3] of BASELINE.json: 128 rows per GPU (N=8 -> global batch 1024)
-  --workload C            configs[2]: Dense 4096->4096->4096 autoencoder, bs 512, sum-of-squares loss —
-                          the MFMA roofline run (one GPU)
-  --workload E            configs[4] per GPU: 8192-wide 4-layer MLP, bf16 storage / fp32 accumulate / fp32 master
-                          weights + Adam state, bs 512, sum-of-squares loss (no cpu_baseline: one float64 step of
-                          the 268 M-parameter net takes minutes on the host)
-  --path fused (default)  whole-step trainer (tnn_mlp_*), hipGraph replay at N=1
-  --path ops              the drop-in Tensor/ops/Model path (same maths, one launch per op)
-  --path opsgraph         the same op-level loop body captured into a hipGraph and replayed
+Protocol: `--repeats` (default 5) timed repeats of [W warm-up steps, then K timed steps], each bracketed
+by barrier + stream sync + torch.cuda.synchronize(); when K steps take less than `--min-ms` (50 ms) a repeat times
+R consecutive K-step segments instead (R chosen from an untimed pilot, equal on all ranks) so the clock never brackets
+less than that.  `value` / `ms_per_step` = MEDIAN over the repeats of (max over ranks); min / max are on the line.
 
-Extra objects on the line:
-  roofline      the dominant kernel of the step (the fp32 MFMA GEMM family): algorithmic FLOPs of the
-                step's GEMMs / their summed average durations, each measured with HIP events on the
-                library stream; peak = 157.3 TFLOP/s (MI355X fp32 MFMA, guide)
-  roofline_gemm4096  the same measurement on the five 512x4096x4096 GEMMs of config C (north_star's
-                ">= 50 % of fp32 MFMA roofline" target), always reported
-  cpu_baseline  the numpy port of the reference (oracle/ref_nn.py: same op graph, 4x backward traversal,
-                float64) timed on this host for a bounded number of steps (rank 0, N=1 only)
+What `value` is:
+  N = 1   configs[1] of BASELINE.json: bs 128 on one GPU (the configuration the metric is quoted on).
+  N > 1   configs[3]: STRONG scaling — global batch 1024, 1024/N rows per rank, same global batches on every N
+          ("scaling": "strong"); every line also carries
+            strong_scaling  the config-D point of THIS N (N = 1: bs 1024 on one GPU = `--workload A --rows 1024`), and at
+                            N > 1 the single-GPU bs-1024 step measured on rank 0 of the same run
+            weak_scaling    128 rows per rank (global batch 128 N)
+          so both curves can be drawn from the driver's N = 1/2/4/8 lines.
+  Transports at N > 1: RCCL (north_star's named transport) is timed FIRST, the xGMI peer-to-peer path second; both are
+  reported unconditionally under config.collectives.  `value` is the peer-to-peer run when that transport passed its
+  bit-exact self-test before and after the run, no barrier timed out and all replicas hold identical parameters —
+  otherwise the RCCL run.  (A rule, not a best-of-two.)
+
+Extra objects on the N = 1 line:
+  roofline           config A is launch-latency bound (129 MFLOP = ~1 us of MFMA time): bound "latency"; peak = the
+                     launch-floor model (launches/step x 1.45 us dependent-kernel boundary, MI355X guide price table),
+                     achieved = the measured step, both as ksteps/s; per-launch HIP-event times of the step's own
+                     launches (tnn_mlp_launch_window), gemm_frac = the step's GEMM FLOPs / their event time / 157.3 TF
+  roofline_gemm4096  north_star's ">= 50 % of fp32 MFMA roofline" target: the five 512x4096x4096 GEMMs of config C,
+                     HIP events on the library stream, peak 157.3 TFLOP/s, traffic from the PMC passes in profiles/
+  config_C           whole-step samples/s of configs[2] (4096-4096-4096, bs 512)
+  paths              the same config-A step on the drop-in Tensor/ops/Model API: eager and captured (tn.capture)
+  cpu_baseline       the numpy port of the reference (oracle/ref_nn.py) on this host, all BLAS threads and 1 thread
 """
 
 import argparse
 import json
+import math
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -47,13 +59,18 @@ from tinynn_autograd_amd import device_array as da    # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense (AMD's 5 PF headline includes 2:1 sparsity)
+PEAK_HBM_TBS = 8.0
+LAUNCH_BOUNDARY_US = 1.45             # dependent kernel boundary, same stream (MI355X_MICROARCH.md price table)
 WIDTHS_A = [784, 256, 128, 10]
 WIDTHS_C = [4096, 4096, 4096]
 WIDTHS_E = [8192, 8192, 8192, 8192, 8192]
+GLOBAL_BATCH_D = 1024
+PROFILE_ROUND = "r02"
 
 
+# ------------------------------------------------------------------------------------------------ data / nets
 def synth_batches(n_batches, rows, widths, kind, rank, world, seed=1234):
-    """Global batches of rows*world samples from one seeded stream; this rank keeps its row block."""
+    """Global batches of rows*world samples from one seeded stream; this rank keeps its row block (SURVEY §8e)."""
     rs = np.random.RandomState(seed)
     xs, ys = [], []
     for _ in range(n_batches):
@@ -82,7 +99,7 @@ def build_net(widths):
 
 
 def gemm_list(widths, rows):
-    """(transA, transB, M, N, K) of every GEMM in one step: fwd NN, dW TN, dX NT (no dX for layer 1)."""
+    """(name, transA, transB, M, N, K) of every GEMM in one step: fwd NN, dW TN, dX NT (no dX for layer 1)."""
     out = []
     for l in range(len(widths) - 1):
         out.append(("fwd%d" % l, 0, 0, rows, widths[l + 1], widths[l]))
@@ -93,54 +110,66 @@ def gemm_list(widths, rows):
     return out
 
 
+def step_algorithmic(widths, rows):
+    """Algorithmic work of one step: GEMM FLOPs; bytes = GEMM operands + 28 B/param Adam."""
+    flops = sum(2.0 * M * N * K for _, _, _, M, N, K in gemm_list(widths, rows))
+    gemm_bytes = sum(4 * (M * K + K * N + M * N) for _, _, _, M, N, K in gemm_list(widths, rows))
+    n_params = sum(widths[l] * widths[l + 1] + widths[l + 1] for l in range(len(widths) - 1))
+    return flops, gemm_bytes, 28 * n_params
+
+
+# ------------------------------------------------------------------------------------------------ kernel-level timing
+def events_us(fn, reps):
+    """Average duration of `fn`'s launches: `reps` back-to-back calls replayed from ONE hipGraph, HIP events on the
+    library stream around the replay (torch.cuda.Event would watch torch's stream, not this one)."""
+    for _ in range(3):
+        fn()
+    graph = _lib.Graph()
+    with graph:
+        for _ in range(reps):
+            fn()
+    graph.launch()
+    samples = []
+    for _ in range(3):
+        e0, e1 = _lib.Event(), _lib.Event()
+        e0.record()
+        graph.launch()
+        e1.record()
+        samples.append(e0.elapsed_ms(e1) / reps * 1e3)
+    return float(np.median(samples))
+
+
 def time_gemms(widths, rows, reps=20):
-    """Average duration of each GEMM of the step: HIP events on the library stream around `reps`
-    back-to-back launches replayed from one hipGraph (for the microsecond-sized GEMMs of config A the
-    figure therefore still contains the ~1.3 us dependent-kernel boundary; profiles/ has the rocprofv3
-    kernel-only durations)."""
+    """Each fp32 GEMM of the step on operands shaped like the step's own (activations uniform in [0, 1), weights
+    Xavier-uniform: the MFMA data path's power draw, and with it the sustained clock, depends on the values)."""
     lib = _lib.get()
     rs = np.random.RandomState(7)
-    results, tot_flops, tot_ms = [], 0.0, 0.0
+    results, tot_flops, tot_us = [], 0.0, 0.0
     for name, ta, tb, M, N, K in gemm_list(widths, rows):
-        # operands shaped like the step's own: activations / inputs uniform in [0, 1) (the synthetic x of SURVEY §8d),
-        # weights Xavier-uniform — the MFMA data path's power draw, and with it the sustained clock, depends on the values
         lim = float(np.sqrt(6.0 / (K + N)))
         a = da.asarray(rs.rand(*((K, M) if ta else (M, K))).astype(np.float32))
         b = da.asarray(rs.uniform(-lim, lim, (N, K) if tb else (K, N)).astype(np.float32))
         c = da.empty((M, N), np.float32)
         lda, ldb = (M if ta else K), (K if tb else N)
-        for _ in range(3):
-            lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32)
-        graph = _lib.Graph()                           # replayed from a hipGraph: no host launch cost inside
-        with graph:
-            for _ in range(reps):
-                lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32)
-        graph.launch()
-        e0, e1 = _lib.Event(), _lib.Event()
-        e0.record()
-        graph.launch()
-        e1.record()
-        ms = e0.elapsed_ms(e1) / reps
+        us = events_us(lambda: lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32), reps)
         flops = 2.0 * M * N * K
         results.append({"gemm": name, "layout": "NT"[ta] + "NT"[tb], "M": M, "N": N, "K": K,
-                        "us": round(ms * 1e3, 3), "tflops": round(flops / (ms * 1e-3) / 1e12, 3)})
+                        "us": round(us, 3), "tflops": round(flops / us / 1e6, 3)})
         tot_flops += flops
-        tot_ms += ms
-    achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+        tot_us += us
+    achieved = tot_flops / tot_us / 1e6
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
             "kernel": "gemm_f32_mfma_kernel (v_mfma_f32_32x32x2_f32)",
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 4),
-            "gemm_us_per_step": round(tot_ms * 1e3, 2), "per_gemm": results}
+            "gemm_us_per_step": round(tot_us, 2), "per_gemm": results}
 
 
 def time_gemms_bf16(widths, rows, reps=10):
-    """The bf16 step's GEMMs, all in the K-contiguous form the bf16 trainer uses (tnn_gemm_bf16_nt):
-    forward [rows,out] <- a[rows,in] W^T[out,in]; dX [rows,in] <- dz[rows,out] W[in,out]; dW [in,out] (f32) <-
-    a^T[in,rows] dz^T[out,rows]."""
+    """The bf16 step's GEMMs in the K-contiguous form the bf16 trainer uses (tnn_gemm_bf16_nt)."""
     from tinynn_autograd_amd import bf16
     rs = np.random.RandomState(7)
-    results, tot_flops, tot_ms = [], 0.0, 0.0
+    results, tot_flops, tot_us = [], 0.0, 0.0
     shapes = []
     for l in range(len(widths) - 1):
         shapes.append(("fwd%d" % l, rows, widths[l + 1], widths[l], np.uint16))
@@ -161,84 +190,369 @@ def time_gemms_bf16(widths, rows, reps=10):
             for _ in range(reps):
                 bf16.gemm_nt(A, B, out_dtype=out)
             e1.record()
-            cache[key] = e0.elapsed_ms(e1) / reps
-        ms = cache[key]
+            cache[key] = e0.elapsed_ms(e1) / reps * 1e3
+        us = cache[key]
         flops = 2.0 * M * N * K
-        results.append({"gemm": name, "layout": "NT(bf16)", "M": M, "N": N, "K": K, "us": round(ms * 1e3, 2),
-                        "tflops": round(flops / (ms * 1e-3) / 1e12, 1)})
+        results.append({"gemm": name, "layout": "NT(bf16)", "M": M, "N": N, "K": K, "us": round(us, 2),
+                        "tflops": round(flops / us / 1e6, 1)})
         tot_flops += flops
-        tot_ms += ms
-    achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+        tot_us += us
+    achieved = tot_flops / tot_us / 1e6
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
             "kernel": "gemm_bf16_nt_kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
-            "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "gemm_us_per_step": round(tot_ms * 1e3, 1),
+            "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "gemm_us_per_step": round(tot_us, 1),
             "per_gemm": results}
 
 
-def attach_traffic(roof, tag):
-    """roofline.traffic = HBM-side bytes per step of the GEMM launches, from the PMC passes committed under
-    profiles/ (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; collected with rocprofv3 --pmc on this same
-    command, see the file's _provenance).  None when no profile of this round is present."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if not os.path.exists(path):
+def load_traffic_table():
+    """HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 correction
+    + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command; tools/traffic_from_pmc.py)."""
+    for rnd in (PROFILE_ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
+        if os.path.exists(path):
+            return json.load(open(path)), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def attach_gemm_traffic(roof, tag):
+    table, src = load_traffic_table()
+    if table is None:
         return
-    table = json.load(open(path))["kernels"]
     total, algorithmic = 0, 0
     for gm in roof["per_gemm"]:
         akc, bkc = gm["layout"][0] == "N", gm["layout"][1] == "T"
         flags = "%s, %s" % ("true" if akc else "false", "true" if bkc else "false")
-        small = 2.0 * gm["M"] * gm["N"] * gm["K"] <= 1.6e8
         hit = None
-        for name, per in table.items():
-            if tag not in per:
-                continue
-            if small and name.startswith("gemm_small_f32_kernel<" + flags):
-                hit = per[tag] if hit is None or per[tag]["launches"] > hit["launches"] else hit
-            if not small and name.startswith("gemm_f32_mfma_kernel<") and (", " + flags + ", true>") in name:
+        for name, per in table["kernels"].items():
+            if tag in per and name.startswith("gemm_f32_mfma_kernel<") and (", " + flags + ", true>") in name:
                 hit = per[tag]
         if hit is None:
             return
         total += hit["fetch_bytes"] + hit["write_bytes"]
         algorithmic += 4 * (gm["M"] * gm["K"] + gm["K"] * gm["N"] + gm["M"] * gm["N"])
     roof["traffic"] = int(total)
-    roof["traffic_unit"] = "bytes per step over the step's GEMM launches (PMC, profiles/r01_traffic.json)"
+    roof["traffic_unit"] = "bytes per step over the step's GEMM launches (PMC, %s)" % src
     roof["algorithmic_bytes"] = int(algorithmic)
 
 
-def cpu_baseline(widths, rows, kind, budget_s=12.0):
-    """The numpy port of the reference on this host (bounded sample of the same workload)."""
-    from oracle import ref_nn                              # the reported baseline, never the measured path
-    np.random.seed(0)
-    layers = ref_nn.build_mlp(widths)
-    opt = ref_nn.Adam(lr=1e-3)
-    loss_fn = ref_nn.softmax_nll if kind == "softmax_nll" else ref_nn.squared_error
-    x, y = synth_batches(4, rows, widths, kind, 0, 1)
-    y = y.astype(np.float64)
-    for i in range(2):
-        ref_nn.train_step(layers, opt, loss_fn, x[i * rows:(i + 1) * rows], y[i * rows:(i + 1) * rows])
-    t0, steps = time.perf_counter(), 0
-    while True:
-        i = steps % 4
-        ref_nn.train_step(layers, opt, loss_fn, x[i * rows:(i + 1) * rows], y[i * rows:(i + 1) * rows])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or (steps >= 400 and el > 5.0):
-            break
-    threads = os.cpu_count()
+def step_traffic(tag):
+    """HBM-side bytes of ONE whole step (every kernel of the step's graph) from the same table, or None."""
+    table, src = load_traffic_table()
+    if table is None or "steps" not in table or tag not in table["steps"]:
+        return None, None
+    return int(table["steps"][tag]["bytes_per_step"]), src
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model_name():
     try:
-        from threadpoolctl import threadpool_info
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(widths, rows, kind, budget_s=8.0):
+    """The numpy port of the reference on this host (bounded sample of the same workload), with every BLAS thread
+    the host offers and with ONE thread (SURVEY §8d asks for both)."""
+    from oracle import ref_nn                              # the reported baseline, never the measured path
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+    except Exception:                                      # noqa: BLE001
+        threadpool_info = threadpool_limits = None
+
+    def leg(limit):
+        np.random.seed(0)
+        layers = ref_nn.build_mlp(widths)
+        opt = ref_nn.Adam(lr=1e-3)
+        loss_fn = ref_nn.softmax_nll if kind == "softmax_nll" else ref_nn.squared_error
+        x, y = synth_batches(4, rows, widths, kind, 0, 1)
+        y = y.astype(np.float64)
+
+        def run():
+            for i in range(2):
+                ref_nn.train_step(layers, opt, loss_fn, x[i * rows:(i + 1) * rows], y[i * rows:(i + 1) * rows])
+            t0, steps = time.perf_counter(), 0
+            while True:
+                i = steps % 4
+                ref_nn.train_step(layers, opt, loss_fn, x[i * rows:(i + 1) * rows], y[i * rows:(i + 1) * rows])
+                steps += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or (steps >= 400 and el > 4.0):
+                    return steps, el
+        if limit is not None and threadpool_limits is not None:
+            with threadpool_limits(limits=limit, user_api="blas"):
+                return run()
+        return run()
+
+    threads = os.cpu_count()
+    blas_name = "?"
+    if threadpool_info is not None:
         blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
         if blas:
-            threads = blas[0]["num_threads"]
-    except Exception:
+            threads, blas_name = blas[0]["num_threads"], "%s %s" % (blas[0].get("internal_api"), blas[0].get("version"))
+    steps, el = leg(None)
+    out = {"value": round(steps * rows / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+           "cpu_model": cpu_model_name(), "logical_cpus": os.cpu_count(), "numpy": np.__version__, "blas": blas_name,
+           "sample": "%d steps of the same %s step (bs=%d) through oracle/ref_nn.py (float64, the reference's per-edge "
+                     "backward) in %.1f s with %d BLAS threads" % (steps, "-".join(map(str, widths)), rows, el, threads)}
+    if threadpool_limits is not None:
+        s1, el1 = leg(1)
+        out["single_thread"] = {"value": round(s1 * rows / el1, 1), "unit": "samples/s", "cores": 1,
+                                "sample": "%d steps in %.1f s with BLAS limited to 1 thread" % (s1, el1)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ measured runs
+class Runner(object):
+    """Something that can run `count` consecutive training steps from global step index `first` and report the last
+    loss.  `prepare` builds whatever graphs that range needs BEFORE the clock starts."""
+    n_batches = 1
+
+    def prepare(self, first, count):
         pass
-    return {"value": round(steps * rows / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "%d steps of the same %s step (bs=%d) through oracle/ref_nn.py (numpy %s, float64, "
-                      "reference's per-edge backward) in %.1f s; host has %d logical CPUs"
-                      % (steps, "-".join(map(str, widths)), rows, np.__version__, el, os.cpu_count())}
+
+    def run(self, first, count):
+        raise NotImplementedError
 
 
+class FusedRun(Runner):
+    """Whole-step trainer (tnn_mlp_*): every (first, count) range is replayed from hipGraphs — whole n_batches-step
+    chunks where the step index is aligned, shorter pre-captured segment graphs for the unaligned head and tail."""
+
+    def __init__(self, widths, rows, kind, n_batches, rank=0, world=1, comm=None, force_dp=False, use_graph=True,
+                 dtype=np.float32, seed=1234):
+        self.widths, self.rows, self.kind, self.n_batches = widths, rows, kind, n_batches
+        self.comm, self.use_graph = comm, use_graph
+        x_host, y_host = synth_batches(n_batches, rows, widths, kind, rank, world, seed=seed)
+        self.X, self.Y = da.asarray(x_host), da.asarray(y_host)            # resident in HBM before the timed region
+        self.batches = [(self.X[i * rows:(i + 1) * rows], self.Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
+        if isinstance(dtype, str):                                         # bf16 trainer (configs[4])
+            from tinynn_autograd_amd import bf16
+            from tinynn_autograd_amd.fused import MLPTrainer
+            self.trainer = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=1e-3, dtype=dtype, comm=comm,
+                                      force_dp=force_dp)
+            np.random.seed(0)
+            for l in range(len(widths) - 1):
+                a = np.sqrt(6.0 / (widths[l] + widths[l + 1]))
+                self.trainer.param_view(l, "w")[...] = da.asarray(
+                    np.random.uniform(-a, a, (widths[l], widths[l + 1])).astype(np.float32))
+            _lib.get().mlp_sync_params(self.trainer._h)
+            X16 = bf16.to_bf16(self.X)
+            self.batches = [(X16[i * rows:(i + 1) * rows], X16[i * rows:(i + 1) * rows]) for i in range(n_batches)]
+            self.use_graph = False
+        else:
+            self.trainer = tn.trainer_from_net(build_net(widths), max_rows=rows, loss=kind, optimizer="adam", lr=1e-3,
+                                               comm=comm, use_graph=False, force_dp=force_dp)
+        self.chunk, self.segments = None, {}
+        self.capture()
+
+    def capture(self):
+        """(Re)capture the chunk graph — also after switching the transport under a data-parallel trainer.  With a
+        communicator both collectives of every step are captured too (peer-to-peer kernels, or RCCL which supports
+        stream capture); if that capture is refused the run falls back to eager data-parallel steps."""
+        self.chunk, self.segments = None, {}
+        if not self.use_graph or (self.comm is not None and os.environ.get("TNN_DP_GRAPH", "1") == "0"):
+            return
+        try:
+            self.chunk = self.trainer.capture_steps(self.batches)
+        except Exception as exc:                          # noqa: BLE001
+            if self.comm is None:
+                raise
+            sys.stderr.write("bench: data-parallel graph capture unavailable (%s); eager steps\n" % exc)
+
+    def plan(self, first, count):
+        out, i = [], first
+        while count > 0:
+            off = i % self.n_batches
+            length = min(count, self.n_batches - off)
+            out.append((off, length))
+            i, count = i + length, count - length
+        return out
+
+    def prepare(self, first, count):
+        if self.chunk is None:
+            return
+        for off, length in self.plan(first, count):
+            if length != self.n_batches and (off, length) not in self.segments:
+                self.segments[(off, length)] = self.trainer.capture_steps(self.batches[off:off + length])
+
+    def run(self, first, count):
+        last = None
+        if self.chunk is None:
+            for i in range(first, first + count):
+                last = self.trainer.step(*self.batches[i % self.n_batches])
+            return last
+        for off, length in self.plan(first, count):
+            g = self.chunk if length == self.n_batches else self.segments[(off, length)]
+            last = g.launch()[length - 1]
+        return last
+
+    def params_crc(self):
+        return int(np.frombuffer(np.asarray(self.trainer.params).tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
+
+    def launches_per_step(self):
+        """Primitive calls (= kernel launches at this size) of the single-GPU step, counted by the library itself."""
+        n = __import__("ctypes").c_int(0)
+        self.trainer._lib.mlp_step(self.trainer._h, self.batches[0][0]._ptr, self.batches[0][1]._ptr, self.rows, None)
+        self.trainer._lib.mlp_launch_window(self.trainer._h, 0, -1, __import__("ctypes").byref(n))
+        return n.value
+
+    def per_launch_us(self, reps=200):
+        """HIP-event time of each launch of the step on its own (tnn_mlp_launch_window: the step restricted to its
+        k-th primitive call, `reps` back-to-back replays from one hipGraph — so every figure still contains one
+        dependent-kernel boundary, like inside the real step)."""
+        lib, h = self.trainer._lib, self.trainer._h
+        x, y = self.batches[0]
+        n = self.launches_per_step()
+        out = []
+        try:
+            for k in range(n):
+                lib.mlp_launch_window(h, k, 1, None)
+                out.append(round(events_us(lambda: lib.mlp_step(h, x._ptr, y._ptr, self.rows, None), reps), 3))
+        finally:
+            lib.mlp_launch_window(h, 0, -1, None)
+        return out
+
+
+def fixture_check(widths, rows, kind, rank, world, comm, force_dp, use_graph):
+    """Parity of the very trainer + transport being timed, against the REFERENCE's own trajectory: when the global batch is
+    one the fixtures were captured at (tests/golden/traj_A_adam.npz: bs 128, 20 steps; traj_D_adam.npz: bs 1024, 5 steps
+    — written by oracle/gen_golden.py from the imported reference), a fresh trainer is fed the fixture's batches (this
+    rank's row block) and its per-step losses are compared with the reference's (rtol 1e-5)."""
+    name = {128: "A_adam", 1024: "D_adam"}.get(rows * world) if (kind == "softmax_nll" and widths == WIDTHS_A) else None
+    path = os.path.join(ROOT, "tests", "golden", "traj_%s.npz" % name)
+    if name is None or not os.path.exists(path):
+        return None
+    gold = np.load(path)
+    cfg = json.loads(str(gold["config"]))
+    steps = int(cfg["steps"])
+    fr = FusedRun(widths, rows, kind, steps, rank, world, comm, force_dp, use_graph=use_graph, seed=cfg["data_seed"])
+    if fr.chunk is not None:
+        losses = np.asarray(fr.chunk.launch(), dtype=np.float64)
+    else:
+        losses = np.array([float(fr.trainer.step(*b)) for b in fr.batches])
+    ref = np.asarray(gold["loss"], dtype=np.float64)[:steps]
+    err = float(np.max(np.abs(losses - ref) / np.abs(ref)))
+    return {"fixture": "tests/golden/traj_%s.npz (the reference's per-step losses)" % name, "steps": steps,
+            "max_rel_err": float("%.3g" % err), "rtol": 1e-5, "ok": bool(err <= 1e-5)}
+
+
+class OpsRun(Runner):
+    """The drop-in API path (core/tensor.py:13-171 / core/ops.py:12-384 are the seam): unmodified-style
+    loop body on Tensor / ops / Dense / SoftmaxCrossEntropyLoss / Adam / Model — eager, or captured once with
+    tn.capture and replayed (each batch copied into two staging tensors at fixed addresses first)."""
+
+    def __init__(self, widths, rows, kind, n_batches, rank=0, world=1, comm=None, graph=False):
+        from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss, SquaredErrorLoss
+        from tinynn_autograd_amd.core.model import Model
+        from tinynn_autograd_amd.core.optimizer import Adam
+        from tinynn_autograd_amd.core.tensor import Tensor
+        self.n_batches, self.rows = n_batches, rows
+        x_host, y_host = synth_batches(n_batches, rows, widths, kind, rank, world)
+        X, Y = da.asarray(x_host), da.asarray(y_host)
+        self.batches = [(X[i * rows:(i + 1) * rows], Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
+        loss_layer = SoftmaxCrossEntropyLoss(comm=comm) if kind == "softmax_nll" else SquaredErrorLoss()
+        model = Model(net=build_net(widths), loss=loss_layer, optimizer=Adam(lr=1e-3), comm=comm)
+        tbatches = [(Tensor(a), Tensor(b)) for a, b in self.batches]
+
+        def eager(i):
+            xb, yb = tbatches[i % n_batches]
+            model.zero_grad()
+            out = loss_layer.loss(model.forward(xb), yb)
+            out.backward()
+            model.step()
+            return out.values
+        self.step = eager
+        if graph:
+            x_stage, y_stage = Tensor(self.batches[0][0].copy()), Tensor(self.batches[0][1].copy())
+
+            def body():
+                model.zero_grad()
+                out = loss_layer.loss(model.forward(x_stage), y_stage)
+                out.backward()
+                model.step()
+                return out
+            captured = tn.capture(body, warmup=2)
+
+            def replay(i):
+                xb, yb = self.batches[i % n_batches]
+                x_stage.values[...] = xb
+                y_stage.values[...] = yb
+                return captured().values
+            self.step = replay
+
+    def run(self, first, count):
+        last = None
+        for i in range(first, first + count):
+            last = self.step(i)
+        return last
+
+
+class Clock(object):
+    """The bench contract's timed region: barrier + stream sync + torch.cuda.synchronize() on both sides, wall clock,
+    max over ranks."""
+
+    def __init__(self, torch, comm, world):
+        self.torch, self.comm, self.world = torch, comm, world
+
+    def fence(self):
+        if self.comm is not None:
+            self.comm.barrier()
+        _lib.synchronize()                                   # the library's own stream (kernels + RCCL)
+        self.torch.cuda.synchronize()                        # device-wide, as the bench contract asks
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            import torch.distributed as dist
+            t = self.torch.tensor([dt], dtype=self.torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
+
+    def timed(self, runner, first, warmup, count):
+        runner.prepare(first, warmup)
+        runner.prepare(first + warmup, count)                # every graph of the timed region exists before the clock
+        runner.run(first, warmup)
+        self.fence()
+        t0 = time.perf_counter()
+        last = runner.run(first + warmup, count)
+        self.fence()
+        return self.max_over_ranks(time.perf_counter() - t0), last
+
+
+def measure(clock, runner, warmup, steps, repeats, min_ms, rows_global):
+    """`repeats` timed repeats of [warmup, R x steps]; R from an untimed pilot so that a repeat lasts >= min_ms."""
+    nb = runner.n_batches
+    span = lambda r: (warmup + r * steps + nb - 1) // nb * nb           # noqa: E731  chunk-aligned stride per repeat
+    pilot, _ = clock.timed(runner, 0, warmup, steps)
+    R = max(1, int(math.ceil(min_ms * 1e-3 / max(pilot, 1e-9))))
+    R = min(R, 4096)
+    first = span(1)
+    per_step, last = [], None
+    for _ in range(repeats):
+        dt, last = clock.timed(runner, first, warmup, R * steps)
+        per_step.append(dt / (R * steps))
+        first += span(R)
+    med = float(np.median(per_step))
+    return {"ms_per_step": med * 1e3, "value": rows_global / med, "min_ms_per_step": min(per_step) * 1e3,
+            "max_ms_per_step": max(per_step) * 1e3, "repeats": repeats, "segments_per_repeat": R,
+            "timed_steps_per_repeat": R * steps, "final_loss": float(last)}
+
+
+def brief(res, **extra):
+    out = {"value": round(res["value"], 1), "unit": "samples/s", "ms_per_step": round(res["ms_per_step"], 5),
+           "min_ms_per_step": round(res["min_ms_per_step"], 5), "max_ms_per_step": round(res["max_ms_per_step"], 5),
+           "final_loss": round(res["final_loss"], 6)}
+    out.update(extra)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,19 +560,30 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="A", choices=["A", "C", "E"])
     ap.add_argument("--path", default="fused", choices=["fused", "ops", "opsgraph"])
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU for workload A (default 128; N>1: 1024/N)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1, workload A: which curve `value` is on (the other one is reported beside it)")
+    ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--min-ms", type=float, default=50.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (config_C, paths, ...)")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON result: native libraries print there too (RCCL writes a version /
     # hostname banner to stdout when a communicator is created), so file descriptor 1 is pointed at stderr for the
-    # whole run and the result goes to a saved duplicate of the original stdout.
+    # whole run and the result goes to a saved duplicate of the original stdout — once, whoever gets there first.
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    emit_lock, emitted = threading.Lock(), [False]
 
     def emit(obj):
-        os.write(result_fd, (json.dumps(obj) + "\n").encode())
+        with emit_lock:
+            if emitted[0] or obj is None:
+                return
+            emitted[0] = True
+            os.write(result_fd, (json.dumps(obj) + "\n").encode())
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -267,12 +592,8 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
         args.gpus = world
 
-    # ORDER MATTERS: torch first, libtnn_hip.so second.  torch preloads its own bundled libamdhip64 / librccl by
-    # absolute path; loaded first, they are the process's ONE HIP runtime and libtnn_hip.so (DT_NEEDED
-    # libamdhip64.so.7) and RCCL (dlopen librccl.so.1) bind to them by soname.  The other order maps two HIP
-    # runtimes: torch.cuda then reports "No HIP GPUs" and the process aborts at exit ("double free") — measured
-    # on the MI355X box with tools/probes/rccl_torch_order_test.py.  torch itself is only the control plane
-    # (gloo rendezvous / barrier) and the contract's torch.cuda.synchronize().
+    # ORDER MATTERS: torch first, libtnn_hip.so second (one HIP runtime per process).  torch itself is
+    # only the control plane (gloo rendezvous / barrier) and the contract's torch.cuda.synchronize().
     import torch
     import torch.distributed                              # noqa: F401
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -281,339 +602,283 @@ def main():
     assert tn.backend_name() == "hip-gfx950", "bench.py measures the HIP library only"
     comm = tn.dist.init_from_env() if (world > 1 or os.environ.get("TNN_FORCE_COMM") == "1") else None
     force_dp = comm is not None and world == 1
+    clock = Clock(torch, comm, world)
+    solo = Clock(torch, None, 1)                         # rank-local measurements (no barrier, no max over ranks)
+    use_graph = not args.no_graph
+    line = None
+    exit_code = 0
 
     if args.workload == "A":
-        widths, rows, kind, loss = WIDTHS_A, 128, "softmax_nll", "softmax_nll"
+        widths, kind = WIDTHS_A, "softmax_nll"
+        if args.rows is not None:
+            rows = args.rows
+        elif world > 1 and args.scaling == "strong":
+            if GLOBAL_BATCH_D % world:
+                raise SystemExit("strong scaling splits the global batch of %d evenly: %d ranks do not" % (GLOBAL_BATCH_D, world))
+            rows = GLOBAL_BATCH_D // world
+        else:
+            rows = 128
         steps = args.steps if args.steps is not None else 2000
         warmup = args.warmup if args.warmup is not None else 64
-        n_batches = 64
+        n_batches = 64 if rows <= 256 else 32
     elif args.workload == "C":
-        widths, rows, kind, loss = WIDTHS_C, 512, "mse", "mse"
+        widths, rows, kind = WIDTHS_C, args.rows or 512, "mse"
         steps = args.steps if args.steps is not None else 50
         warmup = args.warmup if args.warmup is not None else 5
         n_batches = 2
     else:
-        widths, rows, kind, loss = WIDTHS_E, 512, "mse", "mse"
+        widths, rows, kind = WIDTHS_E, args.rows or 512, "mse"
         steps = args.steps if args.steps is not None else 20
         warmup = args.warmup if args.warmup is not None else 3
         n_batches = 2
 
-    x_host, y_host = synth_batches(n_batches, rows, widths, kind, rank, world)
-    X, Y = da.asarray(x_host), da.asarray(y_host)      # resident in HBM before the timed region
-    batches = [(X[i * rows:(i + 1) * rows], Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
-
-    chunk = None
-    if args.workload == "E":
-        # bf16 storage / fp32 master weights (configs[4]); 268 M parameters: initialise layer by layer on the host
-        from tinynn_autograd_amd import bf16
-        from tinynn_autograd_amd.fused import MLPTrainer
-        args.path = "fused"
-        trainer = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16", comm=comm,
-                             force_dp=force_dp)
-        np.random.seed(0)
-        for l in range(len(widths) - 1):
-            a = np.sqrt(6.0 / (widths[l] + widths[l + 1]))
-            trainer.param_view(l, "w")[...] = da.asarray(
-                np.random.uniform(-a, a, (widths[l], widths[l + 1])).astype(np.float32))
-        lib.mlp_sync_params(trainer._h)
-        X16 = bf16.to_bf16(X)
-        batches = [(X16[i * rows:(i + 1) * rows], X16[i * rows:(i + 1) * rows]) for i in range(n_batches)]
-
-        def step(i):
-            return trainer.step(*batches[i % n_batches])
-    elif args.path == "fused":
-        net = build_net(widths)
-        trainer = tn.trainer_from_net(net, max_rows=rows, loss=loss, optimizer="adam", lr=1e-3, comm=comm,
-                                      use_graph=not args.no_graph, force_dp=force_dp)
-        def build_chunk():
-            # every batch is resident at a fixed HBM address: capture one step per batch into ONE hipGraph
-            # and replay it (n_batches steps per hipGraphLaunch, no staging copies).  With a communicator the two
-            # collectives of every step are captured too (peer-to-peer kernels, or RCCL which supports stream
-            # capture); if the capture is refused the run falls back to eager data-parallel steps.
-            # TNN_DP_GRAPH=0 forces the eager form.
-            if args.no_graph or not (comm is None or os.environ.get("TNN_DP_GRAPH", "1") != "0"):
-                return None
-            try:
-                return trainer.capture_steps(batches)
-            except Exception as exc:                          # noqa: BLE001
-                if comm is None:
-                    raise
-                sys.stderr.write("bench: data-parallel graph capture unavailable (%s); eager steps\n" % exc)
-                return None
-        chunk = build_chunk()
-
-        def step(i):
-            return trainer.step(*batches[i % n_batches])
-    else:
-        net = build_net(widths)
-        from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss, SquaredErrorLoss
-        from tinynn_autograd_amd.core.model import Model
-        from tinynn_autograd_amd.core.optimizer import Adam
-        from tinynn_autograd_amd.core.tensor import Tensor
-        loss_layer = SoftmaxCrossEntropyLoss(comm=comm) if kind == "softmax_nll" else SquaredErrorLoss()
-        model = Model(net=net, loss=loss_layer, optimizer=Adam(lr=1e-3), comm=comm)
-        tbatches = [(Tensor(a), Tensor(b)) for a, b in batches]
-
-        def step(i):
-            xb, yb = tbatches[i % n_batches]
-            model.zero_grad()
-            out = loss_layer.loss(model.forward(xb), yb)
-            out.backward()
-            model.step()
-            return out.values
-
-        if args.path == "opsgraph":
-            # the same reference-style loop body, captured once into a hipGraph (tinynn_autograd_amd.graph) and
-            # replayed; each batch is copied into two staging tensors at fixed addresses first
-            x_stage, y_stage = Tensor(batches[0][0].copy()), Tensor(batches[0][1].copy())
-
-            def body():
-                model.zero_grad()
-                out = loss_layer.loss(model.forward(x_stage), y_stage)
-                out.backward()
-                model.step()
-                return out
-
-            captured = tn.capture(body, warmup=2)
-
-            def step(i):                                     # noqa: F811
-                xb, yb = batches[i % n_batches]
-                x_stage.values[...] = xb
-                y_stage.values[...] = yb
-                return captured().values
-
-    def fence():
-        if comm is not None:
-            comm.barrier()
-        _lib.synchronize()                                   # the library's own stream (kernels + RCCL)
-        torch.cuda.synchronize()                             # device-wide, as the bench contract asks
-
-    # Any (warmup, steps) pair runs from hipGraphs: whole n_batches-step chunks where the step index is aligned, and
-    # shorter "segment" graphs (captured on first use, BEFORE the timed region — see measure) for the unaligned head
-    # and tail.  `trainer.step` (one launch sequence per host call) is only the fallback when capture is off.
-    segments = {}
-
-    def plan(first, count):
-        """[(offset in the batch cycle, length)] covering `count` steps from global step `first`."""
-        out, i = [], first
-        while count > 0:
-            off = i % n_batches
-            length = min(count, n_batches - off)
-            out.append((off, length))
-            i, count = i + length, count - length
-        return out
-
-    def prepare(first, count):
-        if chunk is None or not hasattr(trainer, "capture_steps"):
-            return
-        for off, length in plan(first, count):
-            if length != n_batches and (off, length) not in segments:
-                segments[(off, length)] = trainer.capture_steps(batches[off:off + length])
-
-    def run(first, count):
-        """`count` consecutive steps starting at global step index `first`; returns the last loss."""
-        i, last = first, None
-        if chunk is None:
-            for _ in range(count):
-                last = step(i)
-                i += 1
-            return last
-        for off, length in plan(first, count):
-            g = chunk if length == n_batches else segments[(off, length)]
-            last = g.launch()[length - 1]
-        return last
-
-    def measure(first):
-        prepare(first, warmup)
-        prepare(first + warmup, steps)               # every graph of the timed region exists before the clock starts
-        run(first, warmup)
-        fence()
-        t0 = time.perf_counter()
-        last_loss = run(first + warmup, steps)
-        fence()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, last_loss
-
-    def p2p_alive():
-        """True when the xGMI peer-to-peer path is live and no rank saw a barrier time out (collective check)."""
-        st = comm.p2p_status() if comm is not None and hasattr(comm, "p2p_status") else None
-        bad = 0 if (st and st["enabled"] and not st["dead"]) else 1
-        if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([bad])
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            bad = int(t.item())
-        return bad == 0
-
+    # ---------------------------------------------------------------- primary measurement
     transports = None
-    compare_rccl = False
-    if comm is not None and args.path == "fused":
-        # Data-parallel run: the peer-to-peer transport was mapped and self-tested by init_from_env(); time the K
-        # steps on it and make sure no barrier timed out (else: re-measure on RCCL).  `value` comes from this run.
-        # The same K steps are timed over RCCL afterwards for comparison (see below).
-        transports = {}
-        second = (warmup + steps + n_batches - 1) // n_batches * n_batches      # chunk-aligned start of a second run
-        # the latency path carries f32 sums up to its mapped capacity: config A's 0.94 MB arena, not C's 134 MB or E's
-        # 1 GB — those go to RCCL whatever the transport's state
-        arena_bytes = (int(trainer.params.size) + 1) * 4
-        used_p2p = p2p_alive() and arena_bytes <= getattr(comm, "p2p_bytes", 0)
-        elapsed, last = measure(0)
-        if used_p2p and not p2p_alive():
-            sys.stderr.write("bench: xGMI peer-to-peer barrier timed out during the run; measuring on RCCL\n")
-            used_p2p = False
-            comm.set_p2p(False)
-            segments.clear()                                  # captured with the other transport's kernels
-            chunk = build_chunk()
-            elapsed, last = measure(second)
-        transports["xgmi_p2p_ms_per_step" if used_p2p else "rccl_ms_per_step"] = round(elapsed / steps * 1e3, 5)
-        if used_p2p:
-            # the transport again after the run, bit-exact against locally reproducible sums (all ranks must agree)
-            try:
-                ok = 1 if comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6) else 0
-            except Exception as exc:                          # noqa: BLE001 - every rank must reach the vote below
-                sys.stderr.write("bench: post-run peer-to-peer check raised: %s\n" % exc)
-                ok = 0
-            if world > 1:
-                import torch.distributed as dist
-                t = torch.tensor([ok])
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                ok = int(t.item())
-            transports["xgmi_p2p_verified_after_run"] = bool(ok)
-        transports["used"] = "xgmi-p2p" if used_p2p else "rccl"
-        compare_rccl = (used_p2p and getattr(comm, "_rccl", False)
-                        and os.environ.get("TNN_BENCH_COMPARE_RCCL", "1") != "0")
-        # replicas must still hold bit-identical parameters
-        crc = int(np.frombuffer(np.asarray(trainer.params).tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
+    if args.workload == "E":
+        args.path = "fused"
+        runner = FusedRun(widths, rows, kind, n_batches, rank, world, comm, force_dp, dtype="bfloat16")
+    elif args.path == "fused":
+        runner = FusedRun(widths, rows, kind, n_batches, rank, world, comm, force_dp, use_graph=use_graph)
+    else:
+        runner = OpsRun(widths, rows, kind, n_batches, rank, world, comm, graph=args.path == "opsgraph")
+
+    def replicas_identical(r):
+        crc = r.params_crc()
         if world > 1:
             import torch.distributed as dist
             box = [None] * world
             dist.all_gather_object(box, crc)
-            transports["replicas_identical"] = bool(all(c == box[0] for c in box))
-        else:
-            transports["replicas_identical"] = True
-    else:
-        elapsed, last = measure(0)
-    final_loss = float(last)
+            return bool(all(c == box[0] for c in box))
+        return True
 
+    def all_ranks(flag):
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([1 if flag else 0])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        return bool(flag)
+
+    def p2p_alive():
+        st = comm.p2p_status() if comm is not None and hasattr(comm, "p2p_status") else None
+        return all_ranks(bool(st and st["enabled"] and not st["dead"]))
+
+    if comm is not None and args.path == "fused" and isinstance(runner, FusedRun):
+        # Data-parallel run.  RCCL first (north_star's named transport), the xGMI peer-to-peer path second; both are
+        # reported.  The latency path carries f32 sums up to its mapped capacity: config A's 0.94 MB arena, not C's
+        # 134 MB or E's 1 GB — those go to RCCL whatever the transport's state.
+        transports = {}
+        arena_bytes = (int(runner.trainer.params.size) + 1) * 4
+        have_rccl = bool(getattr(comm, "_rccl", False))
+        have_p2p = p2p_alive() and arena_bytes <= getattr(comm, "p2p_bytes", 0)
+        res_rccl = res_p2p = None
+        if have_rccl:
+            if have_p2p:
+                comm.set_p2p(False)
+                runner.capture()
+            res_rccl = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
+            transports["rccl"] = brief(res_rccl, replicas_identical=replicas_identical(runner),
+                                       graph_captured=runner.chunk is not None)
+        primary, used = res_rccl, "rccl"
+        if have_p2p:
+            # nothing below may cost the RCCL result: a watchdog emits the line as it stands (RCCL as `value`) and ends
+            # the process with a NON-ZERO code if the peer-to-peer run does not come back (bounded spins make that a
+            # 20 s affair per stuck barrier; a hard hang is what the timer is for)
+            limit = int(os.environ.get("TNN_BENCH_P2P_TIMEOUT_S", "120"))
+            partial = {"line": None}
+
+            def give_up():
+                if partial["line"] is not None:
+                    partial["line"]["exit_code"] = 3
+                    partial["line"]["config"]["collectives"]["xgmi_p2p"] = "did not finish in %d s" % limit
+                    emit(partial["line"])
+                os._exit(3)
+            dog = threading.Timer(limit, give_up)
+            dog.daemon = True
+            if res_rccl is not None and rank == 0:
+                partial["line"] = make_line(args, widths, rows, kind, world, warmup, steps, res_rccl, runner,
+                                            dict(transports, used="rccl"), force_dp)
+            if res_rccl is not None:
+                dog.start()
+            comm.set_p2p(True)
+            runner.capture()
+            res_p2p = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
+            alive = p2p_alive()
+            try:
+                verified = all_ranks(alive and comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6))
+            except Exception as exc:                          # noqa: BLE001 - every rank must reach the vote
+                sys.stderr.write("bench: post-run peer-to-peer check raised: %s\n" % exc)
+                verified = all_ranks(False)
+            same = replicas_identical(runner)
+            dog.cancel()
+            transports["xgmi_p2p"] = brief(res_p2p, barrier_timed_out=not alive, verified_after_run=verified,
+                                           replicas_identical=same, graph_captured=runner.chunk is not None)
+            if verified and same and alive:
+                primary, used = res_p2p, "xgmi-p2p"
+            elif res_rccl is None:
+                raise SystemExit("bench: the peer-to-peer transport failed its checks and no RCCL communicator exists")
+        transports["used"] = used
+        transports["rule"] = "value = xgmi_p2p when verified bit-exact after the run, no barrier timed out and replicas identical; else rccl"
+        if primary is None:
+            raise SystemExit("bench: no usable transport")
+        res = primary
+    else:
+        res = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
+
+    if comm is not None and transports is not None:
+        comm.set_p2p(transports["used"] == "xgmi-p2p")       # everything below runs on the primary transport
+    check = None
+    if args.path == "fused" and args.workload == "A":
+        check = fixture_check(widths, rows, kind, rank, world, comm, force_dp, use_graph)
+        if check is not None:
+            check["ok"] = all_ranks(check["ok"])
     if rank == 0:
-        value = steps * rows * world / elapsed
-        line = {
-            "metric": {"A": "training samples/sec, MNIST 3-layer MLP (784-256-128-10), bs=128, at 1/2/4/8 GPUs",
-                       "C": "training samples/sec, Dense 4096-4096-4096 autoencoder, bs=512",
-                       "E": "training samples/sec, 8192-wide 4-layer MLP bf16, bs=512 per GPU"}[args.workload],
-            "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16 (fp32 accumulate, fp32 master weights)" if args.workload == "E" else "f32",
-            "data": "synthetic",
-            "config": {"workload": "%s: Dense/ReLU MLP %s, %d rows per GPU (global batch %d), whole-batch "
-                                   "softmax NLL%s, Adam lr=1e-3" % (
-                                       {"A": "configs[1]", "C": "configs[2]", "E": "configs[4]"}[args.workload],
-                                       "-".join(map(str, widths)), rows, rows * world,
-                                       "" if kind == "softmax_nll" else " replaced by sum-of-squares/m"),
-                       "path": args.path + ("+hipGraph(%d steps/launch)" % n_batches if chunk is not None else "")
-                               + ("+comm(world=1, forced)" if force_dp else ""),
-                       "parallelism": "dp%d" % world, "global_batch": rows * world,
-                       "data_resident_in_hbm": True,
-                       **({"collectives": transports} if transports else {})},
-            "final_loss": round(final_loss, 6),
-            "device": _lib.device_props()["name"],
-        }
+        line = make_line(args, widths, rows, kind, world, warmup, steps, res, runner, transports, force_dp)
+        if check is not None:
+            line["parity_vs_reference_fixture"] = check
+            if not check["ok"]:
+                exit_code = line["exit_code"] = 4            # a fast step with the wrong losses is not a result
+
+    # ---------------------------------------------------------------- scaling curves (workload A)
+    if args.workload == "A" and args.path == "fused" and not args.no_extras and args.rows is None:
+        other_rows = None
+        if world > 1:
+            other_rows = 128 if args.scaling == "strong" else GLOBAL_BATCH_D // world
+        point = {"global_batch": rows * world, "rows_per_rank": rows, "value": round(res["value"], 1),
+                 "ms_per_step": round(res["ms_per_step"], 5)}
+        curves = {("strong_scaling" if (world > 1 and args.scaling == "strong") else "weak_scaling"): point}
+        if world == 1:
+            # N = 1 point of the strong curve: the whole global batch of config D on one GPU
+            d1 = FusedRun(widths, GLOBAL_BATCH_D, kind, 32, 0, 1, None, False, use_graph=use_graph)
+            r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, GLOBAL_BATCH_D)
+            curves["strong_scaling"] = brief(r1, global_batch=GLOBAL_BATCH_D, rows_per_rank=GLOBAL_BATCH_D,
+                                             launches_per_step=d1.launches_per_step())
+            del d1
+        elif other_rows != rows:
+            other = FusedRun(widths, other_rows, kind, 64 if other_rows <= 256 else 32, rank, world, comm, False,
+                             use_graph=use_graph)
+            ro = measure(clock, other, warmup, steps, 3, args.min_ms, other_rows * world)
+            curves["weak_scaling" if args.scaling == "strong" else "strong_scaling"] = brief(
+                ro, global_batch=other_rows * world, rows_per_rank=other_rows, transport=transports["used"],
+                replicas_identical=replicas_identical(other))
+            del other
+        if world > 1:
+            # the single-GPU reference of the strong curve, measured in THIS run on rank 0 while the others wait
+            if rank == 0:
+                d1 = FusedRun(widths, GLOBAL_BATCH_D, kind, 32, 0, 1, None, False, use_graph=use_graph)
+                r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, GLOBAL_BATCH_D)
+                curves["single_gpu_bs%d" % GLOBAL_BATCH_D] = brief(r1, note="rank 0 alone, no communicator")
+                del d1
+            comm.barrier()
+        if line is not None:
+            line.update(curves)
+
+    # ---------------------------------------------------------------- secondary objects (rank 0, N = 1)
+    if line is not None and world == 1 and not args.no_extras:
         if args.workload == "E":
             line["roofline"] = time_gemms_bf16(widths, rows)
+        elif args.workload == "C":
+            line["roofline"] = time_gemms(widths, rows, reps=20)
+            attach_gemm_traffic(line["roofline"], "C")
         else:
-            line["roofline"] = time_gemms(widths, rows, reps=200 if args.workload == "A" else 20)
-            attach_traffic(line["roofline"], args.workload)
-        if args.workload == "A":
+            line["roofline"] = latency_roofline(widths, rows, res, runner)
             line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
-            attach_traffic(line["roofline_gemm4096"], "C")
-        if world == 1 and not args.no_cpu_baseline and args.workload != "E":
-            line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=12.0 if args.workload == "A" else 20.0)
-    else:
-        line = None
+            attach_gemm_traffic(line["roofline_gemm4096"], "C")
+            if args.path == "fused" and args.rows is None and comm is None:
+                paths = {}
+                for name, graph in (("ops_eager", False), ("ops_graph", True)):
+                    r = OpsRun(widths, rows, kind, 64, graph=graph)
+                    paths[name] = brief(measure(solo, r, 20, 200, 3, args.min_ms, rows))
+                    del r
+                paths["note"] = ("the same step on the drop-in Tensor/ops/Dense/SoftmaxCrossEntropyLoss/Adam/Model API: one "
+                                 "launch per op issued from Python (eager) / the same loop body recorded once with tn.capture and "
+                                 "replayed as a hipGraph (graph)")
+                line["paths"] = paths
+                c = FusedRun(WIDTHS_C, 512, "mse", 2, use_graph=use_graph)
+                rc = measure(solo, c, 3, 20, 3, 0.0, 512)
+                line["config_C"] = brief(rc, workload="configs[2]: Dense 4096-4096-4096 autoencoder, bs 512, sum-of-squares/m, Adam",
+                                         algorithmic_gflop_per_step=85.8993,
+                                         mfma_frac_of_whole_step=round(85.8993e9 / (rc["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+                del c
+        if not args.no_cpu_baseline and args.workload != "E":
+            line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
 
-    def graph_latency_us(fn, reps=100, launches=3):
-        g = _lib.Graph()
-        with g:
-            for _ in range(reps):
-                fn()
-        g.launch()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(launches):
-            g.launch()
-        fence()
-        return round((time.perf_counter() - t0) / (reps * launches) * 1e6, 2)
-
-    def p2p_latency_table(with_rccl):
-        """Per-call latency of the peer-to-peer all-reduce on the gradient-arena size for several workgroup counts, and
-        of the small all-gather — replayed from hipGraphs, every rank in lockstep.  Tuning data for the next round:
-        the development boxes have one GPU, real xGMI hops are only ever seen by this run."""
-        table = {}
-        n_arena = int(trainer.params.size) + 1
-        scratch = da.zeros((n_arena,), np.float32)
-        pair, out = da.zeros((2,), np.float32), da.zeros((world, 2), np.float32)
-        for blocks in (0, 16, 32, 64, 128):
-            lib.p2p_tune(blocks)
-            table["allreduce_us_blocks_%s" % (blocks or "auto")] = graph_latency_us(lambda: comm.allreduce(scratch))
-        lib.p2p_tune(0)
-        table["allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
-        if with_rccl:
-            comm.set_p2p(False)                               # the same two calls over RCCL
-            table["rccl_allreduce_us"] = graph_latency_us(lambda: comm.allreduce(scratch))
-            table["rccl_allgather_us"] = graph_latency_us(lambda: lib.allgather(pair._ptr, out._ptr, 2, _lib.F32))
-            comm.set_p2p(True)
-        return table
-
-    if transports is not None and transports.get("used") == "xgmi-p2p":
-        # Secondary measurements, never allowed to cost the primary one: the per-call latency table of the transport
-        # and (when an RCCL communicator exists) the same K steps with both collectives on RCCL, captured into the
-        # step graph like the primary run.  A watchdog prints the line as it stands and ends the process if this does
-        # not come back (none of it has ever run across real xGMI links on this code's one-GPU development boxes).
-        import threading
-
-        def give_up():
-            if line is not None:
-                line["config"]["collectives"]["secondary_measurements"] = "did not finish in %d s" % limit
-                emit(line)
-            os._exit(0)
-        limit = int(os.environ.get("TNN_BENCH_COMPARE_TIMEOUT_S", "90"))
-        dog = threading.Timer(limit, give_up)
-        dog.daemon = True
-        dog.start()
-        comm.barrier()           # rank 0 has just spent seconds timing GEMMs for the roofline: enter together
-        try:
-            lat = p2p_latency_table(with_rccl=bool(getattr(comm, "_rccl", False)))
-            if line is not None:
-                line["config"]["collectives"]["xgmi_p2p_latency"] = lat
-        except Exception as exc:                              # noqa: BLE001
-            sys.stderr.write("bench: peer-to-peer latency table skipped: %s\n" % exc)
-        if compare_rccl:
-            comm.set_p2p(False)
-            segments.clear()
-            chunk = build_chunk()
-            dt_rccl, last_rccl = measure(second)
-            if line is not None:
-                coll = line["config"]["collectives"]
-                coll["rccl_ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
-                if dt_rccl < elapsed:
-                    # both transports ran the same K timed steps after the same warm-up: report the faster one
-                    coll["used"] = "rccl"
-                    line["value"] = round(steps * rows * world / dt_rccl, 1)
-                    line["ms_per_step"] = round(dt_rccl / steps * 1e3, 5)
-                    line["final_loss"] = round(float(last_rccl), 6)
-        dog.cancel()
-    if line is not None:
-        emit(line)
+    emit(line)
     if comm is not None:
         comm.barrier()
         if hasattr(comm, "close"):
             comm.close()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([exit_code])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exit_code = int(t.item())
+    return exit_code
+
+
+def latency_roofline(widths, rows, res, runner):
+    """Config A/D: neither MFMA nor HBM bounds the step — the launch chain does."""
+    flops, gemm_bytes, adam_bytes = step_algorithmic(widths, rows)
+    step_us = res["ms_per_step"] * 1e3
+    roof = {"bound": "latency", "unit": "ksteps/s", "achieved": round(1e3 / step_us, 3)}
+    gem = time_gemms(widths, rows, reps=200)
+    if isinstance(runner, FusedRun) and runner.comm is None:
+        launches = runner.launches_per_step()
+        per = runner.per_launch_us()
+        floor_us = launches * LAUNCH_BOUNDARY_US
+        roof.update({"peak": round(1e3 / floor_us, 3), "frac": round(floor_us / step_us, 4),
+                     "launches_per_step": launches, "launch_boundary_us": LAUNCH_BOUNDARY_US,
+                     "launch_floor_us_per_step": round(floor_us, 3), "step_us": round(step_us, 3),
+                     "per_launch_us": per, "sum_per_launch_us": round(sum(per), 3),
+                     "model": "peak = 1 / (launches x dependent-kernel boundary); each per_launch_us is that launch replayed "
+                              "back to back (HIP events), i.e. boundary + kernel"})
+    else:
+        roof.update({"peak": None, "frac": None, "step_us": round(step_us, 3)})
+    traffic, src = step_traffic("A")
+    roof["traffic"] = traffic
+    if src:
+        roof["traffic_unit"] = "HBM-side bytes per step, all kernels of the step (PMC, %s)" % src
+    roof.update({"algorithmic_bytes": int(gemm_bytes + adam_bytes), "algorithmic_gflop_per_step": round(flops / 1e9, 4),
+                 "hbm_frac": round((gemm_bytes + adam_bytes) / (step_us * 1e-6) / (PEAK_HBM_TBS * 1e12), 4),
+                 "mfma_frac_of_whole_step": round(flops / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 "gemm_frac": gem["frac"], "gemm_tflops": gem["achieved"], "gemm_us_per_step": gem["gemm_us_per_step"],
+                 "per_gemm": gem["per_gemm"]})
+    return roof
+
+
+def make_line(args, widths, rows, kind, world, warmup, steps, res, runner, transports, force_dp):
+    cfg_name = {"A": "configs[1]" if world == 1 and rows == 128 else "configs[3]", "C": "configs[2]", "E": "configs[4]"}[args.workload]
+    graph = getattr(runner, "chunk", None) is not None
+    scaling = "weak"
+    if args.workload == "A" and world > 1 and args.rows is None:
+        scaling = args.scaling
+    line = {
+        "metric": {"A": "training samples/sec, MNIST 3-layer MLP (784-256-128-10), bs=128, at 1/2/4/8 GPUs",
+                   "C": "training samples/sec, Dense 4096-4096-4096 autoencoder, bs=512",
+                   "E": "training samples/sec, 8192-wide 4-layer MLP bf16, bs=512 per GPU"}[args.workload],
+        "value": round(res["value"], 1), "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(res["ms_per_step"], 5), "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "bf16 (fp32 accumulate, fp32 master weights)" if args.workload == "E" else "f32",
+        "data": "synthetic",
+        "timing": {"statistic": "median of %d repeats of [%d warm-up steps + %d timed steps] (max over ranks each)"
+                                % (res["repeats"], warmup, res["timed_steps_per_repeat"]),
+                   "min_ms_per_step": round(res["min_ms_per_step"], 5), "max_ms_per_step": round(res["max_ms_per_step"], 5),
+                   "segments_per_repeat": res["segments_per_repeat"], "timed_ms_per_repeat": round(res["ms_per_step"] * res["timed_steps_per_repeat"], 2)},
+        "config": {"workload": "%s: Dense/ReLU MLP %s, %d rows per GPU (global batch %d), whole-batch "
+                               "softmax NLL%s, Adam lr=1e-3" % (
+                                   cfg_name, "-".join(map(str, widths)), rows, rows * world,
+                                   "" if kind == "softmax_nll" else " replaced by sum-of-squares/m"),
+                   "path": args.path + ("+hipGraph(%d steps/launch)" % runner.n_batches if graph else "")
+                           + ("+comm(world=1, forced)" if force_dp else ""),
+                   "parallelism": "dp%d" % world, "global_batch": rows * world, "rows_per_rank": rows,
+                   "data_resident_in_hbm": True,
+                   **({"collectives": transports} if transports else {})},
+        "final_loss": round(res["final_loss"], 6),
+        "device": _lib.device_props()["name"],
+        "exit_code": 0,
+    }
+    return line
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

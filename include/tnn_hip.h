@@ -314,6 +314,10 @@ TNN_API int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t row
 /* one data-parallel step through the communicator of tnn_comm_init: forward + shard stats, all-gather + merge,
  * loss/backward with the global batch size, all-reduce of the gradient arena (+ loss slot), update */
 TNN_API int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
+/* Measurement hook (bench.py's per-launch timings): restrict tnn_mlp_step to its primitive calls number
+ * [first, first + count) in issue order (count < 0: the whole step again); *calls_in_last_step = primitive calls (= kernel
+ * launches for the MNIST-size step) the last tnn_mlp_step went through.  No reference counterpart (new). */
+TNN_API int tnn_mlp_launch_window(void* handle, int first, int count, int* calls_in_last_step);
 /* after the parameter arena was written from outside (initial weights): refresh derived copies — the bf16
  * working copies W, W^T of a TNN_BF16 trainer; no-op for f32 / f64 */
 TNN_API int tnn_mlp_sync_params(void* handle);

@@ -119,9 +119,54 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 128 and d["warmup"] == 64 and d["scaling"] == "weak"
-    assert d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp2"
+    assert d["n_gpus"] == 2 and d["steps"] == 128 and d["warmup"] == 64 and d["scaling"] == "strong"
+    # configs[3] as SURVEY §8(e) defines it: global batch 1024, 1024/W rows per rank
+    assert d["config"]["global_batch"] == 1024 and d["config"]["rows_per_rank"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert d["exit_code"] == 0 and d["timing"]["segments_per_repeat"] >= 1
     coll = d["config"]["collectives"]
-    assert coll["used"] == "xgmi-p2p" and coll["replicas_identical"] and coll["xgmi_p2p_verified_after_run"]
-    assert d["value"] > 0 and "roofline" in d
-    assert coll["xgmi_p2p_latency"]["allreduce_us_blocks_auto"] > 0 and coll["xgmi_p2p_latency"]["allgather_us"] > 0
+    assert coll["used"] == "xgmi-p2p" and "rccl" not in coll            # TNN_COMM=xgmi: no RCCL communicator exists
+    p2p = coll["xgmi_p2p"]
+    assert p2p["replicas_identical"] and p2p["verified_after_run"] and not p2p["barrier_timed_out"] and p2p["graph_captured"]
+    assert d["value"] == p2p["value"] > 0
+    # the sharded step on this transport reproduces the REFERENCE's bs-1024 losses (traj_D_adam, all 5 steps)
+    chk = d["parity_vs_reference_fixture"]
+    assert chk["ok"] and chk["steps"] == 5 and "traj_D_adam" in chk["fixture"] and chk["max_rel_err"] <= 1e-5
+    # both curves on the one line: this N's strong point, the weak point (128 rows per rank), the single-GPU reference
+    assert d["strong_scaling"]["global_batch"] == 1024 and d["strong_scaling"]["value"] == d["value"]
+    assert d["weak_scaling"]["global_batch"] == 256 and d["weak_scaling"]["rows_per_rank"] == 128
+    assert d["weak_scaling"]["replicas_identical"] and d["single_gpu_bs1024"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_the_contract_objects():
+    """The driver's N = 1 command: one JSON line with the median-of-repeats protocol, the latency-bound roofline with the
+    per-launch event times, the 4096 GEMM roofline, config C's whole step, the drop-in API paths, the strong-scaling
+    N = 1 point (= `--workload A --rows 1024`), the parity check against the reference fixture and both CPU legs."""
+    import json
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["global_batch"] == 128
+    assert "configs[1]" in d["config"]["workload"] and d["exit_code"] == 0
+    t = d["timing"]
+    assert t["min_ms_per_step"] <= d["ms_per_step"] <= t["max_ms_per_step"] and t["timed_ms_per_repeat"] >= 45.0
+    roof = d["roofline"]
+    assert roof["bound"] == "latency" and roof["launches_per_step"] == len(roof["per_launch_us"]) and 0 < roof["frac"] <= 1
+    assert roof["gemm_frac"] > 0 and d["roofline_gemm4096"]["bound"] == "mfma" and d["roofline_gemm4096"]["frac"] > 0.5
+    assert d["parity_vs_reference_fixture"]["ok"] and "traj_A_adam" in d["parity_vs_reference_fixture"]["fixture"]
+    assert d["paths"]["ops_eager"]["value"] > 0 and d["paths"]["ops_graph"]["value"] > d["paths"]["ops_eager"]["value"]
+    assert d["config_C"]["value"] > 0 and d["strong_scaling"]["global_batch"] == 1024
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["single_thread"]["cores"] == 1 and cpu["cpu_model"]
+    # `--workload A --rows 1024` is the same measurement as the strong-scaling N = 1 point
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
+                         "--rows", "1024", "--no-extras"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.strip()][0])
+    assert d2["config"]["global_batch"] == 1024
+    assert abs(d2["value"] / d["strong_scaling"]["value"] - 1.0) < 0.1

@@ -110,6 +110,7 @@ _SIGNATURES = {
     "tnn_mlp_update": [_p],
     "tnn_mlp_step": [_p, _p, _p, c_int64, _p],
     "tnn_mlp_step_sharded": [_p, _p, _p, c_int64, _p],
+    "tnn_mlp_launch_window": [_p, c_int, c_int, POINTER(c_int)],
     "tnn_mlp_sync_params": [_p],
     "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
     "tnn_comm_unique_id": [_p],

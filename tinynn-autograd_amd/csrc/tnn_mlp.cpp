@@ -56,12 +56,22 @@ struct Mlp {
     std::vector<void*> actT16;       // act[l]^T [w[l+1], max_rows]   (dW operand of layer l+1)
     std::vector<void*> dactT16;      // dact[l]^T [w[l+1], max_rows]  (dW operand of layer l)
     void* xT16 = nullptr;            // x^T [w[0], max_rows]
+    // measurement hook (tnn_mlp_launch_window): primitive calls of a step are numbered 0, 1, ... in issue order and only
+    // those inside [win_lo, win_hi) are executed, so each launch of the step can be replayed and timed on its own
+    int win_lo = 0, win_hi = 1 << 30, call_idx = 0;
 };
 
 #define MLP_TRY(call)            \
     do {                         \
         int rc__ = (call);       \
         if (rc__) return rc__;   \
+    } while (0)
+
+// one primitive call (= one launch for the MNIST-size step) of a training step, subject to the launch window
+#define STEP_CALL(h, call)                                              \
+    do {                                                                \
+        const int idx__ = (h)->call_idx++;                              \
+        if (idx__ >= (h)->win_lo && idx__ < (h)->win_hi) MLP_TRY(call); \
     } while (0)
 
 inline void* at(char* base, int64_t elem_off, size_t esz) { return base + elem_off * (int64_t)esz; }
@@ -71,11 +81,11 @@ int mlp_forward(Mlp* h, const void* x, int64_t rows, int n_layers = -1) {
     if (n_layers < 0) n_layers = h->L;
     for (int l = 0; l < n_layers; ++l) {
         bool hidden = l < h->L - 1;
-        MLP_TRY(tnn_gemm_bias_act(0, 0, rows, h->w[l + 1], h->w[l], in, h->w[l],
-                                  at(h->params, h->w_off[l], h->esz), h->w[l + 1],
-                                  at(h->params, h->b_off[l], h->esz),
-                                  hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, h->act[l],
-                                  h->w[l + 1], h->dtype));
+        STEP_CALL(h, tnn_gemm_bias_act(0, 0, rows, h->w[l + 1], h->w[l], in, h->w[l],
+                                       at(h->params, h->w_off[l], h->esz), h->w[l + 1],
+                                       at(h->params, h->b_off[l], h->esz),
+                                       hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, h->act[l],
+                                       h->w[l + 1], h->dtype));
         in = h->act[l];
     }
     return 0;
@@ -96,9 +106,9 @@ int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1
     for (int l = from_layer; l >= to_layer; --l) {
         const void* in = l == 0 ? x : h->act[l - 1];
         // dW_l = in^T d, db_l = column-sum d, dZ_{l-1} = (d W_l^T) * [z_{l-1} >= 0]  — one launch per layer
-        MLP_TRY(tnn_dense_bwd(rows, h->w[l], h->w[l + 1], in, h->dact[l], at(h->params, h->w_off[l], h->esz),
-                              at(h->grads, h->w_off[l], h->esz), at(h->grads, h->b_off[l], h->esz),
-                              l > 0 ? h->dact[l - 1] : nullptr, l > 0 ? h->act[l - 1] : nullptr, h->dtype));
+        STEP_CALL(h, tnn_dense_bwd(rows, h->w[l], h->w[l + 1], in, h->dact[l], at(h->params, h->w_off[l], h->esz),
+                                   at(h->grads, h->w_off[l], h->esz), at(h->grads, h->b_off[l], h->esz),
+                                   l > 0 ? h->dact[l - 1] : nullptr, l > 0 ? h->act[l - 1] : nullptr, h->dtype));
         if (h->bucket_comm) MLP_TRY(allreduce_layer_bucket(h, l));
     }
     return 0;
@@ -363,8 +373,8 @@ int tnn_mlp_forward_stats(void* handle, const void* x, int64_t rows, void* stats
     if (h->bf16) return mlp16_forward(h, x, rows);
     MLP_TRY(mlp_forward(h, x, rows));
     if (h->loss_kind == 0)
-        MLP_TRY(tnn_softmax_nll_stats(h->act[h->L - 1], rows, h->w[h->L], stats ? stats : h->stats,
-                                      h->dtype));
+        STEP_CALL(h, tnn_softmax_nll_stats(h->act[h->L - 1], rows, h->w[h->L], stats ? stats : h->stats,
+                                           h->dtype));
     return 0;
 }
 
@@ -376,11 +386,11 @@ int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, i
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
     if (h->loss_kind == 0)
-        MLP_TRY(tnn_softmax_nll_fwd_bwd(h->act[L - 1], y, rows, h->w[L], m_global,
-                                        stats ? stats : h->stats, loss_slot, h->dact[L - 1], h->dtype));
+        STEP_CALL(h, tnn_softmax_nll_fwd_bwd(h->act[L - 1], y, rows, h->w[L], m_global,
+                                             stats ? stats : h->stats, loss_slot, h->dact[L - 1], h->dtype));
     else
-        MLP_TRY(tnn_mse_fwd_bwd(h->act[L - 1], y, rows * h->w[L], m_global, loss_slot, h->dact[L - 1],
-                                h->dtype));
+        STEP_CALL(h, tnn_mse_fwd_bwd(h->act[L - 1], y, rows * h->w[L], m_global, loss_slot, h->dact[L - 1],
+                                     h->dtype));
     MLP_TRY(mlp_backward_layers(h, x, rows));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;
@@ -390,17 +400,21 @@ int tnn_mlp_update(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) { tnn::set_error("tnn_mlp_update: NULL handle"); return 2; }
     if (h->bf16) return mlp16_update(h);
-    if (h->opt_kind == 0) return tnn_sgd(h->params, h->grads, h->n_params, h->lr, h->dtype);
-    if (h->opt_kind >= 2)   // Momentum / RMSProp / Adagrad / Adadelta: m, v are the two state vectors; b1, b2 = a, b
-        return tnn_optim_step(h->opt_kind - 2, h->params, h->grads, h->m, h->v, nullptr, h->n_params, h->lr, h->b1,
-                              h->b2, h->eps, h->dtype);
-    return tnn_adam(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps,
-                    h->pows, nullptr, h->dtype);
+    if (h->opt_kind == 0)
+        STEP_CALL(h, tnn_sgd(h->params, h->grads, h->n_params, h->lr, h->dtype));
+    else if (h->opt_kind >= 2)   // Momentum / RMSProp / Adagrad / Adadelta: m, v are the two state vectors; b1, b2 = a, b
+        STEP_CALL(h, tnn_optim_step(h->opt_kind - 2, h->params, h->grads, h->m, h->v, nullptr, h->n_params, h->lr,
+                                    h->b1, h->b2, h->eps, h->dtype));
+    else
+        STEP_CALL(h, tnn_adam(h->params, h->grads, h->m, h->v, h->n_params, h->lr, h->b1, h->b2, h->eps,
+                              h->pows, nullptr, h->dtype));
+    return 0;
 }
 
 int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void* loss_out) {
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_step"));
+    h->call_idx = 0;
     if (h->loss_kind != 0) {
         MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
         MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows, nullptr, loss_out));
@@ -415,28 +429,30 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward, the last launch of which also
         // carries the optimizer
         MLP_TRY(mlp_forward(h, x, rows));
-        MLP_TRY(tnn_softmax_nll_fused_tick(h->act[L - 1], y, rows, h->w[L], rows, 0, h->stats, loss_dst,
-                                           h->dact[L - 1], h->dtype, h->pows, h->b1, h->b2));
+        STEP_CALL(h, tnn_softmax_nll_fused_tick(h->act[L - 1], y, rows, h->w[L], rows, 0, h->stats, loss_dst,
+                                                h->dact[L - 1], h->dtype, h->pows, h->b1, h->b2));
         // backward of layers L-1 .. 1, then the first layer's backward with the whole Adam step folded into its
         // launch (its own W / b in the dW epilogue, every other layer's parameters by trailing blocks): 7 launches
         MLP_TRY(mlp_backward_layers(h, x, rows, -1, 1));
         const int64_t rest = L > 1 ? h->w_off[1] : h->n_params;
-        return tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
-                                        at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
-                                        at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
-                                        at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
-                                        at(h->v, h->b_off[0], h->esz), at(h->params, rest, h->esz),
-                                        at(h->grads, rest, h->esz), at(h->m, rest, h->esz), at(h->v, rest, h->esz),
-                                        h->n_params - rest, h->lr, h->b1, h->b2, h->eps, h->pows, h->dtype);
+        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
+                                              at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
+                                              at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
+                                              at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
+                                              at(h->v, h->b_off[0], h->esz), at(h->params, rest, h->esz),
+                                              at(h->grads, rest, h->esz), at(h->m, rest, h->esz),
+                                              at(h->v, rest, h->esz), h->n_params - rest, h->lr, h->b1, h->b2, h->eps,
+                                              h->pows, h->dtype));
+        return 0;
     }
     // hidden layers forward; then the classifier head (last Dense forward + loss + its backward, one launch when
     // TNN_HEAD_FUSION is set); then one launch per remaining layer backward; then the optimizer
     MLP_TRY(mlp_forward(h, x, rows, L - 1));
-    MLP_TRY(tnn_mlp_head(rows, h->w[L - 1], h->w[L], L > 1 ? h->act[L - 2] : x,
-                         at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
-                         h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
-                         at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
-                         L > 1 ? h->dact[L - 2] : nullptr, h->dtype));
+    STEP_CALL(h, tnn_mlp_head(rows, h->w[L - 1], h->w[L], L > 1 ? h->act[L - 2] : x,
+                              at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
+                              h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
+                              at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                              L > 1 ? h->dact[L - 2] : nullptr, h->dtype));
     MLP_TRY(mlp_backward_layers(h, x, rows, L - 2));
     return tnn_mlp_update(handle);
 }
@@ -504,6 +520,19 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
     MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->bf16 ? TNN_F32 : h->dtype, TNN_RSUM));
     MLP_TRY(tnn_mlp_update(handle));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
+    return 0;
+}
+
+int tnn_mlp_launch_window(void* handle, int first, int count, int* calls_in_last_step) {
+    // Measurement hook: from now on tnn_mlp_step executes only its primitive calls number [first, first + count) (in
+    // issue order, one launch each for the MNIST-size step); count < 0 restores the whole step.  While a window is set
+    // only tnn_mlp_step may be called on this handle.  calls_in_last_step: how many primitive calls the last
+    // tnn_mlp_step went through (executed or skipped) = launches per step.
+    Mlp* h = (Mlp*)handle;
+    if (!h || (count >= 0 && first < 0)) { tnn::set_error("tnn_mlp_launch_window: bad arguments"); return 2; }
+    if (calls_in_last_step) *calls_in_last_step = h->call_idx;
+    h->win_lo = count < 0 ? 0 : first;
+    h->win_hi = count < 0 ? (1 << 30) : first + count;
     return 0;
 }
 
