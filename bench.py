@@ -530,7 +530,7 @@ def measure(clock, runner, warmup, steps, repeats, min_ms, rows_global):
     nb = runner.n_batches
     span = lambda r: (warmup + r * steps + nb - 1) // nb * nb           # noqa: E731  chunk-aligned stride per repeat
     pilot, _ = clock.timed(runner, 0, warmup, steps)
-    R = max(1, int(math.ceil(min_ms * 1e-3 / max(pilot, 1e-9))))
+    R = max(1, int(math.ceil(1.25 * min_ms * 1e-3 / max(pilot, 1e-9))))   # the pilot pays one-off costs: margin
     R = min(R, 4096)
     first = span(1)
     per_step, last = [], None

@@ -366,6 +366,11 @@ TNN_API int tnn_p2p_tune(int allreduce_blocks);
 TNN_API int tnn_p2p_enable(int on);                         /* route eligible collectives here (default after connect) */
 /* dead != 0: a barrier timed out (TNN_P2P_TIMEOUT_MS, default 20000) - results since then are invalid; synchronises */
 TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);
+/* *failed = 1 once a peer barrier has timed out (host-pinned mirror of the sticky device word: NO stream
+ * synchronisation, cheap enough to call before every step / graph replay).  From that moment every collective on the
+ * transport — the one that timed out, later launches, captured graph replays — is discarded on the device (buffers,
+ * parameters and optimizer state keep their previous contents) and every host call into it returns an error. */
+TNN_API int tnn_p2p_poll_failed(int* failed);
 TNN_API int tnn_p2p_destroy(void);
 
 #ifdef __cplusplus

@@ -706,8 +706,26 @@ int tnn_adam_master_bf16_2d(void*, const void*, void*, void*, void*, void*, int6
     NO_BF16("tnn_adam_master_bf16_2d");
 }
 
-// ---- comm: single-process identity (multi-process CPU tests use gloo at the Python layer) ----
+// ---- comm: single-process identity by default.  Multi-process CPU tests either use gloo at the Python layer
+// (GlooCommunicator) or — to run the product's own C++ data-parallel step (tnn_mlp_step_sharded: bucketing, per-layer
+// Adam order, loss slot) at world > 1 without a GPU — install two host callbacks here (tnn_twin_set_collectives, TWIN ONLY,
+// not part of include/tnn_hip.h): the twin's "device" memory is host memory, so the test's callbacks run the collective
+// over torch.distributed/gloo in place.
 static int g_comm = 0;
+typedef int (*twin_allreduce_fn)(void* buf, int64_t n, int dtype, int rop);
+typedef int (*twin_allgather_fn)(const void* send, void* recv, int64_t n_per_rank, int dtype);
+static twin_allreduce_fn g_hook_allreduce = nullptr;
+static twin_allgather_fn g_hook_allgather = nullptr;
+static int g_hook_rank = 0, g_hook_world = 1;
+int tnn_twin_set_collectives(int rank, int world, twin_allreduce_fn ar, twin_allgather_fn ag) {
+    REQ(world >= 1 && rank >= 0 && rank < world, "tnn_twin_set_collectives: rank %d / world %d", rank, world);
+    g_hook_allreduce = ar;
+    g_hook_allgather = ag;
+    g_hook_rank = ar ? rank : 0;
+    g_hook_world = ar ? world : 1;
+    g_comm = ar ? 1 : 0;
+    return 0;
+}
 int tnn_comm_unique_id(void* id) { memset(id, 0, 128); return 0; }
 int tnn_comm_init(int rank, int world, const void*) {
     REQ(world == 1 && rank == 0, "cpu twin: tnn_comm supports world size 1 only");
@@ -715,13 +733,23 @@ int tnn_comm_init(int rank, int world, const void*) {
     return 0;
 }
 int tnn_comm_destroy(void) { g_comm = 0; return 0; }
-int tnn_comm_world(int* r, int* w) { if (r) *r = 0; if (w) *w = 1; return 0; }
-int tnn_allreduce(void*, int64_t, int, int) { REQ(g_comm, "tnn_allreduce: tnn_comm_init() has not been called"); return 0; }
+int tnn_comm_world(int* r, int* w) { if (r) *r = g_hook_rank; if (w) *w = g_hook_world; return 0; }
+int tnn_allreduce(void* buf, int64_t n, int dtype, int rop) {
+    REQ(g_comm, "tnn_allreduce: tnn_comm_init() has not been called");
+    if (g_hook_allreduce && n > 0) {
+        REQ(g_hook_allreduce(buf, n, dtype, rop) == 0, "tnn_allreduce: the test's collective callback failed");
+    }
+    return 0;
+}
 int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) { return tnn_allreduce(buf, n, dtype, rop); }
 int tnn_comm_join(void) { return 0; }
 int tnn_comm_wait_oldest(void) { return 0; }
 int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
     REQ(g_comm, "tnn_allgather: tnn_comm_init() has not been called");
+    if (g_hook_allgather) {
+        REQ(g_hook_allgather(s, r, n, dtype) == 0, "tnn_allgather: the test's collective callback failed");
+        return 0;
+    }
     memmove(r, s, (size_t)n * dsize(dtype));
     return 0;
 }
@@ -756,7 +784,13 @@ int tnn_p2p_create(int rank, int world, int64_t, void* h) {
 int tnn_p2p_connect(const void*) { g_comm = 1; return 0; }
 int tnn_p2p_enable(int) { return 0; }
 int tnn_p2p_tune(int) { return 0; }
-int tnn_p2p_status(int* c, int* e, int* d) { if (c) *c = g_comm; if (e) *e = g_comm; if (d) *d = 0; return 0; }
+int tnn_p2p_status(int* c, int* e, int* d) {
+    // with the collective callbacks installed there is no peer-to-peer transport: the step takes the RCCL-shaped path
+    const int on = g_comm && !g_hook_allreduce;
+    if (c) *c = on; if (e) *e = on; if (d) *d = 0;
+    return 0;
+}
+int tnn_p2p_poll_failed(int* f) { if (f) *f = 0; return 0; }
 int tnn_p2p_destroy(void) { g_comm = 0; return 0; }
 
 }  // extern "C"

@@ -56,19 +56,40 @@ def main():
     want = np.float32(sum(1.0 + r for r in range(world))) / np.float32(world)
     np.testing.assert_allclose(np.asarray(buf), want, rtol=1e-5)
     comm.barrier()
-    # a peer that never shows up must not hang the GPU: rank 0 alone enters one more all-reduce, its barrier times
-    # out (TNN_P2P_TIMEOUT_MS), the kernel finishes and the sticky `dead` word reports it
+    # a peer that never shows up must not hang the GPU and must not corrupt training: rank 0 alone enters one more
+    # sharded training step (loss exchange + all-reduce with the Adam tail).  Its barriers time out (TNN_P2P_TIMEOUT_MS),
+    # the kernels finish, the sticky `dead` word and its host mirror report it — and parameters, Adam moments and the
+    # beta powers' consumers are left exactly as they were (partial sums are never applied).
     if os.environ.get("TNN_P2P_TEST_TIMEOUT") == "1":
+        from tinynn_autograd_amd import _lib
+        from tinynn_autograd_amd.dist import PeerTimeout
         if rank == 0:
             import time
+            before = [np.asarray(a).copy() for a in (trainer.params, trainer.adam_m, trainer.adam_v)]
+            x, y = data[0]
             t0 = time.time()
-            comm.allreduce(buf)
-            st = comm.p2p_status()
-            assert st["dead"], "timeout was not reported"
+            trainer.step(tn.asarray(x[sl]), tn.asarray(y[sl]))
+            st = comm.p2p_status()                   # synchronises the stream
+            assert st["dead"] and comm.p2p_failed(), "timeout was not reported"
             assert time.time() - t0 < 10.0
-            comm.allreduce(buf)                      # later launches no longer wait at all
-            assert comm.p2p_status()["dead"]
-        comm.barrier()
+            after = [np.asarray(a) for a in (trainer.params, trainer.adam_m, trainer.adam_v)]
+            assert all(np.array_equal(a, b) for a, b in zip(before, after)), "a timed-out step changed parameters / Adam state"
+            for call in (lambda: comm.allreduce(buf), lambda: trainer.step(tn.asarray(x[sl]), tn.asarray(y[sl])),
+                         lambda: graph.launch()):
+                try:                                 # later calls into the dead transport fail loudly
+                    call()
+                    raise AssertionError("a call into the dead transport must raise")
+                except (_lib.TnnError, PeerTimeout):
+                    pass
+            after = [np.asarray(a) for a in (trainer.params, trainer.adam_m, trainer.adam_v)]
+            assert all(np.array_equal(a, b) for a, b in zip(before, after))
+        # barrier() mirrors the dead word collectively: EVERY rank learns of it, the transport goes off everywhere
+        try:
+            comm.barrier()
+            raise AssertionError("barrier() must raise PeerTimeout on every rank after a timeout on any rank")
+        except PeerTimeout:
+            pass
+        assert not comm.p2p_status()["enabled"]
     comm.close()
     print("p2p_worker rank %d/%d ok" % (rank, world))
 

@@ -129,6 +129,7 @@ _SIGNATURES = {
     "tnn_p2p_enable": [c_int],
     "tnn_p2p_tune": [c_int],
     "tnn_p2p_status": [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+    "tnn_p2p_poll_failed": [POINTER(c_int)],
     "tnn_p2p_destroy": [],
 }
 

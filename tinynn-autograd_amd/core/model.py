@@ -107,7 +107,20 @@ class Model(object):
         all_grads = [{k: p.grad for k, p in layer.items()} for layer in params]
 
         if self.comm is not None and self.comm.world > 1:
-            if self._grad_arena is not None:
+            # ONE collective over the flat arena only when every gradient really lives there; a gradient that was
+            # assigned from outside (`p.grad = ...`, clipping that replaces the array) is first copied home, and a
+            # parameter without a gradient keeps the per-tensor loop — never reduce stale arena bytes in its place
+            at_home = self._grad_arena is not None
+            if at_home:
+                for t in self._arena_tensors:
+                    if t._grad is None:
+                        at_home = False
+                        break
+                    if t._grad is not t._grad_home:
+                        t._grad_home[...] = t._grad
+                        t._grad, t._grad_shared, t._grad_zero = t._grad_home, False, False
+            if at_home:
+                all_grads = [{k: p.grad for k, p in layer.items()} for layer in params]
                 self.comm.allreduce(self._grad_arena)
             else:
                 for layer in all_grads:

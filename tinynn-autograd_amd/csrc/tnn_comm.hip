@@ -33,7 +33,27 @@ struct Rccl {
 };
 Rccl R;
 hipStream_t g_comm_stream = nullptr;            // bucketed all-reduces run here (tnn_allreduce_async)
-std::vector<hipEvent_t>* g_pending = nullptr;       // their "bucket done" events not yet joined
+// "bucket done" events not yet joined, oldest first.  One data-parallel step issues and joins all of its own buckets
+// inside ONE C call (tnn_mlp_step_sharded; its error paths drain through tnn_comm_join), so the list is empty between
+// steps and trainers cannot pick up each other's events.  Events are recycled through g_event_pool: none is created or
+// destroyed per bucket once the pool has warmed up.
+std::vector<hipEvent_t>* g_pending = nullptr;
+std::vector<hipEvent_t>* g_event_pool = nullptr;
+
+int take_event(hipEvent_t* e) {
+    if (g_event_pool && !g_event_pool->empty()) {
+        *e = g_event_pool->back();
+        g_event_pool->pop_back();
+        return 0;
+    }
+    TNN_CHECK_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return 0;
+}
+void give_event(hipEvent_t e) {
+    // re-recording an event later does not disturb waits already enqueued on its previous recording
+    if (!g_event_pool) g_event_pool = new std::vector<hipEvent_t>();
+    g_event_pool->push_back(e);
+}
 
 int load_rccl() {
     if (R.so) return 0;
@@ -110,6 +130,10 @@ int tnn_comm_destroy(void) {
         if (g_pending) {
             for (hipEvent_t e : *g_pending) (void)hipEventDestroy(e);
             g_pending->clear();
+        }
+        if (g_event_pool) {
+            for (hipEvent_t e : *g_event_pool) (void)hipEventDestroy(e);
+            g_event_pool->clear();
         }
         (void)hipStreamDestroy(g_comm_stream);
         g_comm_stream = nullptr;
@@ -189,14 +213,27 @@ int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) {
         g_pending = new std::vector<hipEvent_t>();
     }
     hipEvent_t produced, done;
-    TNN_CHECK_HIP(hipEventCreateWithFlags(&produced, hipEventDisableTiming));
-    TNN_CHECK_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    TNN_CHECK_HIP(hipEventRecord(produced, tnn::stream()));
-    TNN_CHECK_HIP(hipStreamWaitEvent(g_comm_stream, produced, 0));
-    TNN_CHECK_NCCL(R.AllReduce(buf, buf, (size_t)n, t, ncclSum, R.comm, g_comm_stream));
-    TNN_CHECK_HIP(hipEventRecord(done, g_comm_stream));
+    if (int rc = take_event(&produced)) return rc;
+    if (int rc = take_event(&done)) { give_event(produced); return rc; }
+    const auto fail = [&](void) { give_event(produced); give_event(done); return 1; };
+    if (hipEventRecord(produced, tnn::stream()) != hipSuccess ||
+        hipStreamWaitEvent(g_comm_stream, produced, 0) != hipSuccess) {
+        tnn::set_error("tnn_allreduce_async: ordering the communication stream behind the producer failed");
+        return fail();
+    }
+    give_event(produced);
+    const ncclResult_t r = R.AllReduce(buf, buf, (size_t)n, t, ncclSum, R.comm, g_comm_stream);
+    if (r != ncclSuccess) {
+        tnn::set_error("ncclAllReduce (bucket of %lld) -> %s", (long long)n, R.GetErrorString ? R.GetErrorString(r) : "?");
+        give_event(done);
+        return 1;
+    }
+    if (hipEventRecord(done, g_comm_stream) != hipSuccess) {
+        tnn::set_error("tnn_allreduce_async: recording the bucket-done event failed");
+        give_event(done);
+        return 1;
+    }
     g_pending->push_back(done);
-    (void)hipEventDestroy(produced);                    // released once the recorded work has completed
     return 0;
 }
 
@@ -205,19 +242,24 @@ int tnn_comm_wait_oldest(void) {
     if (!g_pending || g_pending->empty()) return 0;
     hipEvent_t e = g_pending->front();
     g_pending->erase(g_pending->begin());
-    TNN_CHECK_HIP(hipStreamWaitEvent(tnn::stream(), e, 0));
-    (void)hipEventDestroy(e);
+    const hipError_t st = hipStreamWaitEvent(tnn::stream(), e, 0);
+    give_event(e);
+    TNN_CHECK_HIP(st);
     return 0;
 }
 
 int tnn_comm_join(void) {
     TNN_NEED_INIT();
     if (!g_pending) return 0;
+    // also the drain of every error path between the first bucket and the optimizer: nothing stays behind
+    hipError_t first_error = hipSuccess;
     for (hipEvent_t e : *g_pending) {
-        TNN_CHECK_HIP(hipStreamWaitEvent(tnn::stream(), e, 0));
-        (void)hipEventDestroy(e);
+        const hipError_t st = hipStreamWaitEvent(tnn::stream(), e, 0);
+        if (first_error == hipSuccess) first_error = st;
+        give_event(e);
     }
     g_pending->clear();
+    TNN_CHECK_HIP(first_error);
     return 0;
 }
 

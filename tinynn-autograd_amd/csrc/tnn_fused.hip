@@ -650,6 +650,7 @@ int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t 
         TNN_REQUIRE(dtype == TNN_F32, "tnn_softmax_nll_fused_tick: the sharded form is f32 only (dtype %d)", dtype);
         TNN_REQUIRE(m_global >= m, "tnn_softmax_nll_fused_tick: m_global < m");
         tnn::p2p::LaunchCtx ctx;
+        if (int rc = tnn::p2p_refuse_if_failed("tnn_softmax_nll_fused_tick")) return rc;
         TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_softmax_nll_fused_tick: the peer-to-peer transport is not enabled");
         if (rows_kernel)
             hipLaunchKernelGGL((nll_rows_kernel<float, true>), 1, row_threads, 0, tnn::stream(), (const float*)z,

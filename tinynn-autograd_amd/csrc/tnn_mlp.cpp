@@ -36,7 +36,6 @@ struct Mlp {
     std::vector<int64_t> w;          // widths, L+1
     int64_t max_rows = 0;
     int loss_kind = 0, opt_kind = 0, dtype = TNN_F32;
-    bool bucket_comm = false;        // data-parallel step of a large net: all-reduce each layer's gradients as they appear
     double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-8;
     int64_t n_params = 0, arena = 0;
     size_t esz = 4;
@@ -101,7 +100,8 @@ int allreduce_layer_bucket(Mlp* h, int l) {
 }
 
 // gradients of every layer from dact[L-1] (set by the loss kernel) down to layer 0
-int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1, int to_layer = 0) {
+// bucket: data-parallel step of a large net — all-reduce each layer's gradients as soon as they are enqueued
+int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1, int to_layer = 0, bool bucket = false) {
     if (from_layer < 0) from_layer = h->L - 1;
     for (int l = from_layer; l >= to_layer; --l) {
         const void* in = l == 0 ? x : h->act[l - 1];
@@ -109,7 +109,7 @@ int mlp_backward_layers(Mlp* h, const void* x, int64_t rows, int from_layer = -1
         STEP_CALL(h, tnn_dense_bwd(rows, h->w[l], h->w[l + 1], in, h->dact[l], at(h->params, h->w_off[l], h->esz),
                                    at(h->grads, h->w_off[l], h->esz), at(h->grads, h->b_off[l], h->esz),
                                    l > 0 ? h->dact[l - 1] : nullptr, l > 0 ? h->act[l - 1] : nullptr, h->dtype));
-        if (h->bucket_comm) MLP_TRY(allreduce_layer_bucket(h, l));
+        if (bucket) MLP_TRY(allreduce_layer_bucket(h, l));
     }
     return 0;
 }
@@ -137,7 +137,8 @@ int mlp16_forward(Mlp* h, const void* x16, int64_t rows) {
     return 0;
 }
 
-int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64_t m_global, void* loss_out) {
+int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64_t m_global, void* loss_out,
+                   bool bucket = false) {
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, 4);
     if (h->loss_kind != 1) {
@@ -155,7 +156,7 @@ int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64
                                  at(h->grads, h->w_off[l], 4), h->w[l + 1], TNN_F32, nullptr, TNN_ACT_NONE, 0,
                                  nullptr, 0));
         MLP_TRY(tnn_colsum_bf16(h->dact[l], at(h->grads, h->b_off[l], 4), rows, h->w[l + 1]));
-        if (h->bucket_comm) MLP_TRY(allreduce_layer_bucket(h, l));
+        if (bucket) MLP_TRY(allreduce_layer_bucket(h, l));
         // dz_{l-1} = (dz_l W_l^T) * mask : A = dz_l [rows, out] (K = out), B = W_l [in, out]
         if (l > 0)
             MLP_TRY(tnn_gemm_bf16_nt(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, h->w_off[l]),
@@ -378,11 +379,10 @@ int tnn_mlp_forward_stats(void* handle, const void* x, int64_t rows, void* stats
     return 0;
 }
 
-int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, int64_t m_global,
-                     const void* stats, void* loss_out) {
-    Mlp* h = (Mlp*)handle;
+static int mlp_backward_impl(Mlp* h, const void* x, const void* y, int64_t rows, int64_t m_global,
+                             const void* stats, void* loss_out, bool bucket) {
     MLP_TRY(check_rows(h, rows, "tnn_mlp_backward"));
-    if (h->bf16) return mlp16_backward(h, x, y, rows, m_global, loss_out);
+    if (h->bf16) return mlp16_backward(h, x, y, rows, m_global, loss_out, bucket);
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
     if (h->loss_kind == 0)
@@ -391,9 +391,14 @@ int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, i
     else
         STEP_CALL(h, tnn_mse_fwd_bwd(h->act[L - 1], y, rows * h->w[L], m_global, loss_slot, h->dact[L - 1],
                                      h->dtype));
-    MLP_TRY(mlp_backward_layers(h, x, rows));
+    MLP_TRY(mlp_backward_layers(h, x, rows, -1, 0, bucket));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;
+}
+
+int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, int64_t m_global,
+                     const void* stats, void* loss_out) {
+    return mlp_backward_impl((Mlp*)handle, x, y, rows, m_global, stats, loss_out, false);
 }
 
 int tnn_mlp_update(void* handle) {
@@ -493,17 +498,20 @@ int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t row
     }
     // large arenas (config C: 134 MB, config E: 1 GB of fp32 gradients): one all-reduce per layer, issued to the
     // communication stream right behind that layer's backward launch, overlapping the remaining backward
-    if ((size_t)(h->n_params + 1) * h->esz > ((size_t)4 << 20)) {
-        h->bucket_comm = true;
-        const int rc = tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr);
-        h->bucket_comm = false;
-        if (rc) return rc;
+    // (TNN_BUCKET_BYTES moves the switch-over point; default 4 MiB — below it the arena is one latency-bound message)
+    static const size_t bucket_bytes = getenv("TNN_BUCKET_BYTES") ? (size_t)atoll(getenv("TNN_BUCKET_BYTES")) : ((size_t)4 << 20);
+    if ((size_t)(h->n_params + 1) * h->esz > bucket_bytes) {
+        // any failure from here to the optimizer drains the bucket events already issued (tnn_comm_join) before the
+        // error is returned, so the next step never waits on this one's leftovers
+        int rc = mlp_backward_impl(h, x, y, rows, rows * world, h->stats, nullptr, true);
+        if (rc) { (void)tnn_comm_join(); return rc; }
         if (h->opt_kind == 1) {
             // Adam layer by layer in bucket order (last layer first): layer l's update starts when ITS bucket has
             // landed, while the earlier layers' buckets are still on the links
             for (int l = h->L - 1; l >= 0; --l) {
-                MLP_TRY(tnn_comm_wait_oldest());
-                MLP_TRY(adam_layer(h, l, l == h->L - 1, l == h->L - 1 ? loss_out : nullptr));
+                rc = tnn_comm_wait_oldest();
+                if (!rc) rc = adam_layer(h, l, l == h->L - 1, l == h->L - 1 ? loss_out : nullptr);
+                if (rc) { (void)tnn_comm_join(); return rc; }
             }
             return 0;
         }

@@ -31,7 +31,16 @@ struct Peers {
     char* base[MAXW];                             // every rank's region in THIS process' address space
     int rank, world;
     int64_t slice_cap;                            // floats per slice the regions were sized for
+    int* dead_host;                               // host-pinned mirror of the sticky `dead` word (device-visible address):
+                                                  // written once when a barrier times out, read by the host WITHOUT a sync
 };
+
+// A barrier timed out: the sticky device word stops every later wait, the host mirror lets the next host-side call fail
+// loudly (tnn_p2p.hip: p2p_failed) instead of running on partial sums.
+__device__ __forceinline__ void mark_dead(const Peers& p, int* dead) {
+    __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.dead_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct LaunchCtx {                                // what a kernel embedding an exchange needs
     Peers peers;
@@ -56,11 +65,15 @@ __device__ __forceinline__ float* out_of(const Peers& p, int who) {
 // An agent-scope acquire after the meeting (`buffer_inv sc1`) was measured too: +6 us per all-reduce at 64
 // workgroups.  Instead every load of peer-written data carries sc0 sc1 itself (load_sys below), so it cannot be served
 // from a vector-L1 or L2 line whatever the page's cache policy turns out to be.
-__device__ __forceinline__ void exchange_flags(const Peers& p, size_t word_offset_bytes, uint32_t val, int* dead,
+// Returns true (uniformly over the workgroup) when every peer's signal arrived; false when this barrier timed out or
+// the transport was already dead — the caller must then NOT consume peer data (no reduction, no copy-out, no optimizer
+// update: buffers and parameters stay untouched).
+__device__ __forceinline__ bool exchange_flags(const Peers& p, size_t word_offset_bytes, uint32_t val, int* dead,
                                                int64_t timeout_ticks) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int t = threadIdx.x;
+    int failed = 0;
     if (t < p.world) {
         uint32_t* theirs = reinterpret_cast<uint32_t*>(p.base[t] + word_offset_bytes) + p.rank;
         __hip_atomic_store(theirs, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -74,15 +87,19 @@ __device__ __forceinline__ void exchange_flags(const Peers& p, size_t word_offse
                     const uint64_t now = wall_clock64();
                     if (t0 == 0) t0 = now;
                     if ((int64_t)(now - t0) > timeout_ticks) {
-                        __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mark_dead(p, dead);
+                        failed = 1;
                         break;
                     }
                 }
             }
+        } else {
+            failed = 1;
         }
     }
-    __syncthreads();
+    failed = __syncthreads_or(failed);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return failed == 0;
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -140,7 +157,7 @@ __device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, fl
             const uint64_t now = wall_clock64();
             if (t0 == 0) t0 = now;
             if ((int64_t)(now - t0) > timeout_ticks) {
-                __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mark_dead(p, dead);
                 break;
             }
         }
@@ -151,6 +168,8 @@ __device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, fl
 }  // namespace p2p
 
 bool p2p_world(int* rank, int* world);                       // false when no peer group exists
+bool p2p_failed();                                           // a peer barrier timed out (host mirror, no stream sync)
+int p2p_refuse_if_failed(const char* who);                   // 0, or 3 + tnn_last_error() once the transport is dead
 bool p2p_can_allreduce(int64_t n, int dtype, int rop);       // enabled, f32 SUM, fits the mapped regions
 int p2p_allreduce(float* buf, int64_t n);
 // all-reduce with Adam applied in the kernel's last stage (pows already advanced); buf[scalar_index] -> *scalar_dst

@@ -18,9 +18,13 @@
 //     reasoning and the measurements).  Flag values grow monotonically from a per-block epoch kept in DEVICE
 //     memory, so the kernel is replayable from a hipGraph with fixed arguments and never needs a reset;
 //   * (C) can carry the optimizer: the reduced gradient is in registers there, so Adam is applied on the spot;
-//   * spins are bounded by the constant 100 MHz clock: on timeout the kernel sets a sticky `dead` word, stops
-//     waiting (this and every later launch) and the host sees it through tnn_p2p_status() — a lost peer is an
-//     error, not a hung GPU.
+//   * spins are bounded by the constant 100 MHz clock: on timeout the kernel sets a sticky `dead` word (device) and
+//     its host-pinned mirror, and from then on NOTHING is consumed: a workgroup whose barrier failed — in this or any
+//     later launch, captured graph replays included — skips the reduction, the copy-out and the optimizer tail, so
+//     the caller's buffer, the parameters and the Adam moments keep their pre-collective contents instead of being
+//     updated from partial sums; the next host-side call into the transport returns an error (p2p_refuse_if_failed
+//     reads the mirror without a stream sync) and tnn_p2p_status() reports it — a lost peer is a loud error, neither
+//     a hung GPU nor silently diverging replicas.
 //
 // Buffer reuse is safe without extra barriers: a rank enters stage A of call k+1 only after barrier 2 of call k,
 // which every peer signals after its last read of recv[]; out[] of call k+1 is written after barrier 1 of call
@@ -42,6 +46,7 @@ struct State {
     void* mapped[MAXW] = {};                      // hipIpcOpenMemHandle results (NULL for self)
     uint32_t* epoch = nullptr;                    // [MAXB + 1] per-block epochs + the all-gather epoch (local, cached)
     int* dead = nullptr;                          // sticky timeout word (local)
+    int* host_dead = nullptr;                     // its host-pinned mirror (hipHostMalloc, mapped): host address
     int64_t max_floats = 0;
     int64_t timeout_ticks = 0;
     int blocks_override = 0;
@@ -113,11 +118,11 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             }
         }
     }
-    exchange_flags(p, offsetof(Header, flag) + (size_t)(0 * MAXB + b) * FLAG_ROW, 2 * e + 1, dead, timeout_ticks);
+    bool ok = exchange_flags(p, offsetof(Header, flag) + (size_t)(0 * MAXB + b) * FLAG_ROW, 2 * e + 1, dead, timeout_ticks);
 
     // (B) reduce my slice in rank order (all W loads in flight, then a fixed-order sum), broadcast the result slice
     const float* mine = recv_of(p, r);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += THREADS) {
+    for (int64_t i = lo + threadIdx.x; ok && i < hi; i += THREADS) {
         f32x4 part[MAXW] = {};
 #pragma unroll
         for (int q = 0; q < MAXW; ++q)
@@ -132,7 +137,12 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             store_sys(out_of(p, q) + (int64_t)r * cap + 4 * i, acc);
         }
     }
-    exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
+    // a workgroup that lost barrier 1 does not signal barrier 2: no peer can then complete this collective either
+    ok = ok && exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
+    if (!ok) {                     // timed out (now or earlier): buf, parameters and moments stay as they were
+        if (threadIdx.x == 0) epoch[b] = e + 1;
+        return;
+    }
 
     // (C) gathered result -> caller's buffer (+ the optimizer update when ADAM)
     const float* res = out_of(p, r);
@@ -225,8 +235,8 @@ __global__ __launch_bounds__(THREADS) void p2p_allgather_kernel(Peers p, const u
         const int q = t / words, w = t % words;
         store_sys(reinterpret_cast<uint32_t*>(p.base[q] + slots + (size_t)r * AG_BYTES) + w, send[w]);
     }
-    exchange_flags(p, offsetof(Header, ag_flag), e + 1, dead, timeout_ticks);
-    for (int t = threadIdx.x; t < W * words; t += THREADS) {
+    const bool ok = exchange_flags(p, offsetof(Header, ag_flag), e + 1, dead, timeout_ticks);
+    for (int t = threadIdx.x; ok && t < W * words; t += THREADS) {
         const int q = t / words, w = t % words;
         uint32_t v[1] = {0u};
         load_sys(v[0], reinterpret_cast<const uint32_t*>(p.base[r] + slots + (size_t)q * AG_BYTES) + w);
@@ -256,11 +266,23 @@ bool p2p_world(int* rank, int* world) {
     return true;
 }
 
+bool p2p_failed() { return S.open && S.host_dead && *(volatile int*)S.host_dead != 0; }
+
+int p2p_refuse_if_failed(const char* who) {
+    if (!p2p_failed()) return 0;
+    tnn::set_error("%s: an xGMI peer-to-peer barrier timed out earlier (a peer was missing for longer than "
+                   "TNN_P2P_TIMEOUT_MS); that collective and every one since was discarded and left buffers and "
+                   "parameters untouched.  Disable the transport on EVERY rank (tnn_p2p_enable(0)) to continue on "
+                   "RCCL, or restart the job", who);
+    return 3;
+}
+
 bool p2p_can_allreduce(int64_t n, int dtype, int rop) {
     return S.enabled && dtype == TNN_F32 && rop == TNN_RSUM && n > 0 && n <= S.max_floats;
 }
 
 static int launch_allreduce(float* buf, int64_t n, const AdamTail* tail) {
+    if (int rc = p2p_refuse_if_failed("tnn_allreduce")) return rc;
     const int W = S.p.world;
     int64_t slice = (n + W - 1) / W;
     slice = (slice + 3) / 4 * 4;
@@ -292,7 +314,7 @@ int p2p_allreduce_adam(float* buf, int64_t n, float* p, float* m, float* v, int6
 }
 
 bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
-    if (!S.enabled) return false;
+    if (!S.enabled || p2p_failed()) return false;
     ctx->peers = S.p;
     ctx->ag_epoch = S.epoch + MAXB;
     ctx->dead = S.dead;
@@ -306,6 +328,7 @@ bool p2p_can_allgather(int64_t n_per_rank, int dtype) {
 }
 
 int p2p_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
+    if (int rc = p2p_refuse_if_failed("tnn_allgather")) return rc;
     const int words = (int)(n_per_rank * esize(dtype) / 4);
     hipLaunchKernelGGL(p2p_allgather_kernel, dim3(1), dim3(THREADS), 0, tnn::stream(), S.p, (const uint32_t*)send,
                        (uint32_t*)recv, words, S.epoch + MAXB, S.dead, S.timeout_ticks);
@@ -334,12 +357,19 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     void* local = nullptr;
     TNN_CHECK_HIP(hipMalloc(&local, (MAXB + 1) * sizeof(uint32_t) + 64));
     TNN_CHECK_HIP(hipMemset(local, 0, (MAXB + 1) * sizeof(uint32_t) + 64));
+    void* host_dead = nullptr;
+    void* host_dead_dev = nullptr;
+    TNN_CHECK_HIP(hipHostMalloc(&host_dead, 64, hipHostMallocMapped));
+    memset(host_dead, 0, 64);
+    TNN_CHECK_HIP(hipHostGetDevicePointer(&host_dead_dev, host_dead, 0));
     TNN_CHECK_HIP(hipDeviceSynchronize());
     hipIpcMemHandle_t h;
     TNN_CHECK_HIP(hipIpcGetMemHandle(&h, region));
     memcpy(handle64, &h, sizeof(h));
     S = State();
     S.own = (char*)region;
+    S.host_dead = (int*)host_dead;
+    S.p.dead_host = (int*)host_dead_dev;
     S.epoch = (uint32_t*)local;
     S.dead = (int*)((char*)local + (MAXB + 1) * sizeof(uint32_t) + 28);
     S.p.rank = rank;
@@ -401,6 +431,12 @@ int tnn_p2p_status(int* connected, int* enabled, int* dead) {
     return 0;
 }
 
+int tnn_p2p_poll_failed(int* failed) {
+    // the host mirror of the sticky word: no stream synchronisation, safe to call before every graph replay
+    if (failed) *failed = tnn::p2p_failed() ? 1 : 0;
+    return 0;
+}
+
 int tnn_p2p_destroy(void) {
     if (!S.open) return 0;
     if (tnn::initialised()) (void)hipStreamSynchronize(tnn::stream());
@@ -408,6 +444,7 @@ int tnn_p2p_destroy(void) {
         if (S.mapped[q]) (void)hipIpcCloseMemHandle(S.mapped[q]);
     (void)hipFree(S.own);
     (void)hipFree(S.epoch);
+    if (S.host_dead) (void)hipHostFree(S.host_dead);
     S = State();
     return 0;
 }

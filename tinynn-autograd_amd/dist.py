@@ -27,6 +27,13 @@ from . import _lib
 from . import device_array as da
 
 
+class PeerTimeout(RuntimeError):
+    """A peer never reached an xGMI peer-to-peer barrier (TNN_P2P_TIMEOUT_MS).  The collective that timed out and every
+    one issued since were DISCARDED on the device: gradient buffers, parameters and optimizer state still hold what
+    they held before it, on every rank that saw the timeout.  The transport has been switched off on all ranks (RCCL
+    carries the collectives from here on, when a communicator exists); redo the step."""
+
+
 class Communicator(object):
     rank = 0
     world = 1
@@ -128,6 +135,35 @@ class DeviceCommunicator(Communicator):
         _lib.get().p2p_status(ctypes.byref(c), ctypes.byref(e), ctypes.byref(d))
         return {"connected": bool(c.value), "enabled": bool(e.value), "dead": bool(d.value)}
 
+    def p2p_failed(self):
+        """True once a peer barrier has timed out — read from the host-pinned mirror of the device's sticky word, no
+        stream synchronisation (the native calls into the transport return errors from then on anyway; this lets a
+        graph-replay loop look before it launches)."""
+        if not self._p2p:
+            return False
+        f = ctypes.c_int(0)
+        _lib.get().p2p_poll_failed(ctypes.byref(f))
+        return bool(f.value)
+
+    def check(self, collective=True):
+        """Mirror the transport's `dead` word to the host at a synchronisation point.  collective=True (every rank
+        calls it — barrier() does): the ranks vote, and if ANY of them saw a timeout the transport is switched off on
+        ALL of them and PeerTimeout is raised everywhere, so replicas cannot go on with different ideas of which
+        transport is live.  collective=False: local look only."""
+        failed = self.p2p_failed()
+        if collective and self.world > 1:
+            dist = _control_plane()
+            if dist is not None:
+                import torch
+                t = torch.tensor([1 if failed else 0])
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                failed = bool(int(t.item()))
+        if failed:
+            self.set_p2p(False)
+            raise PeerTimeout("xGMI peer-to-peer barrier timed out on rank %d or a peer; collectives since then were "
+                              "discarded (parameters untouched); the transport is now off on every rank%s"
+                              % (self.rank, " and RCCL takes over" if self._rccl else " and no RCCL communicator exists"))
+
     def p2p_selftest(self, sizes=(1, 1000, 235147, 65536), rounds=3):
         """All-reduce inputs every rank can reproduce locally (x_r[i] is a function of r and i), so the expected
         sum — float32 adds in rank order, exactly what the kernel does — needs no second transport: the comparison is
@@ -168,6 +204,8 @@ class DeviceCommunicator(Communicator):
         dist = _control_plane()
         if dist is not None:
             dist.barrier()
+        if self._p2p and self._open:
+            self.check(collective=True)
 
     def close(self):
         if getattr(self, "_open", False):

@@ -257,7 +257,14 @@ class StepGraph(object):
         return len(self.batches)
 
     def launch(self):
-        """Run all captured steps (asynchronous); returns the device array of their losses."""
+        """Run all captured steps (asynchronous); returns the device array of their losses.  A data-parallel graph
+        first looks at the peer-to-peer transport's failure word (host-pinned, no sync): captured collectives of a dead
+        transport would only be discarded on the device, so the replay is refused loudly instead."""
+        comm = self.trainer.comm
+        if comm is not None and hasattr(comm, "p2p_failed") and comm.p2p_failed():
+            from .dist import PeerTimeout
+            raise PeerTimeout("refusing to replay a data-parallel step graph: an xGMI peer-to-peer barrier timed out "
+                              "earlier (steps since then were discarded); call comm.check() on every rank")
         self._graph.launch()
         return self.losses
 
