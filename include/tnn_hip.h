@@ -371,6 +371,9 @@ TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);
  * transport — the one that timed out, later launches, captured graph replays — is discarded on the device (buffers,
  * parameters and optimizer state keep their previous contents) and every host call into it returns an error. */
 TNN_API int tnn_p2p_poll_failed(int* failed);
+/* on != 0: optimizer-update kernels launched from now on become no-ops once the transport's dead word is set (see
+ * above); on == 0: back to unconditional updates.  tnn_mlp_step_sharded brackets itself with the pair. */
+TNN_API int tnn_p2p_guard_updates(int on);
 TNN_API int tnn_p2p_destroy(void);
 
 #ifdef __cplusplus

@@ -791,6 +791,7 @@ int tnn_p2p_status(int* c, int* e, int* d) {
     return 0;
 }
 int tnn_p2p_poll_failed(int* f) { if (f) *f = 0; return 0; }
+int tnn_p2p_guard_updates(int) { return 0; }
 int tnn_p2p_destroy(void) { g_comm = 0; return 0; }
 
 }  // extern "C"

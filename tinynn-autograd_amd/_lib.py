@@ -130,6 +130,7 @@ _SIGNATURES = {
     "tnn_p2p_tune": [c_int],
     "tnn_p2p_status": [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
     "tnn_p2p_poll_failed": [POINTER(c_int)],
+    "tnn_p2p_guard_updates": [c_int],
     "tnn_p2p_destroy": [],
 }
 

@@ -126,6 +126,12 @@ class Model(object):
                 for layer in all_grads:
                     for g in layer.values():
                         self.comm.allreduce(g)
+            # op-level updates are ordinary array expressions: nothing on the device ties them to the collective, so a
+            # peer-to-peer transport is asked (after a stream sync) whether it timed out BEFORE the update is issued
+            if getattr(self.comm, "_p2p", False):
+                from .. import _lib
+                _lib.synchronize()
+                self.comm.check(collective=False)
 
         if (self._param_arena is not None and self._grad_arena is not None
                 and all(t._grad is t._grad_home for t in self._arena_tensors)

@@ -389,7 +389,8 @@ __global__ __launch_bounds__(kThreads) void mse_fwd_bwd_kernel(const T* __restri
 // ------------------------------------------------------------------------------ SGD / Adam
 template <typename T>
 __global__ __launch_bounds__(kThreads) void sgd_kernel(T* __restrict__ p, const T* __restrict__ g,
-                                                       int64_t n, T lr) {
+                                                       int64_t n, T lr, const int* guard) {
+    TNN_GUARD_RETURN(guard);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
         p[i] = p[i] + (-lr * g[i]);
@@ -401,7 +402,9 @@ __global__ __launch_bounds__(kThreads) void sgd_kernel(T* __restrict__ p, const 
 template <typename T, int KIND>
 __global__ __launch_bounds__(kThreads) void optim_kernel(T* __restrict__ p, const T* __restrict__ g,
                                                          T* __restrict__ s1, T* __restrict__ s2,
-                                                         T* __restrict__ step_out, int64_t n, T lr, T a, T b, T eps) {
+                                                         T* __restrict__ step_out, int64_t n, T lr, T a, T b, T eps,
+                                                         const int* guard) {
+    TNN_GUARD_RETURN(guard);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
         const T gi = g[i];
@@ -444,7 +447,8 @@ __global__ __launch_bounds__(kThreads) void optim_kernel(T* __restrict__ p, cons
 // The same single thread can carry one scalar along (esz bytes, 4 or 8): the data-parallel trainer files the
 // all-reduced loss into its loss history this way instead of paying a separate copy launch per step.
 __global__ void adam_advance_kernel(double* __restrict__ state, double b1, double b2, const void* __restrict__ src,
-                                    void* __restrict__ dst, int esz) {
+                                    void* __restrict__ dst, int esz, const int* guard) {
+    TNN_GUARD_RETURN(guard);
     state[0] *= b1;
     state[1] *= b2;
     if (dst) {
@@ -458,7 +462,8 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(T* __restrict__ p, const
                                                         T* __restrict__ m, T* __restrict__ v,
                                                         int64_t n, T lr, T b1, T b2, T eps,
                                                         const double* __restrict__ state,
-                                                        T* __restrict__ step_out) {
+                                                        T* __restrict__ step_out, const int* guard) {
+    TNN_GUARD_RETURN(guard);
     const double p1 = state[0], p2 = state[1];
     const T inv_c1 = (T)(1.0 / (1.0 - p1)), inv_c2 = (T)(1.0 / (1.0 - p2));
     const T one_m_b1 = T(1) - b1, one_m_b2 = T(1) - b2;
@@ -716,8 +721,8 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
     if (n <= 0) return 0;
     unsigned grid = tnn::stream_grid(n, kThreads);
     switch (dtype) {
-        case TNN_F32: hipLaunchKernelGGL((sgd_kernel<float>), grid, kThreads, 0, tnn::stream(), (float*)p, (const float*)g, n, (float)lr); break;
-        case TNN_F64: hipLaunchKernelGGL((sgd_kernel<double>), grid, kThreads, 0, tnn::stream(), (double*)p, (const double*)g, n, lr); break;
+        case TNN_F32: hipLaunchKernelGGL((sgd_kernel<float>), grid, kThreads, 0, tnn::stream(), (float*)p, (const float*)g, n, (float)lr, tnn::update_guard()); break;
+        case TNN_F64: hipLaunchKernelGGL((sgd_kernel<double>), grid, kThreads, 0, tnn::stream(), (double*)p, (const double*)g, n, lr, tnn::update_guard()); break;
         default: tnn::set_error("tnn_sgd: dtype %d is not a float type", dtype); return 2;
     }
     TNN_LAUNCH_OK();
@@ -736,7 +741,7 @@ int tnn_optim_step(int kind, void* p, const void* g, void* s1, void* s2, void* s
     hipStream_t st = tnn::stream();
 #define TNN_OPT_LAUNCH(T, K)                                                                                      \
     hipLaunchKernelGGL((optim_kernel<T, K>), grid, kThreads, 0, st, (T*)p, (const T*)g, (T*)s1, (T*)s2, (T*)step_out, \
-                       n, (T)lr, (T)a, (T)b, (T)eps)
+                       n, (T)lr, (T)a, (T)b, (T)eps, tnn::update_guard())
 #define TNN_OPT_KINDS(T)                                             \
     switch (kind) {                                                  \
         case TNN_OPT_MOMENTUM: TNN_OPT_LAUNCH(T, TNN_OPT_MOMENTUM); break; \
@@ -766,7 +771,7 @@ int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, 
     hipStream_t s = tnn::stream();
     if (advance || scalar_dst)
         hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, advance ? b1 : 1.0, advance ? b2 : 1.0,
-                           scalar_src, scalar_dst, dtype == TNN_F64 ? 8 : 4);
+                           scalar_src, scalar_dst, dtype == TNN_F64 ? 8 : 4, tnn::update_guard());
     if (dtype == TNN_F32) {
         bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                      reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
@@ -775,16 +780,16 @@ int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, 
         if (vec)
             hipLaunchKernelGGL((adam_kernel<float, 4>), grid, kThreads, 0, s, (float*)p, (const float*)g,
                                (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps,
-                               (const double*)pows_f64, (float*)step_out);
+                               (const double*)pows_f64, (float*)step_out, tnn::update_guard());
         else
             hipLaunchKernelGGL((adam_kernel<float, 1>), grid, kThreads, 0, s, (float*)p, (const float*)g,
                                (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps,
-                               (const double*)pows_f64, (float*)step_out);
+                               (const double*)pows_f64, (float*)step_out, tnn::update_guard());
     } else if (dtype == TNN_F64) {
         unsigned grid = tnn::stream_grid(n, kThreads);
         hipLaunchKernelGGL((adam_kernel<double, 1>), grid, kThreads, 0, s, (double*)p, (const double*)g,
                            (double*)m, (double*)v, n, lr, b1, b2, eps, (const double*)pows_f64,
-                           (double*)step_out);
+                           (double*)step_out, tnn::update_guard());
     } else {
         tnn::set_error("tnn_adam: dtype %d is not a float type", dtype);
         return 2;

@@ -379,7 +379,9 @@ __global__ __launch_bounds__(64) void sum_partials_f32_kernel(const double* __re
 __global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                float* __restrict__ m, float* __restrict__ v,
                                                                bf16_t* __restrict__ w16, int64_t n, float lr, float b1,
-                                                               float b2, float eps, const double* __restrict__ state) {
+                                                               float b2, float eps, const double* __restrict__ state,
+                                                               const int* guard) {
+    TNN_GUARD_RETURN(guard);
     const double p1 = state[0], p2 = state[1];
     const float ic1 = (float)(1.0 / (1.0 - p1)), ic2 = (float)(1.0 / (1.0 - p2));
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
@@ -426,7 +428,9 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
                                                                   float* __restrict__ m, float* __restrict__ v,
                                                                   bf16_t* __restrict__ w16, bf16_t* __restrict__ wT16,
                                                                   int64_t R, int64_t C, float lr, float b1, float b2,
-                                                                  float eps, const double* __restrict__ state) {
+                                                                  float eps, const double* __restrict__ state,
+                                                                  const int* guard) {
+    TNN_GUARD_RETURN(guard);
     constexpr int TXN = TC / 4, TR = 4 * (256 / TXN);
     __shared__ __attribute__((aligned(16))) bf16_t tile[WT ? TC : 1][TR + 8];
     const double p1 = state[0], p2 = state[1];
@@ -517,7 +521,8 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
         }
     }
 }
-__global__ void adam_advance16_kernel(double* __restrict__ state, double b1, double b2) {
+__global__ void adam_advance16_kernel(double* __restrict__ state, double b1, double b2, const int* guard) {
+    TNN_GUARD_RETURN(guard);
     state[0] *= b1;
     state[1] *= b2;
 }
@@ -635,10 +640,10 @@ int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* 
     if (n <= 0) return 0;
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_master_bf16: pows state is NULL");
     hipStream_t s = tnn::stream();
-    hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
+    hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2, tnn::update_guard());
     hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid((n + 3) / 4, 256), 256, 0, s, (float*)p_master,
                        (const float*)g, (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2,
-                       (float)eps, (const double*)pows_f64);
+                       (float)eps, (const double*)pows_f64, tnn::update_guard());
     TNN_LAUNCH_OK();
     return 0;
 }
@@ -649,7 +654,7 @@ int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, voi
     TNN_NEED_INIT();
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_master_bf16_2d: pows state is NULL");
     hipStream_t s = tnn::stream();
-    if (advance) hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2);
+    if (advance) hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2, tnn::update_guard());
     if (rows <= 0 || cols <= 0) {
         TNN_LAUNCH_OK();
         return 0;
@@ -663,18 +668,18 @@ int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, voi
         if (wT_bf16)
             hipLaunchKernelGGL((adam_master_bf16_2d_kernel<true, TC>), grid, 256, 0, s, (float*)p_master, (const float*)g,
                                (float*)m, (float*)v, (bf16_t*)w_bf16, (bf16_t*)wT_bf16, rows, cols, (float)lr,
-                               (float)b1, (float)b2, (float)eps, (const double*)pows_f64);
+                               (float)b1, (float)b2, (float)eps, (const double*)pows_f64, tnn::update_guard());
         else
             hipLaunchKernelGGL((adam_master_bf16_2d_kernel<false, TC>), grid, 256, 0, s, (float*)p_master, (const float*)g,
                                (float*)m, (float*)v, (bf16_t*)w_bf16, (bf16_t*)nullptr, rows, cols, (float)lr,
-                               (float)b1, (float)b2, (float)eps, (const double*)pows_f64);
+                               (float)b1, (float)b2, (float)eps, (const double*)pows_f64, tnn::update_guard());
         TNN_LAUNCH_OK();
         return 0;
     }
     const int64_t n = rows * cols;
     hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid(n, 256), 256, 0, s, (float*)p_master, (const float*)g,
                        (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2, (float)eps,
-                       (const double*)pows_f64);
+                       (const double*)pows_f64, tnn::update_guard());
     TNN_LAUNCH_OK();
     if (wT_bf16) return tnn_transpose_bf16(w_bf16, wT_bf16, rows, cols);
     return 0;

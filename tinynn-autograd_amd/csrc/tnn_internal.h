@@ -9,7 +9,18 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 hipStream_t stream();          // the one library stream (valid after tnn_init)
 bool initialised();
 int num_cus();                 // 256 on MI355X
+// Device word the optimizer-update kernels look at before touching anything: non-zero -> the launch is a no-op
+// (parameters, optimizer state and beta powers keep their contents).  nullptr = no guard.  Set around a data-parallel
+// step to the peer-to-peer transport's sticky `dead` word (tnn_p2p_guard_updates), so an update that would consume a
+// discarded collective is discarded too, whichever kernel applies it.
+const int* update_guard();
+void set_update_guard(const int* device_word);
 }  // namespace tnn
+
+#define TNN_GUARD_RETURN(guard)                                                                              \
+    do {                                                                                                     \
+        if ((guard) != nullptr && __hip_atomic_load((guard), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; \
+    } while (0)
 
 #define TNN_CHECK_HIP(expr)                                                              \
     do {                                                                                 \

@@ -462,7 +462,18 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     return tnn_mlp_update(handle);
 }
 
+static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
+
 int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int64_t rows, void* loss_out) {
+    // every update launched inside is tied to the peer-to-peer transport's health: if a peer barrier timed out, the
+    // collectives were discarded on the device and so are the optimizer launches behind them (tnn_p2p_guard_updates)
+    (void)tnn_p2p_guard_updates(1);
+    const int rc = step_sharded_impl(handle, x, y, rows, loss_out);
+    (void)tnn_p2p_guard_updates(0);
+    return rc;
+}
+
+static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t rows, void* loss_out) {
     // One data-parallel step, every phase enqueued from here on the library stream (no host work in between):
     //   forward + shard {max, sum-exp}  ->  C2 all-gather + log-sum-exp merge  ->  loss + backward with the GLOBAL
     //   batch size  ->  C1 in-place all-reduce of grads[0 : n_params + 1] (the loss rides along)  ->  update

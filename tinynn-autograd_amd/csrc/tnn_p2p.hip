@@ -431,6 +431,15 @@ int tnn_p2p_status(int* connected, int* enabled, int* dead) {
     return 0;
 }
 
+int tnn_p2p_guard_updates(int on) {
+    // While on, every optimizer-update kernel this library launches (SGD / Adam / the other four, fp32 and bf16 master)
+    // first looks at the transport's sticky `dead` word and leaves parameters, state and beta powers untouched when it
+    // is set: an update that would consume a discarded collective is discarded with it, also when the update is a
+    // launch of its own behind the all-reduce (tnn_mlp_step_sharded brackets itself with this).
+    tnn::set_update_guard(on && S.open ? S.dead : nullptr);
+    return 0;
+}
+
 int tnn_p2p_poll_failed(int* failed) {
     // the host mirror of the sticky word: no stream synchronisation, safe to call before every graph replay
     if (failed) *failed = tnn::p2p_failed() ? 1 : 0;

@@ -67,6 +67,10 @@ void set_error(const char* fmt, ...) {
 hipStream_t stream() { return g.stream; }
 bool initialised() { return g.ready; }
 int num_cus() { return g.cus; }
+
+static const int* g_update_guard = nullptr;
+const int* update_guard() { return g_update_guard; }
+void set_update_guard(const int* device_word) { g_update_guard = device_word; }
 }  // namespace tnn
 
 extern "C" {
