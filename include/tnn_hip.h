@@ -224,6 +224,16 @@ TNN_API int tnn_mlp_head(int64_t rows, int64_t n_hidden, int64_t n_classes, cons
                          const void* b, const void* y, void* logits, void* dz, void* stats, void* loss,
                          void* dw, void* db, void* da, int dtype);
 
+/* The same head as ONE MULTI-WORKGROUP launch for the single-GPU MNIST-size step (every workgroup recomputes the tiny
+ * logits + loss statistics, then produces its share of dw / da; see csrc/tnn_head.hip) — replaces the three launches
+ * core/layers.py:49 (last Dense forward) | core/losses.py:24-32 (loss) | core/ops.py:156-160 (last Dense backward).
+ * adam_pows_f64 != NULL: {b1^t, b2^t} are advanced here like tnn_softmax_nll_fused_tick does.  logits / dz / stats /
+ * loss / da may be NULL.  Only shapes tnn_mlp_head_fits() accepts (f32, 10 classes, 128 hidden units, <= 128 rows). */
+TNN_API int tnn_mlp_head_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype, int* fits);
+TNN_API int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* a, const void* w,
+                              const void* b, const void* y, void* logits, void* dz, void* stats, void* loss,
+                              void* dw, void* db, void* da, int dtype, void* adam_pows_f64, double b1, double b2);
+
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global
  * (the ops chain sub_ -> pow_(2) -> sum_ -> div_ of core/ops.py:61,121,252,93 in one pass). */

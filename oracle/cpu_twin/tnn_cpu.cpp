@@ -590,6 +590,22 @@ int tnn_mlp_head(int64_t rows, int64_t nh, int64_t nc, const void* a, const void
     if (int rc = tnn_softmax_nll_fused(logits, y, rows, nc, stats, loss, dz, dtype)) return rc;
     return tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da, a, dtype);
 }
+int tnn_mlp_head_fits(int64_t rows, int64_t nh, int64_t nc, int dtype, int* fits) {
+    REQ(fits != nullptr, "tnn_mlp_head_fits: fits is NULL");
+    *fits = (dtype == TNN_F32 && nc == 10 && nh == 128 && rows >= 1 && rows <= 128) ? 1 : 0;    // the HIP kernel's shapes
+    return 0;
+}
+int tnn_softmax_nll_fused_tick(const void*, const void*, int64_t, int64_t, int64_t, int, void*, void*, void*, int, void*,
+                               double, double);
+int tnn_mlp_head_tick(int64_t rows, int64_t nh, int64_t nc, const void* a, const void* w, const void* b, const void* y,
+                      void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* da, int dtype,
+                      void* pows, double b1, double b2) {
+    NEED_INIT();
+    REQ(logits && dz && dw && db, "cpu twin: tnn_mlp_head_tick needs logits and dz scratch");
+    if (int rc = tnn_gemm_bias_act(0, 0, rows, nc, nh, a, nh, w, nc, b, TNN_ACT_NONE, 0, logits, nc, dtype)) return rc;
+    if (int rc = tnn_softmax_nll_fused_tick(logits, y, rows, nc, rows, 0, stats, loss, dz, dtype, pows, b1, b2)) return rc;
+    return tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da, a, dtype);
+}
 int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t mg, void* loss_out, void* dpred, int dtype) {
     NEED_INIT();
     REQ(n > 0 && mg > 0, "tnn_mse_fwd_bwd: empty batch");

@@ -288,6 +288,54 @@ def classifier_head_kernel_vs_numpy():
     assert mask[3, 5] and np.asarray(dA)[3, 5] != 0.0
 
 
+def classifier_head_one_launch_multi_workgroup_vs_numpy():
+    """tnn_mlp_head_tick (the 5-launch step's head: last Dense forward + whole-batch softmax NLL + last Dense backward +
+    Adam's beta powers in ONE multi-workgroup launch) against float64 numpy: full and ragged batches (128, 104, 80, 37, 1
+    rows), sign-encoded ReLU zeros in the activations incl. an exactly-zero pre-activation, soft labels."""
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(23)
+    Hn, C = 128, 10
+    for m in (128, 104, 80, 37, 1):
+        fits = ctypes.c_int(0)
+        lib.mlp_head_fits(m, Hn, C, _lib.F32, ctypes.byref(fits))
+        assert fits.value == 1
+        pre = rs.randn(m, Hn).astype(np.float32)
+        a = np.where(pre < 0, np.float32(-0.0), np.abs(pre)).astype(np.float32)
+        a[0, 5] = 0.0                                                          # exactly-zero pre-activation: mask = 1
+        w = (rs.randn(Hn, C) * 0.3).astype(np.float32)
+        b = rs.randn(C).astype(np.float32)
+        y = rs.rand(m, C).astype(np.float32) if m % 2 else np.eye(C, dtype=np.float32)[rs.randint(0, C, m)]
+        A, W, B, Y = (tn.asarray(v) for v in (a, w, b, y))
+        logits, dz = tn.empty((m, C)), tn.empty((m, C))
+        stats, loss = tn.empty((2,)), tn.empty(())
+        dw, db, dA = tn.zeros((Hn, C)), tn.zeros((C,)), tn.zeros((m, Hn))
+        pows = tn.asarray(np.array([0.9, 0.999, 0, 0]), dtype=np.float64)
+        lib.mlp_head_tick(m, Hn, C, A._ptr, W._ptr, B._ptr, Y._ptr, logits._ptr, dz._ptr, stats._ptr, loss._ptr,
+                          dw._ptr, db._ptr, dA._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
+        a64, w64, y64 = a.astype(np.float64), w.astype(np.float64), y.astype(np.float64)
+        z = a64 @ w64 + b
+        e = np.exp(z - z.max()); S = e.sum(); q = (e * y64).sum(1, keepdims=True)
+        ref_loss = (np.log(S) - np.log(q)).sum() / m
+        ref_dz = e / S - (e * y64 / q) / m
+        mask = ~np.signbit(a)
+        tag = "rows=%d" % m
+        np.testing.assert_allclose(np.asarray(logits), z, rtol=0, atol=2e-5 * np.abs(z).max(), err_msg=tag)
+        np.testing.assert_allclose(float(loss), ref_loss, rtol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(np.asarray(stats), [z.max(), S], rtol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(np.asarray(dz), ref_dz, rtol=0, atol=1e-5 * np.abs(ref_dz).max(), err_msg=tag)
+        ref_dw = a64.T @ ref_dz
+        np.testing.assert_allclose(np.asarray(dw), ref_dw, rtol=0, atol=1e-5 * np.abs(ref_dw).max(), err_msg=tag)
+        np.testing.assert_allclose(np.asarray(db), ref_dz.sum(0), rtol=0, atol=1e-5 * np.abs(ref_dz.sum(0)).max() + 1e-9, err_msg=tag)
+        ref_da = (ref_dz @ w64.T) * mask
+        np.testing.assert_allclose(np.asarray(dA), ref_da, rtol=0, atol=1e-5 * np.abs(ref_da).max(), err_msg=tag)
+        assert mask[0, 5] and np.asarray(dA)[0, 5] != 0.0
+        np.testing.assert_allclose(np.asarray(pows)[:2], [0.81, 0.999 ** 2], rtol=1e-14)
+    lib.mlp_head_fits(129, Hn, C, _lib.F32, ctypes.byref(fits))
+    assert fits.value == 0                                                     # the trainer then takes the 7-launch step
+
+
 def dense_backward_one_launch_vs_numpy():
     import ctypes
     from tinynn_autograd_amd import _lib

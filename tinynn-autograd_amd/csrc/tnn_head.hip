@@ -201,6 +201,182 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// MULTI-WORKGROUP head: the last Dense forward, the whole-batch softmax NLL and the last Dense backward of the
+// single-GPU MNIST-size step in ONE launch WITHOUT serialising on one CU (the single-workgroup kernel above: 14.7 us).
+// The head's inputs are so small — 128 x 128 activations, 128 x 10 weights — that EVERY workgroup recomputes the
+// logits and the loss statistics for itself (164 k FMAs = 0.5 us of one CU's VALU time, all workgroups in parallel)
+// and then produces only its own share of the outputs:
+//     all G = H / 8 workgroups : z = a W + b, {M, S, L} -> dz [m, C] (kept in LDS)
+//     workgroup g              : da rows [g * rpb, (g + 1) * rpb) = (dz W^T) * !signbit(a);  dW rows [8 g, 8 g + 8) = a^T dz
+//     workgroup 0              : loss, stats, db = column sums of dz, Adam's beta powers advanced (tick)
+//     workgroup G - 1          : logits (and dz, when asked for) written out
+// so the step's forward-of-last-layer / loss / backward-of-last-layer triple (three launches, ~9.4 us of launch
+// boundaries and first-load round trips around ~1 us of math) becomes one launch.  (DESIGN.md §8 of round 1 named this.)
+//   * logits: thread (row r = t & 127, K-quarter kq = t >> 7) holds its 32 activations in registers (8 x 16-B loads,
+//     requested first thing) and multiplies them with W rows read through the SCALAR cache (kq is wave-uniform, so
+//     W[k][c] is an SGPR operand of v_fma: no LDS or vector traffic for W); the four K-quarter partials meet in LDS;
+//   * statistics: one thread per row (waves 0-1), per-row normalisation against the row's own maximum, then ONE
+//     combined reduction of {max, rescaled sum-exp, sum(log u + max)} by DPP wave reductions (tnn_internal.h) and a
+//     2-entry LDS exchange — the arithmetic of nll_rows_body (tnn_nll_rows.h), so the numbers are the loss kernel's;
+//   * da: thread (column j, row group) with W[j][:] in registers and dz rows broadcast from LDS; dW: 8 x C outputs per
+//     workgroup, 4 row-quarters per output summed with two quad-permute DPP steps.
+struct HeadMArgs {
+    int m, rpb;                      // rows (<= 128); da rows per workgroup
+    const float *a, *w, *b, *y;
+    float *logits, *dz, *stats, *loss, *dw, *db, *da;
+    double* tick;
+    double b1, b2;
+};
+
+template <int H, int C>
+__global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
+    constexpr int ROWS = 128, KQ = 4, KS = H / KQ, ZS = C + 1, JPB = 8, G = H / JPB;
+    static_assert(H == ROWS, "thread (t & 127) doubles as the hidden-unit index of the da phase");
+    __shared__ float zp[KQ][ROWS * ZS];            // partial logits; zp[0] is reused for dz
+    __shared__ float aslice[ROWS][JPB + 1];        // a[:, 8g : 8g + 8] for this workgroup's dW rows
+    __shared__ double red[2][4];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = t & (ROWS - 1), kq = t >> 7;
+    const int m = p.m, g = blockIdx.x;
+    const bool live = r < m;
+
+    // ---- every global read of the kernel is requested here, before the first use.  No exec-mask branches: rows beyond
+    // m read a clamped (valid) address and are neutralised in the arithmetic instead (their dz is 0, so whatever they
+    // loaded never reaches an output).
+    const int rl = min(r, m - 1);
+    f32x4 a4[KS / 4];
+#pragma unroll
+    for (int i = 0; i < KS / 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(p.a + (size_t)rl * H + kq * KS + 4 * i);
+    float wrow[C], yrow[C], am[2];
+    const int r0 = g * p.rpb, rend = min(m, r0 + p.rpb);
+#pragma unroll
+    for (int c = 0; c < C; ++c) wrow[c] = p.w[(size_t)r * C + c];      // W[j = r][c] for the da phase
+#pragma unroll
+    for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
+#pragma unroll
+    for (int c = 0; c < C; ++c) yrow[c] = p.y[(size_t)rl * C + c];
+    const f32x4 asl = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
+
+    // ---- partial logits of this thread's row over its K-quarter (W through the scalar cache)
+    {
+        const int kb = __builtin_amdgcn_readfirstlane(kq) * KS;
+        const float* __restrict__ wk = p.w + (size_t)kb * C;
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const float av = a4[kk >> 2][kk & 3];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = fmaf(av, wk[kk * C + c], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) zp[kq][r * ZS + c] = acc[c];
+    }
+    if (t < 2 * ROWS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aslice[t >> 1][4 * (t & 1) + i] = asl[i];
+    }
+    __syncthreads();
+
+    // ---- per-row softmax pieces (waves 0-1: one thread per row), combined reduction
+    float z[C], e[C], ey[C];
+    double mi = -INFINITY, si = 0.0, li = 0.0, ui = 1.0;
+    if (kq == 0) {                                             // wave-uniform
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            z[c] = p.b[c] + ((zp[0][r * ZS + c] + zp[1][r * ZS + c]) + (zp[2][r * ZS + c] + zp[3][r * ZS + c]));
+        if (live) {
+            float mx = z[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) mx = z[c] > mx ? z[c] : mx;
+            double s = 0.0, u = 0.0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const double ek = (double)expf(z[c] - mx);
+                e[c] = (float)ek;
+                ey[c] = (float)((double)e[c] * (double)yrow[c]);
+                s += ek;
+                u += (double)ey[c];
+            }
+            mi = (double)mx; si = s; ui = u;
+            li = (double)logf((float)u) + (double)mx;
+        }
+        const double wm = tnn::wave_max_dpp(mi);
+        const double ws = tnn::wave_sum_dpp(live ? si * (double)expf((float)(mi - wm)) : 0.0);
+        const double wl = tnn::wave_sum_dpp(li);
+        if (lane == 0) { red[wid][0] = wm; red[wid][1] = ws; red[wid][2] = wl; }
+    }
+    __syncthreads();
+    double M = fmax(red[0][0], red[1][0]), S = 0.0;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+        if (red[w][0] > -INFINITY) S += red[w][1] * (double)expf((float)(red[w][0] - M));
+    const double L = red[0][2] + red[1][2];
+    const double inv_m = 1.0 / (double)m;
+    if (kq == 0) {
+        const float sf = live ? (float)((double)expf((float)(mi - M)) / S) : 0.f, uf = live ? (float)(inv_m / ui) : 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) zp[0][r * ZS + c] = live ? e[c] * sf - ey[c] * uf : 0.f;   // dz (0 in the padding rows)
+    }
+    __syncthreads();
+    const float* dzs = zp[0];
+
+    // ---- da rows of this workgroup: thread (column j = r, row group kq)
+    if (p.da) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = r0 + kq + 4 * i;                    // wave-uniform: the dz row is an LDS broadcast
+            if (row < rend) {
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) d = fmaf(dzs[row * ZS + c], wrow[c], d);
+                p.da[(size_t)row * H + r] = (__float_as_uint(am[i]) >> 31) ? 0.f : d;
+            }
+        }
+    }
+    // ---- dW rows [8g, 8g + 8): output o = (jl, c), four row-quarters per output on neighbouring lanes
+    if (t < JPB * C * 4) {                                      // 320 threads = 5 whole waves
+        const int q = t & 3, o = t >> 2, jl = o / C, c = o - jl * C;
+        float s = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < ROWS / 4; ++i) s = fmaf(aslice[32 * q + i][jl], dzs[(32 * q + i) * ZS + c], s);
+        s += tnn::dpp_move<0xB1, 0xf>(0.f, s);
+        s += tnn::dpp_move<0x4E, 0xf>(0.f, s);
+        if (q == 0) p.dw[(size_t)(g * JPB + jl) * C + c] = s;
+    }
+    if (g == 0) {
+        if (wid == 7) {                                         // db[c] = sum_r dz[r][c]
+            const int c = lane & 15, rq = lane >> 4;
+            float s = 0.f;
+            if (c < C)
+                for (int i = 0; i < ROWS / 4; ++i) s += dzs[(32 * rq + i) * ZS + c];
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < C) p.db[lane] = s;
+        }
+        if (t == 0) {
+            if (p.loss) p.loss[0] = (float)((double)logf((float)S) + M - L * inv_m);
+            if (p.stats) { p.stats[0] = (float)M; p.stats[1] = (float)S; }
+            if (p.tick) { p.tick[0] *= p.b1; p.tick[1] *= p.b2; }
+        }
+    }
+    if (g == G - 1 && kq == 0 && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (p.logits) p.logits[(size_t)r * C + c] = z[c];
+            if (p.dz) p.dz[(size_t)r * C + c] = dzs[r * ZS + c];
+        }
+    }
+}
+
+bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype) {
+    static const bool off = getenv("TNN_HEAD_MULTI") != nullptr && atoi(getenv("TNN_HEAD_MULTI")) == 0;
+    return !off && dtype == TNN_F32 && n_classes == 10 && n_hidden == 128 && rows >= 1 && rows <= 128;
+}
+
 size_t head_lds_bytes(int64_t m, int64_t H) {
     int64_t mp = (m + 15) & ~int64_t(15);
     return (size_t)(mp * (H + 4) + H * kCP + 2 * mp * kCP) * 4 + (size_t)(mp + 20 + 2) * 8;
@@ -244,6 +420,32 @@ int tnn_mlp_head(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* 
         return rc;
     if (int rc = tnn_softmax_nll_fused(logits, y, rows, n_classes, stats, loss, dz, dtype)) return rc;
     return tnn_dense_bwd(rows, n_hidden, n_classes, a, dz, w, dw, db, da, a, dtype);
+}
+
+int tnn_mlp_head_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype, int* fits) {
+    TNN_REQUIRE(fits != nullptr, "tnn_mlp_head_fits: fits is NULL");
+    *fits = head_multi_fits(rows, n_hidden, n_classes, dtype) ? 1 : 0;
+    return 0;
+}
+
+int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* a, const void* w,
+                      const void* b, const void* y, void* logits, void* dz, void* stats, void* loss, void* dw,
+                      void* db, void* da, int dtype, void* adam_pows_f64, double b1, double b2) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(rows > 0 && n_hidden > 0 && n_classes > 0, "tnn_mlp_head_tick: empty head");
+    TNN_REQUIRE(a && w && b && y && dw && db, "tnn_mlp_head_tick: a, w, b, y, dw and db are required");
+    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype) && (reinterpret_cast<uintptr_t>(a) & 15) == 0,
+                "tnn_mlp_head_tick: this head does not fit the one-launch form (ask tnn_mlp_head_fits first)");
+    HeadMArgs p;
+    p.m = (int)rows;
+    p.rpb = (int)((rows + 15) / 16);
+    p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
+    p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
+    p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
+    p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
+    hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10>), 16, 512, 0, tnn::stream(), p);
+    TNN_LAUNCH_OK();
+    return 0;
 }
 
 }  // extern "C"

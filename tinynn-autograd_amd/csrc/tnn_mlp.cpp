@@ -430,6 +430,31 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     const int L = h->L;
     void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
     static const bool head_fusion = getenv("TNN_HEAD_FUSION") != nullptr;
+    int head_multi = 0;
+    if (!h->bf16 && h->opt_kind == 1 && L >= 2)
+        MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
+    if (head_multi) {
+        // 2L - 1 launches (5 for the MNIST net): forward of the hidden layers | the classifier head as ONE multi-workgroup
+        // launch (last Dense forward + loss + last Dense backward + Adam's beta powers) | backward of the hidden layers,
+        // the first layer's carrying the whole optimizer
+        MLP_TRY(mlp_forward(h, x, rows, L - 1));
+        STEP_CALL(h, tnn_mlp_head_tick(rows, h->w[L - 1], h->w[L], h->act[L - 2],
+                                       at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
+                                       h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
+                                       at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                       h->dact[L - 2], h->dtype, h->pows, h->b1, h->b2));
+        MLP_TRY(mlp_backward_layers(h, x, rows, L - 2, 1));
+        const int64_t rest = h->w_off[1];
+        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
+                                              at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
+                                              at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
+                                              at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
+                                              at(h->v, h->b_off[0], h->esz), at(h->params, rest, h->esz),
+                                              at(h->grads, rest, h->esz), at(h->m, rest, h->esz),
+                                              at(h->v, rest, h->esz), h->n_params - rest, h->lr, h->b1, h->b2, h->eps,
+                                              h->pows, h->dtype));
+        return 0;
+    }
     if (!head_fusion && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
         // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward, the last launch of which also
         // carries the optimizer
