@@ -224,15 +224,26 @@ TNN_API int tnn_mlp_head(int64_t rows, int64_t n_hidden, int64_t n_classes, cons
                          const void* b, const void* y, void* logits, void* dz, void* stats, void* loss,
                          void* dw, void* db, void* da, int dtype);
 
-/* The same head as ONE MULTI-WORKGROUP launch for the single-GPU MNIST-size step (every workgroup recomputes the tiny
- * logits + loss statistics, then produces its share of dw / da; see csrc/tnn_head.hip) — replaces the three launches
- * core/layers.py:49 (last Dense forward) | core/losses.py:24-32 (loss) | core/ops.py:156-160 (last Dense backward).
+/* The same head as ONE MULTI-WORKGROUP launch for the single-GPU MNIST-size step (csrc/tnn_head.hip) — replaces the three
+ * launches core/layers.py:49 (last Dense forward) | core/losses.py:24-32 (loss) | core/ops.py:156-160 (last Dense
+ * backward): every workgroup obtains the logits and the loss statistics for itself, then produces its share of dw / da.
+ * logit_partials != NULL: [n_hidden / 16][rows][n_classes] partial logits written by tnn_dense_fwd_head_partials (the
+ * previous layer's tiles); they are only added up.  NULL: the workgroups compute a w themselves.
  * adam_pows_f64 != NULL: {b1^t, b2^t} are advanced here like tnn_softmax_nll_fused_tick does.  logits / dz / stats /
  * loss / da may be NULL.  Only shapes tnn_mlp_head_fits() accepts (f32, 10 classes, 128 hidden units, <= 128 rows). */
 TNN_API int tnn_mlp_head_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype, int* fits);
 TNN_API int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* a, const void* w,
-                              const void* b, const void* y, void* logits, void* dz, void* stats, void* loss,
-                              void* dw, void* db, void* da, int dtype, void* adam_pows_f64, double b1, double b2);
+                              const void* b, const void* y, const void* logit_partials, void* logits, void* dz,
+                              void* stats, void* loss, void* dw, void* db, void* da, int dtype, void* adam_pows_f64,
+                              double b1, double b2);
+/* Forward of the hidden Dense layer in front of the classifier, C = act(A B + bias) like tnn_gemm_bias_act (NN form,
+ * core/layers.py:49,98), which ALSO emits the next layer's logits as per-tile partial sums:
+ *   head_z[tn][row][c] = sum_{col in [16 tn, 16 tn + 16)} C[row][col] * head_w[col][c]      (head_z: [ceil(N/16)][M][head_c])
+ * — the first half of the classifier's forward (core/layers.py:49 of the NEXT layer) done where the activations are
+ * still in registers.  One launch for MNIST-size layers; other shapes run the GEMM and a small second kernel. f32 only. */
+TNN_API int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                                        int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
+                                        const void* head_w, int64_t head_c, void* head_z, int dtype);
 
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global

@@ -598,13 +598,43 @@ int tnn_mlp_head_fits(int64_t rows, int64_t nh, int64_t nc, int dtype, int* fits
 int tnn_softmax_nll_fused_tick(const void*, const void*, int64_t, int64_t, int64_t, int, void*, void*, void*, int, void*,
                                double, double);
 int tnn_mlp_head_tick(int64_t rows, int64_t nh, int64_t nc, const void* a, const void* w, const void* b, const void* y,
-                      void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* da, int dtype,
-                      void* pows, double b1, double b2) {
+                      const void* zpart, void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* da,
+                      int dtype, void* pows, double b1, double b2) {
     NEED_INIT();
     REQ(logits && dz && dw && db, "cpu twin: tnn_mlp_head_tick needs logits and dz scratch");
-    if (int rc = tnn_gemm_bias_act(0, 0, rows, nc, nh, a, nh, w, nc, b, TNN_ACT_NONE, 0, logits, nc, dtype)) return rc;
+    REQ(dtype == TNN_F32, "cpu twin: tnn_mlp_head_tick is f32 only");
+    RECORD(tnn_mlp_head_tick(rows, nh, nc, a, w, b, y, zpart, logits, dz, stats, loss, dw, db, da, dtype, pows, b1, b2));
+    if (zpart) {      // logits = bias + the tiles' partial sums (what the HIP kernel does with them)
+        const int64_t tiles = (nh + 15) / 16;
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t c = 0; c < nc; ++c) {
+                float s = 0.f;
+                for (int64_t tn = 0; tn < tiles; ++tn) s += ((const float*)zpart)[(tn * rows + r) * nc + c];
+                ((float*)logits)[r * nc + c] = s + ((const float*)b)[c];
+            }
+    } else if (int rc = tnn_gemm_bias_act(0, 0, rows, nc, nh, a, nh, w, nc, b, TNN_ACT_NONE, 0, logits, nc, dtype)) {
+        return rc;
+    }
     if (int rc = tnn_softmax_nll_fused_tick(logits, y, rows, nc, rows, 0, stats, loss, dz, dtype, pows, b1, b2)) return rc;
     return tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da, a, dtype);
+}
+int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* hw, int64_t hc,
+                                void* hz, int dtype) {
+    NEED_INIT();
+    REQ(dtype == TNN_F32 && hw && hz && hc >= 1 && hc <= 16, "tnn_dense_fwd_head_partials: f32, head_w, head_z, 1 <= head_c <= 16");
+    RECORD(tnn_dense_fwd_head_partials(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, hw, hc, hz, dtype));
+    if (int rc = tnn_gemm_bias_act(0, 0, M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, dtype)) return rc;
+    const int64_t tiles = (N + 15) / 16;
+    for (int64_t tn = 0; tn < tiles; ++tn)
+        for (int64_t r = 0; r < M; ++r)
+            for (int64_t c = 0; c < hc; ++c) {
+                float s = 0.f;
+                for (int64_t col = tn * 16; col < tn * 16 + 16 && col < N; ++col)
+                    s += ((const float*)C)[r * ldc + col] * ((const float*)hw)[col * hc + c];
+                ((float*)hz)[(tn * M + r) * hc + c] = s;
+            }
+    return 0;
 }
 int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t mg, void* loss_out, void* dpred, int dtype) {
     NEED_INIT();

@@ -385,42 +385,61 @@ def epoch_fixture(ref):
     from utils.data_iterator import BatchIterator
     from utils.seeder import random_seed
     cfg = synth.EPOCH_CFG
-    train_x, train_lab, test_x, test_lab = synth.epoch_dataset(cfg)
+    train_x, train_lab, pool_x, pool_lab = synth.epoch_dataset(cfg)
     train_y = np.eye(10)[np.array(train_lab).reshape(-1)]            # get_one_hot, run.py:27-28
-    random_seed(cfg["seed"])
-    tx, ty, sx = rt.Tensor(train_x), rt.Tensor(train_y), rt.Tensor(test_x)
     w = cfg["widths"]
-    layers = []
-    for i in range(1, len(w)):
-        layers.append(rlayers.Dense(w[i]))                            # lazy: shapes from the first batch
-        if i < len(w) - 1:
-            layers.append(rlayers.ReLU())
-    net = rnn.Net(layers)
-    model = rmodel.Model(net=net, loss=rlosses.SoftmaxCrossEntropyLoss(), optimizer=ropt.Adam(lr=cfg["lr"]))
-    loss_layer = rlosses.SoftmaxCrossEntropyLoss()
-    iterator = BatchIterator(batch_size=cfg["batch_size"])
-    evaluator = reval.AccEvaluator()
-    loss_list, sizes, preds, results, margins = [], [], [], [], []
-    for epoch in range(cfg["num_ep"]):
-        for batch in iterator(tx, ty):
-            model.zero_grad()
-            pred = model.forward(batch.inputs)
-            loss = loss_layer.loss(pred, batch.targets)
-            loss.backward()
-            model.step()
-            loss_list.append(float(loss.values))
-            sizes.append(len(batch.inputs))
-        model.set_phase("TEST")
-        test_pred = model.forward(sx)
-        idx = np.argmax(test_pred, axis=1)                             # on the Tensor, as run.py:89 does
-        assert np.array_equal(idx, np.argmax(test_pred.values, axis=1))
-        results.append(evaluator.evaluate(idx, test_lab))
-        preds.append(np.asarray(idx, dtype=np.int64))
-        top2 = np.sort(np.asarray(test_pred.values), axis=1)[:, -2:]
-        margins.append(float((top2[:, 1] - top2[:, 0]).min()))
-        model.set_phase("TRAIN")
-    # the smallest top-2 logit gap must be far above float32 round-off, or "identical hit_num" would be luck
-    assert min(margins) > 1e-4, "pick another seed: top-2 margin %g" % min(margins)
+
+    def run(test_x, test_lab, probe=None):
+        """The loop of run.py:45-93.  probe: extra rows forwarded after each epoch (no RNG use, no state change) whose
+        top-2 logit gaps are returned — how the well-conditioned evaluation rows are chosen."""
+        random_seed(cfg["seed"])
+        tx, ty, sx = rt.Tensor(train_x), rt.Tensor(train_y), rt.Tensor(test_x)
+        layers = []
+        for i in range(1, len(w)):
+            layers.append(rlayers.Dense(w[i]))                        # lazy: shapes from the first batch
+            if i < len(w) - 1:
+                layers.append(rlayers.ReLU())
+        net = rnn.Net(layers)
+        model = rmodel.Model(net=net, loss=rlosses.SoftmaxCrossEntropyLoss(), optimizer=ropt.Adam(lr=cfg["lr"]))
+        loss_layer = rlosses.SoftmaxCrossEntropyLoss()
+        iterator = BatchIterator(batch_size=cfg["batch_size"])
+        evaluator = reval.AccEvaluator()
+        loss_list, sizes, preds, results, margins, probe_gaps = [], [], [], [], [], []
+        for epoch in range(cfg["num_ep"]):
+            for batch in iterator(tx, ty):
+                model.zero_grad()
+                pred = model.forward(batch.inputs)
+                loss = loss_layer.loss(pred, batch.targets)
+                loss.backward()
+                model.step()
+                loss_list.append(float(loss.values))
+                sizes.append(len(batch.inputs))
+            model.set_phase("TEST")
+            test_pred = model.forward(sx)
+            idx = np.argmax(test_pred, axis=1)                         # on the Tensor, as run.py:89 does
+            assert np.array_equal(idx, np.argmax(test_pred.values, axis=1))
+            results.append(evaluator.evaluate(idx, test_lab))
+            preds.append(np.asarray(idx, dtype=np.int64))
+            top2 = np.sort(np.asarray(test_pred.values), axis=1)[:, -2:]
+            margins.append(float((top2[:, 1] - top2[:, 0]).min()))
+            if probe is not None:
+                z = np.asarray(model.forward(rt.Tensor(probe)).values)
+                t2 = np.sort(z, axis=1)[:, -2:]
+                probe_gaps.append(t2[:, 1] - t2[:, 0])
+            model.set_phase("TRAIN")
+        return loss_list, sizes, preds, results, margins, probe_gaps
+
+    # pass 1: train, look at the whole candidate pool after each epoch; keep the first n_test rows whose top-2 gap
+    # exceeds min_margin after BOTH epochs
+    first = run(pool_x[:8], pool_lab[:8], probe=pool_x)
+    gap = np.minimum.reduce(first[5])
+    rows = np.nonzero(gap > cfg["min_margin"])[0][:cfg["n_test"]]
+    assert len(rows) == cfg["n_test"], "only %d pool rows clear the margin" % len(rows)
+    test_x, test_lab = pool_x[rows], pool_lab[rows]
+    # pass 2: the run proper, evaluating those rows exactly like run.py does
+    loss_list, sizes, preds, results, margins, _ = run(test_x, test_lab)
+    assert loss_list == first[0], "the probe forward changed the training trajectory"
+    assert min(margins) > cfg["min_margin"]
     # --- pin the oracle's restatement of the loop
     random_seed(cfg["seed"])
     o_losses, o_preds, o_results = ref_nn.train_epochs(w, train_x, train_y, test_x, test_lab, cfg["num_ep"],
@@ -428,12 +447,13 @@ def epoch_fixture(ref):
     assert o_losses == loss_list, "ref_nn.train_epochs losses differ from the reference loop"
     assert all(np.array_equal(a, b) for a, b in zip(o_preds, preds)) and o_results == results
     np.savez_compressed(os.path.join(GOLDEN, "epoch.npz"), loss=np.array(loss_list), batch_sizes=np.array(sizes),
+                        test_rows=rows.astype(np.int64),
                         argmax=np.stack(preds), hit_num=np.array([r["hit_num"] for r in results], dtype=np.int64),
                         total_num=np.array([r["total_num"] for r in results], dtype=np.int64),
                         accuracy=np.array([r["accuracy"] for r in results]), min_top2_margin=np.array(margins),
                         config=np.array(json.dumps(cfg)))
-    print("  epoch: %d steps (batch sizes %s), loss %.4f -> %.4f, eval %s, min top-2 margin %.2e"
-          % (len(loss_list), sorted(set(sizes)), loss_list[0], loss_list[-1], results, min(margins)))
+    print("  epoch: %d steps (batch sizes %s), loss %.4f -> %.4f, eval %s on %d of %d pool rows, min top-2 margin %.2e"
+          % (len(loss_list), sorted(set(sizes)), loss_list[0], loss_list[-1], results, len(rows), len(pool_x), min(margins)))
 
 
 def reference_own_tests():

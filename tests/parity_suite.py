@@ -288,10 +288,28 @@ def classifier_head_kernel_vs_numpy():
     assert mask[3, 5] and np.asarray(dA)[3, 5] != 0.0
 
 
+def _check_head_outputs(m, a, z, w64, y64, logits, loss, stats, dz, dw, db, dA, tag):
+    a64 = a.astype(np.float64)
+    e = np.exp(z - z.max()); S = e.sum(); q = (e * y64).sum(1, keepdims=True)
+    ref_loss = (np.log(S) - np.log(q)).sum() / m
+    ref_dz = e / S - (e * y64 / q) / m
+    mask = ~np.signbit(a)
+    np.testing.assert_allclose(np.asarray(logits), z, rtol=0, atol=2e-5 * np.abs(z).max(), err_msg=tag)
+    np.testing.assert_allclose(float(loss), ref_loss, rtol=1e-5, err_msg=tag)
+    np.testing.assert_allclose(np.asarray(stats), [z.max(), S], rtol=1e-5, err_msg=tag)
+    np.testing.assert_allclose(np.asarray(dz), ref_dz, rtol=0, atol=1e-5 * np.abs(ref_dz).max(), err_msg=tag)
+    ref_dw = a64.T @ ref_dz
+    np.testing.assert_allclose(np.asarray(dw), ref_dw, rtol=0, atol=1e-5 * np.abs(ref_dw).max(), err_msg=tag)
+    np.testing.assert_allclose(np.asarray(db), ref_dz.sum(0), rtol=0, atol=1e-5 * np.abs(ref_dz.sum(0)).max() + 1e-9, err_msg=tag)
+    ref_da = (ref_dz @ w64.T) * mask
+    np.testing.assert_allclose(np.asarray(dA), ref_da, rtol=0, atol=1e-5 * np.abs(ref_da).max(), err_msg=tag)
+
+
 def classifier_head_one_launch_multi_workgroup_vs_numpy():
     """tnn_mlp_head_tick (the 5-launch step's head: last Dense forward + whole-batch softmax NLL + last Dense backward +
     Adam's beta powers in ONE multi-workgroup launch) against float64 numpy: full and ragged batches (128, 104, 80, 37, 1
-    rows), sign-encoded ReLU zeros in the activations incl. an exactly-zero pre-activation, soft labels."""
+    rows), sign-encoded ReLU zeros in the activations incl. an exactly-zero pre-activation, soft labels; with the logits
+    computed inside the head and with the per-tile partial logits of tnn_dense_fwd_head_partials (a 52-wide layer in front)."""
     import ctypes
     from tinynn_autograd_amd import _lib
     lib = _lib.get()
@@ -312,26 +330,32 @@ def classifier_head_one_launch_multi_workgroup_vs_numpy():
         stats, loss = tn.empty((2,)), tn.empty(())
         dw, db, dA = tn.zeros((Hn, C)), tn.zeros((C,)), tn.zeros((m, Hn))
         pows = tn.asarray(np.array([0.9, 0.999, 0, 0]), dtype=np.float64)
-        lib.mlp_head_tick(m, Hn, C, A._ptr, W._ptr, B._ptr, Y._ptr, logits._ptr, dz._ptr, stats._ptr, loss._ptr,
-                          dw._ptr, db._ptr, dA._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
         a64, w64, y64 = a.astype(np.float64), w.astype(np.float64), y.astype(np.float64)
         z = a64 @ w64 + b
-        e = np.exp(z - z.max()); S = e.sum(); q = (e * y64).sum(1, keepdims=True)
-        ref_loss = (np.log(S) - np.log(q)).sum() / m
-        ref_dz = e / S - (e * y64 / q) / m
-        mask = ~np.signbit(a)
-        tag = "rows=%d" % m
-        np.testing.assert_allclose(np.asarray(logits), z, rtol=0, atol=2e-5 * np.abs(z).max(), err_msg=tag)
-        np.testing.assert_allclose(float(loss), ref_loss, rtol=1e-5, err_msg=tag)
-        np.testing.assert_allclose(np.asarray(stats), [z.max(), S], rtol=1e-5, err_msg=tag)
-        np.testing.assert_allclose(np.asarray(dz), ref_dz, rtol=0, atol=1e-5 * np.abs(ref_dz).max(), err_msg=tag)
-        ref_dw = a64.T @ ref_dz
-        np.testing.assert_allclose(np.asarray(dw), ref_dw, rtol=0, atol=1e-5 * np.abs(ref_dw).max(), err_msg=tag)
-        np.testing.assert_allclose(np.asarray(db), ref_dz.sum(0), rtol=0, atol=1e-5 * np.abs(ref_dz.sum(0)).max() + 1e-9, err_msg=tag)
-        ref_da = (ref_dz @ w64.T) * mask
-        np.testing.assert_allclose(np.asarray(dA), ref_da, rtol=0, atol=1e-5 * np.abs(ref_da).max(), err_msg=tag)
-        assert mask[0, 5] and np.asarray(dA)[0, 5] != 0.0
-        np.testing.assert_allclose(np.asarray(pows)[:2], [0.81, 0.999 ** 2], rtol=1e-14)
+        for use_partials in (False, True):
+            zpart_ptr = None
+            if use_partials:
+                # the activations as the previous layer's forward: a = relu(x w1 + b1) with the logits' partial sums
+                K1 = 52
+                x = rs.randn(m, K1).astype(np.float32)
+                w1 = (rs.randn(K1, Hn) * 0.3).astype(np.float32)
+                b1v = rs.randn(Hn).astype(np.float32)
+                X, W1, B1 = (tn.asarray(v) for v in (x, w1, b1v))
+                zpart = tn.zeros((Hn // 16, m, C))
+                lib.dense_fwd_head_partials(m, Hn, K1, X._ptr, K1, W1._ptr, Hn, B1._ptr, _lib.ACT_RELU, 1, A._ptr, Hn,
+                                            W._ptr, C, zpart._ptr, _lib.F32)
+                a = np.asarray(A).copy()
+                pre = x.astype(np.float64) @ w1.astype(np.float64) + b1v
+                np.testing.assert_allclose(np.abs(a), np.maximum(pre, 0), rtol=0, atol=2e-5 * np.abs(pre).max())
+                a64 = a.astype(np.float64)
+                ref_part = np.stack([a64[:, 16 * k:16 * k + 16] @ w64[16 * k:16 * k + 16] for k in range(Hn // 16)])
+                np.testing.assert_allclose(np.asarray(zpart), ref_part, rtol=0, atol=1e-5 * np.abs(ref_part).max())
+                z = a64 @ w64 + b
+                zpart_ptr = zpart._ptr
+            lib.mlp_head_tick(m, Hn, C, A._ptr, W._ptr, B._ptr, Y._ptr, zpart_ptr, logits._ptr, dz._ptr, stats._ptr,
+                              loss._ptr, dw._ptr, db._ptr, dA._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
+            _check_head_outputs(m, a, z, w64, y64, logits, loss, stats, dz, dw, db, dA, "rows=%d partials=%s" % (m, use_partials))
+        np.testing.assert_allclose(np.asarray(pows)[:2], [0.9 ** 3, 0.999 ** 3], rtol=1e-14)     # two ticks
     lib.mlp_head_fits(129, Hn, C, _lib.F32, ctypes.byref(fits))
     assert fits.value == 0                                                     # the trainer then takes the 7-launch step
 
@@ -555,14 +579,16 @@ def _check_epoch_loop(trainer):
     gold = dict(np.load(H.GOLDEN + "/epoch.npz"))
     cfg = json.loads(str(gold["config"]))
     assert cfg == synth.EPOCH_CFG
-    train_x, train_y, test_x, test_y = synth.epoch_dataset(cfg)
+    train_x, train_y, pool_x, pool_y = synth.epoch_dataset(cfg)
+    test_x, test_y = pool_x[gold["test_rows"]], pool_y[gold["test_rows"]]      # the fixture's well-conditioned rows
     random_seed(cfg["seed"])
     losses, preds, results = mnist_run.train(train_x, train_y, test_x, test_y, cfg["widths"][1:-1], cfg["num_ep"],
                                              cfg["batch_size"], cfg["lr"], trainer=trainer)
     assert len(losses) == len(gold["loss"]) == 16 and gold["batch_sizes"].tolist() == ([128] * 7 + [104]) * 2
     np.testing.assert_allclose(losses, gold["loss"], rtol=RTOL)
     for ep in range(cfg["num_ep"]):
-        assert preds[ep].dtype == np.int64 and np.array_equal(preds[ep], gold["argmax"][ep]), "epoch %d argmax" % ep
+        assert preds[ep].dtype == np.int64 and np.array_equal(preds[ep], gold["argmax"][ep]), \
+            "epoch %d argmax: %d of %d rows differ" % (ep, int((preds[ep] != gold["argmax"][ep]).sum()), len(preds[ep]))
         assert results[ep]["hit_num"] == int(gold["hit_num"][ep]) and results[ep]["total_num"] == int(gold["total_num"][ep])
         assert results[ep]["accuracy"] == float(gold["accuracy"][ep])
 

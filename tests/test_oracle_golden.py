@@ -79,7 +79,8 @@ def test_layers_and_epoch_loop_bit_exact():
     np.testing.assert_allclose(gold["tanh_f64_out"], np.tanh(x / 2), rtol=1e-12, atol=1e-15)
     ep = dict(np.load(H.GOLDEN + "/epoch.npz"))
     cfg = json.loads(str(ep["config"]))
-    train_x, train_y, test_x, test_y = synth.epoch_dataset(cfg)
+    train_x, train_y, pool_x, pool_y = synth.epoch_dataset(cfg)
+    test_x, test_y = pool_x[ep["test_rows"]], pool_y[ep["test_rows"]]
     np.random.seed(cfg["seed"])
     losses, preds, results = ref_nn.train_epochs(cfg["widths"], train_x, np.eye(10)[train_y], test_x, test_y, 1,
                                                  cfg["batch_size"], cfg["lr"])

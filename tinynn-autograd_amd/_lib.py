@@ -83,7 +83,9 @@ _SIGNATURES = {
     "tnn_softmax_nll_fused_tick": [_p, _p, c_int64, c_int64, c_int64, c_int, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mlp_head_fits": [c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
-    "tnn_mlp_head_tick": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, _p, c_double, c_double],
+    "tnn_mlp_head_tick": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, _p, c_double, c_double],
+    "tnn_dense_fwd_head_partials": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
+                                    _p, c_int64, _p, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_dense_bwd_first_adam": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64,

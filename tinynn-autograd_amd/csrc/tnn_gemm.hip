@@ -43,6 +43,11 @@ struct GemmArgs {
     int splits;
     float* ws;             // [splits, M, N] partial sums when splits > 1
     int tiles_m, tiles_n;
+    // small/latency kernel only (tnn_dense_fwd_head_partials): the NEXT (classifier) layer's weights head_w [N, head_c]
+    // and where this tile's share of that layer's logits goes, head_z [tiles_n][M][head_c]
+    const float* head_w;
+    float* head_z;
+    int head_c;
 #ifdef TNN_GEMM_TRACE
     unsigned long long* trace;   // debug build only: [grid][8] timeline words (nullptr = off)
 #endif
@@ -658,6 +663,8 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
         else if (g.epi == EPI_MASK) e_pre = g.Y[e_row * g.ldy + e_col];
         else if (g.beta != 0.f) e_pre = g.C[e_row * g.ldc + e_col];
     }
+    float head_pre = 0.f;                                     // head_w[n0 + tid / hc][tid % hc]: rows n0 .. n0 + 15 are contiguous
+    if (g.head_z != nullptr && tid < 16 * g.head_c && n0 * g.head_c + tid < g.N * g.head_c) head_pre = g.head_w[n0 * g.head_c + tid];
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
@@ -709,17 +716,42 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
     for (int r = 0; r < 4; ++r) red[wid][r][lane] = acc[r];
     bsum[wid][lane] = bs;
     __syncthreads();
+    float e_val = 0.f;
     if (tid < 256) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += red[w][e_r][e_ln];
-        if (e_live) g.C[e_row * g.ldc + e_col] = finish_epilogue(g, s, e_pre);
+        if (e_live) {
+            e_val = finish_epilogue(g, s, e_pre);
+            g.C[e_row * g.ldc + e_col] = e_val;
+        }
     }
     if (colsum != nullptr && tm == 0 && tid < 16 && n0 + tid < g.N) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += (bsum[w][tid] + bsum[w][16 + tid]) + (bsum[w][32 + tid] + bsum[w][48 + tid]);
         colsum[n0 + tid] = s;
+    }
+    if (g.head_z != nullptr) {
+        // This tile's share of the NEXT layer's logits: head_z[tn][row][c] = sum over the tile's 16 columns of
+        // out[row][col] * head_w[n0 + col][c] (a sign-encoded ReLU zero, -0.0, contributes -0 * w = 0).  The classifier
+        // head then only ADDS tiles_n partials per logit instead of re-reading the whole activation and redoing the
+        // product in every workgroup (csrc/tnn_head.hip).  The finished tile goes through LDS (the K-split partials in
+        // `red` are dead once every thread has summed them), head_w's 16 rows arrive in one coalesced load.
+        const int hc = g.head_c;
+        float* tile_s = &red[0][0][0];                        // [16][17]
+        float* hw_s = tile_s + 16 * 17;                         // [16][hc]
+        __syncthreads();
+        if (tid < 256) tile_s[((e_ln >> 4) * 4 + e_r) * 17 + (e_ln & 15)] = e_val;
+        if (tid < 16 * hc) hw_s[tid] = head_pre;
+        __syncthreads();
+        if (tid < 16 * hc) {
+            const int row_l = tid / hc, c = tid - row_l * hc;
+            float acc = 0.f;
+#pragma unroll
+            for (int col = 0; col < 16; ++col) acc = fmaf(tile_s[row_l * 17 + col], hw_s[col * hc + c], acc);
+            if (m0 + row_l < g.M) g.head_z[((int64_t)tn * g.M + m0 + row_l) * hc + c] = acc;
+        }
     }
 }
 
@@ -1012,6 +1044,21 @@ int check_shapes(const char* fn, int transA, int transB, int64_t M, int64_t N, i
     return 0;
 }
 
+// fallback of tnn_dense_fwd_head_partials for shapes the latency kernel does not take: the same partial sums from the
+// finished output, one thread per (tile, row, class)
+__global__ __launch_bounds__(256) void head_partials_kernel(const float* __restrict__ out, int64_t M, int64_t N, int64_t ldc,
+                                                            const float* __restrict__ hw, int hc, float* __restrict__ hz) {
+    const int64_t tiles_n = (N + 15) / 16, total = tiles_n * M * hc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % hc);
+        const int64_t row = (i / hc) % M, tn = i / (hc * M);
+        float acc = 0.f;
+        for (int col = 0; col < 16 && tn * 16 + col < N; ++col)
+            acc = fmaf(out[row * ldc + tn * 16 + col], hw[(tn * 16 + col) * hc + c], acc);
+        hz[i] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1163,6 +1210,35 @@ int tnn_gemm_bias_act(int transA, int transB, int64_t M, int64_t N, int64_t K, c
     g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_BIAS_ACT;
     g.bias = (const float*)bias; g.act = act; g.relu_sign = relu_sign;
     return gemm_f32(g, transA, transB);
+}
+
+int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                                           int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
+                                           const void* head_w, int64_t head_c, void* head_z, int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_dense_fwd_head_partials", 0, 0, M, N, K, lda, ldb, ldc)) return rc;
+    TNN_REQUIRE(dtype == TNN_F32, "tnn_dense_fwd_head_partials: f32 only (dtype %d)", dtype);
+    TNN_REQUIRE(head_w && head_z && head_c >= 1 && head_c <= 16, "tnn_dense_fwd_head_partials: head_w, head_z and 1 <= head_c <= 16");
+    TNN_REQUIRE(act == TNN_ACT_NONE || act == TNN_ACT_RELU, "tnn_dense_fwd_head_partials: activation %d", act);
+    if (M == 0 || N == 0) return 0;
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)B; g.C = (float*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_BIAS_ACT;
+    g.bias = (const float*)bias; g.act = act; g.relu_sign = relu_sign;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    g.vecA = al(A) && lda % 4 == 0 && K % 4 == 0;
+    g.vecB = al(B) && ldb % 4 == 0 && N % 4 == 0;
+    if (use_small_path(g) && small_fast_ok(g, 0, 0)) {
+        g.head_w = (const float*)head_w; g.head_z = (float*)head_z; g.head_c = (int)head_c;
+        return gemm_small(g, 0, 0, nullptr);                   // the partials ride in the tile epilogue: ONE launch
+    }
+    if (int rc = gemm_f32(g, 0, 0)) return rc;
+    const int64_t total = ((N + 15) / 16) * M * head_c;
+    hipLaunchKernelGGL(head_partials_kernel, tnn::stream_grid(total, 256), 256, 0, tnn::stream(), (const float*)C, M, N, ldc,
+                       (const float*)head_w, (int)head_c, (float*)head_z);
+    TNN_LAUNCH_OK();
+    return 0;
 }
 
 int tnn_gemm_mask(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,

@@ -225,107 +225,179 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
 struct HeadMArgs {
     int m, rpb;                      // rows (<= 128); da rows per workgroup
     const float *a, *w, *b, *y;
+    const float* zpart;              // [H / 16][m][C] partial logits from the previous layer's tiles, or NULL
     float *logits, *dz, *stats, *loss, *dw, *db, *da;
     double* tick;
     double b1, b2;
 };
 
-template <int H, int C>
+// PART: the logits arrive as H / 16 partial sums per element (tnn_dense_fwd_head_partials: the previous layer's 16-column
+// tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
+// v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
+// CUT (timing builds only, TNN_HEAD_CUT): 0 = the kernel; 1 = stop after the logits, 2 = after the statistics, 3 = after dz.
+template <int H, int C, bool PART, int CUT = 0>
 __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
-    constexpr int ROWS = 128, KQ = 4, KS = H / KQ, ZS = C + 1, JPB = 8, G = H / JPB;
-    static_assert(H == ROWS, "thread (t & 127) doubles as the hidden-unit index of the da phase");
-    __shared__ float zp[KQ][ROWS * ZS];            // partial logits; zp[0] is reused for dz
+    constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
+    static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
+    __shared__ float zs[ROWS * ZS];                // logits (MFMA form only), then dz; odd row stride: conflict-free
+    __shared__ __attribute__((aligned(16))) float ws[H * WS];   // W, rows padded to 12 (columns >= C hold 0)
     __shared__ float aslice[ROWS][JPB + 1];        // a[:, 8g : 8g + 8] for this workgroup's dW rows
-    __shared__ double red[2][4];
+    __shared__ double red[8][4];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int r = t & (ROWS - 1), kq = t >> 7;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int r = t & (ROWS - 1), kq = t >> 7;     // da phase: column r, row group kq
+    const int srow = t >> 2, sub = t & 3;          // statistics: row srow, classes sub, sub + 4, sub + 8
     const int m = p.m, g = blockIdx.x;
-    const bool live = r < m;
+    const bool slive = srow < m;
 
-    // ---- every global read of the kernel is requested here, before the first use.  No exec-mask branches: rows beyond
-    // m read a clamped (valid) address and are neutralised in the arithmetic instead (their dz is 0, so whatever they
-    // loaded never reaches an output).
-    const int rl = min(r, m - 1);
-    f32x4 a4[KS / 4];
+    // ---- every global read of the kernel is requested here, before the first use, in as few vector-memory
+    // instructions as possible; no exec-mask branches around loads: rows beyond m read a clamped (valid) address and
+    // are neutralised in the arithmetic (their dz is 0, so whatever they loaded never reaches an output).
+    const int sr = min(srow, m - 1);
+    float zc[3] = {0.f, 0.f, 0.f}, yc[3];
+    float part[PART ? 3 : 1][PART ? NP : 1];
+    f32x4 av[PART ? 1 : KC];
+    if constexpr (PART) {
 #pragma unroll
-    for (int i = 0; i < KS / 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(p.a + (size_t)rl * H + kq * KS + 4 * i);
-    float wrow[C], yrow[C], am[2];
+        for (int i = 0; i < 3; ++i) {
+            const int c = min(sub + 4 * i, C - 1);
+#pragma unroll
+            for (int tn = 0; tn < NP; ++tn) part[i][tn] = p.zpart[((size_t)tn * m + sr) * C + c];
+        }
+    } else {
+        const float* arow = p.a + (size_t)min(16 * wid + i16, m - 1) * H + 4 * grp;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) av[c] = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
+    float bc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bc[i] = p.b[min(sub + 4 * i, C - 1)];
+    constexpr int WV = H * C / 4;                                       // float4 pieces of W (320)
+    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+    if (t < WV) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
+    float am[2];
     const int r0 = g * p.rpb, rend = min(m, r0 + p.rpb);
 #pragma unroll
-    for (int c = 0; c < C; ++c) wrow[c] = p.w[(size_t)r * C + c];      // W[j = r][c] for the da phase
-#pragma unroll
     for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
-#pragma unroll
-    for (int c = 0; c < C; ++c) yrow[c] = p.y[(size_t)rl * C + c];
     const f32x4 asl = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
 
-    // ---- partial logits of this thread's row over its K-quarter (W through the scalar cache)
-    {
-        const int kb = __builtin_amdgcn_readfirstlane(kq) * KS;
-        const float* __restrict__ wk = p.w + (size_t)kb * C;
-        float acc[C];
+    // ---- W and the dW slice of a -> LDS (visible after the first barrier below)
+    if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
+    if (t < WV) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const float av = a4[kk >> 2][kk & 3];
-#pragma unroll
-            for (int c = 0; c < C; ++c) acc[c] = fmaf(av, wk[kk * C + c], acc[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) zp[kq][r * ZS + c] = acc[c];
+        for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
     }
     if (t < 2 * ROWS) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) aslice[t >> 1][4 * (t & 1) + i] = asl[i];
     }
-    __syncthreads();
 
-    // ---- per-row softmax pieces (waves 0-1: one thread per row), combined reduction
-    float z[C], e[C], ey[C];
-    double mi = -INFINITY, si = 0.0, li = 0.0, ui = 1.0;
-    if (kq == 0) {                                             // wave-uniform
+    if constexpr (PART) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            z[c] = p.b[c] + ((zp[0][r * ZS + c] + zp[1][r * ZS + c]) + (zp[2][r * ZS + c] + zp[3][r * ZS + c]));
-        if (live) {
-            float mx = z[0];
+        for (int i = 0; i < 3; ++i)
+            zc[i] = (((part[i][0] + part[i][1]) + (part[i][2] + part[i][3])) + ((part[i][4] + part[i][5]) + (part[i][6] + part[i][7]))) + bc[i];
+        static_assert(!PART || NP == 8, "the partial-sum tree is written for 8 tiles");
+    } else {
+        // wave w owns the 16-row tile [16 w, 16 w + 16) over the whole K = H: lane (i16, grp) holds a[row i16][16 c + 4 grp + j]
+        // (registers, from global) and W[16 c + 4 grp + j][col i16] (LDS; columns 10, 11 are zeros, lanes i16 >= 12 re-read
+        // column 11); two accumulator chains (40-cycle dependent latency against a 32-cycle issue)
+        __syncthreads();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* wl = ws + (4 * grp) * WS + min(i16, WS - 1);
 #pragma unroll
-            for (int c = 1; c < C; ++c) mx = z[c] > mx ? z[c] : mx;
-            double s = 0.0, u = 0.0;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const double ek = (double)expf(z[c] - mx);
-                e[c] = (float)ek;
-                ey[c] = (float)((double)e[c] * (double)yrow[c]);
-                s += ek;
-                u += (double)ey[c];
-            }
-            mi = (double)mx; si = s; ui = u;
-            li = (double)logf((float)u) + (double)mx;
+        for (int c = 0; c < KC; ++c) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][0], wl[(16 * c + 0) * WS], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][1], wl[(16 * c + 1) * WS], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][2], wl[(16 * c + 2) * WS], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][3], wl[(16 * c + 3) * WS], acc1, 0, 0, 0);
         }
-        const double wm = tnn::wave_max_dpp(mi);
-        const double ws = tnn::wave_sum_dpp(live ? si * (double)expf((float)(mi - wm)) : 0.0);
-        const double wl = tnn::wave_sum_dpp(li);
-        if (lane == 0) { red[wid][0] = wm; red[wid][1] = ws; red[wid][2] = wl; }
-    }
-    __syncthreads();
-    double M = fmax(red[0][0], red[1][0]), S = 0.0;
+        if (i16 < C) {
+            const float bias = p.b[i16];
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
-        if (red[w][0] > -INFINITY) S += red[w][1] * (double)expf((float)(red[w][0] - M));
-    const double L = red[0][2] + red[1][2];
-    const double inv_m = 1.0 / (double)m;
-    if (kq == 0) {
-        const float sf = live ? (float)((double)expf((float)(mi - M)) / S) : 0.f, uf = live ? (float)(inv_m / ui) : 0.f;
+            for (int q = 0; q < 4; ++q) zs[(16 * wid + 4 * grp + q) * ZS + i16] = (acc0[q] + acc1[q]) + bias;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int c = 0; c < C; ++c) zp[0][r * ZS + c] = live ? e[c] * sf - ey[c] * uf : 0.f;   // dz (0 in the padding rows)
+        for (int i = 0; i < 3; ++i) zc[i] = zs[srow * ZS + min(sub + 4 * i, C - 1)];
     }
-    __syncthreads();
-    const float* dzs = zp[0];
+    if constexpr (CUT == 1) {
+        p.da[(size_t)g * 512 + t] = zc[0] + zc[1] + zc[2] + am[0] + am[1] + yc[0];
+        return;
+    }
 
-    // ---- da rows of this workgroup: thread (column j = r, row group kq)
+    // ---- whole-batch softmax statistics: FOUR threads per row (classes sub, sub + 4, sub + 8), row max / sums by
+    // quad-permute DPP; then ONE combined reduction of {max, rescaled sum-exp, sum(log u + max)} over the workgroup
+    // (DPP wave reductions + an 8-entry LDS exchange).  Row sums in f32 (10 terms), cross-row sums in f64 — the
+    // arithmetic of nll_rows_body (tnn_nll_rows.h) up to summation order.
+    bool valid[3];
+    float ec[3], eyc[3];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        valid[i] = sub + 4 * i < C;
+        if (valid[i]) mx = zc[i] > mx ? zc[i] : mx;
+    }
+    { float o = tnn::dpp_move<0xB1, 0xf>(-INFINITY, mx); mx = o > mx ? o : mx; }
+    { float o = tnn::dpp_move<0x4E, 0xf>(-INFINITY, mx); mx = o > mx ? o : mx; }
+    float srow_sum = 0.f, urow = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ec[i] = valid[i] ? expf(zc[i] - mx) : 0.f;
+        eyc[i] = ec[i] * (valid[i] ? yc[i] : 0.f);
+        srow_sum += ec[i];
+        urow += eyc[i];
+    }
+    srow_sum += tnn::dpp_move<0xB1, 0xf>(0.f, srow_sum);
+    srow_sum += tnn::dpp_move<0x4E, 0xf>(0.f, srow_sum);
+    urow += tnn::dpp_move<0xB1, 0xf>(0.f, urow);
+    urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
+    const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
+    const float wm = tnn::wave_max_dpp(slive ? mx : -INFINITY);
+    const double wsum = tnn::wave_sum_dpp(counts ? (double)srow_sum * (double)expf(mx - wm) : 0.0);
+    const double wlog = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
+    if (lane == 0) { red[wid][0] = (double)wm; red[wid][1] = wsum; red[wid][2] = wlog; }
+    __syncthreads();
+    double Md = red[0][0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) Md = fmax(Md, red[w][0]);
+    const float M = (float)Md;
+    double S = 0.0, L = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        if (red[w][0] > -INFINITY) S += red[w][1] * (double)expf((float)red[w][0] - M);
+        L += red[w][2];
+    }
+    const double inv_m = 1.0 / (double)m;
+    if constexpr (CUT == 2) {
+        p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
+        return;
+    }
+    float dzc[3];
+    {
+        const float sf = slive ? expf(mx - M) / (float)S : 0.f, uf = slive ? (float)inv_m / urow : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dzc[i] = ec[i] * sf - eyc[i] * uf;                  // 0 in the padding rows
+            if (valid[i]) zs[srow * ZS + sub + 4 * i] = dzc[i];
+        }
+    }
+    __syncthreads();
+    const float* dzs = zs;
+    if constexpr (CUT == 3) {
+        p.da[(size_t)g * 512 + t] = dzs[r * ZS] + aslice[r][0] + am[0] + am[1];
+        return;
+    }
+
+    // ---- da rows of this workgroup: thread (column j = r, row group kq), W[j][:] as three conflict-free 16-B LDS reads
     if (p.da) {
+        float wrow[WS];
+#pragma unroll
+        for (int i = 0; i < WS / 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + r * WS + 4 * i);
+            wrow[4 * i] = v[0]; wrow[4 * i + 1] = v[1]; wrow[4 * i + 2] = v[2]; wrow[4 * i + 3] = v[3];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = r0 + kq + 4 * i;                    // wave-uniform: the dz row is an LDS broadcast
@@ -337,12 +409,13 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
             }
         }
     }
-    // ---- dW rows [8g, 8g + 8): output o = (jl, c), four row-quarters per output on neighbouring lanes
+    // ---- dW rows [8g, 8g + 8): output o = (jl, c), four interleaved row classes (row = 4 i + q: neighbouring lanes
+    // read neighbouring rows, i.e. different banks — rows 32 q + i put all four on one bank, 4-way conflicts, +0.5 us)
     if (t < JPB * C * 4) {                                      // 320 threads = 5 whole waves
         const int q = t & 3, o = t >> 2, jl = o / C, c = o - jl * C;
         float s = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < ROWS / 4; ++i) s = fmaf(aslice[32 * q + i][jl], dzs[(32 * q + i) * ZS + c], s);
+        for (int i = 0; i < ROWS / 4; ++i) s = fmaf(aslice[4 * i + q][jl], dzs[(4 * i + q) * ZS + c], s);
         s += tnn::dpp_move<0xB1, 0xf>(0.f, s);
         s += tnn::dpp_move<0x4E, 0xf>(0.f, s);
         if (q == 0) p.dw[(size_t)(g * JPB + jl) * C + c] = s;
@@ -352,23 +425,24 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
             const int c = lane & 15, rq = lane >> 4;
             float s = 0.f;
             if (c < C)
-                for (int i = 0; i < ROWS / 4; ++i) s += dzs[(32 * rq + i) * ZS + c];
+                for (int i = 0; i < ROWS / 4; ++i) s += dzs[(4 * i + rq) * ZS + c];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             if (lane < C) p.db[lane] = s;
         }
         if (t == 0) {
-            if (p.loss) p.loss[0] = (float)((double)logf((float)S) + M - L * inv_m);
-            if (p.stats) { p.stats[0] = (float)M; p.stats[1] = (float)S; }
+            if (p.loss) p.loss[0] = (float)((double)logf((float)S) + (double)M - L * inv_m);
+            if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
             if (p.tick) { p.tick[0] *= p.b1; p.tick[1] *= p.b2; }
         }
     }
-    if (g == G - 1 && kq == 0 && live) {
+    if (g == G - 1 && slive) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if (p.logits) p.logits[(size_t)r * C + c] = z[c];
-            if (p.dz) p.dz[(size_t)r * C + c] = dzs[r * ZS + c];
-        }
+        for (int i = 0; i < 3; ++i)
+            if (valid[i]) {
+                if (p.logits) p.logits[(size_t)srow * C + sub + 4 * i] = zc[i];
+                if (p.dz) p.dz[(size_t)srow * C + sub + 4 * i] = dzc[i];
+            }
     }
 }
 
@@ -429,8 +503,8 @@ int tnn_mlp_head_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dty
 }
 
 int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* a, const void* w,
-                      const void* b, const void* y, void* logits, void* dz, void* stats, void* loss, void* dw,
-                      void* db, void* da, int dtype, void* adam_pows_f64, double b1, double b2) {
+                      const void* b, const void* y, const void* logit_partials, void* logits, void* dz, void* stats,
+                      void* loss, void* dw, void* db, void* da, int dtype, void* adam_pows_f64, double b1, double b2) {
     TNN_NEED_INIT();
     TNN_REQUIRE(rows > 0 && n_hidden > 0 && n_classes > 0, "tnn_mlp_head_tick: empty head");
     TNN_REQUIRE(a && w && b && y && dw && db, "tnn_mlp_head_tick: a, w, b, y, dw and db are required");
@@ -440,10 +514,20 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.m = (int)rows;
     p.rpb = (int)((rows + 15) / 16);
     p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
+    p.zpart = (const float*)logit_partials;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
-    hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10>), 16, 512, 0, tnn::stream(), p);
+    static const int cut = getenv("TNN_HEAD_CUT") ? atoi(getenv("TNN_HEAD_CUT")) : 0;     // timing builds
+    hipStream_t st = tnn::stream();
+    if (p.zpart) {
+        if (cut == 1) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 1>), 16, 512, 0, st, p);
+        else if (cut == 2) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 2>), 16, 512, 0, st, p);
+        else if (cut == 3) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 3>), 16, 512, 0, st, p);
+        else hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true>), 16, 512, 0, st, p);
+    } else {
+        hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, false>), 16, 512, 0, st, p);
+    }
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -42,6 +42,7 @@ struct Mlp {
     char *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
     void* pows = nullptr;            // Adam state, double[4]
     void* stats = nullptr;           // {M, S} of the last forward_stats
+    void* zpart = nullptr;           // [w[L-1] / 16][max_rows][w[L]] partial logits (5-launch step, see tnn_mlp_step)
     void* stats_all = nullptr;       // [world, 2] gathered shard stats (data-parallel step)
     int stats_all_world = 0;
     std::vector<int64_t> w_off, b_off;
@@ -273,6 +274,8 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     rc |= tnn_malloc(bytes, (void**)&h->v);
     rc |= tnn_malloc(4 * sizeof(double), &h->pows);
     rc |= tnn_malloc(2 * 8, &h->stats);
+    if (n_layers >= 2 && dtype == TNN_F32)
+        rc |= tnn_malloc((size_t)((widths[n_layers - 1] + 15) / 16 * max_rows * widths[n_layers]) * 4, &h->zpart);
     const size_t act_esz = h->bf16 ? 2 : h->esz;
     for (int l = 0; l < n_layers && !rc; ++l) {
         void *a = nullptr, *d = nullptr;
@@ -314,7 +317,7 @@ int tnn_mlp_destroy(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) return 0;
     tnn_free(h->params); tnn_free(h->grads); tnn_free(h->m); tnn_free(h->v);
-    tnn_free(h->pows); tnn_free(h->stats); tnn_free(h->stats_all);
+    tnn_free(h->pows); tnn_free(h->stats); tnn_free(h->stats_all); tnn_free(h->zpart);
     for (void* p : h->act) tnn_free(p);
     for (void* p : h->dact) tnn_free(p);
     for (void* p : h->wT16) tnn_free(p);
@@ -437,10 +440,17 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // 2L - 1 launches (5 for the MNIST net): forward of the hidden layers | the classifier head as ONE multi-workgroup
         // launch (last Dense forward + loss + last Dense backward + Adam's beta powers) | backward of the hidden layers,
         // the first layer's carrying the whole optimizer
-        MLP_TRY(mlp_forward(h, x, rows, L - 1));
+        // the hidden layer in front of the classifier also emits the logits as per-tile partial sums (its activations
+        // are in registers there), so no workgroup of the head has to redo a W
+        MLP_TRY(mlp_forward(h, x, rows, L - 2));
+        STEP_CALL(h, tnn_dense_fwd_head_partials(rows, h->w[L - 1], h->w[L - 2], L > 2 ? h->act[L - 3] : x, h->w[L - 2],
+                                                 at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                 at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                 h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                 h->dtype));
         STEP_CALL(h, tnn_mlp_head_tick(rows, h->w[L - 1], h->w[L], h->act[L - 2],
                                        at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
-                                       h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
+                                       h->zpart, h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
                                        at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
                                        h->dact[L - 2], h->dtype, h->pows, h->b1, h->b2));
         MLP_TRY(mlp_backward_layers(h, x, rows, L - 2, 1));
