@@ -633,7 +633,7 @@ __device__ __forceinline__ float finish_epilogue(const GemmArgs& g, float acc, f
 //     instead of after the cross-wave reduction.
 template <bool AKC, bool BKC, int WAVES>
 __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __restrict__ colsum, int block,
-                                                float (*red)[4][64], float (*bsum)[64]) {
+                                                float (*red)[4][64], float (*bsum)[64], float* head_lds = nullptr) {
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     constexpr uint32_t OOB = 0xffffffffu;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -663,8 +663,12 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
         else if (g.epi == EPI_MASK) e_pre = g.Y[e_row * g.ldy + e_col];
         else if (g.beta != 0.f) e_pre = g.C[e_row * g.ldc + e_col];
     }
-    float head_pre = 0.f;                                     // head_w[n0 + tid / hc][tid % hc]: rows n0 .. n0 + 15 are contiguous
-    if (g.head_z != nullptr && tid < 16 * g.head_c && n0 * g.head_c + tid < g.N * g.head_c) head_pre = g.head_w[n0 * g.head_c + tid];
+    float head_pre[4] = {0.f, 0.f, 0.f, 0.f};                 // wave 0: head_w[n0 + 4 grp + j][i16], the B fragment of the partial-logit product
+    if (g.head_z != nullptr && wid == 0 && i16 < g.head_c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + 4 * grp + j < g.N) head_pre[j] = g.head_w[(n0 + 4 * grp + j) * g.head_c + i16];
+    }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
@@ -732,25 +736,27 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
         for (int w = 0; w < WAVES; ++w) s += (bsum[w][tid] + bsum[w][16 + tid]) + (bsum[w][32 + tid] + bsum[w][48 + tid]);
         colsum[n0 + tid] = s;
     }
-    if (g.head_z != nullptr) {
+    if (head_lds != nullptr && g.head_z != nullptr) {
         // This tile's share of the NEXT layer's logits: head_z[tn][row][c] = sum over the tile's 16 columns of
         // out[row][col] * head_w[n0 + col][c] (a sign-encoded ReLU zero, -0.0, contributes -0 * w = 0).  The classifier
         // head then only ADDS tiles_n partials per logit instead of re-reading the whole activation and redoing the
-        // product in every workgroup (csrc/tnn_head.hip).  The finished tile goes through LDS (the K-split partials in
-        // `red` are dead once every thread has summed them), head_w's 16 rows arrive in one coalesced load.
-        const int hc = g.head_c;
-        float* tile_s = &red[0][0][0];                        // [16][17]
-        float* hw_s = tile_s + 16 * 17;                         // [16][hc]
+        // product in every workgroup (csrc/tnn_head.hip).  The finished 16 x 16 tile goes through LDS once and wave 0
+        // multiplies it with head_w's 16 rows (fragments requested at kernel start) in four 16x16x4 MFMAs.
+        float* tile_s = head_lds;                               // [16][20]: 16-B aligned rows, conflict-free 16-B reads
+        if (tid < 256) tile_s[((e_ln >> 4) * 4 + e_r) * 20 + (e_ln & 15)] = e_val;
         __syncthreads();
-        if (tid < 256) tile_s[((e_ln >> 4) * 4 + e_r) * 17 + (e_ln & 15)] = e_val;
-        if (tid < 16 * hc) hw_s[tid] = head_pre;
-        __syncthreads();
-        if (tid < 16 * hc) {
-            const int row_l = tid / hc, c = tid - row_l * hc;
-            float acc = 0.f;
+        if (wid == 0) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(tile_s + i16 * 20 + 4 * grp);     // out[row i16][col 4 grp + j]
+            f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int col = 0; col < 16; ++col) acc = fmaf(tile_s[row_l * 17 + col], hw_s[col * hc + c], acc);
-            if (m0 + row_l < g.M) g.head_z[((int64_t)tn * g.M + m0 + row_l) * hc + c] = acc;
+            for (int j = 0; j < 4; ++j) hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], head_pre[j], hacc, 0, 0, 0);
+            if (i16 < g.head_c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = m0 + 4 * grp + q;
+                    if (row < g.M) g.head_z[((int64_t)tn * g.M + row) * g.head_c + i16] = hacc[q];
+                }
+            }
         }
     }
 }
@@ -759,8 +765,12 @@ template <bool AKC, bool BKC, int WAVES, bool FAST>
 __global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, float* __restrict__ colsum) {
     __shared__ float red[WAVES][4][64];
     __shared__ float bsum[WAVES][64];
-    if constexpr (FAST) small_tile_fast<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum);
-    else small_tile<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum);
+    if constexpr (FAST) {
+        __shared__ __attribute__((aligned(16))) float head_lds[16 * 20];   // tnn_dense_fwd_head_partials: the finished tile
+        small_tile_fast<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum, head_lds);
+    } else {
+        small_tile<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum);
+    }
 }
 
 // Backward of one Dense layer in ONE launch: blocks [0, n_dw) compute dW = X^T dZ (TN) + db = colsum(dZ),

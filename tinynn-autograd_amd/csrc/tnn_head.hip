@@ -239,9 +239,12 @@ template <int H, int C, bool PART, int CUT = 0>
 __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
-    __shared__ float zs[ROWS * ZS];                // logits (MFMA form only), then dz; odd row stride: conflict-free
-    __shared__ __attribute__((aligned(16))) float ws[H * WS];   // W, rows padded to 12 (columns >= C hold 0)
-    __shared__ float aslice[ROWS][JPB + 1];        // a[:, 8g : 8g + 8] for this workgroup's dW rows
+    constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
+    __shared__ float zs[ROWS * ZS];                // logits (MFMA form only); odd row stride: conflict-free with lane = row
+    __shared__ __attribute__((aligned(16))) float ws[H * WS];      // W, rows padded to 12 (columns >= C hold 0)
+    __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];  // dz [row][12]: the da phase reads whole rows (16-B broadcasts)
+    __shared__ __attribute__((aligned(16))) float dzT[C * TS];     // dz^T [c][row]: the dW / db phases read 4 rows at a time
+    __shared__ __attribute__((aligned(16))) float asT[JPB * TS];   // a[:, 8g : 8g + 8]^T [j][row] for this workgroup's dW rows
     __shared__ double red[8][4];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
@@ -282,6 +285,9 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
     const f32x4 asl = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
+    // Adam's beta powers: read NOW (a dependent global round trip at the very end of workgroup 0 cost 1.3 us of the launch)
+    double pw0 = 0.0, pw1 = 0.0;
+    if (g == 0 && t == 0 && p.tick) { pw0 = p.tick[0]; pw1 = p.tick[1]; }
 
     // ---- W and the dW slice of a -> LDS (visible after the first barrier below)
     if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
     }
     if (t < 2 * ROWS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) aslice[t >> 1][4 * (t & 1) + i] = asl[i];
+        for (int i = 0; i < 4; ++i) asT[(4 * (t & 1) + i) * TS + (t >> 1)] = (t >> 1) < m ? asl[i] : 0.f;
     }
 
     if constexpr (PART) {
@@ -380,52 +386,67 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             dzc[i] = ec[i] * sf - eyc[i] * uf;                  // 0 in the padding rows
-            if (valid[i]) zs[srow * ZS + sub + 4 * i] = dzc[i];
+            if (valid[i]) {
+                dzr[srow * WS + sub + 4 * i] = dzc[i];
+                dzT[(sub + 4 * i) * TS + srow] = dzc[i];
+            }
         }
+        if (sub >= 2) dzr[srow * WS + 8 + sub] = 0.f;          // columns 10, 11 of the 16-B row reads
     }
     __syncthreads();
-    const float* dzs = zs;
     if constexpr (CUT == 3) {
-        p.da[(size_t)g * 512 + t] = dzs[r * ZS] + aslice[r][0] + am[0] + am[1];
+        p.da[(size_t)g * 512 + t] = dzr[r * WS] + asT[r] + am[0] + am[1];
         return;
     }
 
-    // ---- da rows of this workgroup: thread (column j = r, row group kq), W[j][:] as three conflict-free 16-B LDS reads
+    // ---- da rows of this workgroup: thread (column j = r, row group kq); W[j][:] and the dz row as three 16-B LDS reads
+    // each (the dz row is wave-uniform: a broadcast)
     if (p.da) {
-        float wrow[WS];
+        f32x4 wv[WS / 4];
 #pragma unroll
-        for (int i = 0; i < WS / 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(ws + r * WS + 4 * i);
-            wrow[4 * i] = v[0]; wrow[4 * i + 1] = v[1]; wrow[4 * i + 2] = v[2]; wrow[4 * i + 3] = v[3];
-        }
+        for (int i = 0; i < WS / 4; ++i) wv[i] = *reinterpret_cast<const f32x4*>(ws + r * WS + 4 * i);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = r0 + kq + 4 * i;                    // wave-uniform: the dz row is an LDS broadcast
+            const int row = r0 + kq + 4 * i;
             if (row < rend) {
                 float d = 0.f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) d = fmaf(dzs[row * ZS + c], wrow[c], d);
+                for (int k = 0; k < WS / 4; ++k) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dzr + row * WS + 4 * k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d = fmaf(dv[e], wv[k][e], d);      // columns 10, 11: 0 * 0
+                }
                 p.da[(size_t)row * H + r] = (__float_as_uint(am[i]) >> 31) ? 0.f : d;
             }
         }
     }
-    // ---- dW rows [8g, 8g + 8): output o = (jl, c), four interleaved row classes (row = 4 i + q: neighbouring lanes
-    // read neighbouring rows, i.e. different banks — rows 32 q + i put all four on one bank, 4-way conflicts, +0.5 us)
+    if constexpr (CUT == 4) return;
+    // ---- dW rows [8g, 8g + 8): output o = (jl, c); lane q of a quad takes the 4-row chunks q, q + 4, q + 8 ... of the
+    // transposed images (two 16-B reads per 4 FMAs; neighbouring lanes read neighbouring 16-B pieces: conflict-free).
+    // The first version read a[row][j] and dz[row][c] element by element: 64 LDS reads per thread, 0.7 us.
     if (t < JPB * C * 4) {                                      // 320 threads = 5 whole waves
         const int q = t & 3, o = t >> 2, jl = o / C, c = o - jl * C;
-        float s = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < ROWS / 4; ++i) s = fmaf(aslice[4 * i + q][jl], dzs[(4 * i + q) * ZS + c], s);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(asT + jl * TS + 16 * i + 4 * q);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dzT + c * TS + 16 * i + 4 * q);
+            s0 = fmaf(a4[0], d4[0], s0); s1 = fmaf(a4[1], d4[1], s1);
+            s0 = fmaf(a4[2], d4[2], s0); s1 = fmaf(a4[3], d4[3], s1);
+        }
+        float s = s0 + s1;
         s += tnn::dpp_move<0xB1, 0xf>(0.f, s);
         s += tnn::dpp_move<0x4E, 0xf>(0.f, s);
         if (q == 0) p.dw[(size_t)(g * JPB + jl) * C + c] = s;
     }
+    if constexpr (CUT == 5) return;
     if (g == 0) {
-        if (wid == 7) {                                         // db[c] = sum_r dz[r][c]
-            const int c = lane & 15, rq = lane >> 4;
-            float s = 0.f;
-            if (c < C)
-                for (int i = 0; i < ROWS / 4; ++i) s += dzs[(4 * i + rq) * ZS + c];
+        if (wid == 7) {                                         // db[c] = sum_r dz[r][c]: lane (c, row quarter)
+            const int c = min(lane & 15, C - 1), rq = lane >> 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < ROWS / 16; ++i) acc += *reinterpret_cast<const f32x4*>(dzT + c * TS + 32 * rq + 4 * i);
+            float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             if (lane < C) p.db[lane] = s;
@@ -433,7 +454,7 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
         if (t == 0) {
             if (p.loss) p.loss[0] = (float)((double)logf((float)S) + (double)M - L * inv_m);
             if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
-            if (p.tick) { p.tick[0] *= p.b1; p.tick[1] *= p.b2; }
+            if (p.tick) { p.tick[0] = pw0 * p.b1; p.tick[1] = pw1 * p.b2; }
         }
     }
     if (g == G - 1 && slive) {
@@ -524,6 +545,8 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
         if (cut == 1) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 1>), 16, 512, 0, st, p);
         else if (cut == 2) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 2>), 16, 512, 0, st, p);
         else if (cut == 3) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 3>), 16, 512, 0, st, p);
+        else if (cut == 4) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 4>), 16, 512, 0, st, p);
+        else if (cut == 5) hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true, 5>), 16, 512, 0, st, p);
         else hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, true>), 16, 512, 0, st, p);
     } else {
         hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, false>), 16, 512, 0, st, p);
