@@ -148,6 +148,9 @@ TNN_API int tnn_clip(const void* in, int has_min, double vmin, int has_max, doub
  * from the saved input instead of being stored as a bool array) */
 TNN_API int tnn_clip_bwd(const void* g, const void* x, int has_min, double vmin, int has_max,
                          double vmax, void* out, int64_t n, int dtype);
+/* out = g where the SIGN BIT of y is clear, else 0: the ReLU vjp grad * [z >= 0] (core/ops.py:342-343) when y is a
+ * fused Dense+ReLU output that keeps the mask in the sign bit of zero (z < 0 -> -0.0, z >= 0 -> |z|) */
+TNN_API int tnn_mul_signmask(const void* g, const void* y, void* out, int64_t n, int dtype);
 /* out = g * mask_u8 (grad * (a >= b) style vjps, core/ops.py:170,173,195,198,229,238) */
 TNN_API int tnn_mul_mask(const void* g, const void* mask_u8, void* out, int64_t n, int dtype);
 /* y += alpha * x — core/tensor.py:163 (self.grad += grad) and :66-68 (param += step) */

@@ -381,6 +381,14 @@ int tnn_clip_bwd(const void* g, const void* x, int hmin, double vmin, int hmax, 
     });
     return 0;
 }
+int tnn_mul_signmask(const void* g, const void* y, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    RECORD(tnn_mul_signmask(g, y, out, n, dtype));
+    FLOAT_SWITCH(dtype, "tnn_mul_signmask", {
+        for (int64_t i = 0; i < n; ++i) ((T*)out)[i] = std::signbit(((const T*)y)[i]) ? T(0) : ((const T*)g)[i];
+    });
+    return 0;
+}
 int tnn_mul_mask(const void* g, const void* mask, void* out, int64_t n, int dtype) {
     NEED_INIT();
     RECORD(tnn_mul_mask(g, mask, out, n, dtype));

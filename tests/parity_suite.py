@@ -832,6 +832,55 @@ def dense_vjp_writes_arena_views_and_survives_weight_sharing():
         np.testing.assert_allclose(np.asarray(b.grad), 2 * db, rtol=2e-5, atol=2e-5)
 
 
+def fused_dense_relu_node_matches_generic_chain():
+    """ops.dense_(relu=True) — what Net.forward builds for Dense followed by ReLU — against the literal chain
+    clip(x @ w + b, 0) of core/layers.py:49,97-98: values, all gradients, an exactly-zero pre-activation (mask is >=),
+    a ReLU output with TWO consumers (one fused Dense whose dX arrives pre-masked, one generic op whose gradient does
+    not), an input that itself requires grad, a frozen weight, and accumulation over two backward calls."""
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.nn import Net
+    rs = np.random.RandomState(41)
+    m, k, h, c = 24, 12, 16, 5
+    xh = rs.randn(m, k).astype(np.float32)
+    xh[3] = 0.0                                                   # z1[3] = b1 = 0 exactly -> gradient passes (mask >=)
+    w1h, w2h = (rs.randn(k, h) * 0.5).astype(np.float32), (rs.randn(h, c) * 0.5).astype(np.float32)
+    b1h, b2h = np.zeros((1, h), np.float32), rs.randn(1, c).astype(np.float32)
+    results = []
+    for fused in (True, False):
+        x = Tensor(xh, requires_grad=True)
+        w1, b1 = Tensor(w1h, requires_grad=True), Tensor(b1h, requires_grad=True)
+        w2, b2 = Tensor(w2h, requires_grad=not fused or True), Tensor(b2h, requires_grad=True)
+        if fused:
+            a = ops.dense_(x, w1, b1, relu=True)
+            out = ops.dense_(a, w2, b2)
+        else:
+            a = ops.clip(x @ w1 + b1, 0.0)
+            out = a @ w2 + b2
+        loss = (out * out).sum() + (a * 3.0).sum()                # the ReLU output has a second, generic consumer
+        loss.backward()
+        loss.backward()                                           # accumulates (core/tensor.py:163)
+        results.append([np.asarray(t) for t in (a.values, out.values, x.grad, w1.grad, b1.grad, w2.grad, b2.grad)])
+    for name, got, ref in zip(("a", "out", "dx", "dw1", "db1", "dw2", "db2"), *results):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * max(np.abs(ref).max(), 1e-6), err_msg=name)
+    assert np.abs(results[0][2][3]).max() > 0                     # row 3: z == 0 keeps its gradient
+    # Net.forward fuses Dense -> ReLU pairs and nothing else; one tnn_dense_bwd launch per layer in backward
+    np.random.seed(2)
+    net = Net([Dense(h, num_in=k), ReLU(), Dense(h, num_in=h), ReLU(), Dense(c, num_in=h)])
+    np.random.seed(2)
+    ref_net = Net([Dense(h, num_in=k, fused=False), ReLU(), Dense(h, num_in=h, fused=False), ReLU(), Dense(c, num_in=h, fused=False)])
+    grads = []
+    for n_ in (net, ref_net):
+        for layer in n_.layers:
+            for p_ in layer.params.values():
+                p_.zero_grad()
+        pred = n_.forward(Tensor(xh))
+        (pred * pred).sum().backward()
+        grads.append([np.asarray(p_.grad) for layer in n_.layers for p_ in layer.params.values()] + [np.asarray(pred.values)])
+    for got, ref in zip(*grads):
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * max(np.abs(ref).max(), 1e-6))
+    assert net.layers[1].inputs is not None and np.asarray(net.layers[1].inputs.values).min() >= 0.0
+
+
 def trainer_with_other_optimizers_matches_op_level_model():
     """The whole-step trainer driving Momentum / RMSProp / Adagrad / Adadelta (tnn_optim_step on the arenas) against
     the op-level Model with the same optimizer class (itself pinned to the reference's steps): three training

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "tnn_clip": [_p, c_int, c_double, c_int, c_double, _p, c_int64, c_int],
     "tnn_clip_bwd": [_p, _p, c_int, c_double, c_int, c_double, _p, c_int64, c_int],
     "tnn_mul_mask": [_p, _p, _p, c_int64, c_int],
+    "tnn_mul_signmask": [_p, _p, _p, c_int64, c_int],
     "tnn_axpy": [_p, c_double, _p, c_int64, c_int],
     "tnn_cast": [_p, c_int, _p, c_int, c_int64],
     "tnn_reduce": [c_int, _p, _p, c_int64, c_int64, c_int64, c_int],

@@ -55,14 +55,16 @@ class Dense(Layer):
             self.params[name] = tensor
         self.is_init = True
 
-    def forward(self, inputs):
+    def forward(self, inputs, relu=False):
+        """relu=True is passed by Net.forward when the next layer is a ReLU: one launch for both (ops.dense_)."""
         if not self.is_init:
             self._init_parameters(inputs.shape[1])
         self.inputs = inputs                     # kept like the reference does (core/layers.py:48)
         w, b = (self.params[name] for name in PARAM_ORDER)
         if not self.fused:
-            return inputs @ w + b
-        return ops.dense_(inputs, w, b)
+            out = inputs @ w + b
+            return ops.clip(out, 0.0) if relu else out
+        return ops.dense_(inputs, w, b, relu=relu)
 
 
 class Activation(Layer):

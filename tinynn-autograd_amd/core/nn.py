@@ -2,7 +2,6 @@
 iteration over parameter tensors in the optimizer's flattening order, parameter counting and the Dense/ReLU
 structure query the whole-step trainer uses."""
 
-from functools import reduce
 
 
 class Net(object):
@@ -15,7 +14,22 @@ class Net(object):
 
     # ------------------------------------------------------------------ reference API
     def forward(self, inputs):
-        return reduce(lambda activations, layer: layer.forward(activations), self.layers, inputs)
+        """Thread the input through the layers (core/nn.py:10-13).  A fused `Dense` directly followed by a `ReLU` runs
+        as ONE node (GEMM + bias + clip(., 0) epilogue, ops.dense_(relu=True)); the ReLU layer object is then skipped —
+        its `inputs` attribute (cached but never read by the reference, core/layers.py:67) holds the fused output."""
+        from .layers import Dense, ReLU
+        layers, i, activations = self.layers, 0, inputs
+        while i < len(layers):
+            layer = layers[i]
+            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            if type(layer) is Dense and layer.fused and type(nxt) is ReLU:
+                activations = layer.forward(activations, relu=True)
+                nxt.inputs = activations
+                i += 2
+            else:
+                activations = layer.forward(activations)
+                i += 1
+        return activations
 
     def get_parameters(self):
         return [layer.params for layer in self.layers]

@@ -246,34 +246,57 @@ def clip_(ts, min, max):
 
 
 # ---------------------------------------------------------------------- fused nodes (this package's own)
-def dense_(x, w, b):
+def dense_(x, w, b, relu=False):
     """x @ w + b as ONE GEMM with a bias epilogue (core/layers.py:49); the vjps are the NT / TN GEMMs of
-    dot_ (core/ops.py:156-160) and the column-sum of add_'s un-broadcast (:49-55)."""
+    dot_ (core/ops.py:156-160) and the column-sum of add_'s un-broadcast (:49-55).
+
+    relu=True (Net.forward fuses a Dense that is directly followed by a ReLU layer): the epilogue also applies
+    clip(., 0) (core/layers.py:97-98) and keeps the vjp mask z >= 0 (core/ops.py:338, gradient 1 AT zero) in the sign
+    bit of zero — z < 0 is stored as -0.0, z >= 0 as |z| — so no pre-activation and no mask array exist.
+
+    Backward is ONE launch per layer whenever the scheduler (Tensor.backward) offers all edges at once
+    (`_fused_vjp`): tnn_dense_bwd writes dW and db (straight into the parameters' arena views when they are lent)
+    and, if x is itself a sign-encoded ReLU output, dX = (g W^T) * [z_prev >= 0] from the same launch.  That dX is
+    tagged as already masked for x's producer, whose own vjp then skips its mask pass; a gradient that reaches a ReLU
+    node untagged (several consumers were summed, or a foreign consumer) is masked there — masking twice is harmless
+    (the mask is idempotent), so the rule never changes a value."""
     xv, wv, bv = x.values, w.values, b.values
     if xv.ndim != 2 or wv.ndim != 2 or xv.shape[1] != wv.shape[0] or bv.size != wv.shape[1]:
         raise ValueError("dense_: shapes %s @ %s + %s do not line up" % (xv.shape, wv.shape, bv.shape))
     m, k = xv.shape
     n = wv.shape[1]
     dt = da._float_result_dtype(xv, wv)
-    xv, wv, bv = xv._as_float(dt)._contig(), wv._as_float(dt)._contig(), bv._as_float(dt)._contig()
+    x_relu = xv._tag is da.RELU_SIGN and xv.dtype == dt and not xv._t and xv._hv is None
+    xc = xv._as_float(dt)._contig()
+    x_relu = x_relu and xc is xv                      # the sign bits must be the producer's own buffer
+    xv, wv, bv = xc, wv._as_float(dt)._contig(), bv._as_float(dt)._contig()
     out = da.empty((m, n), dt)
     if out.size:
-        _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_NONE, 0,
-                                 out._ptr, n, out._code())
-    # vjps.  dW and db come out of ONE launch (tnn_gemm_tn_colsum: the bias gradient is the column sum of the B
-    # fragments the dW GEMM already holds); `into` lets the backward scheduler hand over the parameter's own
-    # gradient buffer (a view of the flat arena) so nothing is copied afterwards.
+        _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr,
+                                 _lib.ACT_RELU if relu else _lib.ACT_NONE, 1 if relu else 0, out._ptr, n, out._code())
+    if relu:
+        out._tag = da.RELU_SIGN
+
+    def dz_of(g_in):
+        """Gradient w.r.t. the pre-activation: g itself, or g * [z >= 0] for the fused ReLU unless a consumer's dX
+        launch applied that mask already."""
+        g = da.asarray(g_in)
+        if not relu or g._tag is out:
+            return g
+        return da.mul_signmask(g, out)
+
+    # ---- per-edge vjps (used when the scheduler cannot offer all edges at once, e.g. the reference's own recursion)
     shared = []                       # [(g object, db)] computed together with dW, waiting for the bias vjp
 
     def d_x(g):
-        return da.asarray(g) @ wv.T
+        return dz_of(g) @ wv.T
 
-    def _dw_db(g_in, out):
-        g = da.asarray(g_in)
+    def _dw_db(g_in, dest):
+        g = dz_of(g_in)
         if g.shape != (m, n) or g.dtype != dt or g._hv is not None or not g.size:
             return None
         g = g._contig()
-        dw = out if out is not None else da.empty((k, n), dt)
+        dw = dest if dest is not None else da.empty((k, n), dt)
         db = None
         if b.requires_grad:
             home = getattr(b, "_grad_home", None)
@@ -292,7 +315,7 @@ def dense_(x, w, b):
 
     def d_w(g):
         dw = _dw_db(g, None)
-        return dw if dw is not None else xv.T @ da.asarray(g)
+        return dw if dw is not None else xv.T @ dz_of(g)
 
     def d_w_into(g, dest):
         if dest.shape != (k, n) or dest.dtype != dt or dest._t or dest._hv is not None:
@@ -304,10 +327,44 @@ def dense_(x, w, b):
     def d_b(g):
         if shared and shared[0][0] is g:
             return shared.pop()[1]
-        return _unbroadcast(g, b.shape)
+        return _unbroadcast(dz_of(g), b.shape)
 
     parents = [(x, d_x), (w, d_w), (b, d_b)]
-    return _make_node(x.__class__, out, parents)
+    node = _make_node(x.__class__, out, parents)
+    edges = [name for name, t in (("x", x), ("w", w), ("b", b)) if t.requires_grad]
+
+    def fused_vjp(g_in, homes):
+        """All edges from ONE tnn_dense_bwd launch.  homes[i]: the arena view of edge i's tensor when the scheduler
+        lends it (first contribution of a lazily-zero leaf), else None.  Returns None to decline (odd gradients)."""
+        g = da.asarray(g_in)
+        if g.shape != (m, n) or g.dtype != dt or g._hv is not None or g._t or not g.size:
+            return None
+        if "x" in edges and not x_relu:
+            return None                               # dX without a mask epilogue: the per-edge GEMMs
+        g = dz_of(g)._contig()
+        res = {}
+        dw = db = dx = None
+        for name, home in zip(edges, homes):
+            if name == "w":
+                ok = home is not None and home.shape == (k, n) and home.dtype == dt and not home._t and home._hv is None
+                dw = home if ok else da.empty((k, n), dt)
+                res["w"] = dw
+            elif name == "b":
+                ok = home is not None and home.size == n and home.dtype == dt and not home._t and home._hv is None
+                db = home if ok else da.empty(tuple(b.shape), dt)
+                res["b"] = db
+            else:
+                dx = da.empty((m, k), dt)
+                dx._tag = xv                          # already multiplied by x's ReLU mask
+                res["x"] = dx
+        if dw is None:
+            dw = da.empty((k, n), dt)                 # w frozen: the launch still needs somewhere to write
+        _lib.get().dense_bwd(m, k, n, xv._ptr, g._ptr, wv._ptr, dw._ptr, db._ptr if db is not None else None,
+                             dx._ptr if dx is not None else None, xv._ptr if dx is not None else None, dw._code())
+        return [res[name] for name in edges]
+
+    node._fused_vjp = fused_vjp
+    return node
 
 
 def sigmoid_(ts):

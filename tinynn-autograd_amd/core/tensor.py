@@ -45,6 +45,7 @@ class Tensor(object):
         self.dependency = dependency
         if self.dependency is None:
             self.dependency = []
+        self._fused_vjp = None       # optional: all edges' contributions from one launch (see backward)
 
     # ------------------------------------------------------------------ values / grad
     @property
@@ -299,14 +300,27 @@ class Tensor(object):
             if g is None:
                 continue
             node._accumulate(g)
-            for dep in node.dependency:
+
+            def lendable(child):
+                """The child's arena view, if this is the first contribution of a lazily-zero, arena-backed leaf."""
+                home = getattr(child, "_grad_home", None)
+                if (home is not None and id(child) not in pending and not child.dependency
+                        and child._grad is None and child._grad_zero):
+                    return home
+                return None
+
+            # a node may offer ALL its edges from one launch (ops.dense_: dW + db + masked dX)
+            contribs, fused = None, getattr(node, "_fused_vjp", None)
+            if fused is not None and len({id(d["tensor"]) for d in node.dependency}) == len(node.dependency):
+                contribs = fused(g, [lendable(d["tensor"]) for d in node.dependency])
+            for j, dep in enumerate(node.dependency):
                 child, fn = dep["tensor"], dep["grad_fn"]
                 key = id(child)
                 into = getattr(fn, "into", None)
-                home = getattr(child, "_grad_home", None)
-                if (into is not None and home is not None and key not in pending and not child.dependency
-                        and child._grad is None and child._grad_zero):
-                    contrib = into(g, home)          # first contribution of a lazily-zero, arena-backed leaf
+                if contribs is not None:
+                    contrib = contribs[j]
+                elif into is not None and lendable(child) is not None:
+                    contrib = into(g, child._grad_home)
                 else:
                     contrib = fn(g)
                 if key in pending:

@@ -407,6 +407,10 @@ struct ClipBwdF {
     }
 };
 template <typename T>
+struct SignMaskF {      // g where the sign bit of y is clear, else 0 (y = a sign-encoded ReLU output: -0.0 marks z < 0)
+    __device__ __forceinline__ T operator()(T g, T y) const { return signbit(y) ? T(0) : g; }
+};
+template <typename T>
 struct AxpyF {
     T alpha;
     __device__ __forceinline__ T operator()(T y, T x) const { return y + alpha * x; }
@@ -700,6 +704,11 @@ int tnn_mul_mask(const void* g, const void* mask_u8, void* out, int64_t n, int d
     }
     TNN_LAUNCH_OK();
     return 0;
+}
+
+int tnn_mul_signmask(const void* g, const void* y, void* out, int64_t n, int dtype) {
+    TNN_NEED_INIT();
+    TNN_FLOAT_SWITCH(dtype, "tnn_mul_signmask", (launch_flat2<T>(g, y, out, n, SignMaskF<T>{})));
 }
 
 int tnn_axpy(void* y, double alpha, const void* x, int64_t n, int dtype) {

@@ -70,7 +70,7 @@ def _is_scalar_like(x):
 
 
 class DeviceArray(object):
-    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "__weakref__")
+    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "__weakref__")
     __array_priority__ = 1000.0
 
     # ------------------------------------------------------------------ construction
@@ -86,6 +86,8 @@ class DeviceArray(object):
         self._base = base
         self._hv = hv
         self._t = t
+        self._tag = None             # free-form marker: RELU_SIGN on a fused Dense+ReLU output; the producer's output array
+                                     # on a gradient whose ReLU mask has already been applied (core/ops.py dense_)
         return self
 
     @classmethod
@@ -762,6 +764,19 @@ def clip_bwd(grad, x, a_min=None, a_max=None):
     if res.size:
         _lib.get().clip_bwd(grad._dev(), x._ptr, int(a_min is not None), float(a_min or 0.0),
                             int(a_max is not None), float(a_max or 0.0), res._ptr, res.size, res._code())
+    return res
+
+
+RELU_SIGN = "relu-mask-in-sign-bit"      # _tag of a fused Dense+ReLU output (core/ops.py dense_(relu=True))
+
+
+def mul_signmask(grad, y):
+    """grad where the sign bit of y is clear, else 0 (y: sign-encoded ReLU output)."""
+    y = asarray(y)._contig()
+    grad = asarray(grad)._as_float(y.dtype)._broadcast_to(y.shape)._contig()
+    res = DeviceArray._new(y.shape, y.dtype)
+    if res.size:
+        _lib.get().mul_signmask(grad._ptr, y._ptr, res._ptr, res.size, res._code())
     return res
 
 
