@@ -310,19 +310,43 @@ def cpu_baseline(widths, rows, kind, budget_s=8.0):
 # ------------------------------------------------------------------------------------------------ measured runs
 class Runner(object):
     """Something that can run `count` consecutive training steps from global step index `first` and report the last
-    loss.  `prepare` builds whatever graphs that range needs BEFORE the clock starts."""
+    loss.  Every (first, count) range is replayed from hipGraphs — whole n_batches-step chunks where the step index is
+    aligned, shorter pre-captured segment graphs for the unaligned head and tail; `prepare` captures whatever a range
+    needs BEFORE the clock starts.  Subclasses provide capture_range(off, length) -> object whose launch() returns the
+    per-step losses, and eager_step(i) for the graph-less form."""
     n_batches = 1
+    chunk = None
+
+    def plan(self, first, count):
+        out, i = [], first
+        while count > 0:
+            off = i % self.n_batches
+            length = min(count, self.n_batches - off)
+            out.append((off, length))
+            i, count = i + length, count - length
+        return out
 
     def prepare(self, first, count):
-        pass
+        if self.chunk is None:
+            return
+        for off, length in self.plan(first, count):
+            if length != self.n_batches and (off, length) not in self.segments:
+                self.segments[(off, length)] = self.capture_range(off, length)
 
     def run(self, first, count):
-        raise NotImplementedError
+        last = None
+        if self.chunk is None:
+            for i in range(first, first + count):
+                last = self.eager_step(i)
+            return last
+        for off, length in self.plan(first, count):
+            g = self.chunk if length == self.n_batches else self.segments[(off, length)]
+            last = g.launch()[length - 1]
+        return last
 
 
 class FusedRun(Runner):
-    """Whole-step trainer (tnn_mlp_*): every (first, count) range is replayed from hipGraphs — whole n_batches-step
-    chunks where the step index is aligned, shorter pre-captured segment graphs for the unaligned head and tail."""
+    """Whole-step trainer (tnn_mlp_*), replayed from hipGraphs of whole steps bound to their resident batches."""
 
     def __init__(self, widths, rows, kind, n_batches, rank=0, world=1, comm=None, force_dp=False, use_graph=True,
                  dtype=np.float32, seed=1234):
@@ -365,32 +389,11 @@ class FusedRun(Runner):
                 raise
             sys.stderr.write("bench: data-parallel graph capture unavailable (%s); eager steps\n" % exc)
 
-    def plan(self, first, count):
-        out, i = [], first
-        while count > 0:
-            off = i % self.n_batches
-            length = min(count, self.n_batches - off)
-            out.append((off, length))
-            i, count = i + length, count - length
-        return out
+    def capture_range(self, off, length):
+        return self.trainer.capture_steps(self.batches[off:off + length])
 
-    def prepare(self, first, count):
-        if self.chunk is None:
-            return
-        for off, length in self.plan(first, count):
-            if length != self.n_batches and (off, length) not in self.segments:
-                self.segments[(off, length)] = self.trainer.capture_steps(self.batches[off:off + length])
-
-    def run(self, first, count):
-        last = None
-        if self.chunk is None:
-            for i in range(first, first + count):
-                last = self.trainer.step(*self.batches[i % self.n_batches])
-            return last
-        for off, length in self.plan(first, count):
-            g = self.chunk if length == self.n_batches else self.segments[(off, length)]
-            last = g.launch()[length - 1]
-        return last
+    def eager_step(self, i):
+        return self.trainer.step(*self.batches[i % self.n_batches])
 
     def params_crc(self):
         return int(np.frombuffer(np.asarray(self.trainer.params).tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
@@ -442,17 +445,27 @@ def fixture_check(widths, rows, kind, rank, world, comm, force_dp, use_graph):
             "max_rel_err": float("%.3g" % err), "rtol": 1e-5, "ok": bool(err <= 1e-5)}
 
 
+class _OpsGraph(object):
+    def __init__(self, captured):
+        self.captured = captured
+
+    def launch(self):
+        return [t.values for t in self.captured()]
+
+
 class OpsRun(Runner):
-    """The drop-in API path (core/tensor.py:13-171 / core/ops.py:12-384 are the seam): unmodified-style
-    loop body on Tensor / ops / Dense / SoftmaxCrossEntropyLoss / Adam / Model — eager, or captured once with
-    tn.capture and replayed (each batch copied into two staging tensors at fixed addresses first)."""
+    """The drop-in API path (core/tensor.py:13-171 / core/ops.py:12-384 are the seam): the reference's loop
+    body on Tensor / ops / Dense / ReLU / SoftmaxCrossEntropyLoss / Adam / Model — eager (one launch per op issued from
+    Python), or recorded with tn.capture and replayed: like the trainer's graphs, one capture covers a run of steps,
+    each bound to its own HBM-resident batch (row slices of the resident dataset, utils/data_iterator.py:30-33), so no
+    staging copies are needed."""
 
     def __init__(self, widths, rows, kind, n_batches, rank=0, world=1, comm=None, graph=False):
         from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss, SquaredErrorLoss
         from tinynn_autograd_amd.core.model import Model
         from tinynn_autograd_amd.core.optimizer import Adam
         from tinynn_autograd_amd.core.tensor import Tensor
-        self.n_batches, self.rows = n_batches, rows
+        self.n_batches, self.rows, self.segments = n_batches, rows, {}
         x_host, y_host = synth_batches(n_batches, rows, widths, kind, rank, world)
         X, Y = da.asarray(x_host), da.asarray(y_host)
         self.batches = [(X[i * rows:(i + 1) * rows], Y[i * rows:(i + 1) * rows]) for i in range(n_batches)]
@@ -460,37 +473,24 @@ class OpsRun(Runner):
         model = Model(net=build_net(widths), loss=loss_layer, optimizer=Adam(lr=1e-3), comm=comm)
         tbatches = [(Tensor(a), Tensor(b)) for a, b in self.batches]
 
-        def eager(i):
+        def step(i):
             xb, yb = tbatches[i % n_batches]
             model.zero_grad()
             out = loss_layer.loss(model.forward(xb), yb)
             out.backward()
             model.step()
-            return out.values
-        self.step = eager
+            return out
+        self._step = step
         if graph:
-            x_stage, y_stage = Tensor(self.batches[0][0].copy()), Tensor(self.batches[0][1].copy())
+            for i in range(2):                                 # real steps first: arena binding, optimizer state
+                step(i)
+            self.chunk = self.capture_range(0, n_batches)
 
-            def body():
-                model.zero_grad()
-                out = loss_layer.loss(model.forward(x_stage), y_stage)
-                out.backward()
-                model.step()
-                return out
-            captured = tn.capture(body, warmup=2)
+    def capture_range(self, off, length):
+        return _OpsGraph(tn.capture(lambda: [self._step(i) for i in range(off, off + length)], warmup=0))
 
-            def replay(i):
-                xb, yb = self.batches[i % n_batches]
-                x_stage.values[...] = xb
-                y_stage.values[...] = yb
-                return captured().values
-            self.step = replay
-
-    def run(self, first, count):
-        last = None
-        for i in range(first, first + count):
-            last = self.step(i)
-        return last
+    def eager_step(self, i):
+        return self._step(i).values
 
 
 class Clock(object):
@@ -640,7 +640,7 @@ def main():
     elif args.path == "fused":
         runner = FusedRun(widths, rows, kind, n_batches, rank, world, comm, force_dp, use_graph=use_graph)
     else:
-        runner = OpsRun(widths, rows, kind, n_batches, rank, world, comm, graph=args.path == "opsgraph")
+        runner = OpsRun(widths, rows, kind, min(n_batches, 16), rank, world, comm, graph=args.path == "opsgraph")
 
     def replicas_identical(r):
         crc = r.params_crc()
@@ -787,12 +787,12 @@ def main():
             if args.path == "fused" and args.rows is None and comm is None:
                 paths = {}
                 for name, graph in (("ops_eager", False), ("ops_graph", True)):
-                    r = OpsRun(widths, rows, kind, 64, graph=graph)
+                    r = OpsRun(widths, rows, kind, 16, graph=graph)
                     paths[name] = brief(measure(solo, r, 20, 200, 3, args.min_ms, rows))
                     del r
-                paths["note"] = ("the same step on the drop-in Tensor/ops/Dense/SoftmaxCrossEntropyLoss/Adam/Model API: one "
-                                 "launch per op issued from Python (eager) / the same loop body recorded once with tn.capture and "
-                                 "replayed as a hipGraph (graph)")
+                paths["note"] = ("the same step on the drop-in Tensor/ops/Dense/ReLU/SoftmaxCrossEntropyLoss/Adam/Model API: one "
+                                 "launch per op issued from Python (eager) / the same loop body recorded with tn.capture, 16 steps on "
+                                 "their resident batches per hipGraph, and replayed (graph)")
                 line["paths"] = paths
                 c = FusedRun(WIDTHS_C, 512, "mse", 2, use_graph=use_graph)
                 rc = measure(solo, c, 3, 20, 3, 0.0, 512)
