@@ -123,7 +123,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
 #define TNN_TRACE(i)
 #endif
     TNN_TRACE(0);
-
     // tile order: each XCD (private 4 MB L2) gets a contiguous range of ids (xcd_remap); inside the range the
     // ids sweep N for a GROUP of 8 M-tiles at a time, so the group's A panels stay L2-resident while the B
     // panels stream through once (measured before this: 469 MB fetched by the 4096x4096x512 TN GEMM for
@@ -307,7 +306,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][mi][j], bf[kk][ni][j],
+                    // operands SWAPPED: the block accumulates (A B)^T, i.e. lane l31 owns output ROW l31 of the block and
+                    // its registers (r & 3) hold 4 CONSECUTIVE COLUMNS — the epilogue leaves through 16-B stores
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[kk][ni][j], af[kk][mi][j],
                                                                        acc[mi][ni], 0, 0, 0);
     };
 
@@ -437,24 +438,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     }
 
     TNN_TRACE(2);
-    // epilogue: lane holds col = l31, rows (r&3) + 8*(r>>2) + 4*lhi of each 32x32 block
+    // epilogue: with the swapped operands lane l31 holds ROW l31 of each 32x32 block and register r the column
+    // (r & 3) + 8 (r >> 2) + 4 lhi: four consecutive columns per register quad -> one 16-B store per quad (4 store
+    // instructions per block instead of 16 dword stores; 8 instead of 32 per wave for the 128x64 tile)
+    {
+        float* const dst = g.splits > 1 ? g.ws + (int64_t)blockIdx.z * g.M * g.N : g.C;
+        const int64_t ldd = g.splits > 1 ? g.N : g.ldc;
+        const bool vec_c = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ldd % 4 == 0;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            int64_t col = n0 + wn * TN + ni * 32 + l31;
-            if (col >= g.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int64_t row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t row = m0 + wm * TM + mi * 32 + l31;
                 if (row >= g.M) continue;
-                float a = acc[mi][ni][r];
-                if (g.splits > 1)
-                    g.ws[((int64_t)blockIdx.z * g.M + row) * g.N + col] = a;
-                else
-                    g.C[row * g.ldc + col] = apply_epilogue(g, a, row, col);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t col = n0 + wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                    if (col >= g.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[mi][ni][4 * q + j];
+                        if (g.splits == 1 && col + j < g.N) v[j] = apply_epilogue(g, v[j], row, col + j);
+                    }
+                    if (vec_c && col + 3 < g.N) {
+                        *reinterpret_cast<float4*>(dst + row * ldd + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (col + j < g.N) dst[row * ldd + col + j] = v[j];
+                    }
+                }
             }
-        }
+    }
 #ifdef TNN_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TNN_TRACE(3);

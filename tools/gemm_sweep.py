@@ -22,7 +22,7 @@ def main():
         c = da.empty((M, N), np.float32)
         lda, ldb = (M if ta else K), (K if tb else N)
         for cfg in extra_cfgs():
-            for sk in (1, 2):
+            for sk in [int(x) for x in os.environ.get("SWEEP_SPLITK", "1,2").split(",")]:
                 os.environ["TNN_GEMM_CFG"], os.environ["TNN_GEMM_SPLITK"] = str(cfg), str(sk)
                 try:
                     for _ in range(2):
