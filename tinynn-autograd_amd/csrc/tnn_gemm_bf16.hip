@@ -24,6 +24,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint16_t bf16_t;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native 16-B vector (HIP's uint4 struct ended up in scratch)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { BEPI_PLAIN = 0, BEPI_BIAS_ACT = 1, BEPI_MASK = 2 };
 
@@ -257,13 +259,12 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
         }
 }
 
+#include "tnn_gemm_bf16_dma.h"     // gemm_bf16_dma_kernel<NW, NS>: the LDS-DMA variant (experimental, see its header)
+
 // bf16 [R, C] -> [C, R], 64x64 tiles.  2-byte accesses made the first version instruction-bound (2.2 TB/s), so:
 // every thread loads a 4x4 block with four 8-B loads, transposes it in registers, writes the four transposed
 // 8-B rows into an LDS image of the OUTPUT tile, and after the barrier the tile leaves with 16-B stores, eight
 // lanes per 128-B output row.  Requires R % 4 == 0 and C % 4 == 0 (else the element-wise fallback below).
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in,
                                                              bf16_t* __restrict__ out, int64_t R, int64_t C) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];     // [c][r], 144-B rows
@@ -554,7 +555,20 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     g.Y = (const bf16_t*)mask_y; g.ldy = ldy;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n)), NT, 0, tnn::stream(), g);
+    // TNN_BF16_KERNEL selects the LDS-DMA variants for measurements: dma8 / dma4 (8 / 4 waves, 4 stages), dma8s / dma4s (2 stages)
+    static const char* which = getenv("TNN_BF16_KERNEL");
+    const unsigned tiles = (unsigned)(g.tiles_m * g.tiles_n);
+    const bool dma = which != nullptr && which[0] == 'd' && which[1] == 'm' && which[2] == 'a';
+    if (dma && which[3] == '8' && which[4] == 's')
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<8, 2>), dim3(tiles), 512, 0, tnn::stream(), g);
+    else if (dma && which[3] == '4' && which[4] == 's')
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<4, 2>), dim3(tiles), 256, 0, tnn::stream(), g);
+    else if (dma && which[3] == '8')
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<8, 4>), dim3(tiles), 512, 0, tnn::stream(), g);
+    else if (dma)
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<4, 4>), dim3(tiles), 256, 0, tnn::stream(), g);
+    else
+        hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), NT, 0, tnn::stream(), g);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -1,0 +1,242 @@
+// LDS-DMA variant of the bf16 K-contiguous GEMM (included by tnn_gemm_bf16.hip inside its anonymous namespace; uses its
+// BfArgs, bf16x8, f32x16, u32x4, u32x2, f32x4, f2bf, xcd_remap16 and the BEPI_* codes).
+//
+// Same product and the same 128 x 128 x 64 tile as the register-staged kernel — the M = 512 shapes of config E need
+// >= 256 tiles to fill 256 CUs, so the tile cannot grow without split-K — but:
+//   * operands go global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass;
+//   * the DMA writes lane-linear (wave-uniform base + lane * 16 B), so LDS rows cannot be padded; the bank conflicts of
+//     the ds_read_b128 fragment reads are avoided with an XOR swizzle applied on BOTH sides: the 16-B chunk c of row r
+//     lives in slot c ^ ((r >> 1) & 7) — the loading lane picks its global chunk accordingly, the reading lane its slot;
+//   * an NS-stage LDS ring (32 KB per stage): the DMA of tile kt + NS is issued while tile kt is multiplied, each wave
+//     waits only for its OWN share of the tile it is about to publish (counted vmcnt, never 0 in steady state when
+//     NS > 2) and ONE raw s_barrier per K-tile both publishes tile kt + 1 and frees the stage of tile kt;
+//   * MFMA operands swapped like the fp32 kernel: the accumulator block is (A B^T)^T, lane l31 owns an output ROW and
+//     its registers 4 consecutive columns -> 8-B (bf16) / 16-B (f32) stores instead of 2-B / 4-B ones.
+// MEASURED (MI355X, tools/gemm_bf16_sweep.py, TFLOP/s on 512x8192x8192 / 8192x8192x512 / 4096^3 / 8192^3):
+//     register-staged, 4 waves, 2 workgroups per CU (default)      805 / 491 / 927 / 859
+//     DMA, 8 waves of 64x32, 4 stages (1 workgroup per CU)          801 / 348 / 744 / 774
+//     DMA, 4 waves of 64x64, 4 stages (1 workgroup per CU)          734 / 303 / 686 / 736
+// i.e. the DMA removes the ds_write pass but a 128^2 tile re-reads its fragments 3x (8 waves) / 2x (4 waves) from LDS per
+// K-tile either way, and ONE resident workgroup cannot overlap its own barrier / prologue / epilogue the way two
+// register-staged ones do.  The kernel stays selectable (TNN_BF16_KERNEL=dma8 | dma4 | dma8s | dma4s) as the base of
+// the 256-wide, split-K variant; the register-staged kernel remains the default.
+namespace g8 {
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int ROWB = BK * 2;                 // bytes per LDS row (no padding)
+constexpr int TILE_B = BM * ROWB;            // 16 KB per operand tile
+constexpr int STAGE_B = 2 * TILE_B;          // A tile + B tile
+constexpr int KK = BK / 16;
+}  // namespace g8
+
+#define TNN_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define TNN_VMCNT_LGKM0(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)" ::: "memory")
+
+// one LDS-DMA instruction: 64 lanes x 16 B, global (buffer resource + per-lane byte offset + scalar offset) -> LDS at
+// lds_dst + lane * 16.  A NON-template function on purpose: inside the kernel template the cast to the LDS address space
+// is a dependent expression and hipcc's host pass then silently drops the whole instantiation (undefined __device_stub__)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+// NW = 8: eight waves of 64 x 32 (2 per SIMD);  NW = 4: four waves of 64 x 64 (one per SIMD, a third less fragment traffic)
+// NS = LDS stages: 4 -> one workgroup per CU, tile kt + 4 in flight; 2 -> two workgroups per CU, tile kt + 2 in flight
+template <int NW, int NS>
+__global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
+    constexpr int BM = g8::BM, BN = g8::BN, BK = g8::BK;
+    constexpr int WN = NW == 8 ? 4 : 2, TM = 64, TN = BN / WN, MI = 2, NI = TN / 32;
+    constexpr int ROWB = g8::ROWB, TILE_B = g8::TILE_B, STAGE_B = g8::STAGE_B, KK = g8::KK;
+    constexpr int DJ = 16 / NW;                  // DMA instructions per wave, operand and tile (1 KB each)
+    static_assert((NS & (NS - 1)) == 0 && NS >= 2, "stage count must be a power of two");
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE_B];        // ONE shared object (a second one makes hipcc
+                                                                             // drain the DMA queue before every ds_read)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int nb = g.tiles_m * g.tiles_n;
+    const int t = xcd_remap16((int)blockIdx.x, nb);
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * g.tiles_n;
+    const int first_m = (t / per_group) * GROUP_M;
+    const int gsz = min(g.tiles_m - first_m, GROUP_M);
+    const int64_t m0 = (int64_t)(first_m + (t % per_group) % gsz) * BM;
+    const int64_t n0 = (int64_t)((t % per_group) / gsz) * BN;
+    const int nk = (int)(g.K / BK);
+
+    // ---- DMA geometry: instruction gi = wid + NW j fills LDS bytes [gi * 1024, + 1024) of an operand tile = rows
+    // 8 gi .. 8 gi + 7; lane L writes slot L % 8 of row 8 gi + L / 8 and therefore LOADS chunk slot ^ swz(row)
+    uint32_t a_voff[DJ], b_voff[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) {
+        const int row = 8 * (wid + NW * j) + (lane >> 3), slot = lane & 7;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int64_t gm = m0 + row, gn = n0 + row;
+        a_voff[j] = (uint32_t)(((gm < g.M ? gm : 0) * g.lda + chunk * 8) * 2);
+        b_voff[j] = (uint32_t)(((gn < g.N ? gn : 0) * g.ldb + chunk * 8) * 2);
+    }
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.B), 0, 0xffffffffu, 0x00020000);
+    auto issue_tile = [&](int kt) {
+        char* stage = lds + (kt & (NS - 1)) * STAGE_B;
+        const uint32_t koff = (uint32_t)kt * ROWB;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j) {
+            dma16(a_rsrc, stage + (wid + NW * j) * 1024, a_voff[j], koff);
+            dma16(b_rsrc, stage + TILE_B + (wid + NW * j) * 1024, b_voff[j], koff);
+        }
+    };
+    // "at most `later` whole tiles issued after the one I need may still be in flight" (2 DJ DMAs per tile and wave)
+    auto wait_tiles = [&](int later, bool lgkm) {
+        const int n = later * 2 * DJ;
+        if (lgkm) {
+            switch (n) {
+                case 0: TNN_VMCNT_LGKM0(0); break;
+                case 4: TNN_VMCNT_LGKM0(4); break;
+                case 8: TNN_VMCNT_LGKM0(8); break;
+                case 12: TNN_VMCNT_LGKM0(12); break;
+                case 16: TNN_VMCNT_LGKM0(16); break;
+                default: TNN_VMCNT_LGKM0(24); break;
+            }
+        } else {
+            switch (n) {
+                case 0: TNN_VMCNT(0); break;
+                case 4: TNN_VMCNT(4); break;
+                case 8: TNN_VMCNT(8); break;
+                case 12: TNN_VMCNT(12); break;
+                case 16: TNN_VMCNT(16); break;
+                default: TNN_VMCNT(24); break;
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: lane (row l31, k-group lhi) reads chunk 2 kk + lhi of its row; (row >> 1) & 7 == (l31 >> 1) & 7
+    // for every block row offset used (multiples of 32)
+    const int swz = (l31 >> 1) & 7;
+    int foff[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) foff[kk] = ((2 * kk + lhi) ^ swz) * 16;
+    const int a_base = (wm * TM + l31) * ROWB;
+    const int b_base = TILE_B + (wn * TN + l31) * ROWB;
+
+    // ---- software pipeline (the fp32 kernel's, with the DMA in place of the register staging).  Fragment sets F(kt, kk),
+    // kk = 0..3, are read half a tile ahead of their MFMAs:
+    //     read F(kt,2), F(kt,3)            | MFMA F(kt,0), F(kt,1)
+    //     wait own DMA share of tile kt+1, s_barrier   (tile kt+1 published; every wave has read all of tile kt)
+    //     DMA tile kt+NS -> the stage of tile kt
+    //     read F(kt+1,0), F(kt+1,1)        | MFMA F(kt,2), F(kt,3)
+    bf16x8 fa[KK][MI], fb[KK][NI];
+    auto read_frag = [&](int tile, int kk) {
+        const char* stage = lds + (tile & (NS - 1)) * STAGE_B;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            fb[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + b_base + j * 32 * ROWB + foff[kk]));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            fa[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(stage + a_base + i * 32 * ROWB + foff[kk]));
+    };
+    auto mfma_set = [&](int kk) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)      // operands swapped: the block is (A B^T)^T, lane = output row
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < NS; ++p)
+        if (p < nk) issue_tile(p);
+    wait_tiles(min(nk - 1, NS - 1), false);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frag(0, 0);
+    read_frag(0, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        read_frag(kt, 2);
+        read_frag(kt, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(0);
+        mfma_set(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            wait_tiles(min(nk - 2 - kt, NS - 2), true);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NS < nk) issue_tile(kt + NS);
+            read_frag(kt + 1, 0);
+            read_frag(kt + 1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(2);
+        mfma_set(3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: block (mi, ni) is rows m0 + wm 64 + mi 32 + l31, register r the column (r & 3) + 8 (r >> 2) + 4 lhi
+    const bool vec_out = g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                         (g.epi != BEPI_MASK || (g.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 7) == 0));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int64_t row = m0 + wm * TM + mi * 32 + l31;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = n0 + wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                if (col >= g.N) continue;
+                const bool full = vec_out && col + 3 < g.N;
+                float v[4];
+                uint16_t ymask[4] = {0, 0, 0, 0};
+                if (g.epi == BEPI_MASK) {
+                    if (full) {
+                        const u32x2 yv = *reinterpret_cast<const u32x2*>(g.Y + row * g.ldy + col);
+                        ymask[0] = (uint16_t)yv.x; ymask[1] = (uint16_t)(yv.x >> 16);
+                        ymask[2] = (uint16_t)yv.y; ymask[3] = (uint16_t)(yv.y >> 16);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < g.N) ymask[j] = g.Y[row * g.ldy + col + j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[mi][ni][4 * q + j];
+                    if (g.epi == BEPI_BIAS_ACT) {
+                        x += (g.bias && col + j < g.N) ? g.bias[col + j] : 0.f;
+                        if (g.act == TNN_ACT_RELU) x = x < 0.f ? (g.relu_sign ? -0.0f : 0.f) : fabsf(x);
+                    } else if (g.epi == BEPI_MASK) {
+                        if (ymask[j] & 0x8000u) x = 0.f;
+                    }
+                    v[j] = x;
+                }
+                if (g.c_bf16) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(g.C) + row * g.ldc + col;
+                    if (full) {
+                        u32x2 pk;
+                        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(dst) = pk;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < g.N) dst[j] = f2bf(v[j]);
+                    }
+                } else {
+                    float* dst = reinterpret_cast<float*>(g.C) + row * g.ldc + col;
+                    if (full) {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < g.N) dst[j] = v[j];
+                    }
+                }
+            }
+    }
+}
+#undef TNN_VMCNT
+#undef TNN_VMCNT_LGKM0
