@@ -555,18 +555,25 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     g.Y = (const bf16_t*)mask_y; g.ldy = ldy;
     g.tiles_m = (int)((M + BM - 1) / BM);
     g.tiles_n = (int)((N + BN - 1) / BN);
-    // TNN_BF16_KERNEL selects the LDS-DMA variants for measurements: dma8 / dma4 (8 / 4 waves, 4 stages), dma8s / dma4s (2 stages)
-    static const char* which = getenv("TNN_BF16_KERNEL");
+    // Kernel choice.  The LDS-DMA kernel with 8 waves and a 2-stage ring (64 KB of LDS: TWO workgroups per CU) wins wherever
+    // the grid has at least two tiles per CU — the dW products (4096 tiles: 597 vs 503 TFLOP/s) and large squares (4096^3:
+    // 978 vs 934) — the register-staged 4-wave kernel where there is one tile per CU (the M = 512 forward / dX shapes:
+    // 810 vs 794).  TNN_BF16_KERNEL overrides for measurements: reg | dma8s | dma4s | dma8 | dma4 (8 / 4 waves; s = 2 stages).
+    static const char* env_which = getenv("TNN_BF16_KERNEL");
     const unsigned tiles = (unsigned)(g.tiles_m * g.tiles_n);
-    const bool dma = which != nullptr && which[0] == 'd' && which[1] == 'm' && which[2] == 'a';
-    if (dma && which[3] == '8' && which[4] == 's')
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<8, 2>), dim3(tiles), 512, 0, tnn::stream(), g);
-    else if (dma && which[3] == '4' && which[4] == 's')
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<4, 2>), dim3(tiles), 256, 0, tnn::stream(), g);
-    else if (dma && which[3] == '8')
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<8, 4>), dim3(tiles), 512, 0, tnn::stream(), g);
-    else if (dma)
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<4, 4>), dim3(tiles), 256, 0, tnn::stream(), g);
+    const char* which = env_which ? env_which : (tiles >= 2u * (unsigned)tnn::num_cus() ? "dma8s" : "reg");
+    const bool dma = which[0] == 'd' && which[1] == 'm' && which[2] == 'a';
+    const bool swap = g.c_bf16 != 0;          // bf16 outputs: 8-B stores per lane; fp32 outputs: whole 128-B row segments
+#define TNN_DMA_LAUNCH(NW_, NS_)                                                                                         \
+    do {                                                                                                                 \
+        if (swap) hipLaunchKernelGGL((gemm_bf16_dma_kernel<NW_, NS_, true>), dim3(tiles), NW_ * 64, 0, tnn::stream(), g);  \
+        else hipLaunchKernelGGL((gemm_bf16_dma_kernel<NW_, NS_, false>), dim3(tiles), NW_ * 64, 0, tnn::stream(), g);      \
+    } while (0)
+    if (dma && which[3] == '8' && which[4] == 's') TNN_DMA_LAUNCH(8, 2);
+    else if (dma && which[3] == '4' && which[4] == 's') TNN_DMA_LAUNCH(4, 2);
+    else if (dma && which[3] == '8') TNN_DMA_LAUNCH(8, 4);
+    else if (dma) TNN_DMA_LAUNCH(4, 4);
+#undef TNN_DMA_LAUNCH
     else
         hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), NT, 0, tnn::stream(), g);
     TNN_LAUNCH_OK();

@@ -10,16 +10,19 @@
 //   * an NS-stage LDS ring (32 KB per stage): the DMA of tile kt + NS is issued while tile kt is multiplied, each wave
 //     waits only for its OWN share of the tile it is about to publish (counted vmcnt, never 0 in steady state when
 //     NS > 2) and ONE raw s_barrier per K-tile both publishes tile kt + 1 and frees the stage of tile kt;
-//   * MFMA operands swapped like the fp32 kernel: the accumulator block is (A B^T)^T, lane l31 owns an output ROW and
-//     its registers 4 consecutive columns -> 8-B (bf16) / 16-B (f32) stores instead of 2-B / 4-B ones.
-// MEASURED (MI355X, tools/gemm_bf16_sweep.py, TFLOP/s on 512x8192x8192 / 8192x8192x512 / 4096^3 / 8192^3):
-//     register-staged, 4 waves, 2 workgroups per CU (default)      805 / 491 / 927 / 859
-//     DMA, 8 waves of 64x32, 4 stages (1 workgroup per CU)          801 / 348 / 744 / 774
-//     DMA, 4 waves of 64x64, 4 stages (1 workgroup per CU)          734 / 303 / 686 / 736
-// i.e. the DMA removes the ds_write pass but a 128^2 tile re-reads its fragments 3x (8 waves) / 2x (4 waves) from LDS per
-// K-tile either way, and ONE resident workgroup cannot overlap its own barrier / prologue / epilogue the way two
-// register-staged ones do.  The kernel stays selectable (TNN_BF16_KERNEL=dma8 | dma4 | dma8s | dma4s) as the base of
-// the 256-wide, split-K variant; the register-staged kernel remains the default.
+//   * SWAP (bf16 outputs): MFMA operands swapped like the fp32 kernel — the accumulator block is (A B^T)^T, lane l31
+//     owns an output ROW and its registers 4 consecutive columns -> 8-B stores instead of 2-B ones.  fp32 outputs keep
+//     lane = column: a store instruction then writes whole 128-B row segments, which the 268 MB dW outputs need (with the
+//     swapped form every store touches 32 rows x 32 B and the dW product fell from 597 to 358 TFLOP/s).
+// MEASURED (MI355X, tools/gemm_bf16_sweep.py, TFLOP/s on 512x8192x8192 -> bf16 / 8192x8192x512 -> f32 / 4096^3 -> f32 /
+// 8192^3 -> bf16, uniform [-1, 1) operands):
+//     register-staged, 4 waves, 2 workgroups per CU                      810 / 503 / 934 / 862
+//     DMA, 8 waves of 64x32, 2 stages (2 workgroups per CU)   "dma8s"    794 / 597 / 978 / 900
+//     DMA, 4 waves of 64x64, 2 stages (2 workgroups per CU)   "dma4s"    714 / 477 / 977 / 871
+//     DMA, 8 waves of 64x32, 4 stages (1 workgroup per CU)    "dma8"     806 / 353 / 745 / 771
+// Two resident workgroups matter more than the depth of the ring: one workgroup cannot overlap its own barrier, prologue
+// and epilogue.  The M = 512 shapes have exactly one 128 x 128 tile per CU whatever the kernel (~800 TFLOP/s, 32 % of
+// peak): more needs 256-wide tiles + split-K over this kernel's DMA / swizzle machinery.
 namespace g8 {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int ROWB = BK * 2;                 // bytes per LDS row (no padding)
@@ -40,7 +43,10 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst
 
 // NW = 8: eight waves of 64 x 32 (2 per SIMD);  NW = 4: four waves of 64 x 64 (one per SIMD, a third less fragment traffic)
 // NS = LDS stages: 4 -> one workgroup per CU, tile kt + 4 in flight; 2 -> two workgroups per CU, tile kt + 2 in flight
-template <int NW, int NS>
+// SWAP: MFMA operands swapped -> lane = output row, 4 consecutive columns per register quad (8-B / 16-B stores, but every
+// store instruction touches 32 rows x 32 B: partial lines).  !SWAP: lane = output column, a store instruction writes whole
+// 128-B row segments (fp32) — what the 268 MB dW outputs want.
+template <int NW, int NS, bool SWAP>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
     constexpr int BM = g8::BM, BN = g8::BN, BK = g8::BK;
     constexpr int WN = NW == 8 ? 4 : 2, TM = 64, TN = BN / WN, MI = 2, NI = TN / 32;
@@ -146,8 +152,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)      // operands swapped: the block is (A B^T)^T, lane = output row
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NI; ++j) {
+                if constexpr (SWAP)           // the block is (A B^T)^T, lane = output row
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+            }
     };
 #pragma unroll
     for (int p = 0; p < NS; ++p)
@@ -178,6 +188,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (!SWAP) {
+        // epilogue, lane = column: col = l31, row = (r & 3) + 8 (r >> 2) + 4 lhi of each 32 x 32 block
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t col = n0 + wn * TN + ni * 32 + l31;
+                if (col >= g.N) continue;
+                const float bias = (g.epi == BEPI_BIAS_ACT && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                    if (row >= g.M) continue;
+                    float v = acc[mi][ni][r];
+                    if (g.epi == BEPI_BIAS_ACT) {
+                        v += bias;
+                        if (g.act == TNN_ACT_RELU) v = v < 0.f ? (g.relu_sign ? -0.0f : 0.f) : fabsf(v);
+                    } else if (g.epi == BEPI_MASK) {
+                        if (g.Y[row * g.ldy + col] & 0x8000u) v = 0.f;
+                    }
+                    if (g.c_bf16) reinterpret_cast<bf16_t*>(g.C)[row * g.ldc + col] = f2bf(v);
+                    else reinterpret_cast<float*>(g.C)[row * g.ldc + col] = v;
+                }
+            }
+        return;
+    }
     // ---- epilogue: block (mi, ni) is rows m0 + wm 64 + mi 32 + l31, register r the column (r & 3) + 8 (r >> 2) + 4 lhi
     const bool vec_out = g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
                          (g.epi != BEPI_MASK || (g.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 7) == 0));
