@@ -1,0 +1,45 @@
+#!/bin/bash
+# One profiling pass of the round on the GPU box (run through gpurun from the repository root):
+#   bash tools/profile_round.sh r02
+# Bench lines, rocprofv3 kernel traces of the same commands, separate --pmc passes (FETCH_SIZE / WRITE_SIZE for the HBM-side
+# traffic, SQ counters for the bf16 GEMM).  Everything lands under gpurun_out/<round>prof/; tools/rocpd_summary.py,
+# tools/rocpd_pmc.py and tools/traffic_from_pmc.py turn the databases into the text files committed under profiles/.
+R=${1:-r02}
+export TMPDIR=/tmp
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/${R}prof
+mkdir -p $OUT
+run() { echo "== $*" >> $OUT/log.txt; "$@" >> $OUT/log.txt 2>&1; echo "rc=$?" >> $OUT/log.txt; }
+
+python3 bench.py --steps 20 --warmup 5 > $OUT/benchA.json 2>> $OUT/log.txt
+python3 bench.py --workload C > $OUT/benchC.json 2>> $OUT/log.txt
+python3 bench.py --workload E > $OUT/benchE.json 2>> $OUT/log.txt
+TNN_FORCE_COMM=1 python3 bench.py --no-extras > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
+
+run rocprofv3 --kernel-trace --stats -d $OUT/ktA -o A -- python3 bench.py --steps 20 --warmup 5
+run rocprofv3 --kernel-trace --stats -d $OUT/ktAstep -o Astep -- python3 bench.py --no-extras --steps 2000 --warmup 64
+run rocprofv3 --kernel-trace --stats -d $OUT/ktC -o C -- python3 bench.py --workload C --no-cpu-baseline
+run rocprofv3 --kernel-trace --stats -d $OUT/ktE -o E -- python3 bench.py --workload E
+
+run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcA_fetch -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
+run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcA_write -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
+run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcC_fetch -o C -- python3 bench.py --workload C --no-extras
+run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcC_write -o C -- python3 bench.py --workload C --no-extras
+run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcbf_sq -o bf -- python3 tools/gemm_bf16_sweep.py
+run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcg32_sq -o g32 -- python3 tools/gemm_pmc_driver.py
+
+for d in ktA ktAstep ktC ktE; do
+    db=$(find $OUT/$d -name "*.db" | head -1)
+    [ -n "$db" ] && python3 tools/rocpd_summary.py $db > $OUT/${d}_kernel_stats.txt 2>> $OUT/log.txt
+done
+for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcbf_sq pmcg32_sq; do
+    db=$(find $OUT/$d -name "*.db" | head -1)
+    [ -n "$db" ] && python3 tools/rocpd_pmc.py $db > $OUT/${d}.txt 2>> $OUT/log.txt
+done
+fa=$(find $OUT/pmcA_fetch -name "*.db" | head -1); wa=$(find $OUT/pmcA_write -name "*.db" | head -1)
+fc=$(find $OUT/pmcC_fetch -name "*.db" | head -1); wc=$(find $OUT/pmcC_write -name "*.db" | head -1)
+python3 tools/traffic_from_pmc.py --round $R A:$fa:$wa C:$fc:$wc > $OUT/traffic.json 2>> $OUT/log.txt
+# the databases themselves are large: keep only the summaries in what gpurun merges back
+find $OUT -name "*.db" -size +20M -delete
+tail -5 $OUT/log.txt
+ls -la $OUT

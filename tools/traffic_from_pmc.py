@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from rocprofv3 --pmc passes (rocpd SQLite): per kernel and workload tag, the average
-HBM-side bytes per launch.  FETCH_SIZE is reported in KiB and counts a wide coalesced stream at HALF its bytes on gfx950
-(MI355X_MICROARCH.md, HBM / rocprofv3 section) -> doubled; WRITE_SIZE (KiB) is taken as is.
-  python tools/traffic_from_pmc.py A:fetch.db:write.db C:fetch.db:write.db > profiles/r01_traffic.json"""
+"""profiles/<round>_traffic.json from rocprofv3 --pmc passes (rocpd SQLite): per kernel and workload tag, the average
+HBM-side bytes per launch, and per workload the bytes of ONE training step.  FETCH_SIZE is reported in KiB and counts a
+wide coalesced stream at HALF its bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section) -> doubled; WRITE_SIZE
+(KiB) is taken as is.
+  python tools/traffic_from_pmc.py --round r02 A:fetch.db:write.db C:fetch.db:write.db > profiles/r02_traffic.json
+The passes must profile a command that runs NOTHING but training steps (`bench.py --no-extras`): bytes per step =
+sum over kernels of (average bytes per launch x launches per step), launches per step = launches / launches of the
+kernel that runs exactly once per step (the optimizer-carrying one)."""
 import json
 import re
 import sqlite3
 import sys
+
+ONCE_PER_STEP = ("dense_bwd0_adam_kernel", "adam_kernel<", "adam_master_bf16_2d_kernel<true")
 
 
 def per_kernel(path, counter):
@@ -21,8 +27,12 @@ def per_kernel(path, counter):
 
 
 def main():
-    table = {}
-    for spec in sys.argv[1:]:
+    args = sys.argv[1:]
+    rnd = "r02"
+    if args and args[0] == "--round":
+        rnd, args = args[1], args[2:]
+    table, steps = {}, {}
+    for spec in args:
         tag, fetch_db, write_db = spec.split(":")
         fetch, write = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
         for k in sorted(set(fetch) | set(write)):
@@ -30,10 +40,23 @@ def main():
             w, _ = write.get(k, (0.0, 0))
             table.setdefault(k, {})[tag] = {"fetch_bytes": int(round(f * 1024 * 2)), "write_bytes": int(round(w * 1024)),
                                             "launches": int(n)}
+        once = [k for k in table if tag in table[k] and k.startswith(ONCE_PER_STEP)]
+        if once:
+            n_steps = max(table[k][tag]["launches"] for k in once)
+            total, parts = 0.0, {}
+            for k, per in table.items():
+                if tag not in per or k.startswith("__amd_rocclr"):
+                    continue
+                share = (per[tag]["fetch_bytes"] + per[tag]["write_bytes"]) * per[tag]["launches"] / float(n_steps)
+                total += share
+                parts[k[:70]] = int(round(share))
+            steps[tag] = {"bytes_per_step": int(round(total)), "steps_profiled": int(n_steps), "by_kernel": parts}
     print(json.dumps({"_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
-                      "`python3 bench.py [--workload C]`, round 1, tools/traffic_from_pmc.py; FETCH_SIZE is reported in KiB "
-                      "and read at HALF the bytes of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section) -> "
-                      "doubled here; WRITE_SIZE (KiB) taken as is.  Bytes per launch.", "kernels": table}, indent=1))
+                      "`python3 bench.py --no-extras [--workload C]`, round %s, tools/profile_round.sh + tools/traffic_from_pmc.py; "
+                      "FETCH_SIZE is reported in KiB and read at HALF the bytes of a wide coalesced stream on gfx950 "
+                      "(MI355X_MICROARCH.md, HBM section) -> doubled here; WRITE_SIZE (KiB) taken as is.  kernels: bytes "
+                      "per launch; steps: bytes of one training step over all its kernels." % rnd,
+                      "kernels": table, "steps": steps}, indent=1))
 
 
 if __name__ == "__main__":
