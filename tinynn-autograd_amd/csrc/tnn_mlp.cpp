@@ -472,7 +472,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         STEP_CALL(h, tnn_softmax_nll_fused_tick(h->act[L - 1], y, rows, h->w[L], rows, 0, h->stats, loss_dst,
                                                 h->dact[L - 1], h->dtype, h->pows, h->b1, h->b2));
         // backward of layers L-1 .. 1, then the first layer's backward with the whole Adam step folded into its
-        // launch (its own W / b in the dW epilogue, every other layer's parameters by trailing blocks): 7 launches
+        // launch (its own W / b in the dW epilogue, every other layer's parameters by trailing blocks): 2L + 1 launches
         MLP_TRY(mlp_backward_layers(h, x, rows, -1, 1));
         const int64_t rest = L > 1 ? h->w_off[1] : h->n_params;
         STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
