@@ -239,6 +239,20 @@ TNN_API int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes,
                               const void* b, const void* y, const void* logit_partials, void* logits, void* dz,
                               void* stats, void* loss, void* dw, void* db, void* da, int dtype, void* adam_pows_f64,
                               double b1, double b2);
+
+/* The head above AND the backward of the hidden layer in front of it in ONE launch (4-launch step: csrc/tnn_head.hip,
+ * mlp_head_bwd_kernel) — core/ops.py:156-160 for the last two Dense layers + core/ops.py:342-343 (ReLU mask) +
+ * core/losses.py:24-32: the tiles of the hidden layer's backward derive their slice of its dz = (dz_head w^T) * [a >= 0]
+ * themselves from the partial logits, so that dz is never written to memory.
+ *   x [rows, n_in]: the hidden layer's input (sign-encoded ReLU output, it is also dx's mask source), w1 [n_in, n_hidden],
+ *   a / w / b / y / logit_partials / logits / dz / stats / loss / dw / db as in tnn_mlp_head_tick (logit_partials required),
+ *   dw1 [n_in, n_hidden], db1 [n_hidden], dx [rows, n_in] = (dz1 w1^T) * [x >= 0].
+ * Shapes: tnn_mlp_head_fits() and n_in % 16 == 0. */
+TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x,
+                                  const void* w1, const void* a, const void* w, const void* b, const void* y,
+                                  const void* logit_partials, void* logits, void* dz, void* stats, void* loss, void* dw,
+                                  void* db, void* dw1, void* db1, void* dx, int dtype, void* adam_pows_f64, double b1,
+                                  double b2);
 /* Forward of the hidden Dense layer in front of the classifier, C = act(A B + bias) like tnn_gemm_bias_act (NN form,
  * core/layers.py:49,98), which ALSO emits the next layer's logits as per-tile partial sums:
  *   head_z[tn][row][c] = sum_{col in [16 tn, 16 tn + 16)} C[row][col] * head_w[col][c]      (head_z: [ceil(N/16)][M][head_c])

@@ -626,6 +626,20 @@ int tnn_mlp_head_tick(int64_t rows, int64_t nh, int64_t nc, const void* a, const
     if (int rc = tnn_softmax_nll_fused_tick(logits, y, rows, nc, rows, 0, stats, loss, dz, dtype, pows, b1, b2)) return rc;
     return tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da, a, dtype);
 }
+int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1, const void* a,
+                          const void* w, const void* b, const void* y, const void* zpart, void* logits, void* dz, void* stats,
+                          void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype, void* pows, double b1,
+                          double b2) {
+    NEED_INIT();
+    REQ(x && w1 && zpart && logits && dz && dw && db && dw1 && db1 && dx, "cpu twin: tnn_mlp_head_bwd_tick needs every buffer");
+    REQ(dtype == TNN_F32 && n_in % 16 == 0, "cpu twin: tnn_mlp_head_bwd_tick is f32 only, n_in % 16 == 0");
+    RECORD(tnn_mlp_head_bwd_tick(rows, n_in, nh, nc, x, w1, a, w, b, y, zpart, logits, dz, stats, loss, dw, db, dw1, db1, dx,
+                                 dtype, pows, b1, b2));
+    std::vector<float> da((size_t)(rows * nh));              // the hidden layer's dz: never materialised by the HIP kernel
+    if (int rc = tnn_mlp_head_tick(rows, nh, nc, a, w, b, y, zpart, logits, dz, stats, loss, dw, db, da.data(), dtype, pows, b1, b2))
+        return rc;
+    return tnn_dense_bwd(rows, n_in, nh, x, da.data(), w1, dw1, db1, dx, x, dtype);
+}
 int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                 const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* hw, int64_t hc,
                                 void* hz, int dtype) {

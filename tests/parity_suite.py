@@ -360,6 +360,53 @@ def classifier_head_one_launch_multi_workgroup_vs_numpy():
     assert fits.value == 0                                                     # the trainer then takes the 7-launch step
 
 
+def head_and_hidden_backward_one_launch_vs_numpy():
+    """tnn_mlp_head_bwd_tick (the 4-launch step's third launch: classifier head + the backward of the hidden layer in front
+    of it, whose dz is derived inside every tile and never stored) against float64 numpy: full and ragged batches, hidden
+    layer inputs 256 / 48 / 784 wide, sign-encoded ReLU zeros in both activations incl. exactly-zero pre-activations."""
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(29)
+    Hn, C = 128, 10
+    for m, n_in in ((128, 256), (104, 256), (37, 48), (1, 16), (128, 784)):
+        pre0 = rs.randn(m, n_in).astype(np.float32)
+        x = np.where(pre0 < 0, np.float32(-0.0), np.abs(pre0)).astype(np.float32)        # the hidden layer's input (ReLU output)
+        x[0, 3] = 0.0
+        w1 = (rs.randn(n_in, Hn) * 0.2).astype(np.float32)
+        b1v = rs.randn(Hn).astype(np.float32)
+        w = (rs.randn(Hn, C) * 0.3).astype(np.float32)
+        b = rs.randn(C).astype(np.float32)
+        y = rs.rand(m, C).astype(np.float32) if m % 2 else np.eye(C, dtype=np.float32)[rs.randint(0, C, m)]
+        X, W1, B1, W, B, Y = (tn.asarray(v) for v in (x, w1, b1v, w, b, y))
+        A = tn.empty((m, Hn))
+        zpart = tn.zeros((Hn // 16, m, C))
+        lib.dense_fwd_head_partials(m, Hn, n_in, X._ptr, n_in, W1._ptr, Hn, B1._ptr, _lib.ACT_RELU, 1, A._ptr, Hn,
+                                    W._ptr, C, zpart._ptr, _lib.F32)
+        a = np.asarray(A).copy()
+        logits, dz = tn.empty((m, C)), tn.empty((m, C))
+        stats, loss = tn.empty((2,)), tn.empty(())
+        dw, db = tn.zeros((Hn, C)), tn.zeros((C,))
+        dw1, db1, dx = tn.zeros((n_in, Hn)), tn.zeros((Hn,)), tn.zeros((m, n_in))
+        pows = tn.asarray(np.array([0.9, 0.999, 0, 0]), dtype=np.float64)
+        lib.mlp_head_bwd_tick(m, n_in, Hn, C, X._ptr, W1._ptr, A._ptr, W._ptr, B._ptr, Y._ptr, zpart._ptr, logits._ptr,
+                              dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, dw1._ptr, db1._ptr, dx._ptr, _lib.F32,
+                              pows._ptr, 0.9, 0.999)
+        a64, w64, y64, x64, w164 = (v.astype(np.float64) for v in (a, w, y, x, w1))
+        z = a64 @ w64 + b
+        tag = "rows=%d n_in=%d" % (m, n_in)
+        e = np.exp(z - z.max()); S = e.sum(); q = (e * y64).sum(1, keepdims=True)
+        ref_dz = e / S - (e * y64 / q) / m
+        ref_da = (ref_dz @ w64.T) * ~np.signbit(a)                                          # the hidden layer's dz
+        _check_head_outputs(m, a, z, w64, y64, logits, loss, stats, dz, dw, db, ref_da, tag)
+        for name, got, ref in (("dw1", dw1, x64.T @ ref_da), ("db1", db1, ref_da.sum(0)),
+                               ("dx", dx, (ref_da @ w164.T) * ~np.signbit(x))):
+            np.testing.assert_allclose(np.asarray(got), ref, rtol=0, atol=1e-5 * np.abs(ref).max() + 1e-12,
+                                       err_msg="%s %s" % (name, tag))
+        assert np.asarray(dx)[0, 3] != 0.0 or m == 1                                         # mask = 1 at an exactly-zero input
+        np.testing.assert_allclose(np.asarray(pows)[:2], [0.9 ** 2, 0.999 ** 2], rtol=1e-14)
+
+
 def dense_backward_one_launch_vs_numpy():
     import ctypes
     from tinynn_autograd_amd import _lib

@@ -202,6 +202,62 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
 }
 
 
+struct HeadStats {
+    bool valid[3];
+    float ec[3], eyc[3];             // exp(z - row max), times the label
+    float mx, urow, M;               // row max, row sum of e * y, batch max
+    double S, L;                     // batch sum-exp (relative to M), sum over rows of log u + row max
+};
+
+// zc / yc: this thread's three logits / labels of row (t >> 2) (classes sub, sub + 4, sub + 8); one barrier inside.
+template <int C>
+__device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&yc)[3], const bool slive, const int sub,
+                                           const int lane, const int wid, double (*red)[4], HeadStats& o) {
+    // ---- whole-batch softmax statistics: FOUR threads per row (classes sub, sub + 4, sub + 8), row max / sums by
+    // quad-permute DPP; then ONE combined reduction of {max, rescaled sum-exp, sum(log u + max)} over the workgroup
+    // (DPP wave reductions + an 8-entry LDS exchange).  Row sums in f32 (10 terms), cross-row sums in f64 — the
+    // arithmetic of nll_rows_body (tnn_nll_rows.h) up to summation order.
+    bool (&valid)[3] = o.valid;
+    float (&ec)[3] = o.ec, (&eyc)[3] = o.eyc;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        valid[i] = sub + 4 * i < C;
+        if (valid[i]) mx = zc[i] > mx ? zc[i] : mx;
+    }
+    { float q = tnn::dpp_move<0xB1, 0xf>(-INFINITY, mx); mx = q > mx ? q : mx; }
+    { float q = tnn::dpp_move<0x4E, 0xf>(-INFINITY, mx); mx = q > mx ? q : mx; }
+    float srow_sum = 0.f, urow = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ec[i] = valid[i] ? expf(zc[i] - mx) : 0.f;
+        eyc[i] = ec[i] * (valid[i] ? yc[i] : 0.f);
+        srow_sum += ec[i];
+        urow += eyc[i];
+    }
+    srow_sum += tnn::dpp_move<0xB1, 0xf>(0.f, srow_sum);
+    srow_sum += tnn::dpp_move<0x4E, 0xf>(0.f, srow_sum);
+    urow += tnn::dpp_move<0xB1, 0xf>(0.f, urow);
+    urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
+    const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
+    const float wm = tnn::wave_max_dpp(slive ? mx : -INFINITY);
+    const double wsum = tnn::wave_sum_dpp(counts ? (double)srow_sum * (double)expf(mx - wm) : 0.0);
+    const double wlog = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
+    if (lane == 0) { red[wid][0] = (double)wm; red[wid][1] = wsum; red[wid][2] = wlog; }
+    __syncthreads();
+    double Md = red[0][0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) Md = fmax(Md, red[w][0]);
+    const float M = (float)Md;
+    double S = 0.0, L = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        if (red[w][0] > -INFINITY) S += red[w][1] * (double)expf((float)red[w][0] - M);
+        L += red[w][2];
+    }
+    o.mx = mx; o.urow = urow; o.M = M; o.S = S; o.L = L;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // MULTI-WORKGROUP head: the last Dense forward, the whole-batch softmax NLL and the last Dense backward of the
 // single-GPU MNIST-size step in ONE launch WITHOUT serialising on one CU (the single-workgroup kernel above: 14.7 us).
@@ -235,8 +291,9 @@ struct HeadMArgs {
 // tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
 // v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
 // CUT (timing builds only, TNN_HEAD_CUT): 0 = the kernel; 1 = stop after the logits, 2 = after the statistics, 3 = after dz.
-template <int H, int C, bool PART, int CUT = 0>
-__global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
+// DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
+template <int H, int C, bool PART, int CUT, bool DA>
+__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
     constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
@@ -250,7 +307,7 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
     const int i16 = lane & 15, grp = lane >> 4;
     const int r = t & (ROWS - 1), kq = t >> 7;     // da phase: column r, row group kq
     const int srow = t >> 2, sub = t & 3;          // statistics: row srow, classes sub, sub + 4, sub + 8
-    const int m = p.m, g = blockIdx.x;
+    const int m = p.m;
     const bool slive = srow < m;
 
     // ---- every global read of the kernel is requested here, before the first use, in as few vector-memory
@@ -280,10 +337,12 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
     constexpr int WV = H * C / 4;                                       // float4 pieces of W (320)
     f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
     if (t < WV) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
-    float am[2];
+    float am[2] = {0.f, 0.f};
     const int r0 = g * p.rpb, rend = min(m, r0 + p.rpb);
+    if constexpr (DA) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
+        for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
+    }
     const f32x4 asl = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
     // Adam's beta powers: read NOW (a dependent global round trip at the very end of workgroup 0 cost 1.3 us of the launch)
     double pw0 = 0.0, pw1 = 0.0;
@@ -333,48 +392,12 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
         return;
     }
 
-    // ---- whole-batch softmax statistics: FOUR threads per row (classes sub, sub + 4, sub + 8), row max / sums by
-    // quad-permute DPP; then ONE combined reduction of {max, rescaled sum-exp, sum(log u + max)} over the workgroup
-    // (DPP wave reductions + an 8-entry LDS exchange).  Row sums in f32 (10 terms), cross-row sums in f64 — the
-    // arithmetic of nll_rows_body (tnn_nll_rows.h) up to summation order.
-    bool valid[3];
-    float ec[3], eyc[3];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        valid[i] = sub + 4 * i < C;
-        if (valid[i]) mx = zc[i] > mx ? zc[i] : mx;
-    }
-    { float o = tnn::dpp_move<0xB1, 0xf>(-INFINITY, mx); mx = o > mx ? o : mx; }
-    { float o = tnn::dpp_move<0x4E, 0xf>(-INFINITY, mx); mx = o > mx ? o : mx; }
-    float srow_sum = 0.f, urow = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        ec[i] = valid[i] ? expf(zc[i] - mx) : 0.f;
-        eyc[i] = ec[i] * (valid[i] ? yc[i] : 0.f);
-        srow_sum += ec[i];
-        urow += eyc[i];
-    }
-    srow_sum += tnn::dpp_move<0xB1, 0xf>(0.f, srow_sum);
-    srow_sum += tnn::dpp_move<0x4E, 0xf>(0.f, srow_sum);
-    urow += tnn::dpp_move<0xB1, 0xf>(0.f, urow);
-    urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
-    const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
-    const float wm = tnn::wave_max_dpp(slive ? mx : -INFINITY);
-    const double wsum = tnn::wave_sum_dpp(counts ? (double)srow_sum * (double)expf(mx - wm) : 0.0);
-    const double wlog = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
-    if (lane == 0) { red[wid][0] = (double)wm; red[wid][1] = wsum; red[wid][2] = wlog; }
-    __syncthreads();
-    double Md = red[0][0];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) Md = fmax(Md, red[w][0]);
-    const float M = (float)Md;
-    double S = 0.0, L = 0.0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        if (red[w][0] > -INFINITY) S += red[w][1] * (double)expf((float)red[w][0] - M);
-        L += red[w][2];
-    }
+    HeadStats st;
+    head_stats<C>(zc, yc, slive, sub, lane, wid, red, st);
+    const bool (&valid)[3] = st.valid;
+    const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
+    const float mx = st.mx, urow = st.urow, M = st.M;
+    const double S = st.S, L = st.L;
     const double inv_m = 1.0 / (double)m;
     if constexpr (CUT == 2) {
         p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
 
     // ---- da rows of this workgroup: thread (column j = r, row group kq); W[j][:] and the dz row as three 16-B LDS reads
     // each (the dz row is wave-uniform: a broadcast)
-    if (p.da) {
+    if (DA && p.da) {
         f32x4 wv[WS / 4];
 #pragma unroll
         for (int i = 0; i < WS / 4; ++i) wv[i] = *reinterpret_cast<const f32x4*>(ws + r * WS + 4 * i);
@@ -464,6 +487,183 @@ __global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
                 if (p.logits) p.logits[(size_t)srow * C + sub + 4 * i] = zc[i];
                 if (p.dz) p.dz[(size_t)srow * C + sub + 4 * i] = dzc[i];
             }
+    }
+}
+
+template <int H, int C, bool PART, int CUT = 0>
+__global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
+    head_block<H, C, PART, CUT, true>(p, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Head + the hidden layer's backward in ONE launch (4-launch step: fwd0 | fwd1 + partial logits | THIS | bwd0 + Adam).
+// The hidden layer's dz (rows x H) is   dz1 = (dz W2^T) * !signbit(a1)   with dz = the loss gradient of the rows x C logits:
+// 10 FMAs per element once dz is known, and dz costs every workgroup the same ~1 us the head's workgroups already spend
+// (sum 8 partial logits, whole-batch statistics).  So the tiles of the hidden layer's backward derive the slice of dz1
+// they contract over THEMSELVES instead of waiting for a launch boundary behind the head:
+//     blocks [0, G)                 the head's workgroups (head_block, no da rows): dW2, db2, loss, stats, beta powers, logits
+//     blocks [G, G + n_dw)          dW1 tile (16 inputs x 16 hidden units) = x^T dz1[:, 16 units]   (K = rows), db1 = column sums
+//     blocks [G + n_dw, ...)        dx tile (16 rows x 16 inputs) = (dz1[16 rows, :] W1^T) * !signbit(x)   (K = H)
+// Tile products as in small_tile_fast (v_mfma_f32_16x16x4_f32, one 16-deep K chunk per wave, 8 waves, partials summed
+// through LDS); the dz1 operand comes from LDS (panel computed in place), the other operand through loads requested first
+// thing.  dz1 is never written to HBM.
+struct HeadBwdArgs {
+    const float* x;                  // [m][n_in]   the hidden layer's input (sign-encoded ReLU output of the layer before)
+    const float* w1;                 // [n_in][H]
+    float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
+    int n_in, tiles_in;              // tiles_in = n_in / 16
+};
+
+template <int H, int C>
+__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
+    constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16;
+    static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
+    if ((int)blockIdx.x < G) {
+        head_block<H, C, true, 0, false>(p, (int)blockIdx.x);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float ws[H * WS];       // W2 rows (dW tiles: only the tile's 16), padded to 12
+    __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];   // dz [row][12]
+    __shared__ __attribute__((aligned(16))) float pan[ROWS * 20];   // dz1 panel: [128 rows][16 units] (stride 20) or [16 rows][H] (stride 132)
+    __shared__ float redm[8][4][64];
+    __shared__ float bsum[8][64];
+    __shared__ double red[8][4];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int srow = t >> 2, sub = t & 3;
+    const int m = p.m;
+    const bool slive = srow < m;
+    const int sr = min(srow, m - 1);
+    const int n_dw = q.tiles_in * TH;
+    const int blk = (int)blockIdx.x - G;
+    const bool is_dw = blk < n_dw;
+    const int n_in = q.n_in;
+
+    // ---- every global read, up front
+    float part[3][NP], yc[3], bc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = min(sub + 4 * i, C - 1);
+#pragma unroll
+        for (int tn = 0; tn < NP; ++tn) part[i][tn] = p.zpart[((size_t)tn * m + sr) * C + c];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bc[i] = p.b[min(sub + 4 * i, C - 1)];
+
+    // tile coordinates.  dW: tm over the inputs, tn over the hidden units; dx: tm over the rows, tn over the inputs
+    int tm, tn;
+    if (is_dw) { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
+    else { const int b2 = blk - n_dw, tr = (m + 15) / 16; tm = b2 % tr; tn = b2 / tr; }
+    const int m0 = tm * 16, n0 = tn * 16;
+    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};            // W2 pieces
+    f32x4 a1v;                                   // a1 (mask of dz1) for this thread's 4 panel elements
+    float af[4] = {0.f, 0.f, 0.f, 0.f};          // dW: x fragment
+    f32x4 bf = {0.f, 0.f, 0.f, 0.f};             // dx: W1 fragment
+    float e_pre = 0.f;                           // dx: mask source
+    const int e_r = (t >> 6) & 3, e_ln = t & 63;
+    if (is_dw) {
+        // W2 rows [n0, n0 + 16): 160 contiguous floats
+        if (t < 16 * C / 4) w4 = *reinterpret_cast<const f32x4*>(p.w + (size_t)n0 * C + 4 * t);
+        a1v = *reinterpret_cast<const f32x4*>(p.a + (size_t)sr * H + n0 + 4 * sub);          // panel element (row srow, units 4 sub ..)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = q.x[(size_t)min(16 * wid + 4 * grp + j, m - 1) * n_in + m0 + i16];
+    } else {
+        if (t < H * C / 4) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
+        a1v = *reinterpret_cast<const f32x4*>(p.a + (size_t)min(m0 + (t >> 5), m - 1) * H + 4 * (t & 31));   // (tile row t >> 5, units 4 (t & 31) ..)
+        bf = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + i16) * H + 16 * wid + 4 * grp);
+        if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, m - 1) * n_in + n0 + (e_ln & 15)];
+    }
+
+    // ---- W2 -> LDS
+    if (is_dw) {
+        if (t < 16) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
+        if (t < 16 * C / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
+        }
+    } else {
+        if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
+        if (t < H * C / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
+        }
+    }
+
+    // ---- logits = sum of the 8 tile partials + bias; statistics; dz
+    float zc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        zc[i] = (((part[i][0] + part[i][1]) + (part[i][2] + part[i][3])) + ((part[i][4] + part[i][5]) + (part[i][6] + part[i][7]))) + bc[i];
+    HeadStats st;
+    head_stats<C>(zc, yc, slive, sub, lane, wid, red, st);
+    {
+        const double inv_m = 1.0 / (double)m;
+        const float sf = slive ? expf(st.mx - st.M) / (float)st.S : 0.f, uf = slive ? (float)inv_m / st.urow : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (st.valid[i]) dzr[srow * WS + sub + 4 * i] = st.ec[i] * sf - st.eyc[i] * uf;      // 0 in the padding rows
+        if (sub >= 2) dzr[srow * WS + 8 + sub] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- the dz1 slice this tile contracts over, 4 elements per thread: (dz row) . (W2 row), masked by a1's sign
+    {
+        const int prow = is_dw ? srow : m0 + (t >> 5);            // dz row
+        const int u0 = is_dw ? 4 * sub : 4 * (t & 31);            // first of 4 units (row of ws)
+        f32x4 dv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dv[k] = *reinterpret_cast<const f32x4*>(dzr + min(prow, ROWS - 1) * WS + 4 * k);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + (u0 + e) * WS + 4 * k);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d = fmaf(dv[k][c], wv[c], d);
+            }
+            o[e] = (__float_as_uint(a1v[e]) >> 31) ? 0.f : d;
+        }
+        if (is_dw) *reinterpret_cast<f32x4*>(pan + srow * 20 + u0) = o;
+        else *reinterpret_cast<f32x4*>(pan + (t >> 5) * 132 + u0) = (m0 + (t >> 5) < m) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+
+    // ---- the tile product: wave wid owns K chunk wid
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bs = 0.f;
+    if (is_dw) {
+        float b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = pan[(16 * wid + 4 * grp + j) * 20 + i16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], b[j], acc, 0, 0, 0);
+        bs = (b[0] + b[1]) + (b[2] + b[3]);
+    } else {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pan + i16 * 132 + 16 * wid + 4 * grp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) redm[wid][r][lane] = acc[r];
+    bsum[wid][lane] = bs;
+    __syncthreads();
+    if (t < 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += redm[w][e_r][e_ln];
+        const int row = m0 + (e_ln >> 4) * 4 + e_r, col = n0 + (e_ln & 15);           // 16x16x4 C/D layout
+        if (is_dw) q.dw1[(size_t)row * H + col] = s;
+        else if (row < m) q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+    }
+    if (is_dw && tm == 0 && t < 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += (bsum[w][t] + bsum[w][16 + t]) + (bsum[w][32 + t] + bsum[w][48 + t]);
+        q.db1[n0 + t] = s;
     }
 }
 
@@ -551,6 +751,35 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     } else {
         hipLaunchKernelGGL((mlp_head_multi_kernel<128, 10, false>), 16, 512, 0, st, p);
     }
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
+                          const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
+                          void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
+                          void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(rows > 0 && n_in > 0 && n_hidden > 0 && n_classes > 0, "tnn_mlp_head_bwd_tick: empty head");
+    TNN_REQUIRE(x && w1 && a && w && b && y && logit_partials && dw && db && dw1 && db1 && dx,
+                "tnn_mlp_head_bwd_tick: x, w1, a, w, b, y, logit_partials, dw, db, dw1, db1 and dx are required");
+    auto al = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype) && n_in % 16 == 0 && al(a) && al(w) && al(w1),
+                "tnn_mlp_head_bwd_tick: this head does not fit the merged form (tnn_mlp_head_fits, n_in %% 16 == 0, 16-B aligned a / w / w1)");
+    HeadMArgs p;
+    p.m = (int)rows;
+    p.rpb = (int)((rows + 15) / 16);
+    p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
+    p.zpart = (const float*)logit_partials;
+    p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
+    p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
+    p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
+    HeadBwdArgs q;
+    q.x = (const float*)x; q.w1 = (const float*)w1;
+    q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
+    q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
+    const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
+    hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, tnn::stream(), p, q);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -437,7 +437,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     if (!h->bf16 && h->opt_kind == 1 && L >= 2)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
     if (head_multi) {
-        // 2L - 1 launches (5 for the MNIST net): forward of the hidden layers | the classifier head as ONE multi-workgroup
+        // 2L - 1 launches (5 for the MNIST net; 2L - 2 = 4 with the merge below): forward of the hidden layers | the classifier head as ONE multi-workgroup
         // launch (last Dense forward + loss + last Dense backward + Adam's beta powers) | backward of the hidden layers,
         // the first layer's carrying the whole optimizer
         // the hidden layer in front of the classifier also emits the logits as per-tile partial sums (its activations
@@ -448,12 +448,26 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                                  at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
                                                  h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
                                                  h->dtype));
-        STEP_CALL(h, tnn_mlp_head_tick(rows, h->w[L - 1], h->w[L], h->act[L - 2],
-                                       at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
-                                       h->zpart, h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
-                                       at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
-                                       h->dact[L - 2], h->dtype, h->pows, h->b1, h->b2));
-        MLP_TRY(mlp_backward_layers(h, x, rows, L - 2, 1));
+        static const bool merge_off = getenv("TNN_STEP_MERGE") != nullptr && atoi(getenv("TNN_STEP_MERGE")) == 0;
+        if (L >= 3 && h->w[L - 2] % 16 == 0 && !merge_off) {
+            // 2L - 2 launches (4 for the MNIST net): the head's launch also carries the backward of the hidden layer in
+            // front of it — its tiles derive their slice of that layer's dz from the partial logits themselves
+            STEP_CALL(h, tnn_mlp_head_bwd_tick(rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
+                                               at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
+                                               at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
+                                               y, h->zpart, h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
+                                               at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                               at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
+                                               h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
+            MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 1));
+        } else {
+            STEP_CALL(h, tnn_mlp_head_tick(rows, h->w[L - 1], h->w[L], h->act[L - 2],
+                                           at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,
+                                           h->zpart, h->act[L - 1], h->dact[L - 1], h->stats, loss_dst,
+                                           at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                           h->dact[L - 2], h->dtype, h->pows, h->b1, h->b2));
+            MLP_TRY(mlp_backward_layers(h, x, rows, L - 2, 1));
+        }
         const int64_t rest = h->w_off[1];
         STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
                                               at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
