@@ -210,9 +210,12 @@ struct HeadStats {
 };
 
 // zc / yc: this thread's three logits / labels of row (t >> 2) (classes sub, sub + 4, sub + 8); one barrier inside.
-template <int C>
+// LOSS = false (workgroups that only need dz): no sum of logs, cross-row sums in f32 — a 1280-term DPP tree is good to
+// ~1e-6 relative, dz's tolerance is 1e-5 — which takes the f64 DPP reductions and the logf off their critical path.
+template <int C, bool LOSS = true>
 __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&yc)[3], const bool slive, const int sub,
-                                           const int lane, const int wid, double (*red)[4], HeadStats& o) {
+                                           const int lane, const int wid, double (*red)[4], HeadStats& o,
+                                           const bool want_loss = true) {
     // ---- whole-batch softmax statistics: FOUR threads per row (classes sub, sub + 4, sub + 8), row max / sums by
     // quad-permute DPP; then ONE combined reduction of {max, rescaled sum-exp, sum(log u + max)} over the workgroup
     // (DPP wave reductions + an 8-entry LDS exchange).  Row sums in f32 (10 terms), cross-row sums in f64 — the
@@ -240,21 +243,45 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
     urow += tnn::dpp_move<0xB1, 0xf>(0.f, urow);
     urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
     const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
+    // A wave holds 16 rows: its {max, sum-exp relative to that max} in f32 (160 terms, DPP tree).  The eight waves' results
+    // meet in LDS; every lane then takes entry (lane & 7) and an 8-lane DPP butterfly (quad_perm x 2, row_half_mirror)
+    // leaves M, S (and L) in ALL lanes — one exp per lane instead of a serial 8-term loop per thread (measured: the
+    // f64 loop + f64 64-lane reductions cost 1.5 us of the head's 4.4).  Across waves S and L are summed in f64 (LOSS).
     const float wm = tnn::wave_max_dpp(slive ? mx : -INFINITY);
-    const double wsum = tnn::wave_sum_dpp(counts ? (double)srow_sum * (double)expf(mx - wm) : 0.0);
-    const double wlog = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
-    if (lane == 0) { red[wid][0] = (double)wm; red[wid][1] = wsum; red[wid][2] = wlog; }
-    __syncthreads();
-    double Md = red[0][0];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) Md = fmax(Md, red[w][0]);
-    const float M = (float)Md;
-    double S = 0.0, L = 0.0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        if (red[w][0] > -INFINITY) S += red[w][1] * (double)expf((float)red[w][0] - M);
-        L += red[w][2];
+    const float wsf = tnn::wave_sum_dpp(counts ? srow_sum * expf(mx - wm) : 0.f);
+    const int w8 = lane & 7;
+    if constexpr (!LOSS) {
+        float* redf = reinterpret_cast<float*>(red);            // [8][2] floats in the same LDS words
+        if (lane == 0) { redf[2 * wid] = wm; redf[2 * wid + 1] = wsf; }
+        __syncthreads();
+        const float rm = redf[2 * w8], rs = redf[2 * w8 + 1];
+        float Mf = rm, q;
+        q = tnn::dpp_move<0xB1, 0xf>(-INFINITY, Mf); Mf = q > Mf ? q : Mf;
+        q = tnn::dpp_move<0x4E, 0xf>(-INFINITY, Mf); Mf = q > Mf ? q : Mf;
+        q = tnn::dpp_move<0x141, 0xf>(-INFINITY, Mf); Mf = q > Mf ? q : Mf;
+        float Sf = rm > -INFINITY ? rs * expf(rm - Mf) : 0.f;
+        Sf += tnn::dpp_move<0xB1, 0xf>(0.f, Sf);
+        Sf += tnn::dpp_move<0x4E, 0xf>(0.f, Sf);
+        Sf += tnn::dpp_move<0x141, 0xf>(0.f, Sf);
+        o.mx = mx; o.urow = urow; o.M = Mf; o.S = (double)Sf; o.L = 0.0;
+        return;
     }
+    double wlog = 0.0;
+    if (want_loss) wlog = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);     // block-uniform branch
+    if (lane == 0) { red[wid][0] = (double)wm; red[wid][1] = (double)wsf; red[wid][2] = wlog; }
+    __syncthreads();
+    const double rm = red[w8][0], rs = red[w8][1];
+    float M = (float)rm, q;
+    q = tnn::dpp_move<0xB1, 0xf>(-INFINITY, M); M = q > M ? q : M;
+    q = tnn::dpp_move<0x4E, 0xf>(-INFINITY, M); M = q > M ? q : M;
+    q = tnn::dpp_move<0x141, 0xf>(-INFINITY, M); M = q > M ? q : M;
+    double S = rm > -INFINITY ? rs * (double)expf((float)rm - M) : 0.0, L = red[w8][2];
+    S += tnn::dpp_move<0xB1, 0xf>(0.0, S);
+    S += tnn::dpp_move<0x4E, 0xf>(0.0, S);
+    S += tnn::dpp_move<0x141, 0xf>(0.0, S);
+    L += tnn::dpp_move<0xB1, 0xf>(0.0, L);
+    L += tnn::dpp_move<0x4E, 0xf>(0.0, L);
+    L += tnn::dpp_move<0x141, 0xf>(0.0, L);
     o.mx = mx; o.urow = urow; o.M = M; o.S = S; o.L = L;
 }
 
@@ -280,12 +307,54 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
 //     workgroup, 4 row-quarters per output summed with two quad-permute DPP steps.
 struct HeadMArgs {
     int m, rpb;                      // rows (<= 128); da rows per workgroup
+    int vec;                         // rows even, zpart / y 16-B aligned: the partial logits are staged with 16-B loads
     const float *a, *w, *b, *y;
     const float* zpart;              // [H / 16][m][C] partial logits from the previous layer's tiles, or NULL
     float *logits, *dz, *stats, *loss, *dw, *db, *da;
     double* tick;
     double b1, b2;
 };
+
+// Partial logits -> logits, staged through LDS.  The [NP][m][C] partial array and the [m][C] labels are flat and contiguous,
+// so thread f < m C / 4 sums its 16-B piece of every tile's array (NP + 1 fully coalesced loads) instead of each
+// (row, class-triple) thread gathering 3 x NP scalars (24 vector-memory instructions per thread, ~6 cache lines each).
+// RQ: the request (registers), ST: sum + bias -> zs / ys.  The caller puts its other loads between the two and a barrier
+// after.  Odd row counts / unaligned labels take the element-wise loop.
+template <int C, int NP>
+struct HeadStage {
+    f32x4 v[NP], yv;
+};
+template <int C, int NP>
+__device__ __forceinline__ void head_stage_request(const HeadMArgs& p, const int t, HeadStage<C, NP>& h) {
+    const int n = p.m * C;
+    if (p.vec && t < (n >> 2)) {
+#pragma unroll
+        for (int tn = 0; tn < NP; ++tn) h.v[tn] = *reinterpret_cast<const f32x4*>(p.zpart + (size_t)tn * n + 4 * t);
+        h.yv = *reinterpret_cast<const f32x4*>(p.y + 4 * t);
+    }
+}
+template <int C, int NP>
+__device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t, const HeadStage<C, NP>& h, float* zs, float* ys) {
+    static_assert(NP == 8, "the partial-sum tree is written for 8 tiles");
+    const int n = p.m * C;
+    if (p.vec) {
+        if (t < (n >> 2)) {
+            f32x4 s = ((h.v[0] + h.v[1]) + (h.v[2] + h.v[3])) + ((h.v[4] + h.v[5]) + (h.v[6] + h.v[7]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += p.b[(4 * t + i) % C];
+            *reinterpret_cast<f32x4*>(zs + 4 * t) = s;
+            *reinterpret_cast<f32x4*>(ys + 4 * t) = h.yv;
+        }
+    } else {
+        for (int e = t; e < n; e += 512) {
+            float u[NP];
+#pragma unroll
+            for (int tn = 0; tn < NP; ++tn) u[tn] = p.zpart[(size_t)tn * n + e];
+            zs[e] = (((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]))) + p.b[e % C];
+            ys[e] = p.y[e];
+        }
+    }
+}
 
 // PART: the logits arrive as H / 16 partial sums per element (tnn_dense_fwd_head_partials: the previous layer's 16-column
 // tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
@@ -315,25 +384,20 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     // are neutralised in the arithmetic (their dz is 0, so whatever they loaded never reaches an output).
     const int sr = min(srow, m - 1);
     float zc[3] = {0.f, 0.f, 0.f}, yc[3];
-    float part[PART ? 3 : 1][PART ? NP : 1];
+    __shared__ __attribute__((aligned(16))) float zst[PART ? ROWS * C : 4], yst[PART ? ROWS * C : 4];   // staged logits / labels
+    HeadStage<C, NP> stg;
     f32x4 av[PART ? 1 : KC];
     if constexpr (PART) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int c = min(sub + 4 * i, C - 1);
-#pragma unroll
-            for (int tn = 0; tn < NP; ++tn) part[i][tn] = p.zpart[((size_t)tn * m + sr) * C + c];
-        }
+        head_stage_request<C, NP>(p, t, stg);
     } else {
         const float* arow = p.a + (size_t)min(16 * wid + i16, m - 1) * H + 4 * grp;
 #pragma unroll
         for (int c = 0; c < KC; ++c) av[c] = *reinterpret_cast<const f32x4*>(arow + 16 * c);
     }
+    if constexpr (!PART) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
-    float bc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) bc[i] = p.b[min(sub + 4 * i, C - 1)];
+        for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
+    }
     constexpr int WV = H * C / 4;                                       // float4 pieces of W (320)
     f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
     if (t < WV) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
@@ -360,10 +424,13 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
 
     if constexpr (PART) {
+        head_stage_store<C, NP>(p, t, stg, zst, yst);
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            zc[i] = (((part[i][0] + part[i][1]) + (part[i][2] + part[i][3])) + ((part[i][4] + part[i][5]) + (part[i][6] + part[i][7]))) + bc[i];
-        static_assert(!PART || NP == 8, "the partial-sum tree is written for 8 tiles");
+        for (int i = 0; i < 3; ++i) {
+            zc[i] = zst[sr * C + min(sub + 4 * i, C - 1)];
+            yc[i] = yst[sr * C + min(sub + 4 * i, C - 1)];
+        }
     } else {
         // wave w owns the 16-row tile [16 w, 16 w + 16) over the whole K = H: lane (i16, grp) holds a[row i16][16 c + 4 grp + j]
         // (registers, from global) and W[16 c + 4 grp + j][col i16] (LDS; columns 10, 11 are zeros, lanes i16 >= 12 re-read
@@ -393,7 +460,7 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
 
     HeadStats st;
-    head_stats<C>(zc, yc, slive, sub, lane, wid, red, st);
+    head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
     const float mx = st.mx, urow = st.urow, M = st.M;
@@ -405,7 +472,8 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
     float dzc[3];
     {
-        const float sf = slive ? expf(mx - M) / (float)S : 0.f, uf = slive ? (float)inv_m / urow : 0.f;
+        // v_rcp_f32 (1 ulp) instead of two IEEE divisions on the way to dz (tolerance 1e-5)
+        const float sf = slive ? expf(mx - M) * __builtin_amdgcn_rcpf((float)S) : 0.f, uf = slive ? (float)inv_m * __builtin_amdgcn_rcpf(urow) : 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             dzc[i] = ec[i] * sf - eyc[i] * uf;                  // 0 in the padding rows
@@ -514,17 +582,18 @@ struct HeadBwdArgs {
     int n_in, tiles_in;              // tiles_in = n_in / 16
 };
 
-template <int H, int C>
+// CUT (timing builds only, TNN_HBW_CUT): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
+template <int H, int C, int CUT = 0>
 __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
-    constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16;
+    constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
     if ((int)blockIdx.x < G) {
         head_block<H, C, true, 0, false>(p, (int)blockIdx.x);
         return;
     }
-    __shared__ __attribute__((aligned(16))) float ws[H * WS];       // W2 rows (dW tiles: only the tile's 16), padded to 12
-    __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];   // dz [row][12]
-    __shared__ __attribute__((aligned(16))) float pan[ROWS * 20];   // dz1 panel: [128 rows][16 units] (stride 20) or [16 rows][H] (stride 132)
+    __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
+    __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];   // dz [row][12] (columns 10, 11 hold 0)
+    __shared__ __attribute__((aligned(16))) float pan[16 * PS];     // dx tiles: dz1 [16 rows][H], stride H + 4
     __shared__ float redm[8][4][64];
     __shared__ float bsum[8][64];
     __shared__ double red[8][4];
@@ -538,112 +607,102 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     const int blk = (int)blockIdx.x - G;
     const bool is_dw = blk < n_dw;
     const int n_in = q.n_in;
-
-    // ---- every global read, up front
-    float part[3][NP], yc[3], bc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = min(sub + 4 * i, C - 1);
-#pragma unroll
-        for (int tn = 0; tn < NP; ++tn) part[i][tn] = p.zpart[((size_t)tn * m + sr) * C + c];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) bc[i] = p.b[min(sub + 4 * i, C - 1)];
-
     // tile coordinates.  dW: tm over the inputs, tn over the hidden units; dx: tm over the rows, tn over the inputs
     int tm, tn;
     if (is_dw) { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
     else { const int b2 = blk - n_dw, tr = (m + 15) / 16; tm = b2 % tr; tn = b2 / tr; }
     const int m0 = tm * 16, n0 = tn * 16;
-    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};            // W2 pieces
-    f32x4 a1v;                                   // a1 (mask of dz1) for this thread's 4 panel elements
+
+    // ---- every global read, up front.  The dz1 slice of a tile is itself a 16x16x4 MFMA product
+    //   P[row][unit] = sum_c dz[row][c] W2[unit][c]    (K = 12: 10 classes + 2 zero columns, 3 MFMAs per wave)
+    // dW tile: wave w takes rows 16 w .. 16 w + 15 x units n0 .. n0 + 15; dx tile: rows m0 .. m0 + 15 x units 16 w .. 16 w + 15.
+    // Lane (i16, grp) supplies B[k = grp][n = i16] = W2[unit i16][class 4 s + grp] and receives P[row 4 grp + r][unit i16],
+    // r = 0..3 — for the dW tile that IS the B fragment of the tile product (b[j] = dz1[16 w + 4 grp + j][n0 + i16]).
+    HeadStage<C, NP> stg;
+    head_stage_request<C, NP>(p, t, stg);
+    const int urow = (is_dw ? n0 : 16 * wid) + i16;                  // this lane's hidden unit
+    const int prow0 = (is_dw ? 16 * wid : m0) + 4 * grp;             // first of this lane's 4 panel rows
+    float w2f[3], a1m[4];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) w2f[s3] = p.w[(size_t)urow * C + min(4 * s3 + grp, C - 1)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a1m[r] = p.a[(size_t)min(prow0 + r, m - 1) * H + urow];
     float af[4] = {0.f, 0.f, 0.f, 0.f};          // dW: x fragment
     f32x4 bf = {0.f, 0.f, 0.f, 0.f};             // dx: W1 fragment
     float e_pre = 0.f;                           // dx: mask source
     const int e_r = (t >> 6) & 3, e_ln = t & 63;
     if (is_dw) {
-        // W2 rows [n0, n0 + 16): 160 contiguous floats
-        if (t < 16 * C / 4) w4 = *reinterpret_cast<const f32x4*>(p.w + (size_t)n0 * C + 4 * t);
-        a1v = *reinterpret_cast<const f32x4*>(p.a + (size_t)sr * H + n0 + 4 * sub);          // panel element (row srow, units 4 sub ..)
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[j] = q.x[(size_t)min(16 * wid + 4 * grp + j, m - 1) * n_in + m0 + i16];
     } else {
-        if (t < H * C / 4) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
-        a1v = *reinterpret_cast<const f32x4*>(p.a + (size_t)min(m0 + (t >> 5), m - 1) * H + 4 * (t & 31));   // (tile row t >> 5, units 4 (t & 31) ..)
         bf = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + i16) * H + 16 * wid + 4 * grp);
         if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, m - 1) * n_in + n0 + (e_ln & 15)];
     }
+    if (grp >= 2) w2f[2] = 0.f;                  // classes 10, 11 do not exist (the clamped address read class 9)
+    static_assert(C == 10, "the zero columns of the K = 12 product are written for 10 classes");
 
-    // ---- W2 -> LDS
-    if (is_dw) {
-        if (t < 16) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
-        if (t < 16 * C / 4) {
+    head_stage_store<C, NP>(p, t, stg, zs, ys);
+    __syncthreads();
+    float zc[3], yc[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
-        }
-    } else {
-        if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
-        if (t < H * C / 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
-        }
+    for (int i = 0; i < 3; ++i) {
+        zc[i] = zs[sr * C + min(sub + 4 * i, C - 1)];
+        yc[i] = ys[sr * C + min(sub + 4 * i, C - 1)];
     }
-
-    // ---- logits = sum of the 8 tile partials + bias; statistics; dz
-    float zc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-        zc[i] = (((part[i][0] + part[i][1]) + (part[i][2] + part[i][3])) + ((part[i][4] + part[i][5]) + (part[i][6] + part[i][7]))) + bc[i];
+    if constexpr (CUT == 1) {
+        q.dx[(size_t)(blk % 64) * 512 + t] = zc[0] + zc[1] + zc[2] + yc[0] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
+        return;
+    }
     HeadStats st;
-    head_stats<C>(zc, yc, slive, sub, lane, wid, red, st);
+    head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
+    if constexpr (CUT == 2) {
+        q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
+        return;
+    }
     {
-        const double inv_m = 1.0 / (double)m;
-        const float sf = slive ? expf(st.mx - st.M) / (float)st.S : 0.f, uf = slive ? (float)inv_m / st.urow : 0.f;
+        const float sf = slive ? expf(st.mx - st.M) * __builtin_amdgcn_rcpf((float)st.S) : 0.f;
+        const float uf = slive ? __builtin_amdgcn_rcpf((float)m * st.urow) : 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (st.valid[i]) dzr[srow * WS + sub + 4 * i] = st.ec[i] * sf - st.eyc[i] * uf;      // 0 in the padding rows
         if (sub >= 2) dzr[srow * WS + 8 + sub] = 0.f;
     }
-    __syncthreads();
-
-    // ---- the dz1 slice this tile contracts over, 4 elements per thread: (dz row) . (W2 row), masked by a1's sign
-    {
-        const int prow = is_dw ? srow : m0 + (t >> 5);            // dz row
-        const int u0 = is_dw ? 4 * sub : 4 * (t & 31);            // first of 4 units (row of ws)
-        f32x4 dv[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) dv[k] = *reinterpret_cast<const f32x4*>(dzr + min(prow, ROWS - 1) * WS + 4 * k);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float d = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + (u0 + e) * WS + 4 * k);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d = fmaf(dv[k][c], wv[c], d);
-            }
-            o[e] = (__float_as_uint(a1v[e]) >> 31) ? 0.f : d;
-        }
-        if (is_dw) *reinterpret_cast<f32x4*>(pan + srow * 20 + u0) = o;
-        else *reinterpret_cast<f32x4*>(pan + (t >> 5) * 132 + u0) = (m0 + (t >> 5) < m) ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+    // dW tile: wave w reads back only the 16 rows it wrote itself (srow = 16 w + lane / 4) — no workgroup barrier, the
+    // LDS queue of a wave is in order; dx tile: the 16 rows of the tile were written by wave tm
+    if (is_dw) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+    if constexpr (CUT == 3) {
+        q.dx[(size_t)(blk % 64) * 512 + t] = dzr[t] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
+        return;
     }
-    __syncthreads();
 
-    // ---- the tile product: wave wid owns K chunk wid
+    f32x4 pz = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* drow = dzr + ((is_dw ? 16 * wid : m0) + i16) * WS + grp;          // A[m = i16][k = grp] = dz[row][4 s + grp]
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(drow[4 * s3], w2f[s3], pz, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pz[r] = (__float_as_uint(a1m[r]) >> 31) ? 0.f : pz[r];   // rows >= m: dz = 0 there
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     if (is_dw) {
-        float b[4];
+        if constexpr (CUT == 4) {
+            q.dx[(size_t)(blk % 64) * 512 + t] = pz[0] + pz[1] + pz[2] + pz[3] + af[0] + af[1] + af[2] + af[3];
+            return;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = pan[(16 * wid + 4 * grp + j) * 20 + i16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], b[j], acc, 0, 0, 0);
-        bs = (b[0] + b[1]) + (b[2] + b[3]);
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], pz[j], acc, 0, 0, 0);
+        bs = (pz[0] + pz[1]) + (pz[2] + pz[3]);
     } else {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pan + i16 * 132 + 16 * wid + 4 * grp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pan[(4 * grp + r) * PS + 16 * wid + i16] = pz[r];
+        __syncthreads();
+        if constexpr (CUT == 4) {
+            q.dx[(size_t)(blk % 64) * 512 + t] = pan[t] + bf[0] + e_pre;
+            return;
+        }
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pan + i16 * PS + 16 * wid + 4 * grp);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[j], acc, 0, 0, 0);
     }
@@ -736,6 +795,7 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.rpb = (int)((rows + 15) / 16);
     p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
     p.zpart = (const float*)logit_partials;
+    p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -771,6 +831,7 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
     p.rpb = (int)((rows + 15) / 16);
     p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
     p.zpart = (const float*)logit_partials;
+    p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -779,7 +840,13 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
     q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
     q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
-    hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, tnn::stream(), p, q);
+    static const int cut = getenv("TNN_HBW_CUT") ? atoi(getenv("TNN_HBW_CUT")) : 0;        // timing builds
+    hipStream_t st = tnn::stream();
+    if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q);
+    else if (cut == 2) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 2>), grid, 512, 0, st, p, q);
+    else if (cut == 3) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 3>), grid, 512, 0, st, p, q);
+    else if (cut == 4) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 4>), grid, 512, 0, st, p, q);
+    else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, st, p, q);
     TNN_LAUNCH_OK();
     return 0;
 }

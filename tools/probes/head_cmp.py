@@ -28,3 +28,17 @@ def call(part):
 print("head alone, partial logits given: %.2f us" % bench.events_us(call(True), 200))
 if not os.environ.get("TNN_HEAD_CUT"):
     print("head alone, logits by MFMA inside: %.2f us" % bench.events_us(call(False), 200))
+
+# the merged launch of the 4-launch step (head + the hidden layer's backward); TNN_HBW_CUT=1..4 stops its tile blocks
+# after the logits / statistics / dz / dz1 panel
+x_r = tn.asarray(np.abs(rs.randn(128, 256)).astype(np.float32))
+w1_r = tn.asarray((rs.randn(256, 128) * 0.1).astype(np.float32))
+dw1, db1, dx = tn.empty((256, 128)), tn.empty((128,)), tn.empty((128, 256))
+def merged():
+    lib.mlp_head_bwd_tick(128, 256, 128, 10, x_r._ptr, w1_r._ptr, a_r._ptr, w_r._ptr, b_r._ptr, y_r._ptr, zp._ptr, logits._ptr,
+                          dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, dw1._ptr, db1._ptr, dx._ptr, _lib.F32, pows._ptr,
+                          0.9, 0.999)
+print("head + hidden backward, one launch (TNN_HBW_CUT=%s): %.2f us" % (os.environ.get("TNN_HBW_CUT", "0"), bench.events_us(merged, 200)))
+def bwd1():
+    lib.dense_bwd(128, 256, 128, x_r._ptr, da._ptr, w1_r._ptr, dw1._ptr, db1._ptr, dx._ptr, x_r._ptr, _lib.F32)
+print("hidden backward alone: %.2f us" % bench.events_us(bwd1, 200))
