@@ -43,6 +43,10 @@ struct GemmArgs {
     int splits;
     float* ws;             // [splits, M, N] partial sums when splits > 1
     int tiles_m, tiles_n;
+    // small/latency kernel: XCD-aware tile order.  Workgroup b runs on XCD b % 8 and each XCD has a private L2; with
+    // xg_m x xg_n == 8 the tile grid is cut into 8 rectangles of (tiles_m / xg_m) x (tiles_n / xg_n) tiles, one per XCD,
+    // so an L2 fills only the operand rows / columns of its rectangle.  0 = plain order.
+    int xg_m, xg_n;
     // small/latency kernel only (tnn_dense_fwd_head_partials): the NEXT (classifier) layer's weights head_w [N, head_c]
     // and where this tile's share of that layer's logits goes, head_z [tiles_n][M][head_c]
     const float* head_w;
@@ -524,7 +528,15 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
                                            float (*red)[4][64], float (*bsum)[64], const AdamEpi* ad = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
-    const int tm = block % g.tiles_m, tn = block / g.tiles_m;
+    int tm, tn;
+    if (g.xg_m) {                                    // XCD-aware tile order (GemmArgs::xg_m)
+        const int xcd = block & 7, idx = block >> 3, pm = g.tiles_m / g.xg_m, pn = g.tiles_n / g.xg_n;
+        tm = (xcd % g.xg_m) * pm + idx % pm;
+        tn = (xcd / g.xg_m) * pn + idx / pm;
+    } else {
+        tm = block % g.tiles_m;
+        tn = block / g.tiles_m;
+    }
     const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
     const int64_t am = m0 + i16, bn = n0 + i16;
     const bool a_ok = am < g.M, b_ok = bn < g.N;
@@ -654,7 +666,15 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
     constexpr uint32_t OOB = 0xffffffffu;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
-    const int tm = block % g.tiles_m, tn = block / g.tiles_m;
+    int tm, tn;
+    if (g.xg_m) {
+        const int xcd = block & 7, idx = block >> 3, pm = g.tiles_m / g.xg_m, pn = g.tiles_n / g.xg_n;
+        tm = (xcd % g.xg_m) * pm + idx % pm;
+        tn = (xcd / g.xg_m) * pn + idx / pm;
+    } else {
+        tm = block % g.tiles_m;
+        tn = block / g.tiles_m;
+    }
     const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
     const int64_t am = m0 + i16, bn = n0 + i16;
     const bool a_ok = am < g.M, b_ok = bn < g.N;
@@ -810,6 +830,23 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd_small_kernel(GemmArgs gw
     }
 }
 
+// XCD-aware cut of a 16 x 16 tile grid (GemmArgs::xg_m / xg_n): the one with the smallest operand footprint per XCD
+void pick_xcd_cut(GemmArgs& g) {
+    static const int mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
+    g.xg_m = g.xg_n = 0;
+    int best = 0;
+    if (mode >= 10) {                                 // tuning: force xg_m = mode - 10 where the grid divides
+        const int xm = mode - 10, xn = xm > 0 ? 8 / xm : 0;
+        if (xm > 0 && xm * xn == 8 && g.tiles_m % xm == 0 && g.tiles_n % xn == 0) { g.xg_m = xm; g.xg_n = xn; return; }
+    }
+    for (int xm = 1; xm <= 8 && mode; xm *= 2) {
+        const int xn = 8 / xm;
+        if (g.tiles_m % xm || g.tiles_n % xn) continue;
+        const int cost = g.tiles_m / xm + g.tiles_n / xn;
+        if (!best || cost < best) { best = cost; g.xg_m = xm; g.xg_n = xn; }
+    }
+}
+
 // branch-free buffer-load variant: 16-B loads on the K-contiguous operands need alignment and K % 4 == 0; 32-bit
 // offsets need every extent below 4 GiB (always true at this kernel's problem sizes, checked anyway)
 bool small_fast_ok(const GemmArgs& g, int transA, int transB) {
@@ -856,6 +893,7 @@ int launch_small(GemmArgs& g, int transA, int transB, float* colsum) {
     dim3 grid((unsigned)(g.tiles_m * g.tiles_n));
     hipStream_t s = tnn::stream();
     const bool fast = small_fast_ok(g, transA, transB);
+    pick_xcd_cut(g);
 #define TNN_SMALL(AKC, BKC)                                                                                        \
     do {                                                                                                           \
         if (fast) hipLaunchKernelGGL((gemm_small_f32_kernel<AKC, BKC, WAVES, true>), grid, WAVES * 64, 0, s, g, colsum); \
@@ -1187,6 +1225,7 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
         if (use_small_path(gw)) {
             gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1;
             const int n_dw = gw.tiles_m * gw.tiles_n;
+            pick_xcd_cut(gw);
             AdamEpi ad;
             ad.pw = (float*)p_w; ad.mw = (float*)m_w; ad.vw = (float*)v_w;
             ad.pb = (float*)p_b; ad.mb = (float*)m_b; ad.vb = (float*)v_b;

@@ -580,6 +580,7 @@ struct HeadBwdArgs {
     const float* w1;                 // [n_in][H]
     float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
     int n_in, tiles_in;              // tiles_in = n_in / 16
+    int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8; TNN_XCD_TILES=0 turns it off)
 };
 
 // CUT (timing builds only, TNN_HBW_CUT): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
@@ -609,8 +610,20 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     const int n_in = q.n_in;
     // tile coordinates.  dW: tm over the inputs, tn over the hidden units; dx: tm over the rows, tn over the inputs
     int tm, tn;
-    if (is_dw) { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
-    else { const int b2 = blk - n_dw, tr = (m + 15) / 16; tm = b2 % tr; tn = b2 / tr; }
+    if (is_dw) {
+        if (q.xcd && q.tiles_in % 2 == 0) {          // XCD-aware order: XCD x takes inputs' half x % 2, units' quarter x / 2
+            const int xcd = blk & 7, idx = blk >> 3, pm = q.tiles_in / 2;
+            tm = (xcd & 1) * pm + idx % pm;
+            tn = (xcd >> 1) * (TH / 4) + idx / pm;
+        } else { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
+    } else {
+        const int b2 = blk - n_dw, tr = (m + 15) / 16;
+        if (q.xcd && tr % 2 == 0 && q.tiles_in % 4 == 0 && n_dw % 8 == 0) {
+            const int xcd = b2 & 7, idx = b2 >> 3, pm = tr / 2;
+            tm = (xcd & 1) * pm + idx % pm;
+            tn = (xcd >> 1) * (q.tiles_in / 4) + idx / pm;
+        } else { tm = b2 % tr; tn = b2 / tr; }
+    }
     const int m0 = tm * 16, n0 = tn * 16;
 
     // ---- every global read, up front.  The dz1 slice of a tile is itself a 16x16x4 MFMA product
@@ -839,6 +852,8 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
     q.x = (const float*)x; q.w1 = (const float*)w1;
     q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
     q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
+    static const int xcd_mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
+    q.xcd = xcd_mode;
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
     static const int cut = getenv("TNN_HBW_CUT") ? atoi(getenv("TNN_HBW_CUT")) : 0;        // timing builds
     hipStream_t st = tnn::stream();
