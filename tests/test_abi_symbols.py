@@ -60,3 +60,22 @@ def test_product_loader_has_no_fallback(monkeypatch, tmp_path):
                 body = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", body, flags=re.M), os.path.join(dirpath, f)
     assert "libtnn_cpu" not in src
+
+
+def test_late_torch_import_is_a_loud_warning(monkeypatch):
+    """torch imported after the HIP library initialised = two HIP runtimes in one process: the loader's meta-path guard warns
+    (and get() imports torch itself when WORLD_SIZE / TNN_FORCE_COMM say a communicator is coming)."""
+    import warnings
+    from tinynn_autograd_amd import _lib
+    guard = _lib._TorchAfterLoadGuard()
+    monkeypatch.setattr(_lib, "_lib", object())
+    monkeypatch.setattr(_lib, "_is_test_twin", False)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        assert guard.find_spec("torch") is None and guard.find_spec("numpy") is None
+    assert len(seen) == 1 and "two HIP runtimes" in str(seen[0].message)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        guard.find_spec("torch")
+    assert not seen                                   # nothing loaded yet: importing torch now is the right order

@@ -184,10 +184,35 @@ _lib = None
 _is_test_twin = False
 
 
+class _TorchAfterLoadGuard:
+    """torch bundles its own libamdhip64 / librccl and loads them by absolute path.  Imported BEFORE libtnn_hip.so they are
+    the one HIP runtime both bind to; imported AFTER it, the process holds two runtimes (torch.cuda sees no device memory of
+    ours, RCCL communicators cannot be shared, abort at interpreter exit).  get() imports torch itself when the environment
+    says a communicator will be needed; for everybody else this finder turns the late import into a loud warning."""
+
+    def find_spec(self, name, path=None, target=None):
+        if name == "torch" and _lib is not None and not _is_test_twin:
+            import warnings
+            warnings.warn("torch is being imported AFTER tinynn_autograd_amd initialised its HIP runtime: the process now "
+                          "holds two HIP runtimes (torch.cuda and RCCL will not see this package's memory). "
+                          "`import torch` before the first tinynn_autograd_amd device call.", RuntimeWarning, stacklevel=2)
+        return None
+
+
+_guard_installed = False
+
+
 def get():
     """The initialised library.  Raises if libtnn_hip.so is missing or no MI355X is visible."""
-    global _lib
+    global _lib, _guard_installed
     if _lib is None:
+        import sys
+        if "torch" not in sys.modules:
+            if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("TNN_FORCE_COMM") == "1":
+                import torch  # noqa: F401  (a communicator will be built: torch's HIP runtime must be the process's one)
+            elif not _guard_installed:
+                sys.meta_path.insert(0, _TorchAfterLoadGuard())
+                _guard_installed = True
         lib = _Lib(LIB_PATH)
         # one process per GPU: torchrun's LOCAL_RANK picks the device; TNN_DEVICE overrides (e.g. several ranks
         # sharing one GPU in the peer-to-peer transport test)
