@@ -360,6 +360,9 @@ class FusedRun(Runner):
             from tinynn_autograd_amd.fused import MLPTrainer
             self.trainer = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=1e-3, dtype=dtype, comm=comm,
                                       force_dp=force_dp)
+            # Adam consumes each weight gradient in the epilogue of the GEMM that produces it; the gradient is not also
+            # written to the arena (tests/test_gpu_config_e.py: bit-identical parameters and state either way)
+            self.trainer.keep_grads(os.environ.get("TNN_BENCH_KEEP_GRADS", "0") == "1")
             np.random.seed(0)
             for l in range(len(widths) - 1):
                 a = np.sqrt(6.0 / (widths[l] + widths[l + 1]))

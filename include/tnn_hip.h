@@ -318,6 +318,17 @@ TNN_API int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v
 TNN_API int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, void* w_bf16, void* wT_bf16,
                                     int64_t rows, int64_t cols, double lr, double b1, double b2, double eps,
                                     void* pows_f64, int advance);
+/* dW = A B^T (A [M, K], B [N, K], bf16, K-contiguous, fp32 accumulation — core/ops.py:160 with the transposed copies of
+ * tnn_transpose_bf16 as operands) CONSUMED by Adam in the GEMM epilogue (core/optimizer.py:67-79, the maths of
+ * tnn_adam_master_bf16_2d): p / m / v [M, N] fp32 updated in place, w_bf16 [M, N] and wT_bf16 [N, M] (NULL = skip)
+ * refreshed.  g_out_f32 [M, N] receives the gradient itself when not NULL; NULL saves its 4 B write and the 4 B re-read
+ * of the separate optimizer launch per parameter (of 36).  pows_f64 = {b1^t, b2^t} ALREADY advanced (tnn_adam_tick).
+ * Single-GPU step only: a data-parallel step reduces the gradients between the two. */
+TNN_API int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                  void* g_out_f32, void* p_master, void* m, void* v, void* w_bf16, void* wT_bf16,
+                                  double lr, double b1, double b2, double eps, const void* pows_f64);
+/* {b1^t, b2^t} *= {b1, b2}: the once-per-step advance of Adam's bias-correction state as a launch of its own */
+TNN_API int tnn_adam_tick(void* pows_f64, double b1, double b2);
 
 /* ------------------------------------------------------------------ whole-step MLP trainer ---- */
 /* One object = Dense/ReLU stack + whole-batch softmax NLL (loss_kind 0) or sum-of-squares/m
@@ -356,6 +367,10 @@ TNN_API int tnn_mlp_step_sharded(void* handle, const void* x, const void* y, int
  * [first, first + count) in issue order (count < 0: the whole step again); *calls_in_last_step = primitive calls (= kernel
  * launches for the MNIST-size step) the last tnn_mlp_step went through.  No reference counterpart (new). */
 TNN_API int tnn_mlp_launch_window(void* handle, int first, int count, int* calls_in_last_step);
+/* keep != 0 (default): after tnn_mlp_step every gradient is in the gradient arena (tnn_mlp_arenas).  keep == 0: a step
+ * may consume weight gradients where they are produced (bf16 trainer: tnn_gemm_bf16_nt_adam) without storing them —
+ * bias gradients and the loss are still written. */
+TNN_API int tnn_mlp_keep_grads(void* handle, int keep);
 /* after the parameter arena was written from outside (initial weights): refresh derived copies — the bf16
  * working copies W, W^T of a TNN_BF16 trainer; no-op for f32 / f64 */
 TNN_API int tnn_mlp_sync_params(void* handle);

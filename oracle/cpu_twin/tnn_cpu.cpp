@@ -769,6 +769,16 @@ int tnn_mse_bf16(const void*, const void*, int64_t, int64_t, void*, void*) { NO_
 int tnn_adam_master_bf16(void*, const void*, void*, void*, void*, int64_t, double, double, double, double, void*) {
     NO_BF16("tnn_adam_master_bf16");
 }
+int tnn_gemm_bf16_nt_adam(int64_t, int64_t, int64_t, const void*, int64_t, const void*, int64_t, void*, void*, void*, void*, void*,
+                          void*, double, double, double, double, const void*) { NO_BF16("tnn_gemm_bf16_nt_adam"); }
+int tnn_adam_tick(void* pows, double b1, double b2) {
+    NEED_INIT();
+    REQ(pows != nullptr, "tnn_adam_tick: pows state is NULL");
+    RECORD(tnn_adam_tick(pows, b1, b2));
+    ((double*)pows)[0] *= b1;
+    ((double*)pows)[1] *= b2;
+    return 0;
+}
 int tnn_adam_master_bf16_2d(void*, const void*, void*, void*, void*, void*, int64_t, int64_t, double, double, double,
                             double, void*, int) {
     NO_BF16("tnn_adam_master_bf16_2d");

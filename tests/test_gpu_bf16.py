@@ -130,3 +130,76 @@ def test_bf16_trainer_tracks_float64_oracle():
     # the fp32 master copy moved by Adam, and the bf16 working copy is its rounding
     p = np.asarray(trainer.param_view(0, "w"))
     assert np.abs(p - W[0]).max() > 1e-4
+
+
+@pytest.mark.gpu
+def test_bf16_dw_gemm_with_adam_epilogue_equals_gemm_then_adam():
+    """tnn_gemm_bf16_nt_adam (Adam consumes the weight gradient in the dW GEMM's epilogue) against the two launches it
+    replaces — tnn_gemm_bf16_nt (fp32 out) + tnn_adam_master_bf16_2d: master weights, both moments, the bf16 working copy
+    and its transpose bit-identical over two steps; full, ragged and tiny shapes; with and without the stored gradient."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(47)
+    for (M, N, K) in ((512, 384, 128), (256, 256, 512), (200, 72, 64), (128, 1000, 192), (4, 8, 64)):
+        a = bf16.to_bf16(bf16.round_to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32)))
+        b = bf16.to_bf16(bf16.round_to_bf16((rs.uniform(-1, 1, (N, K)) * 1e-2).astype(np.float32)))
+        p0 = rs.randn(M, N).astype(np.float32)
+        res = []
+        for fused, keep in ((False, True), (True, True), (True, False)):
+            P, M_, V_ = tn.asarray(p0), tn.zeros((M, N)), tn.zeros((M, N))
+            G = tn.asarray(np.full((M, N), 7.0, np.float32))
+            W16, WT16 = tn.empty((M, N), np.uint16), tn.empty((N, M), np.uint16)
+            pows = tn.asarray(np.array([1.0, 1.0, 0, 0]), dtype=np.float64)
+            for _ in range(2):
+                if fused:
+                    lib.adam_tick(pows._ptr, 0.9, 0.999)
+                    lib.gemm_bf16_nt_adam(M, N, K, a._ptr, K, b._ptr, K, G._ptr if keep else None, P._ptr, M_._ptr, V_._ptr,
+                                          W16._ptr, WT16._ptr, 1e-3, 0.9, 0.999, 1e-8, pows._ptr)
+                else:
+                    lib.gemm_bf16_nt(M, N, K, a._ptr, K, b._ptr, K, G._ptr, N, _lib.F32, None, 0, 0, None, 0)
+                    lib.adam_master_bf16_2d(P._ptr, G._ptr, M_._ptr, V_._ptr, W16._ptr, WT16._ptr, M, N,
+                                            1e-3, 0.9, 0.999, 1e-8, pows._ptr, 1)
+            res.append([np.asarray(t) for t in (P, M_, V_, W16, WT16, pows, G)])
+        for got in res[1:]:
+            for name, x0, x1 in zip(("p", "m", "v", "w16", "wT16", "pows"), res[0], got):
+                assert np.array_equal(x0, x1), (name, M, N, K)
+        assert np.array_equal(res[0][6], res[1][6])                      # the stored gradient, when asked for
+        assert (res[2][6] == 7.0).all()                                  # and untouched when not
+        assert np.array_equal(res[0][4], res[0][3].T) and np.abs(res[0][0] - p0).max() > 5e-4
+
+
+@pytest.mark.gpu
+def test_bf16_trainer_fused_step_equals_separate_launches(monkeypatch):
+    """The bf16 trainer's `step` against its forward / backward / update entry points: identical losses, parameters and
+    Adam state after three steps — with the weight gradients stored (default: the same launches) and with
+    keep_grads(False), where Adam consumes each weight gradient in the epilogue of the dW GEMM."""
+    from tinynn_autograd_amd.fused import MLPTrainer
+    rs = np.random.RandomState(48)
+    widths, m = [256, 384, 128, 256], 128
+    W = [bf16.round_to_bf16(rs.uniform(-0.08, 0.08, (widths[i], widths[i + 1])).astype(np.float32)) for i in range(3)]
+    B = [(rs.randn(1, widths[i + 1]) * 0.05).astype(np.float32) for i in range(3)]
+    x16 = bf16.to_bf16(bf16.round_to_bf16(rs.rand(m, 256).astype(np.float32)))
+    runs = []
+    for mode in ("separate", "step", "step_nokeep"):
+        t = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16")
+        t.set_parameters([{"w": W[i], "b": B[i]} for i in range(3)])
+        if mode == "step_nokeep":
+            t.keep_grads(False)                                          # -> Adam in the dW epilogues
+        losses = []
+        for _ in range(3):
+            if mode == "separate":
+                t._lib.mlp_forward_stats(t._h, x16._ptr, m, None)
+                t._lib.mlp_backward(t._h, x16._ptr, x16._ptr, m, m, None, None)
+                t._lib.mlp_update(t._h)
+                losses.append(float(t.loss_slot))
+            else:
+                losses.append(float(t.step(x16, x16)))
+        runs.append((losses, np.asarray(t.params).copy(), np.asarray(t.adam_m).copy(), np.asarray(t.adam_v).copy(),
+                     [np.asarray(t.grad_view(l, "w")).copy() for l in range(3)],
+                     np.asarray(t.forward(x16)).copy()))
+    for got in runs[1:]:
+        assert got[0] == runs[0][0]
+        for k in (1, 2, 3, 5):
+            assert np.array_equal(got[k], runs[0][k]), k
+    for l in range(3):
+        assert np.array_equal(runs[1][4][l], runs[0][4][l])              # stored gradients of the default step

@@ -187,3 +187,13 @@ def test_config_E_trainer_step_at_full_size():
     loss2 = float(trainer.step(x16, x16))
     np.testing.assert_allclose(loss2, ref_loss2, rtol=2e-3)
     assert abs(loss2 - loss) > 0.5 * loss                         # a stale W^T copy would reproduce the first loss
+
+    # ---- the same two steps with the weight gradients consumed in the dW epilogues and never stored (what bench.py times
+    # for this config): losses, master weights and Adam state bit-identical to the run above
+    p_ref = np.asarray(trainer.params).copy()
+    m_ref = np.asarray(trainer.adam_m).copy()
+    del trainer
+    t2 = MLPTrainer(widths, M8, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16").keep_grads(False)
+    t2.set_parameters([{"w": W[i], "b": B[i]} for i in range(L)])
+    assert float(t2.step(x16, x16)) == loss and float(t2.step(x16, x16)) == loss2
+    assert np.array_equal(np.asarray(t2.params), p_ref) and np.array_equal(np.asarray(t2.adam_m), m_ref)

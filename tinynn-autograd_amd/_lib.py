@@ -103,6 +103,8 @@ _SIGNATURES = {
     "tnn_mse_bf16": [_p, _p, c_int64, c_int64, _p, _p],
     "tnn_adam_master_bf16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
     "tnn_adam_master_bf16_2d": [_p, _p, _p, _p, _p, _p, c_int64, c_int64, c_double, c_double, c_double, c_double, _p, c_int],
+    "tnn_gemm_bf16_nt_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
+    "tnn_adam_tick": [_p, c_double, c_double],
     "tnn_mlp_create": [c_int, _i64p, c_int64, c_int, c_int, c_double, c_double, c_double, c_double,
                        c_int, POINTER(c_void_p)],
     "tnn_mlp_destroy": [_p],
@@ -117,6 +119,7 @@ _SIGNATURES = {
     "tnn_mlp_step": [_p, _p, _p, c_int64, _p],
     "tnn_mlp_step_sharded": [_p, _p, _p, c_int64, _p],
     "tnn_mlp_launch_window": [_p, c_int, c_int, POINTER(c_int)],
+    "tnn_mlp_keep_grads": [_p, c_int],
     "tnn_mlp_sync_params": [_p],
     "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
     "tnn_comm_unique_id": [_p],

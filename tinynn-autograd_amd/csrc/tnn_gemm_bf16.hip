@@ -41,6 +41,13 @@ struct BfArgs {
     const bf16_t* Y;
     int64_t ldy;
     int tiles_m, tiles_n;
+    // BEPI_ADAM (tnn_gemm_bf16_nt_adam): the product is a weight gradient that Adam consumes in the epilogue
+    float *ap, *am, *av;             // fp32 master weights and moments, [M][ldc] like C
+    bf16_t *aw16, *awT16;            // bf16 working copy [M][ldc] and its transpose [N][ldt]
+    int64_t ldt;
+    float lr, b1, b2, eps;
+    const double* pows;              // {b1^t, b2^t}, already advanced for this step
+    const int* guard;                // data-parallel update guard (tnn_internal.h)
 };
 
 __device__ __forceinline__ bf16_t f2bf(float f) {       // round to nearest even (finite inputs)
@@ -576,6 +583,46 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
 #undef TNN_DMA_LAUNCH
     else
         hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), NT, 0, tnn::stream(), g);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                          void* g_out_f32, void* p_master, void* m, void* v, void* w_bf16, void* wT_bf16, double lr,
+                          double b1, double b2, double eps, const void* pows_f64) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(M > 0 && N > 0 && K > 0, "tnn_gemm_bf16_nt_adam: empty problem");
+    TNN_REQUIRE(K % BK == 0, "tnn_gemm_bf16_nt_adam: K (%lld) must be a multiple of %d", (long long)K, BK);
+    TNN_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K, "tnn_gemm_bf16_nt_adam: lda/ldb must be >= K and multiples of 8");
+    TNN_REQUIRE(((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0,
+                "tnn_gemm_bf16_nt_adam: operands must be 16-byte aligned");
+    TNN_REQUIRE(M * lda * 2 < (int64_t(1) << 32) && N * ldb * 2 < (int64_t(1) << 32),
+                "tnn_gemm_bf16_nt_adam: operands of 4 GiB or more are not supported (32-bit buffer offsets)");
+    TNN_REQUIRE(p_master && m && v && w_bf16 && pows_f64, "tnn_gemm_bf16_nt_adam: p, m, v, w_bf16 and pows are required");
+    TNN_REQUIRE(wT_bf16 == nullptr || (M % 4 == 0 && (reinterpret_cast<uintptr_t>(wT_bf16) & 7) == 0),
+                "tnn_gemm_bf16_nt_adam: the transposed copy needs M %% 4 == 0 and 8-byte alignment");
+    BfArgs g = {};
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = g_out_f32;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+    g.c_bf16 = 0;
+    g.epi = BEPI_PLAIN;
+    g.tiles_m = (int)((M + BM - 1) / BM);
+    g.tiles_n = (int)((N + BN - 1) / BN);
+    g.ap = (float*)p_master; g.am = (float*)m; g.av = (float*)v;
+    g.aw16 = (bf16_t*)w_bf16; g.awT16 = (bf16_t*)wT_bf16; g.ldt = M;
+    g.lr = (float)lr; g.b1 = (float)b1; g.b2 = (float)b2; g.eps = (float)eps;
+    g.pows = (const double*)pows_f64;
+    g.guard = tnn::update_guard();
+    const unsigned tiles = (unsigned)(g.tiles_m * g.tiles_n);
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<8, 2, false, true>), dim3(tiles), 8 * 64, 0, tnn::stream(), g);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_adam_tick(void* pows_f64, double b1, double b2) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_tick: pows state is NULL");
+    hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, tnn::stream(), (double*)pows_f64, b1, b2, tnn::update_guard());
     TNN_LAUNCH_OK();
     return 0;
 }

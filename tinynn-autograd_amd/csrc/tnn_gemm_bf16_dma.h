@@ -46,8 +46,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst
 // SWAP: MFMA operands swapped -> lane = output row, 4 consecutive columns per register quad (8-B / 16-B stores, but every
 // store instruction touches 32 rows x 32 B: partial lines).  !SWAP: lane = output column, a store instruction writes whole
 // 128-B row segments (fp32) — what the 268 MB dW outputs want.
-template <int NW, int NS, bool SWAP>
+// ADAM (with !SWAP, fp32 product): the tile is a weight gradient and Adam's update of the matching 128 x 128 block of the
+// fp32 master weights / moments, the bf16 working copy and its transpose happens in the epilogue (tnn_gemm_bf16_nt_adam).
+template <int NW, int NS, bool SWAP, bool ADAM = false>
 __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
+    static_assert(!(ADAM && SWAP), "the Adam epilogue is written for lane = column");
     constexpr int BM = g8::BM, BN = g8::BN, BK = g8::BK;
     constexpr int WN = NW == 8 ? 4 : 2, TM = 64, TN = BN / WN, MI = 2, NI = TN / 32;
     constexpr int ROWB = g8::ROWB, TILE_B = g8::TILE_B, STAGE_B = g8::STAGE_B, KK = g8::KK;
@@ -188,6 +191,144 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (ADAM) {
+        // Lane = column (whole 128-B row segments per instruction for the fp32 arrays).  Per 32 x 32 block a lane owns 16
+        // rows of its column: p / m / v are requested for a quad of rows (r = 4 q .. 4 q + 3: 12 loads in flight), updated,
+        // stored; the four bf16 results of the quad are consecutive in the TRANSPOSED copy's row -> one 8-B store there.
+        // The gradient itself goes to C only when asked for (g.C != NULL): 4 of the 32 bytes per parameter that the
+        // separate GEMM + Adam launches move are the write of the gradient and 4 its re-read.
+        if (g.guard != nullptr && *g.guard != 0) return;
+        const float ic1 = (float)(1.0 / (1.0 - g.pows[0])), ic2 = (float)(1.0 / (1.0 - g.pows[1]));
+        const float omb1 = 1.f - g.b1, omb2 = 1.f - g.b2, lr = g.lr, eps = g.eps;
+        float* gout = reinterpret_cast<float*>(g.C);
+        if constexpr (NS * STAGE_B >= BM * BN * 4) {
+            // INTERIOR tiles: the epilogue moves 28 B per element against the 2 x 2 B x K / 128 of the operands — it IS the
+            // kernel (7 of every 8 bytes).  Lane = column means 4-B accesses (4.9 TB/s measured, the stand-alone optimizer
+            // kernel reaches 6.7 with 16-B ones), so the accumulators go through the now idle LDS ring (128 x 128 fp32 =
+            // its 64 KB exactly) and come back as 4 x 4 sub-blocks: thread (a, b) owns rows 4a..4a+3 x columns 4b..4b+3,
+            // a wave instruction covers two whole 512-B tile rows of p / m / v (16-B loads and stores, non-temporal), the
+            // bf16 copy gets 8-B stores and the transposed copy 8-B stores of 4 consecutive rows of one column.
+            const bool interior = m0 + BM <= g.M && n0 + BN <= g.N && g.ldc % 4 == 0 && g.ldt % 4 == 0 &&
+                                  ((reinterpret_cast<uintptr_t>(g.ap) | reinterpret_cast<uintptr_t>(g.am) |
+                                    reinterpret_cast<uintptr_t>(g.av) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0 &&
+                                  ((reinterpret_cast<uintptr_t>(g.aw16) | reinterpret_cast<uintptr_t>(g.awT16)) & 7) == 0;
+            if (interior) {                       // block-uniform
+                float* tile = reinterpret_cast<float*>(lds);
+                __syncthreads();                  // every wave is done with the last stage's fragments
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[(wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * BN + wn * TN + ni * 32 + l31] = acc[mi][ni][r];
+                __syncthreads();
+                constexpr int PASSES = (BM / 4) * (BN / 4) / (NW * 64);
+                const int cb = tid % (BN / 4);
+#pragma unroll 1
+                for (int pass = 0; pass < PASSES; ++pass) {
+                    const int ra = tid / (BN / 4) + pass * (NW * 64 / (BN / 4));
+                    const int64_t o0 = (m0 + 4 * ra) * g.ldc + n0 + 4 * cb;
+                    uint32_t hp[4][2];                     // the sub-block's bf16 results, packed by row
+                    // two rows at a time: 6 x 16-B loads in flight per thread (x 1024 threads per CU) and <= 128 VGPRs, which
+                    // keeps TWO workgroups resident (with all 4 rows at once: 134 VGPRs, one workgroup, 460 us instead of 384)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        f32x4 pv[2], mv[2], vv[2], gv[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int64_t o = o0 + (2 * half + jj) * g.ldc;
+                            pv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ap + o));
+                            mv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.am + o));
+                            vv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.av + o));
+                            gv[jj] = *reinterpret_cast<const f32x4*>(tile + (4 * ra + 2 * half + jj) * BN + 4 * cb);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * half + jj;
+                            const int64_t o = o0 + j * g.ldc;
+                            uint32_t h[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const float gi = gv[jj][c];
+                                mv[jj][c] = mv[jj][c] + omb1 * (gi - mv[jj][c]);
+                                vv[jj][c] = vv[jj][c] + omb2 * (gi * gi - vv[jj][c]);
+                                pv[jj][c] = pv[jj][c] + (-lr * (mv[jj][c] * ic1) / (sqrtf(vv[jj][c] * ic2) + eps));
+                                h[c] = (uint32_t)f2bf(pv[jj][c]);
+                            }
+                            __builtin_nontemporal_store(mv[jj], reinterpret_cast<f32x4*>(g.am + o));
+                            __builtin_nontemporal_store(vv[jj], reinterpret_cast<f32x4*>(g.av + o));
+                            __builtin_nontemporal_store(pv[jj], reinterpret_cast<f32x4*>(g.ap + o));
+                            hp[j][0] = h[0] | (h[1] << 16);
+                            hp[j][1] = h[2] | (h[3] << 16);
+                            *reinterpret_cast<u32x2*>(g.aw16 + o) = u32x2{hp[j][0], hp[j][1]};
+                            if (gout) *reinterpret_cast<f32x4*>(gout + o) = gv[jj];
+                        }
+                    }
+                    if (g.awT16 != nullptr) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int w = c >> 1, sh = 16 * (c & 1);
+                            const uint32_t lo = ((hp[0][w] >> sh) & 0xffffu) | (((hp[1][w] >> sh) & 0xffffu) << 16);
+                            const uint32_t hi = ((hp[2][w] >> sh) & 0xffffu) | (((hp[3][w] >> sh) & 0xffffu) << 16);
+                            *reinterpret_cast<u32x2*>(g.awT16 + (n0 + 4 * cb + c) * g.ldt + m0 + 4 * ra) = u32x2{lo, hi};
+                        }
+                    }
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t col = n0 + wn * TN + ni * 32 + l31;
+                const bool col_ok = col < g.N;
+                const int64_t cc = col_ok ? col : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // edge tiles only (interior ones left through the LDS path above): a quad of rows at a time
+                    const int64_t rbase = m0 + wm * TM + mi * 32 + 8 * q + 4 * lhi;
+                    float pv[4], mv[4], vv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t o = (rbase + j < g.M ? rbase + j : 0) * g.ldc + cc;
+                        pv[j] = g.ap[o];
+                        mv[j] = g.am[o];
+                        vv[j] = g.av[o];
+                    }
+                    uint32_t packed[2] = {0u, 0u};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gi = acc[mi][ni][4 * q + j];
+                        const float m1 = mv[j] + omb1 * (gi - mv[j]);
+                        const float v1 = vv[j] + omb2 * (gi * gi - vv[j]);
+                        const float p1 = pv[j] + (-lr * (m1 * ic1) / (sqrtf(v1 * ic2) + eps));
+                        const bf16_t h = f2bf(p1);
+                        packed[j >> 1] |= (uint32_t)h << (16 * (j & 1));
+                        if (col_ok && rbase + j < g.M) {
+                            const int64_t o = (rbase + j) * g.ldc + col;
+                            __builtin_nontemporal_store(m1, g.am + o);
+                            __builtin_nontemporal_store(v1, g.av + o);
+                            __builtin_nontemporal_store(p1, g.ap + o);
+                            g.aw16[o] = h;
+                            if (gout) gout[o] = gi;
+                        }
+                    }
+                    if (g.awT16 != nullptr && col_ok) {
+                        bf16_t* dst = g.awT16 + col * g.ldt + rbase;
+                        if (rbase + 3 < g.M) {
+                            *reinterpret_cast<u32x2*>(dst) = u32x2{packed[0], packed[1]};
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (rbase + j < g.M) dst[j] = (bf16_t)(packed[j >> 1] >> (16 * (j & 1)));
+                        }
+                    }
+                }
+            }
+        return;
+    }
     if constexpr (!SWAP) {
         // epilogue, lane = column: col = l31, row = (r & 3) + 8 (r >> 2) + 4 lhi of each 32 x 32 block
 #pragma unroll

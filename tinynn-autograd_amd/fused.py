@@ -64,6 +64,14 @@ class MLPTrainer(object):
         self._y_stage = None
         self._stats = da.empty((2,), self.dtype)
 
+    def keep_grads(self, keep=True):
+        """keep=False: `step` may consume weight gradients where they are produced (bf16 trainer: Adam in the epilogue of
+        the dW GEMM) without writing them to the gradient arena — `grad_view(l, "w")` is then undefined after `step`
+        (bias gradients and the loss are still written).  Default: every gradient is stored, as in the reference
+        (core/model.py:24-33 exposes them after backward)."""
+        self._lib.mlp_keep_grads(self._h, 1 if keep else 0)
+        return self
+
     def __del__(self):
         try:
             self._graph = None
