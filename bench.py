@@ -375,6 +375,10 @@ class FusedRun(Runner):
         else:
             self.trainer = tn.trainer_from_net(build_net(widths), max_rows=rows, loss=kind, optimizer="adam", lr=1e-3,
                                                comm=comm, use_graph=False, force_dp=force_dp)
+            if self.trainer.n_params >= (1 << 22) and comm is None:
+                # large nets (configs[2]): Adam in the dW epilogues, weight gradients not also written to the arena
+                # (tests/test_gpu_fullsize.py: bit-identical parameters and state either way)
+                self.trainer.keep_grads(os.environ.get("TNN_BENCH_KEEP_GRADS", "0") == "1")
         self.chunk, self.segments = None, {}
         self.capture()
 

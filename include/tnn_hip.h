@@ -107,6 +107,14 @@ TNN_API int tnn_gemm_mask(int transA, int transB, int64_t M, int64_t N, int64_t 
  * db may be NULL.  Large shapes run the GEMM and the column reduction as two launches. */
 TNN_API int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda,
                                const void* G, int64_t ldg, void* dW, int64_t ldc, void* db, int dtype);
+/* dW[M,N] = A^T G as above, CONSUMED by Adam in the GEMM's epilogue (core/optimizer.py:67-79, the maths of tnn_adam; pows_f64
+ * = {b1^t, b2^t} already advanced — tnn_adam_tick): p / m / v [M, N] (dense, ld = N) are updated in place; g_out [M, N]
+ * receives the gradient itself when not NULL.  The fp32 product is MFMA-bound, so the optimizer's traffic rides under it
+ * and the separate optimizer launch over the weights disappears from the single-GPU step.  Shapes the tiled kernel does
+ * not take (and f64) run the two launches this replaces. */
+TNN_API int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg,
+                             void* g_out, void* p, void* m, void* v, double lr, double b1, double b2, double eps,
+                             const void* pows_f64, int dtype);
 
 /* Backward of one Dense layer y = x w + b given dz = dL/dy (all dense row-major):
  *   dw[n_in,n_out] = x^T dz (core/ops.py:159-160),  db[n_out] = column-sum dz (:52-54),

@@ -283,6 +283,19 @@ int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
     return db ? tnn_reduce(TNN_RSUM, G, db, 1, K, N, dtype) : 0;
 }
 
+int tnn_adam_ex(void*, const void*, void*, void*, int64_t, double, double, double, double, void*, void*, int, int, const void*,
+                void*);
+int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg, void* g_out,
+                     void* p, void* m, void* v, double lr, double b1, double b2, double eps, const void* pows, int dtype) {
+    NEED_INIT();
+    REQ(p && m && v && pows, "tnn_gemm_tn_adam: p, m, v and pows are required");
+    RECORD(tnn_gemm_tn_adam(M, N, K, A, lda, G, ldg, g_out, p, m, v, lr, b1, b2, eps, pows, dtype));
+    std::vector<char> scratch;
+    void* gw = g_out;
+    if (!gw) { scratch.resize((size_t)(M * N) * (dtype == TNN_F64 ? 8 : 4)); gw = scratch.data(); }
+    if (int rc = tnn_gemm_tn_colsum(M, N, K, A, lda, G, ldg, gw, N, nullptr, dtype)) return rc;
+    return tnn_adam_ex(p, gw, m, v, M * N, lr, b1, b2, eps, const_cast<void*>(pows), nullptr, dtype, 0, nullptr, nullptr);
+}
 int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, const void* w,
                   void* dw, void* db, void* dx, const void* mask_src, int dtype) {
     NEED_INIT();

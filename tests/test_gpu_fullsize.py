@@ -48,6 +48,49 @@ def test_config_C_two_steps_match_float64_closed_form():
         p = np.asarray(trainer.param_view(l, "w"))
         assert np.abs(p - W[l]).max() > 1e-4                 # the parameters really moved
         assert np.abs(p - oracle.W[l]).max() <= 2.5e-3       # and stay within ~2 Adam steps (lr = 1e-3) of float64
+    # ---- the same two steps with Adam in the epilogues of the dW GEMMs and the weight gradients never stored (what
+    # bench.py times for this config): losses, parameters and both moments bit-identical to the run above
+    ref = [np.asarray(t).copy() for t in (trainer.params, trainer.adam_m, trainer.adam_v)]
+    del trainer
+    t2 = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3).keep_grads(False)
+    t2.set_parameters([{"w": W[i], "b": B[i]} for i in range(2)])
+    assert float(t2.step(xd, xd)) == loss and float(t2.step(xd, xd)) == loss1
+    for got, want in zip((t2.params, t2.adam_m, t2.adam_v), ref):
+        assert np.array_equal(np.asarray(got), want)
+
+
+@pytest.mark.gpu
+def test_dw_gemm_with_adam_epilogue_equals_gemm_then_adam():
+    """tnn_gemm_tn_adam against tnn_gemm_tn_colsum + tnn_adam: p / m / v bit-identical over two steps on a shape the tiled
+    kernel takes (interior and ragged tiles), on MNIST-size and odd shapes (its fallback), with and without the stored
+    gradient."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(6)
+    for (M, N, K) in ((4096, 4096, 512), (2000, 1100, 96), (784, 256, 128), (33, 20, 7)):
+        a = tn.asarray(rs.uniform(-1, 1, (K, M)).astype(np.float32))
+        gmat = tn.asarray((rs.uniform(-1, 1, (K, N)) * 1e-2).astype(np.float32))
+        p0 = rs.randn(M, N).astype(np.float32)
+        res = []
+        for fused, keep in ((False, True), (True, True), (True, False)):
+            P, M_, V_ = tn.asarray(p0), tn.zeros((M, N)), tn.zeros((M, N))
+            G = tn.asarray(np.full((M, N), 7.0, np.float32))
+            pows = tn.asarray(np.array([1.0, 1.0, 0, 0]), dtype=np.float64)
+            for _ in range(2):
+                lib.adam_tick(pows._ptr, 0.9, 0.999)
+                if fused:
+                    lib.gemm_tn_adam(M, N, K, a._ptr, M, gmat._ptr, N, G._ptr if keep else None, P._ptr, M_._ptr, V_._ptr,
+                                     1e-3, 0.9, 0.999, 1e-8, pows._ptr, _lib.F32)
+                else:
+                    lib.gemm_tn_colsum(M, N, K, a._ptr, M, gmat._ptr, N, G._ptr, N, None, _lib.F32)
+                    lib.adam_ex(P._ptr, G._ptr, M_._ptr, V_._ptr, M * N, 1e-3, 0.9, 0.999, 1e-8, pows._ptr, None,
+                                _lib.F32, 0, None, None)
+            res.append([np.asarray(t) for t in (P, M_, V_, pows, G)])
+        for got in res[1:]:
+            for name, x0, x1 in zip(("p", "m", "v", "pows"), res[0], got):
+                assert np.array_equal(x0, x1), (name, M, N, K)
+        assert np.array_equal(res[0][4], res[1][4]) and (res[2][4] == 7.0).all()
+        assert np.abs(res[0][0] - p0).max() > 5e-4
 
 
 @pytest.mark.gpu

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "tnn_gemm_mask": [c_int, c_int, c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p,
                       c_int64, _p, c_int64, c_int],
     "tnn_gemm_tn_colsum": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, _p, c_int],
+    "tnn_gemm_tn_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p, c_int],
     "tnn_dense_bwd": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_ewise_binary": [c_int, _p, _i64p, _p, _i64p, _p, c_int, _i64p, c_int],
     "tnn_ewise_scalar": [c_int, _p, c_double, c_int, _p, c_int64, c_int],

@@ -25,7 +25,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_AXPBY = 0, EPI_BIAS_ACT = 1, EPI_MASK = 2 };
+enum { EPI_AXPBY = 0, EPI_BIAS_ACT = 1, EPI_MASK = 2, EPI_ADAM = 3 };
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
     const float* A;
@@ -52,6 +53,13 @@ struct GemmArgs {
     const float* head_w;
     float* head_z;
     int head_c;
+    // EPI_ADAM (tiled kernel, tnn_gemm_tn_adam): the product is a weight gradient that Adam consumes in the epilogue;
+    // C (may be NULL) receives the gradient itself
+    float *ad_p, *ad_m, *ad_v;
+    float ad_lr, ad_b1, ad_b2, ad_eps;
+    const double* ad_pows;
+    const int* ad_guard;
+    int staged_c;          // tiled kernel: interior tiles store through an LDS image of the tile (row-major 16-B stores)
 #ifdef TNN_GEMM_TRACE
     unsigned long long* trace;   // debug build only: [grid][8] timeline words (nullptr = off)
 #endif
@@ -445,10 +453,136 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // epilogue: with the swapped operands lane l31 holds ROW l31 of each 32x32 block and register r the column
     // (r & 3) + 8 (r >> 2) + 4 lhi: four consecutive columns per register quad -> one 16-B store per quad (4 store
     // instructions per block instead of 16 dword stores; 8 instead of 32 per wave for the 128x64 tile)
+    if (g.epi == EPI_ADAM) {
+        // The tile is a weight gradient: Adam (core/optimizer.py:67-79, the maths of adam_kernel in tnn_fused.hip) updates the
+        // matching block of p / m / v here, 16 B per lane and array, and the gradient goes to C only if the caller wants it
+        // stored.  The fp32 product is MFMA-bound, so the optimizer's 24 B per parameter ride on an otherwise idle memory
+        // system (host side guarantees: splits == 1, 16-B aligned arrays, ldc % 4 == 0, N % 4 == 0).
+        if (g.ad_guard != nullptr && *g.ad_guard != 0) return;
+        const float ic1 = (float)(1.0 / (1.0 - g.ad_pows[0])), ic2 = (float)(1.0 / (1.0 - g.ad_pows[1]));
+        const float omb1 = 1.f - g.ad_b1, omb2 = 1.f - g.ad_b2, lr = g.ad_lr, eps = g.ad_eps;
+        constexpr int TS = BN + 4;                                    // LDS row stride of the staged tile (floats)
+        if constexpr (BM * TS <= 2 * (A_ELEMS + B_ELEMS) && (BN / 4) <= NT && NT % (BN / 4) == 0) {
+            // Interior tiles leave through LDS.  In the accumulator layout a lane owns a ROW and 4 consecutive columns: a 16-B
+            // access per lane touches 32 rows x 32 B per instruction — fine for the one store of a plain product, but the
+            // optimizer adds three loads and three stores per element (measured: the step got SLOWER, 0.85 -> 1.00 ms, with
+            // that pattern).  Staged row-major, a wave instruction covers 4 whole 256-B tile rows.
+            if (m0 + BM <= g.M && n0 + BN <= g.N) {                   // block-uniform
+                __syncthreads();                                      // every wave is done with the last K-tile's fragments
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<f32x4*>(lds + (wm * TM + mi * 32 + l31) * TS + wn * TN + ni * 32 + 8 * q + 4 * lhi) =
+                                f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                __syncthreads();
+                constexpr int CPR = BN / 4, RPP = NT / CPR, PASSES = BM / RPP;     // 16-B pieces per row, rows per pass
+                const int c4 = tid % CPR, r0 = tid / CPR;
+#pragma unroll 1
+                for (int pb = 0; pb < PASSES; pb += 4) {
+                    f32x4 pv[4], mv[4], vv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {                     // 12 x 16-B loads in flight per lane
+                        const int64_t o = (m0 + r0 + (pb + u) * RPP) * g.ldc + n0 + 4 * c4;
+                        pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ad_p + o));
+                        mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ad_m + o));
+                        vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ad_v + o));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = r0 + (pb + u) * RPP;
+                        const int64_t o = (m0 + row) * g.ldc + n0 + 4 * c4;
+                        const f32x4 gv = *reinterpret_cast<const f32x4*>(lds + row * TS + 4 * c4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            mv[u][j] = mv[u][j] + omb1 * (gv[j] - mv[u][j]);
+                            vv[u][j] = vv[u][j] + omb2 * (gv[j] * gv[j] - vv[u][j]);
+                            pv[u][j] = pv[u][j] + (-lr * (mv[u][j] * ic1) / (sqrtf(vv[u][j] * ic2) + eps));
+                        }
+                        __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4*>(g.ad_m + o));
+                        __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(g.ad_v + o));
+                        *reinterpret_cast<f32x4*>(g.ad_p + o) = pv[u];             // the next forward reads it
+                        if (g.C != nullptr) *reinterpret_cast<f32x4*>(g.C + o) = gv;
+                    }
+                }
+                return;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int64_t row = m0 + wm * TM + mi * 32 + l31;
+                if (row >= g.M) continue;
+                f32x4 pv[4], mv[4], vv[4];
+                bool live[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                      // 12 x 16-B loads in flight per lane
+                    const int64_t col = n0 + wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                    live[q] = col < g.N;
+                    const int64_t o = row * g.ldc + (live[q] ? col : 0);
+                    pv[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ad_p + o));
+                    mv[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ad_m + o));
+                    vv[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ad_v + o));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!live[q]) continue;
+                    const int64_t o = row * g.ldc + n0 + wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                    f32x4 gv;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float gi = acc[mi][ni][4 * q + j];
+                        gv[j] = gi;
+                        mv[q][j] = mv[q][j] + omb1 * (gi - mv[q][j]);
+                        vv[q][j] = vv[q][j] + omb2 * (gi * gi - vv[q][j]);
+                        pv[q][j] = pv[q][j] + (-lr * (mv[q][j] * ic1) / (sqrtf(vv[q][j] * ic2) + eps));
+                    }
+                    __builtin_nontemporal_store(mv[q], reinterpret_cast<f32x4*>(g.ad_m + o));
+                    __builtin_nontemporal_store(vv[q], reinterpret_cast<f32x4*>(g.ad_v + o));
+                    *reinterpret_cast<f32x4*>(g.ad_p + o) = pv[q];                 // the next forward reads it
+                    if (g.C != nullptr) *reinterpret_cast<f32x4*>(g.C + o) = gv;
+                }
+            }
+        return;
+    }
     {
         float* const dst = g.splits > 1 ? g.ws + (int64_t)blockIdx.z * g.M * g.N : g.C;
         const int64_t ldd = g.splits > 1 ? g.N : g.ldc;
         const bool vec_c = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ldd % 4 == 0;
+        constexpr int TS = BN + 4;
+        if constexpr (BM * TS <= 2 * (A_ELEMS + B_ELEMS) && (BN / 4) <= NT && NT % (BN / 4) == 0) {
+            // interior tiles leave through LDS too: row-major 16-B stores, a wave instruction covering whole 256-B tile rows
+            // instead of 32 rows x 32 B (measured, 128x64 tiles: dW 4096x4096x512 103-105 -> 108-109 TFLOP/s, the M = 512
+            // products +1-3 %; TNN_GEMM_STAGED_C=0 restores the direct stores)
+            if (g.staged_c && vec_c && m0 + BM <= g.M && n0 + BN <= g.N) {
+                __syncthreads();
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<f32x4*>(lds + (wm * TM + mi * 32 + l31) * TS + wn * TN + ni * 32 + 8 * q + 4 * lhi) =
+                                f32x4{acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                __syncthreads();
+                constexpr int CPR = BN / 4, RPP = NT / CPR, PASSES = BM / RPP;
+                const int c4 = tid % CPR, r0 = tid / CPR;
+#pragma unroll
+                for (int pb = 0; pb < PASSES; ++pb) {
+                    const int row = r0 + pb * RPP;
+                    f32x4 gv = *reinterpret_cast<const f32x4*>(lds + row * TS + 4 * c4);
+                    if (g.splits == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gv[j] = apply_epilogue(g, gv[j], m0 + row, n0 + 4 * c4 + j);
+                    }
+                    *reinterpret_cast<f32x4*>(dst + (m0 + row) * ldd + n0 + 4 * c4) = gv;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1048,6 +1182,8 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     }
 
     const int cus = tnn::num_cus();
+    static const int staged_mode = getenv("TNN_GEMM_STAGED_C") ? atoi(getenv("TNN_GEMM_STAGED_C")) : 1;
+    g.staged_c = staged_mode;
     int cfg = -1, splits = 0;
     if (const char* e = getenv("TNN_GEMM_CFG")) cfg = atoi(e);       // tuning override
     if (const char* e = getenv("TNN_GEMM_SPLITK")) splits = atoi(e);
@@ -1163,6 +1299,43 @@ int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldg; g.ldc = ldc;
     g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_AXPBY;
     return gemm_f32(g, 1, 0, (float*)db);
+}
+
+int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg, void* g_out,
+                     void* p, void* m, void* v, double lr, double b1, double b2, double eps, const void* pows_f64,
+                     int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_gemm_tn_adam", 1, 0, M, N, K, lda, ldg, N)) return rc;
+    TNN_REQUIRE(p && m && v && pows_f64, "tnn_gemm_tn_adam: p, m, v and pows are required");
+    TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_gemm_tn_adam: dtype %d is not a float type", dtype);
+    if (M == 0 || N == 0) return 0;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)G; g.C = (float*)g_out;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldg; g.ldc = N;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_ADAM;
+    const bool tiled = dtype == TNN_F32 && !use_small_path(g) && N % 4 == 0 && al(p) && al(m) && al(v) && al(g_out) &&
+                       ((M + 127) / 128) * ((N + 63) / 64) >= tnn::num_cus() / 2 && getenv("TNN_GEMM_CFG") == nullptr &&
+                       getenv("TNN_GEMM_SPLITK") == nullptr;
+    if (tiled) {
+        g.ad_p = (float*)p; g.ad_m = (float*)m; g.ad_v = (float*)v;
+        g.ad_lr = (float)lr; g.ad_b1 = (float)b1; g.ad_b2 = (float)b2; g.ad_eps = (float)eps;
+        g.ad_pows = (const double*)pows_f64;
+        g.ad_guard = tnn::update_guard();
+        return gemm_f32(g, 1, 0);                    // >= 128 tiles of 128 x 64: configuration 3, no split-K
+    }
+    // any other shape / dtype: the two launches this replaces (through a scratch gradient when none is wanted)
+    void* scratch = nullptr;
+    void* gw = g_out;
+    const size_t esz = dtype == TNN_F64 ? 8 : 4;
+    if (gw == nullptr) {
+        if (tnn_malloc((size_t)(M * N) * esz, &scratch)) return 1;
+        gw = scratch;
+    }
+    int rc = tnn_gemm_tn_colsum(M, N, K, A, lda, G, ldg, gw, N, nullptr, dtype);
+    if (!rc) rc = tnn_adam_ex(p, gw, m, v, M * N, lr, b1, b2, eps, const_cast<void*>(pows_f64), nullptr, dtype, 0, nullptr, nullptr);
+    if (scratch) tnn_free(scratch);
+    return rc;
 }
 
 int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, const void* w,
