@@ -225,47 +225,58 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
                 __syncthreads();
                 constexpr int PASSES = (BM / 4) * (BN / 4) / (NW * 64);
                 const int cb = tid % (BN / 4);
-#pragma unroll 1
-                for (int pass = 0; pass < PASSES; ++pass) {
-                    const int ra = tid / (BN / 4) + pass * (NW * 64 / (BN / 4));
-                    const int64_t o0 = (m0 + 4 * ra) * g.ldc + n0 + 4 * cb;
-                    uint32_t hp[4][2];                     // the sub-block's bf16 results, packed by row
-                    // two rows at a time: 6 x 16-B loads in flight per thread (x 1024 threads per CU) and <= 128 VGPRs, which
-                    // keeps TWO workgroups resident (with all 4 rows at once: 134 VGPRs, one workgroup, 460 us instead of 384)
+                // Software pipeline over the 2 PASSES x 2 row-pairs of this thread's sub-blocks: the 6 x 16-B loads of stage
+                // s + 1 are in flight while stage s is computed and stored (12 loads per thread, 24 KB per wave of 64 lanes:
+                // the epilogue is the memory-bound part of the kernel and lives on the number of bytes in flight), within
+                // 128 VGPRs so that TWO workgroups stay resident (all 4 rows of a sub-block at once: 134 VGPRs, one
+                // workgroup, 460 us instead of 384 on 8192 x 8192 x 512).
+                static_assert(PASSES == 2, "the stage schedule below is written for two passes");
+                f32x4 pv[2][2], mv[2][2], vv[2][2];
+                uint32_t hp[4][2];                         // the current sub-block's bf16 results, packed by row
+                auto base_of = [&](int stage) -> int64_t {
+                    const int ra = tid / (BN / 4) + (stage >> 1) * (NW * 64 / (BN / 4));
+                    return (m0 + 4 * ra) * g.ldc + n0 + 4 * cb;
+                };
+                auto request = [&](int stage, int buf) {
+                    const int64_t o0 = base_of(stage);
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        f32x4 pv[2], mv[2], vv[2], gv[2];
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int64_t o = o0 + (2 * half + jj) * g.ldc;
-                            pv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ap + o));
-                            mv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.am + o));
-                            vv[jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.av + o));
-                            gv[jj] = *reinterpret_cast<const f32x4*>(tile + (4 * ra + 2 * half + jj) * BN + 4 * cb);
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = 2 * half + jj;
-                            const int64_t o = o0 + j * g.ldc;
-                            uint32_t h[4];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) {
-                                const float gi = gv[jj][c];
-                                mv[jj][c] = mv[jj][c] + omb1 * (gi - mv[jj][c]);
-                                vv[jj][c] = vv[jj][c] + omb2 * (gi * gi - vv[jj][c]);
-                                pv[jj][c] = pv[jj][c] + (-lr * (mv[jj][c] * ic1) / (sqrtf(vv[jj][c] * ic2) + eps));
-                                h[c] = (uint32_t)f2bf(pv[jj][c]);
-                            }
-                            __builtin_nontemporal_store(mv[jj], reinterpret_cast<f32x4*>(g.am + o));
-                            __builtin_nontemporal_store(vv[jj], reinterpret_cast<f32x4*>(g.av + o));
-                            __builtin_nontemporal_store(pv[jj], reinterpret_cast<f32x4*>(g.ap + o));
-                            hp[j][0] = h[0] | (h[1] << 16);
-                            hp[j][1] = h[2] | (h[3] << 16);
-                            *reinterpret_cast<u32x2*>(g.aw16 + o) = u32x2{hp[j][0], hp[j][1]};
-                            if (gout) *reinterpret_cast<f32x4*>(gout + o) = gv[jj];
-                        }
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int64_t o = o0 + (2 * (stage & 1) + jj) * g.ldc;
+                        pv[buf][jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.ap + o));
+                        mv[buf][jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.am + o));
+                        vv[buf][jj] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g.av + o));
                     }
-                    if (g.awT16 != nullptr) {
+                };
+                request(0, 0);
+#pragma unroll
+                for (int stage = 0; stage < 4; ++stage) {
+                    const int buf = stage & 1, half = stage & 1;
+                    if (stage + 1 < 4) request(stage + 1, buf ^ 1);
+                    const int ra = tid / (BN / 4) + (stage >> 1) * (NW * 64 / (BN / 4));
+                    const int64_t o0 = base_of(stage);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = 2 * half + jj;
+                        const int64_t o = o0 + j * g.ldc;
+                        const f32x4 gv = *reinterpret_cast<const f32x4*>(tile + (4 * ra + j) * BN + 4 * cb);
+                        uint32_t h[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float gi = gv[c];
+                            mv[buf][jj][c] = mv[buf][jj][c] + omb1 * (gi - mv[buf][jj][c]);
+                            vv[buf][jj][c] = vv[buf][jj][c] + omb2 * (gi * gi - vv[buf][jj][c]);
+                            pv[buf][jj][c] = pv[buf][jj][c] + (-lr * (mv[buf][jj][c] * ic1) / (sqrtf(vv[buf][jj][c] * ic2) + eps));
+                            h[c] = (uint32_t)f2bf(pv[buf][jj][c]);
+                        }
+                        __builtin_nontemporal_store(mv[buf][jj], reinterpret_cast<f32x4*>(g.am + o));
+                        __builtin_nontemporal_store(vv[buf][jj], reinterpret_cast<f32x4*>(g.av + o));
+                        __builtin_nontemporal_store(pv[buf][jj], reinterpret_cast<f32x4*>(g.ap + o));
+                        hp[j][0] = h[0] | (h[1] << 16);
+                        hp[j][1] = h[2] | (h[3] << 16);
+                        *reinterpret_cast<u32x2*>(g.aw16 + o) = u32x2{hp[j][0], hp[j][1]};
+                        if (gout) *reinterpret_cast<f32x4*>(gout + o) = gv;
+                    }
+                    if (half == 1 && g.awT16 != nullptr) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const int w = c >> 1, sh = 16 * (c & 1);
