@@ -60,6 +60,7 @@ from tinynn_autograd_amd import device_array as da    # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # dense (AMD's 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_TBS = 8.0
+PEAK_HBM_GBS = PEAK_HBM_TBS * 1e3
 LAUNCH_BOUNDARY_US = 1.45             # dependent kernel boundary, same stream (MI355X_MICROARCH.md price table)
 WIDTHS_A = [784, 256, 128, 10]
 WIDTHS_C = [4096, 4096, 4096]
@@ -178,11 +179,23 @@ def time_gemms_bf16(widths, rows, reps=10):
         if l > 0:
             shapes.append(("dX%d" % l, rows, widths[l], widths[l + 1], np.uint16))
     cache = {}
+    rot = 3          # operand sets per shape, used in turn: like the layers of the step, no call finds its weights in the
+                     # 256 MB memory-side cache (one 8192 x 8192 bf16 matrix is 134 MB; a single re-used one would stay there)
     for name, M, N, K, out in shapes:
         key = (M, N, K, out)
         if key not in cache:
-            A = bf16.to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
-            B = bf16.to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+            ops = [(bf16.to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32)),
+                    bf16.to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))) for _ in range(rot)]
+            for A, B in ops:
+                bf16.gemm_nt(A, B, out_dtype=out)
+            e0, e1 = _lib.Event(), _lib.Event()
+            e0.record()
+            for i in range(reps):
+                A, B = ops[i % rot]
+                bf16.gemm_nt(A, B, out_dtype=out)
+            e1.record()
+            rotating = e0.elapsed_ms(e1) / reps * 1e3
+            A, B = ops[0]
             for _ in range(2):
                 bf16.gemm_nt(A, B, out_dtype=out)
             e0, e1 = _lib.Event(), _lib.Event()
@@ -190,19 +203,51 @@ def time_gemms_bf16(widths, rows, reps=10):
             for _ in range(reps):
                 bf16.gemm_nt(A, B, out_dtype=out)
             e1.record()
-            cache[key] = e0.elapsed_ms(e1) / reps * 1e3
-        us = cache[key]
+            cache[key] = (rotating, e0.elapsed_ms(e1) / reps * 1e3)
+            del ops
+        us, us_hot = cache[key]
         flops = 2.0 * M * N * K
         results.append({"gemm": name, "layout": "NT(bf16)", "M": M, "N": N, "K": K, "us": round(us, 2),
-                        "tflops": round(flops / us / 1e6, 1)})
+                        "tflops": round(flops / us / 1e6, 1), "us_same_operands": round(us_hot, 2),
+                        "tflops_same_operands": round(flops / us_hot / 1e6, 1)})
         tot_flops += flops
         tot_us += us
     achieved = tot_flops / tot_us / 1e6
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_bf16_nt_kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+            "kernel": "gemm_bf16_dma_kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate, LDS-DMA operand ring)",
+            "operands": "%d sets per shape used in turn (weights come from HBM as in the step); *_same_operands: one set re-used" % rot,
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "gemm_us_per_step": round(tot_us, 1),
             "per_gemm": results}
+
+
+def time_dw_adam_bf16(widths, rows, reps=10):
+    """configs[4]'s dominant kernel since Adam moved into the dW epilogues: gemm_bf16_dma_kernel<8, 2, false, true>
+    (tnn_gemm_bf16_nt_adam) on the weight-gradient shape.  HBM-bound: per parameter it reads p, m, v (12 B) and writes
+    p, m, v, the bf16 copy and its transpose (16 B); the operands add 2 x 2 B x rows / n per element."""
+    from tinynn_autograd_amd import bf16
+    rs = np.random.RandomState(9)
+    M, N, K = widths[0], widths[1], rows
+    A = bf16.to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+    B = bf16.to_bf16((rs.uniform(-1, 1, (N, K)) * 1e-2).astype(np.float32))
+    P, Mo, Vo = da.zeros((M, N)), da.zeros((M, N)), da.zeros((M, N))
+    W16, WT16 = da.empty((M, N), np.uint16), da.empty((N, M), np.uint16)
+    pows = da.asarray(np.array([0.5, 0.5, 0, 0]), dtype=np.float64)
+    lib = _lib.get()
+
+    def call():
+        lib.gemm_bf16_nt_adam(M, N, K, A._ptr, K, B._ptr, K, None, P._ptr, Mo._ptr, Vo._ptr, W16._ptr, WT16._ptr,
+                              1e-3, 0.9, 0.999, 1e-8, pows._ptr)
+    us = events_us(call, reps)
+    alg = 28.0 * M * N + 2.0 * (M + N) * K
+    gbs = alg / us / 1e3
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": None,
+            "kernel": "gemm_bf16_dma_kernel<8, 2, false, true> (dW = a^T dz with Adam in the epilogue, %d x %d x %d)" % (M, N, K),
+            "algorithmic_bytes": int(alg), "us": round(us, 1), "launches_per_step": len(widths) - 1,
+            "mfma_tflops": round(2.0 * M * N * K / us / 1e6, 1),
+            "model": "28 B per parameter (p, m, v read; p, m, v, bf16 copy, bf16 transpose written) + the operands; the "
+                     "gradient itself never leaves the accumulators"}
 
 
 def load_traffic_table():
@@ -783,7 +828,9 @@ def main():
     # ---------------------------------------------------------------- secondary objects (rank 0, N = 1)
     if line is not None and world == 1 and not args.no_extras:
         if args.workload == "E":
-            line["roofline"] = time_gemms_bf16(widths, rows)
+            line["roofline"] = time_dw_adam_bf16(widths, rows)
+            line["roofline"]["frac_of_step_time"] = round(line["roofline"]["us"] * (len(widths) - 1) / (res["ms_per_step"] * 1e3), 3)
+            line["gemm_roofline"] = time_gemms_bf16(widths, rows)
         elif args.workload == "C":
             line["roofline"] = time_gemms(widths, rows, reps=20)
             attach_gemm_traffic(line["roofline"], "C")

@@ -24,3 +24,7 @@ for name, fn, bytes_ in (("dW GEMM (fp32 out)", gemm, 4 * n), ("Adam + bf16 copi
                          ("fused, gradient not stored", fused(False), 28 * n), ("fused, gradient stored", fused(True), 32 * n)):
     us = bench.events_us(fn, 20)
     print("%-28s %8.1f us   %6.2f TB/s of its algorithmic bytes   %7.1f TFLOP/s" % (name, us, bytes_ / us / 1e6, 2.0 * M * N * K / us / 1e6))
+def fused_no_wt():
+    lib.gemm_bf16_nt_adam(M, N, K, a._ptr, K, b._ptr, K, None, P._ptr, M_._ptr, V_._ptr, W16._ptr, None, 1e-3, 0.9, 0.999, 1e-8, pows._ptr)
+us = bench.events_us(fused_no_wt, 20)
+print("%-28s %8.1f us   %6.2f TB/s" % ("fused, no transposed copy", us, 26 * n / us / 1e6))
