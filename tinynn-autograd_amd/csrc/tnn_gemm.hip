@@ -1358,6 +1358,10 @@ int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, cons
             gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1;
             gx.tiles_m = (int)((gx.M + 15) / 16); gx.tiles_n = (int)((gx.N + 15) / 16); gx.splits = 1;
             int n_dw = gw.tiles_m * gw.tiles_n, n_dx = gx.tiles_m * gx.tiles_n;
+            if (n_dw % 8 == 0) {                       // the dX tiles then start on XCD 0 again: both grids can be cut per XCD
+                pick_xcd_cut(gw);
+                pick_xcd_cut(gx);
+            }
             int nchunks = (int)((std::max(gw.K, gx.K) + 15) / 16);
             hipStream_t s = tnn::stream();
             const bool fast = small_fast_ok(gw, 1, 0) && small_fast_ok(gx, 0, 1);

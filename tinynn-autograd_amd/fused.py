@@ -1,4 +1,4 @@
-"""Whole-step Dense-MLP trainer: the loop body of examples/mnist/run.py:79-83 as 2L - 1 launches (5 for the 3-layer MNIST net).
+"""Whole-step Dense-MLP trainer: the loop body of examples/mnist/run.py:79-83 as 2L - 2 launches (4 for the 3-layer MNIST net).
 
 Python face of the tnn_mlp_* entry points (csrc/tnn_mlp.cpp).  It owns four flat HBM arenas
 (params | grads | m | v, core/optimizer.py:14-15 order) and per-layer activation buffers, and exposes the
