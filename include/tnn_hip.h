@@ -261,6 +261,16 @@ TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, 
                                   const void* logit_partials, void* logits, void* dz, void* stats, void* loss, void* dw,
                                   void* db, void* dw1, void* db1, void* dx, int dtype, void* adam_pows_f64, double b1,
                                   double b2);
+/* The data-parallel form (core/losses.py:26-27 — the softmax spans the GLOBAL batch of m_global rows, this rank holds
+ * `rows` of them): the shards' {max, sum-exp} are exchanged over the xGMI peer-to-peer transport INSIDE the launch
+ * (workgroup 0 talks to the peers and hands the merged pair to every other workgroup), dz / dw / db / dw1 / db1 / dx are this
+ * rank's contributions to the global gradients and *loss its share of the global loss — the all-reduce of the gradient arena
+ * (tnn_allreduce_adam) sums both.  Needs tnn_p2p_connect; the sharded step is then 5 launches instead of 8. */
+TNN_API int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
+                                          const void* x, const void* w1, const void* a, const void* w, const void* b,
+                                          const void* y, const void* logit_partials, void* logits, void* dz, void* stats,
+                                          void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
+                                          void* adam_pows_f64, double b1, double b2);
 /* Forward of the hidden Dense layer in front of the classifier, C = act(A B + bias) like tnn_gemm_bias_act (NN form,
  * core/layers.py:49,98), which ALSO emits the next layer's logits as per-tile partial sums:
  *   head_z[tn][row][c] = sum_{col in [16 tn, 16 tn + 16)} C[row][col] * head_w[col][c]      (head_z: [ceil(N/16)][M][head_c])
@@ -434,6 +444,15 @@ TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);
 TNN_API int tnn_p2p_poll_failed(int* failed);
 /* on != 0: optimizer-update kernels launched from now on become no-ops once the transport's dead word is set (see
  * above); on == 0: back to unconditional updates.  tnn_mlp_step_sharded brackets itself with the pair. */
+/* Ranks of the group share a GPU (one-GPU test boxes)?  set >= 0 stores the answer the host side worked out, current
+ * (may be NULL) returns it.  tnn_mlp_step_sharded uses the 5-launch form (statistics exchanged inside the multi-workgroup
+ * head launch, every workgroup waiting for the merged pair) only when each rank has a GPU of its own — or when
+ * TNN_STEP_MERGE_SHARED=1 vouches that all the ranks' launches fit the shared GPU together. */
+TNN_API int tnn_p2p_shared_device(int set, int* current);
+/* Diagnostics of a timed-out wait, read from the host-pinned mirror without a stream sync: words16[0] = 0, or which
+ * wait gave up first (1 collective flag barrier, 2 statistics exchange, 3 hand-over row of the sharded head), [1] the value
+ * it expected, [2] the last value it saw, [3] peer / workgroup, [4] flag row / slot parity. */
+TNN_API int tnn_p2p_debug(int* words16);
 TNN_API int tnn_p2p_guard_updates(int on);
 TNN_API int tnn_p2p_destroy(void);
 

@@ -653,6 +653,14 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t nh, int64_t nc, co
         return rc;
     return tnn_dense_bwd(rows, n_in, nh, x, da.data(), w1, dw1, db1, dx, x, dtype);
 }
+int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
+                                  const void* a, const void* w, const void* b, const void* y, const void* zpart, void* logits,
+                                  void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
+                                  void* pows, double b1, double b2) {
+    REQ(m_global == rows, "cpu twin: one-rank group only");      // the peer-to-peer transport needs device IPC
+    return tnn_mlp_head_bwd_tick(rows, n_in, nh, nc, x, w1, a, w, b, y, zpart, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
+                                 pows, b1, b2);
+}
 int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                 const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* hw, int64_t hc,
                                 void* hz, int dtype) {
@@ -883,6 +891,8 @@ int tnn_p2p_status(int* c, int* e, int* d) {
 }
 int tnn_p2p_poll_failed(int* f) { if (f) *f = 0; return 0; }
 int tnn_p2p_guard_updates(int) { return 0; }
+int tnn_p2p_shared_device(int, int* cur) { if (cur) *cur = 0; return 0; }
+int tnn_p2p_debug(int* w) { if (w) memset(w, 0, 16 * sizeof(int)); return 0; }
 int tnn_p2p_destroy(void) { g_comm = 0; return 0; }
 
 }  // extern "C"

@@ -29,7 +29,10 @@ def main():
     assert comm.p2p_status() == {"connected": True, "enabled": True, "dead": False}
     assert comm.p2p_selftest(sizes=(1, 5, 1000, 235147, 1 << 20), rounds=3), "self-test failed"
 
-    cfg, gold = H.load_traj("D_adam")
+    # TNN_P2P_TEST_TRAJ: "D_adam" (bs 1024: 512 rows per rank at world 2 — the 8-launch step with the exchange in the
+    # one-workgroup loss kernel) or "A_adam" (bs 128: 64 rows per rank — the 5-launch step whose multi-workgroup head
+    # exchanges the statistics inside the launch)
+    cfg, gold = H.load_traj(os.environ.get("TNN_P2P_TEST_TRAJ", "D_adam"))
     w, m = cfg["widths"], cfg["m"]
     rows = m // world
     sl = slice(rank * rows, (rank + 1) * rows)

@@ -77,14 +77,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.gpu
-def test_p2p_two_processes_share_the_gpu():
+def _run_p2p_workers(world, traj="D_adam"):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), TNN_DEVICE="0", WORLD_SIZE="2",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), TNN_DEVICE="0", WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNN_P2P_TIMEOUT_MS="3000",
-                   TNN_P2P_TEST_TIMEOUT="1",
+                   TNN_P2P_TEST_TIMEOUT="1", TNN_P2P_TEST_TRAJ=traj,
+                   TNN_STEP_MERGE_SHARED="1",          # 2 x 64 rows: both ranks' head launches fit the one GPU together
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -99,7 +99,23 @@ def test_p2p_two_processes_share_the_gpu():
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
-        assert "p2p_worker rank %d/2 ok" % rank in out
+        assert "p2p_worker rank %d/%d ok" % (rank, world) in out
+
+
+@pytest.mark.gpu
+def test_p2p_two_processes_share_the_gpu():
+    """512 rows per rank: the 8-launch sharded step (exchange inside the one-workgroup loss kernel)."""
+    _run_p2p_workers(2)
+
+
+@pytest.mark.gpu
+def test_p2p_two_processes_five_launch_step():
+    """The reference's bs-128 trajectory split over two ranks (64 rows each): the 5-launch sharded step, whose
+    multi-workgroup head exchanges the shards' statistics inside the launch (workgroup 0 with the peer, one hand-over row
+    per other workgroup) — eager, replayed from a hipGraph, replicas identical, and the timeout drill.  (Two ranks keep
+    every workgroup of both ranks resident on the one GPU; the driver's N = 8 point has 128 rows per rank on a GPU each —
+    `TNN_P2P_TEST_TRAJ=D_adam` with 8 workers runs that shape on one GPU too, but only by virtue of queue preemption.)"""
+    _run_p2p_workers(2, "A_adam")
 
 
 @pytest.mark.gpu

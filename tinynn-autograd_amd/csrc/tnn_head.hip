@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "tnn_internal.h"
+#include "tnn_p2p.h"
 
 namespace {
 
@@ -308,6 +309,7 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
 struct HeadMArgs {
     int m, rpb;                      // rows (<= 128); da rows per workgroup
     int vec;                         // rows even, zpart / y 16-B aligned: the partial logits are staged with 16-B loads
+    int m_global;                    // data-parallel (SH kernels): rows of the GLOBAL batch; the loss written is this rank's share
     const float *a, *w, *b, *y;
     const float* zpart;              // [H / 16][m][C] partial logits from the previous layer's tiles, or NULL
     float *logits, *dz, *stats, *loss, *dw, *db, *da;
@@ -356,13 +358,78 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
     }
 }
 
+// ---- data-parallel form of the multi-workgroup head: the softmax spans the GLOBAL batch (core/losses.py:26-27), so the
+// shard's {M_r, S_r} have to meet the other ranks' between the statistics and dz — in EVERY workgroup of the launch.
+// Workgroup `lead` (the head's workgroup 0) does the exchange over xGMI (ll_exchange2: one tagged 8-byte store per word and
+// peer, no acknowledgement round trip), merges M = max_r M_r, S = sum_r S_r exp(M_r - M) and hands the pair to every other
+// workgroup through ONE ROW PER WORKGROUP of the uncached region (Header::bc: a workgroup polls only its own row, so the
+// pollers sit on different HBM channels — with all of them on one page the flag stores queue behind the polls, tnn_p2p.h).
+// The tag is the number of all-reduce launches so far + 1 (LaunchCtx::ar_count): every workgroup of this launch reads the
+// same value, and the step's all-reduce advances it before the next step's head runs.  Slots and rows are double-buffered /
+// overwritten safely for the reason given in tnn_p2p.hip (a rank reaches step k + 2 only through step k + 1's barriers).
+// Spins are bounded; on a timeout (or an already dead transport) the statistics stay local — the gradients are then wrong,
+// and the all-reduce + optimizer launch behind this one discards them (the sticky `dead` word).
+struct HeadGlobal {
+    float M, S;
+};
+__device__ __forceinline__ HeadGlobal head_exchange(const tnn::p2p::LaunchCtx& ctx, const bool lead, const float M_loc,
+                                                    const float S_loc, float (*peer_stats)[2]) {
+    using namespace tnn::p2p;
+    const Peers& P = ctx.peers;
+    const int t = threadIdx.x, W = P.world;
+    const uint32_t cnt = *ctx.ar_count, tag = cnt + 1;
+    HeadGlobal out = {M_loc, S_loc};
+    if (lead) {
+        if (t < 2 * W)
+            peer_stats[t >> 1][t & 1] = ll_exchange2(P, cnt, (t & 1) ? S_loc : M_loc, ctx.dead, ctx.timeout_ticks, offsetof(Header, ll2));
+        __syncthreads();
+        const bool dead_now = __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        float gm = -INFINITY, gs = 0.f;
+        for (int q = 0; q < W; ++q) gm = fmaxf(gm, peer_stats[q][0]);
+        for (int q = 0; q < W; ++q) gs += peer_stats[q][1] * expf(peer_stats[q][0] - gm);
+        if (!dead_now) { out.M = gm; out.S = gs; }
+        // hand-over rows of all the other workgroups (a dead transport publishes nothing: the waiters see the dead word)
+        if (!dead_now) {
+            for (int row = t; row < (int)gridDim.x; row += (int)blockDim.x) {
+                uint64_t* dst = reinterpret_cast<uint64_t*>(P.base[P.rank] + offsetof(Header, bc) + (size_t)row * FLAG_ROW);
+                store_sys(dst, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(out.M));
+                store_sys(dst + 1, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(out.S));
+            }
+        }
+        return out;
+    }
+    if (t < 2) {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(P.base[P.rank] + offsetof(Header, bc) + (size_t)blockIdx.x * FLAG_ROW) + t;
+        uint64_t v[1] = {0};
+        uint64_t t0 = 0;
+        uint32_t polls = 0;
+        bool got = false;
+        while (__hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            load_sys(v[0], src);
+            loads_landed(v);
+            if ((uint32_t)(v[0] >> 32) == tag) { got = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+            if ((++polls & 63u) == 0) {
+                const uint64_t now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if ((int64_t)(now - t0) > ctx.timeout_ticks) { mark_dead(P, ctx.dead, 3, tag, (uint32_t)(v[0] >> 32), blockIdx.x, 0); break; }
+            }
+        }
+        peer_stats[0][t] = got ? __uint_as_float((uint32_t)v[0]) : (t == 0 ? M_loc : S_loc);
+    }
+    __syncthreads();
+    out.M = peer_stats[0][0];
+    out.S = peer_stats[0][1];
+    return out;
+}
+
 // PART: the logits arrive as H / 16 partial sums per element (tnn_dense_fwd_head_partials: the previous layer's 16-column
 // tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
 // v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
 // CUT (timing builds only, TNN_HEAD_CUT): 0 = the kernel; 1 = stop after the logits, 2 = after the statistics, 3 = after dz.
 // DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
-template <int H, int C, bool PART, int CUT, bool DA>
-__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
+template <int H, int C, bool PART, int CUT, bool DA, bool SH = false>
+__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, const tnn::p2p::LaunchCtx* ctx = nullptr) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
     constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
@@ -463,9 +530,18 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
-    const float mx = st.mx, urow = st.urow, M = st.M;
-    const double S = st.S, L = st.L;
-    const double inv_m = 1.0 / (double)m;
+    const float mx = st.mx, urow = st.urow;
+    float M = st.M;
+    double S = st.S;
+    const double L = st.L;
+    double inv_m = 1.0 / (double)m;
+    if constexpr (SH) {
+        __shared__ float peer_stats[tnn::p2p::MAXW][2];
+        const HeadGlobal gl = head_exchange(*ctx, g == 0, M, (float)S, peer_stats);
+        M = gl.M;
+        S = (double)gl.S;
+        inv_m = 1.0 / (double)p.m_global;
+    }
     if constexpr (CUT == 2) {
         p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
         return;
@@ -543,7 +619,9 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
             if (lane < C) p.db[lane] = s;
         }
         if (t == 0) {
-            if (p.loss) p.loss[0] = (float)((double)logf((float)S) + (double)M - L * inv_m);
+            // data parallel: this rank's SHARE of the global loss (the all-reduce of the gradient arena sums the shares)
+            if (p.loss) p.loss[0] = SH ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
+                                       : (float)((double)logf((float)S) + (double)M - L * inv_m);
             if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
             if (p.tick) { p.tick[0] = pw0 * p.b1; p.tick[1] = pw1 * p.b2; }
         }
@@ -584,12 +662,12 @@ struct HeadBwdArgs {
 };
 
 // CUT (timing builds only, TNN_HBW_CUT): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
-template <int H, int C, int CUT = 0>
-__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
+template <int H, int C, int CUT = 0, bool SH = false>
+__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q, tnn::p2p::LaunchCtx ctx) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
     if ((int)blockIdx.x < G) {
-        head_block<H, C, true, 0, false>(p, (int)blockIdx.x);
+        head_block<H, C, true, 0, false, SH>(p, (int)blockIdx.x, &ctx);
         return;
     }
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
@@ -672,9 +750,17 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
         return;
     }
+    float m_norm = (float)m;
+    if constexpr (SH) {
+        __shared__ float peer_stats[tnn::p2p::MAXW][2];
+        const HeadGlobal gl = head_exchange(ctx, false, st.M, (float)st.S, peer_stats);
+        st.M = gl.M;
+        st.S = (double)gl.S;
+        m_norm = (float)p.m_global;
+    }
     {
         const float sf = slive ? expf(st.mx - st.M) * __builtin_amdgcn_rcpf((float)st.S) : 0.f;
-        const float uf = slive ? __builtin_amdgcn_rcpf((float)m * st.urow) : 0.f;
+        const float uf = slive ? __builtin_amdgcn_rcpf(m_norm * st.urow) : 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             if (st.valid[i]) dzr[srow * WS + sub + 4 * i] = st.ec[i] * sf - st.eyc[i] * uf;      // 0 in the padding rows
@@ -751,6 +837,57 @@ size_t head_lds_bytes(int64_t m, int64_t H) {
 
 bool g_attr_set = false;
 
+int head_bwd_launch(const char* fn, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
+                          const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
+                          void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
+                          void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(rows > 0 && n_in > 0 && n_hidden > 0 && n_classes > 0, "%s: empty head", fn);
+    TNN_REQUIRE(x && w1 && a && w && b && y && logit_partials && dw && db && dw1 && db1 && dx,
+                "%s: x, w1, a, w, b, y, logit_partials, dw, db, dw1, db1 and dx are required", fn);
+    auto al = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype) && n_in % 16 == 0 && al(a) && al(w) && al(w1),
+                "%s: this head does not fit the merged form (tnn_mlp_head_fits, n_in %% 16 == 0, 16-B aligned a / w / w1)", fn);
+    HeadMArgs p;
+    p.m = (int)rows;
+    p.rpb = (int)((rows + 15) / 16);
+    p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
+    p.zpart = (const float*)logit_partials;
+    p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
+    p.m_global = (int)m_global;
+    p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
+    p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
+    p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
+    HeadBwdArgs q;
+    q.x = (const float*)x; q.w1 = (const float*)w1;
+    q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
+    q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
+    static const int xcd_mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
+    q.xcd = xcd_mode;
+    const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
+    if (m_global > 0) {                  // data parallel: the exchange of the shards' statistics happens inside the launch
+        TNN_REQUIRE(m_global >= rows, "%s: m_global < rows", fn);
+        if (int rc = tnn::p2p_refuse_if_failed(fn)) return rc;
+        tnn::p2p::LaunchCtx ctx;
+        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "%s: the peer-to-peer transport is not enabled", fn);
+        TNN_REQUIRE(grid <= tnn::p2p::BC_ROWS, "%s: %d workgroups exceed the %d hand-over rows", fn, grid, tnn::p2p::BC_ROWS);
+        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, true>), grid, 512, 0, tnn::stream(), p, q, ctx);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
+    static const int cut = getenv("TNN_HBW_CUT") ? atoi(getenv("TNN_HBW_CUT")) : 0;        // timing builds
+    hipStream_t st = tnn::stream();
+    const tnn::p2p::LaunchCtx none = {};
+    if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q, none);
+    else if (cut == 2) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 2>), grid, 512, 0, st, p, q, none);
+    else if (cut == 3) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 3>), grid, 512, 0, st, p, q, none);
+    else if (cut == 4) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 4>), grid, 512, 0, st, p, q, none);
+    else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, st, p, q, none);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -809,6 +946,7 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
+    p.m_global = 0;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -832,38 +970,18 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
-    TNN_NEED_INIT();
-    TNN_REQUIRE(rows > 0 && n_in > 0 && n_hidden > 0 && n_classes > 0, "tnn_mlp_head_bwd_tick: empty head");
-    TNN_REQUIRE(x && w1 && a && w && b && y && logit_partials && dw && db && dw1 && db1 && dx,
-                "tnn_mlp_head_bwd_tick: x, w1, a, w, b, y, logit_partials, dw, db, dw1, db1 and dx are required");
-    auto al = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
-    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype) && n_in % 16 == 0 && al(a) && al(w) && al(w1),
-                "tnn_mlp_head_bwd_tick: this head does not fit the merged form (tnn_mlp_head_fits, n_in %% 16 == 0, 16-B aligned a / w / w1)");
-    HeadMArgs p;
-    p.m = (int)rows;
-    p.rpb = (int)((rows + 15) / 16);
-    p.a = (const float*)a; p.w = (const float*)w; p.b = (const float*)b; p.y = (const float*)y;
-    p.zpart = (const float*)logit_partials;
-    p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
-    p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
-    p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
-    p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
-    HeadBwdArgs q;
-    q.x = (const float*)x; q.w1 = (const float*)w1;
-    q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
-    q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
-    static const int xcd_mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
-    q.xcd = xcd_mode;
-    const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
-    static const int cut = getenv("TNN_HBW_CUT") ? atoi(getenv("TNN_HBW_CUT")) : 0;        // timing builds
-    hipStream_t st = tnn::stream();
-    if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q);
-    else if (cut == 2) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 2>), grid, 512, 0, st, p, q);
-    else if (cut == 3) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 3>), grid, 512, 0, st, p, q);
-    else if (cut == 4) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 4>), grid, 512, 0, st, p, q);
-    else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, st, p, q);
-    TNN_LAUNCH_OK();
-    return 0;
+    return head_bwd_launch("tnn_mlp_head_bwd_tick", 0, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y, logit_partials, logits,
+                           dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
+}
+
+int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
+                                  const void* x, const void* w1, const void* a, const void* w, const void* b, const void* y,
+                                  const void* logit_partials, void* logits, void* dz, void* stats, void* loss, void* dw,
+                                  void* db, void* dw1, void* db1, void* dx, int dtype, void* adam_pows_f64, double b1,
+                                  double b2) {
+    TNN_REQUIRE(m_global >= 1, "tnn_mlp_head_bwd_tick_sharded: m_global must be the global batch size");
+    return head_bwd_launch("tnn_mlp_head_bwd_tick_sharded", m_global, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y,
+                           logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
 }  // extern "C"

@@ -600,6 +600,39 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     MLP_TRY(tnn_p2p_status(nullptr, &p2p_on, nullptr));
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
+    int head_multi = 0;
+    static const bool merge_off = getenv("TNN_STEP_MERGE") != nullptr && atoi(getenv("TNN_STEP_MERGE")) == 0;
+    int shared_gpu = 0;
+    if (p2p_on) MLP_TRY(tnn_p2p_shared_device(-1, &shared_gpu));
+    static const bool merge_shared = getenv("TNN_STEP_MERGE_SHARED") != nullptr && atoi(getenv("TNN_STEP_MERGE_SHARED")) != 0;
+    if (p2p_on && (!shared_gpu || merge_shared) && h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 &&
+        h->w[L - 2] % 16 == 0 && !merge_off)
+        MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
+    if (head_multi) {
+        // xGMI peer-to-peer transport, a GPU per rank (every workgroup of the head launch waits for the merged statistics: all
+        // the ranks' launches must be resident together — ranks sharing one GPU deadlock as soon as one launch fills it,
+        // measured with 2 x 128 rows) and a classifier head of the one-launch form — 2L - 1 launches (5 for the MNIST net),
+        // the single-GPU step's structure with the exchange INSIDE the head launch:
+        //   forward of the hidden layers (the last one also emits the partial logits) | head + hidden layer's backward, whose
+        //   workgroup 0 exchanges the shards' {max, sum-exp} with the peers and hands the merged pair to the others
+        //   (tnn_mlp_head_bwd_tick_sharded; it also advances Adam's beta powers) | remaining backward | all-reduce whose
+        //   last stage applies Adam and files the loss
+        MLP_TRY(mlp_forward(h, x, rows, L - 2));
+        MLP_TRY(tnn_dense_fwd_head_partials(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                            at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                            at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                            h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart, h->dtype));
+        MLP_TRY(tnn_mlp_head_bwd_tick_sharded(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
+                                              at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
+                                              at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
+                                              y, h->zpart, h->act[L - 1], h->dact[L - 1], h->stats, loss_slot,
+                                              at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                              at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
+                                              h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
+        MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 0));
+        return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
+                                  h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);
+    }
     if (p2p_on && h->dtype == TNN_F32 && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
         // xGMI peer-to-peer transport and a head that fits one workgroup — 8 launches, like the single-GPU step:
         //   forward | loss kernel that exchanges the shards' {max, sum-exp} itself (stats + C2 + merge + loss + dz)

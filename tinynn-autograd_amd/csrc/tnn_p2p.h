@@ -19,11 +19,16 @@ constexpr int THREADS = 512;
 // pollers hit one HBM channel and the flag stores queue behind them (measured: 64 workgroups cost +7 us per
 // all-reduce over one); each workgroup's words therefore get a row of their own, FLAG_ROW bytes apart.
 constexpr int FLAG_ROW = 4096;
+constexpr int BC_ROWS = 1024;     // workgroups of the sharded head launch
 struct Header {                                   // start of every rank's uncached region
     uint8_t flag[2][MAXB][FLAG_ROW];              // [barrier][block] -> uint32_t[MAXW] indexed by source rank
     uint32_t ag_flag[MAXW];                       // [source rank]
     uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
     uint64_t ll[2][MAXW][2];                      // [epoch parity][source rank][word]: (tag << 32) | payload, see ll_exchange2
+    // the multi-workgroup head (tnn_head.hip, sharded form): its own tagged slots (the tags come from a different counter than
+    // the loss kernel's) and one row per workgroup through which workgroup 0 hands the merged {max, sum-exp} to the others
+    uint64_t ll2[2][MAXW][2];
+    uint8_t bc[BC_ROWS][FLAG_ROW];                // row b: uint64_t[2] = (tag << 32) | bits of {M, S}, polled by workgroup b only
 };
 constexpr size_t HEADER_BYTES = (sizeof(Header) + 4095) / 4096 * 4096;
 
@@ -37,14 +42,24 @@ struct Peers {
 
 // A barrier timed out: the sticky device word stops every later wait, the host mirror lets the next host-side call fail
 // loudly (tnn_p2p.hip: p2p_failed) instead of running on partial sums.
-__device__ __forceinline__ void mark_dead(const Peers& p, int* dead) {
-    __hip_atomic_store(dead, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(p.dead_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// `why` (non-zero) says which wait gave up — 1: a flag barrier of a collective, 2: the tagged {max, sum-exp} exchange,
+// 3: a workgroup of the sharded head waiting for its hand-over row; tnn_p2p_status reports the word as it is.
+// The host mirror is 16 ints: [0] the word, [1..4] what the FIRST wait that gave up was looking at (expected value, last
+// value seen, peer / workgroup, a wait-specific detail) — tnn_p2p_debug reads them without a stream sync.
+__device__ __forceinline__ void mark_dead(const Peers& p, int* dead, int why = 1, uint32_t expected = 0, uint32_t seen = 0,
+                                          uint32_t who = 0, uint32_t detail = 0) {
+    if (__hip_atomic_exchange(dead, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        p.dead_host[1] = (int)expected; p.dead_host[2] = (int)seen; p.dead_host[3] = (int)who; p.dead_host[4] = (int)detail;
+        __hip_atomic_store(p.dead_host, why, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 struct LaunchCtx {                                // what a kernel embedding an exchange needs
     Peers peers;
     uint32_t* ag_epoch;                           // epoch of the small all-gather slots (device)
+    const uint32_t* ar_count;                     // all-reduce launches so far (device; advanced by every all-reduce kernel):
+                                                  // the tag source of a MULTI-workgroup exchange, which cannot advance a counter
+                                                  // of its own while other workgroups of the same launch may not have read it
     int* dead;
     int64_t timeout_ticks;
 };
@@ -87,7 +102,8 @@ __device__ __forceinline__ bool exchange_flags(const Peers& p, size_t word_offse
                     const uint64_t now = wall_clock64();
                     if (t0 == 0) t0 = now;
                     if ((int64_t)(now - t0) > timeout_ticks) {
-                        mark_dead(p, dead);
+                        mark_dead(p, dead, 1, val, __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), (uint32_t)t,
+                                  (uint32_t)(word_offset_bytes / FLAG_ROW));
                         failed = 1;
                         break;
                     }
@@ -138,10 +154,11 @@ __device__ __forceinline__ void loads_landed(T (&v)[N]) {
 // no acknowledgement wait on the sender, no separate flag, no second read: one link latency end to end instead of
 // three.  Threads 0 .. 2W-1 take part (thread t: peer t >> 1, word t & 1); returns this thread's received float.
 // Slots are double-buffered on the epoch's parity like the all-gather's.
-__device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, float mine, int* dead, int64_t timeout_ticks) {
+__device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, float mine, int* dead, int64_t timeout_ticks,
+                                              size_t slots = offsetof(Header, ll)) {
     const int t = threadIdx.x, q = t >> 1, idx = t & 1;
     const uint32_t tag = epoch + 1;
-    const size_t base = offsetof(Header, ll) + (size_t)(epoch & 1) * MAXW * 16;
+    const size_t base = slots + (size_t)(epoch & 1) * MAXW * 16;
     store_sys(reinterpret_cast<uint64_t*>(p.base[q] + base + (size_t)p.rank * 16) + idx,
               ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(mine));
     const uint64_t* src = reinterpret_cast<const uint64_t*>(p.base[p.rank] + base + (size_t)q * 16) + idx;
@@ -157,7 +174,7 @@ __device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, fl
             const uint64_t now = wall_clock64();
             if (t0 == 0) t0 = now;
             if ((int64_t)(now - t0) > timeout_ticks) {
-                mark_dead(p, dead);
+                mark_dead(p, dead, 2, tag, (uint32_t)(v[0] >> 32), (uint32_t)q, epoch & 1);
                 break;
             }
         }

@@ -44,12 +44,14 @@ struct State {
     Peers p = {};
     char* own = nullptr;
     void* mapped[MAXW] = {};                      // hipIpcOpenMemHandle results (NULL for self)
-    uint32_t* epoch = nullptr;                    // [MAXB + 1] per-block epochs + the all-gather epoch (local, cached)
+    uint32_t* epoch = nullptr;                    // [MAXB + 2] per-block epochs, the all-gather epoch, the all-reduce launch count
+                                                  // (local, cached)
     int* dead = nullptr;                          // sticky timeout word (local)
     int* host_dead = nullptr;                     // its host-pinned mirror (hipHostMalloc, mapped): host address
     int64_t max_floats = 0;
     int64_t timeout_ticks = 0;
     int blocks_override = 0;
+    bool shared_device = false;                   // some ranks of the group run on the SAME GPU (tests on one-GPU boxes)
 } S;
 
 __device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
@@ -140,7 +142,10 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
     // a workgroup that lost barrier 1 does not signal barrier 2: no peer can then complete this collective either
     ok = ok && exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
     if (!ok) {                     // timed out (now or earlier): buf, parameters and moments stay as they were
-        if (threadIdx.x == 0) epoch[b] = e + 1;
+        if (threadIdx.x == 0) {
+            epoch[b] = e + 1;
+            if (b == 0) epoch[MAXB + 1] += 1;
+        }
         return;
     }
 
@@ -219,7 +224,10 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             }
         }
     }
-    if (threadIdx.x == 0) epoch[b] = e + 1;
+    if (threadIdx.x == 0) {
+        epoch[b] = e + 1;
+        if (b == 0) epoch[MAXB + 1] += 1;          // launches so far: the tag source of the sharded head (LaunchCtx::ar_count)
+    }
 }
 
 // recv[q][0:words] <- rank q's send[0:words]  (words <= 64), one workgroup
@@ -317,6 +325,7 @@ bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
     if (!S.enabled || p2p_failed()) return false;
     ctx->peers = S.p;
     ctx->ag_epoch = S.epoch + MAXB;
+    ctx->ar_count = S.epoch + MAXB + 1;
     ctx->dead = S.dead;
     ctx->timeout_ticks = S.timeout_ticks;
     return true;
@@ -428,6 +437,26 @@ int tnn_p2p_status(int* connected, int* enabled, int* dead) {
             TNN_CHECK_HIP(hipMemcpy(dead, S.dead, sizeof(int), hipMemcpyDeviceToHost));
         }
     }
+    return 0;
+}
+
+int tnn_p2p_shared_device(int set, int* current) {
+    // set >= 0: tell the transport whether ranks of this group share a GPU (the host side knows: dist.py compares the
+    // ranks' host / device pairs).  Kernels in which MANY workgroups of a rank wait for a peer's launch (the sharded
+    // multi-workgroup head) are only safe when every rank's launch can be resident at the same time — on a GPU of its own
+    // always, on a shared one only while all the launches fit it together; tnn_mlp_step_sharded then keeps the form whose
+    // exchange sits in a one-workgroup kernel.  current (may be NULL) receives the flag.
+    TNN_REQUIRE(S.open, "tnn_p2p_shared_device: no peer group");
+    if (set >= 0) S.shared_device = set != 0;
+    if (current) *current = S.shared_device ? 1 : 0;
+    return 0;
+}
+
+int tnn_p2p_debug(int* words16) {
+    // the host mirror as it is: [0] 0 / which wait gave up, [1] value it expected, [2] last value it saw, [3] peer or
+    // workgroup, [4] wait-specific detail (flag row / slot parity)
+    TNN_REQUIRE(words16 != nullptr, "tnn_p2p_debug: words16 is NULL");
+    for (int i = 0; i < 16; ++i) words16[i] = S.open && S.host_dead ? ((volatile int*)S.host_dead)[i] : 0;
     return 0;
 }
 

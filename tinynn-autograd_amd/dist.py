@@ -123,6 +123,15 @@ class DeviceCommunicator(Communicator):
             raise
         self._p2p = True
         self.p2p_bytes = int(max_bytes)
+        # do ranks share a GPU (one-GPU test boxes: TNN_DEVICE=0 for every rank)?  The sharded multi-workgroup head is
+        # only used when every rank has a GPU of its own (tnn_p2p_shared_device)
+        if self.world > 1 and exchange is None:
+            import socket
+            dist = _control_plane()
+            ident = (socket.gethostname(), os.environ.get("TNN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            idents = [None] * self.world
+            dist.all_gather_object(idents, ident)
+            lib.p2p_shared_device(1 if len(set(idents)) < self.world else 0, None)
         return self
 
     def set_p2p(self, on):
@@ -133,7 +142,14 @@ class DeviceCommunicator(Communicator):
         """{'connected', 'enabled', 'dead'}; dead = a peer barrier timed out (synchronises the stream)."""
         c, e, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         _lib.get().p2p_status(ctypes.byref(c), ctypes.byref(e), ctypes.byref(d))
-        return {"connected": bool(c.value), "enabled": bool(e.value), "dead": bool(d.value)}
+        st = {"connected": bool(c.value), "enabled": bool(e.value), "dead": bool(d.value)}
+        if d.value:                  # which wait gave up: 1 collective flag barrier, 2 statistics exchange, 3 hand-over row
+            w = (ctypes.c_int * 16)()
+            _lib.get().p2p_debug(w)
+            st["dead_code"] = int(d.value)
+            st["first_timeout"] = {"wait": w[0], "expected": w[1] & 0xffffffff, "seen": w[2] & 0xffffffff, "peer_or_workgroup": w[3],
+                                   "detail": w[4]}
+        return st
 
     def p2p_failed(self):
         """True once a peer barrier has timed out — read from the host-pinned mirror of the device's sticky word, no
@@ -159,6 +175,7 @@ class DeviceCommunicator(Communicator):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 failed = bool(int(t.item()))
         if failed:
+            sys.stderr.write("[tinynn_autograd_amd] rank %d transport status at the failed check: %s\n" % (self.rank, self.p2p_status()))
             self.set_p2p(False)
             raise PeerTimeout("xGMI peer-to-peer barrier timed out on rank %d or a peer; collectives since then were "
                               "discarded (parameters untouched); the transport is now off on every rank%s"
