@@ -13,6 +13,7 @@
 // the three small GEMMs run on v_mfma_f32_16x16x4_f32 out of LDS, the softmax part is element-parallel.
 //   a  : [m, H]  H % 16 == 0 (rows padded to 16 in LDS with zeros)      W : [H, C], C <= 16 (padded to 16)
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "tnn_internal.h"
@@ -878,6 +879,11 @@ int head_bwd_launch(const char* fn, int64_t m_global, int64_t rows, int64_t n_in
     static const int cut = getenv("TNN_HBW_CUT") ? atoi(getenv("TNN_HBW_CUT")) : 0;        // timing builds
     hipStream_t st = tnn::stream();
     const tnn::p2p::LaunchCtx none = {};
+    if (getenv("TNN_HBW_OCCUPANCY")) {                  // probe: resident workgroups per CU the runtime computes for this kernel
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&mlp_head_bwd_kernel<128, 10, 0, false>), 512, 0);
+        fprintf(stderr, "mlp_head_bwd_kernel: %d workgroups of 512 threads per CU, grid %d\n", nb, grid);
+    }
     if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q, none);
     else if (cut == 2) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 2>), grid, 512, 0, st, p, q, none);
     else if (cut == 3) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 3>), grid, 512, 0, st, p, q, none);
