@@ -352,7 +352,7 @@ TNN_API int tnn_adam_tick(void* pows_f64, double b1, double b2);
 /* One object = Dense/ReLU stack + whole-batch softmax NLL (loss_kind 0) or sum-of-squares/m
  * (loss_kind 1, the (err**2).sum()/m of test/test_autograd.py:119-121) + SGD (opt 0) / Adam (opt 1) /
  * Momentum, RMSProp, Adagrad, Adadelta (opt 2 + TNN_OPT_*; their hyper-parameters a, b travel in b1, b2),
- * i.e. the loop body of examples/mnist/run.py:79-83 as 5 launches (3-layer net, class head that fits tnn_mlp_head_fits; 7 otherwise) on device-resident state:
+ * i.e. the loop body of examples/mnist/run.py:79-83 as 4 launches (3-layer net, class head that fits tnn_mlp_head_fits; 7 otherwise) on device-resident state:
  * params | grads | m | v live in one flat arena each, ordered layer by layer, "w" then "b"
  * (core/layers.py:35, core/optimizer.py:14-15).
  * dtype TNN_BF16 (configs[4]): x, y, activations are bf16; the arenas stay fp32 (master weights, gradients,
