@@ -25,6 +25,8 @@ run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcA_fetch -o A -- python3
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcA_write -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
 run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcC_fetch -o C -- python3 bench.py --workload C --no-extras
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcC_write -o C -- python3 bench.py --workload C --no-extras
+run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcE_fetch -o E -- python3 bench.py --workload E --no-extras
+run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcE_write -o E -- python3 bench.py --workload E --no-extras
 run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcbf_sq -o bf -- python3 tools/gemm_bf16_sweep.py
 run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcg32_sq -o g32 -- python3 tools/gemm_pmc_driver.py
 
@@ -32,13 +34,14 @@ for d in ktA ktAstep ktC ktE; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_summary.py $db > $OUT/${d}_kernel_stats.txt 2>> $OUT/log.txt
 done
-for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcbf_sq pmcg32_sq; do
+for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcE_fetch pmcE_write pmcbf_sq pmcg32_sq; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_pmc.py $db > $OUT/${d}.txt 2>> $OUT/log.txt
 done
 fa=$(find $OUT/pmcA_fetch -name "*.db" | head -1); wa=$(find $OUT/pmcA_write -name "*.db" | head -1)
 fc=$(find $OUT/pmcC_fetch -name "*.db" | head -1); wc=$(find $OUT/pmcC_write -name "*.db" | head -1)
-python3 tools/traffic_from_pmc.py --round $R A:$fa:$wa C:$fc:$wc > $OUT/traffic.json 2>> $OUT/log.txt
+fe=$(find $OUT/pmcE_fetch -name "*.db" | head -1); we=$(find $OUT/pmcE_write -name "*.db" | head -1)
+python3 tools/traffic_from_pmc.py --round $R A:$fa:$wa C:$fc:$wc E:$fe:$we > $OUT/traffic.json 2>> $OUT/log.txt
 # the databases themselves are large: keep only the summaries in what gpurun merges back
 find $OUT -name "*.db" -size +20M -delete
 tail -5 $OUT/log.txt

@@ -6,13 +6,15 @@ wide coalesced stream at HALF its bytes on gfx950 (MI355X_MICROARCH.md, HBM / ro
   python tools/traffic_from_pmc.py --round r02 A:fetch.db:write.db C:fetch.db:write.db > profiles/r02_traffic.json
 The passes must profile a command that runs NOTHING but training steps (`bench.py --no-extras`): bytes per step =
 sum over kernels of (average bytes per launch x launches per step), launches per step = launches / launches of the
-kernel that runs exactly once per step (the optimizer-carrying one)."""
+kernel that runs exactly once per step (ONCE_PER_STEP)."""
 import json
 import re
 import sqlite3
 import sys
 
-ONCE_PER_STEP = ("dense_bwd0_adam_kernel", "adam_kernel<", "adam_master_bf16_2d_kernel<true")
+# kernels that run exactly once per training step: the optimizer-carrying first-layer backward (config A), the loss kernels
+# (configs C / E)
+ONCE_PER_STEP = ("dense_bwd0_adam_kernel", "mse_fwd_bwd_kernel", "mse_bf16_kernel")
 
 
 def per_kernel(path, counter):
