@@ -958,6 +958,47 @@ def trainer_with_other_optimizers_matches_op_level_model():
         np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=5e-5 * np.abs(flat).max(), err_msg=name)
 
 
+def trainer_step_forms_agree_with_the_op_level_model():
+    """Every launch structure tnn_mlp_step can take for a softmax-NLL / Adam MLP with a 128-unit hidden layer in front of
+    10 classes, against the op-level Model (Tensor / ops / Adam, itself pinned to the reference): same losses over three
+    steps, same parameters at the end — full (128-row) and ragged (37-row) batches.
+      [40, 128, 10]          2 layers: forward + partial logits | head | first-layer backward + Adam   (no hidden backward to merge)
+      [30, 48, 128, 10]      the 4-launch step of the MNIST net with a 48-wide first layer
+      [30, 64, 32, 128, 10]  4 layers: two more launches around the merged one
+      [30, 20, 128, 10]      hidden input width not a multiple of 16: head and hidden backward stay separate launches
+      [30, 48, 64, 10]       a head the one-launch form does not take (64 hidden units): the 7-launch step"""
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.optimizer import Adam
+    rs = np.random.RandomState(12)
+    for widths in ([40, 128, 10], [30, 48, 128, 10], [30, 64, 32, 128, 10], [30, 20, 128, 10], [30, 48, 64, 10]):
+        for rows in (128, 37):
+            cfg = dict(widths=widths, seed=5, opt="adam", lr=1e-3, loss="softmax_nll")
+            data = [(rs.rand(rows, widths[0]).astype(np.float32),
+                     np.eye(10, dtype=np.float32)[rs.randint(0, 10, rows)]) for _ in range(3)]
+            ref_model, _ = H.build_model(cfg)
+            loss_layer = SoftmaxCrossEntropyLoss()
+            model = Model(net=ref_model.net, loss=loss_layer, optimizer=Adam(lr=1e-3))
+            trainer = trainer_from_net(ref_model.net, max_rows=rows, loss="softmax_nll", optimizer="adam", lr=1e-3)
+            tag = "%s rows=%d" % (widths, rows)
+            for step, (x, y) in enumerate(data):
+                model.zero_grad()
+                out = loss_layer.loss(model.forward(Tensor(x)), Tensor(y))
+                out.backward()
+                grads = [[np.asarray(layer.params[k].grad).copy() for k in ("w", "b")] for layer in H.dense_layers(model)]
+                model.step()
+                tl = float(trainer.step(tn.asarray(x), tn.asarray(y)))
+                np.testing.assert_allclose(tl, float(out.values), rtol=2e-5, err_msg=tag)
+                if step == 0:                      # same parameters on both sides: the gradients are comparable to 1e-5
+                    for l in range(len(grads)):
+                        for j, k in enumerate(("w", "b")):
+                            g = grads[l][j]
+                            np.testing.assert_allclose(np.asarray(trainer.grad_view(l, k)).reshape(g.shape), g, rtol=0,
+                                                       atol=2e-5 * max(np.abs(g).max(), 1e-6), err_msg="%s grad %d%s" % (tag, l, k))
+            flat = np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
+            np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
+
+
 def trainer_checkpoint_resume_is_bit_exact():
     """Train 3 steps, checkpoint (params + Adam state + beta powers), train 3 more; a fresh trainer restored from the
     checkpoint must produce exactly the same 3 losses and parameters."""
