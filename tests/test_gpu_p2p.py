@@ -126,6 +126,7 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     check, and exactly ONE JSON line on stdout from rank 0."""
     import json
     env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TNN_BENCH_FORM_CHECK_ROWS="64",         # the pre-timing 5-launch vs 8-launch comparison, at a size that fits one GPU
                PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "128",
@@ -144,6 +145,11 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     p2p = coll["xgmi_p2p"]
     assert p2p["replicas_identical"] and p2p["verified_after_run"] and not p2p["barrier_timed_out"] and p2p["graph_captured"]
     assert d["value"] == p2p["value"] > 0
+    # before anything was timed the 5-launch sharded step (exchange inside the multi-workgroup head) was compared with the
+    # 8-launch form on this transport (at 64 rows per rank: both ranks' launches fit the one GPU); the timed runs then
+    # stay on the 8-launch form because the ranks share a GPU
+    form = coll["sharded_step_form"]
+    assert form["five_launch_vs_eight_launch_losses_agree"] and form["rows_per_rank"] == 64 and "share" in form["form_used"]
     # the sharded step on this transport reproduces the REFERENCE's bs-1024 losses (traj_D_adam, all 5 steps)
     chk = d["parity_vs_reference_fixture"]
     assert chk["ok"] and chk["steps"] == 5 and "traj_D_adam" in chk["fixture"] and chk["max_rel_err"] <= 1e-5
