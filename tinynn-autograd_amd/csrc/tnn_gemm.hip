@@ -1417,8 +1417,13 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
         const int extra = ad.fn > 0 ? (int)std::min<int64_t>((ad.fn + W * 64 - 1) / (W * 64), 64) : 0;      \
         hipLaunchKernelGGL((dense_bwd0_adam_kernel<W>), n_dw + extra, W * 64, 0, s, gw, (float*)db, ad, n_dw); \
     } while (0)
-            if (nchunks <= 16) TNN_BWD0(4);
-            else if (nchunks <= 48) TNN_BWD0(8);
+            // measured at bs 128 (8 chunks): 4 waves with two chunks each 21.5 us/step, 8 waves with one chunk each 22.2, 16
+            // waves 23.7 — the launch's 784 workgroups cost more per wave than the second load round trip saves
+            // (TNN_BWD0_WAVES overrides for measurements)
+            static const int waves_env = getenv("TNN_BWD0_WAVES") ? atoi(getenv("TNN_BWD0_WAVES")) : 0;
+            const int waves = waves_env ? waves_env : (nchunks <= 16 ? 4 : nchunks <= 48 ? 8 : 16);
+            if (waves == 4) TNN_BWD0(4);
+            else if (waves == 8) TNN_BWD0(8);
             else TNN_BWD0(16);
 #undef TNN_BWD0
             TNN_LAUNCH_OK();
