@@ -857,7 +857,7 @@ int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t 
                                void* stats_out, void* loss_out, void* dz, int dtype, void* pows, double b1, double b2) {
     NEED_INIT();
     REQ(m_global == m, "cpu twin: one-rank group only");
-    REQ(m * c <= (dtype == TNN_F32 ? 4096 : 2048) && m <= 1024, "tnn_softmax_nll_fused_tick: does not fit one workgroup");
+    REQ(((c <= 16) || m * c <= (dtype == TNN_F32 ? 4096 : 2048)) && m <= 1024, "tnn_softmax_nll_fused_tick: does not fit one workgroup");
     RECORD(tnn_softmax_nll_fused_tick(z, y, m, c, m_global, sharded, stats_out, loss_out, dz, dtype, pows, b1, b2));
     if (pows) { ((double*)pows)[0] *= b1; ((double*)pows)[1] *= b2; }
     return tnn_softmax_nll_fused(z, y, m, c, stats_out, loss_out, dz, dtype);

@@ -619,7 +619,10 @@ int tnn_softmax_nll_fused(const void* z, const void* y, int64_t m, int64_t c, vo
     TNN_NEED_INIT();
     TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fused: dtype %d", dtype);
     TNN_REQUIRE(m > 0 && c > 0, "tnn_softmax_nll_fused: empty batch");
-    if (m * c > (dtype == TNN_F32 ? NllCap<float>::elems : NllCap<double>::elems) || m > kNllMaxRows) {   // too big for one block: the multi-block sequence
+    // classifier heads (c <= 16) take the one-thread-per-row kernel up to 1024 rows whatever m * c is; everything else must
+    // fit the LDS image of the element-parallel kernel
+    const bool rows_form = c <= 16 && m <= kNllMaxRows;
+    if (!rows_form && (m * c > (dtype == TNN_F32 ? NllCap<float>::elems : NllCap<double>::elems) || m > kNllMaxRows)) {   // too big for one block: the multi-block sequence
         void* st = stats_out;
         void* tmp = nullptr;
         if (!st) {
@@ -645,7 +648,8 @@ int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t 
     TNN_NEED_INIT();
     TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_softmax_nll_fused_tick: dtype %d", dtype);
     TNN_REQUIRE(m > 0 && c > 0, "tnn_softmax_nll_fused_tick: empty batch");
-    TNN_REQUIRE(m * c <= (dtype == TNN_F32 ? NllCap<float>::elems : NllCap<double>::elems) && m <= kNllMaxRows,
+    TNN_REQUIRE((c <= 16 && m <= kNllMaxRows) ||
+                    (m * c <= (dtype == TNN_F32 ? NllCap<float>::elems : NllCap<double>::elems) && m <= kNllMaxRows),
                 "tnn_softmax_nll_fused_tick: %lld x %lld does not fit one workgroup", (long long)m, (long long)c);
     double* tick = (double*)adam_pows_f64;
     // classifier heads: one thread per row, one block reduction (nll_rows_kernel)

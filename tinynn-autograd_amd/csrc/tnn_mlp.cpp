@@ -208,7 +208,10 @@ int mlp16_update(Mlp* h) {
 
 // limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
 bool head_fits_one_workgroup(const Mlp* h, int64_t rows) {
-    return !h->bf16 && h->loss_kind == 0 && rows <= 1024 && rows * h->w[h->L] <= (h->dtype == TNN_F32 ? 4096 : 2048);
+    // classifier heads (<= 16 classes): the one-thread-per-row kernel, up to 1024 rows; wider heads: the LDS image of the
+    // element-parallel kernel (tnn_softmax_nll_fused_tick)
+    return !h->bf16 && h->loss_kind == 0 && rows <= 1024 &&
+           (h->w[h->L] <= 16 || rows * h->w[h->L] <= (h->dtype == TNN_F32 ? 4096 : 2048));
 }
 
 // Adam on ONE layer's parameters (W_l and b_l are contiguous in the arenas).  advance: first call of the step
