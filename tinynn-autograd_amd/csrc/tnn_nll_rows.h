@@ -40,14 +40,43 @@ __device__ __forceinline__ void nll_rows_body(const T* __restrict__ z, const T* 
     T e[CMAX], ey[CMAX];
     double mi = -INFINITY, si = 0.0, li = 0.0, ui = 1.0;
     const bool live = tid < m;
+    // f32 batches above 128 rows: z and y are flat [m][c] arrays, so the workgroup first copies them into LDS with coalesced
+    // 16-B loads (5 per thread at 1024 x 10) and every thread then picks its row there.  Row-wise from global memory each
+    // load instruction of a wave touches ~20 cache lines, and this kernel is ONE workgroup on ONE CU: at 1024 rows the
+    // 20 x 16 wave-loads were most of its 11.4 us.
+    constexpr bool kStage = sizeof(T) == 4 && !COH;
+    constexpr int kStageElems = kStage ? 1024 * 10 : 4;
+    __shared__ __attribute__((aligned(16))) float zst[kStageElems], yst[kStageElems];
+    bool staged = false;
+    if constexpr (kStage) {
+        const int n = m * c;
+        staged = m > 128 && n <= kStageElems && (n & 3) == 0 &&
+                 ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;      // block-uniform
+        if (staged) {
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            for (int i = tid; i < (n >> 2); i += blockDim.x) {
+                *reinterpret_cast<f32x4_t*>(zst + 4 * i) = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(z) + 4 * i);
+                *reinterpret_cast<f32x4_t*>(yst + 4 * i) = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(y) + 4 * i);
+            }
+            __syncthreads();
+        }
+    }
     if (live) {
         T zr[CMAX], yr[CMAX];
+        if (staged) {
 #pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            zr[k] = k < c ? (COH ? __hip_atomic_load(z + (int64_t)tid * c + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : z[(int64_t)tid * c + k])
-                          : (T)-INFINITY;
-            yr[k] = k < c ? y[(int64_t)tid * c + k] : (T)0;
+            for (int k = 0; k < CMAX; ++k) {
+                zr[k] = k < c ? (T)zst[tid * c + k] : (T)-INFINITY;
+                yr[k] = k < c ? (T)yst[tid * c + k] : (T)0;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) {
+                zr[k] = k < c ? (COH ? __hip_atomic_load(z + (int64_t)tid * c + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : z[(int64_t)tid * c + k])
+                              : (T)-INFINITY;
+                yr[k] = k < c ? y[(int64_t)tid * c + k] : (T)0;
+            }
         }
         T mx = zr[0];
 #pragma unroll
@@ -64,18 +93,29 @@ __device__ __forceinline__ void nll_rows_body(const T* __restrict__ z, const T* 
         mi = (double)mx; si = s; ui = u;
         li = nll_log((T)u) + (double)mx;
     }
-    // one combined reduction: waves first (shuffles), then <= 16 wave triples through LDS
-    double wm = wave_max(mi);
-    double ws = wave_sum(live ? si * nll_exp((T)(mi - wm)) : 0.0);
-    double wl = wave_sum(li);
+    // one combined reduction: waves first (DPP steps — a 64-bit shuffle tree costs ~700 cycles, three of them per wave and
+    // up to 16 waves sharing one CU here), then <= 16 wave triples through LDS.  All 64 lanes of every wave are active (the
+    // kernel is launched with whole waves; rows beyond m carry the identities).
+    double wm = wave_max_dpp(mi);
+    double ws = wave_sum_dpp(live ? si * nll_exp((T)(mi - wm)) : 0.0);
+    double wl = wave_sum_dpp(li);
     if (lane == 0) { wave_m[wid] = wm; wave_s[wid] = ws; wave_l[wid] = wl; }
     __syncthreads();
-    double M = -INFINITY, S = 0.0, L = 0.0;
-    for (int w = 0; w < nw; ++w) M = fmax(M, wave_m[w]);
-    for (int w = 0; w < nw; ++w) {
-        if (wave_m[w] > -INFINITY) S += wave_s[w] * nll_exp((T)(wave_m[w] - M));
-        L += wave_l[w];
-    }
+    // every lane takes wave entry (lane & 15) and a 16-lane DPP butterfly leaves M, S, L in ALL lanes: one exp per lane instead
+    // of a serial loop over up to 16 entries in every thread (1.4 us of the 1024-row kernel)
+    const int w16 = lane & 15;
+    const bool have = w16 < nw;
+    const double rm = have ? wave_m[w16] : -INFINITY, rs = have ? wave_s[w16] : 0.0, rl = have ? wave_l[w16] : 0.0;
+    double M = rm, q;
+    q = dpp_move<0xB1, 0xf>((double)-INFINITY, M); M = fmax(M, q);
+    q = dpp_move<0x4E, 0xf>((double)-INFINITY, M); M = fmax(M, q);
+    q = dpp_move<0x141, 0xf>((double)-INFINITY, M); M = fmax(M, q);
+    q = dpp_move<0x140, 0xf>((double)-INFINITY, M); M = fmax(M, q);
+    double S = rm > -INFINITY ? rs * nll_exp((T)(rm - M)) : 0.0, L = rl;
+    S += dpp_move<0xB1, 0xf>(0.0, S); L += dpp_move<0xB1, 0xf>(0.0, L);
+    S += dpp_move<0x4E, 0xf>(0.0, S); L += dpp_move<0x4E, 0xf>(0.0, L);
+    S += dpp_move<0x141, 0xf>(0.0, S); L += dpp_move<0x141, 0xf>(0.0, L);
+    S += dpp_move<0x140, 0xf>(0.0, S); L += dpp_move<0x140, 0xf>(0.0, L);
     double inv_m = 1.0 / (double)m;
     double loss;
     if constexpr (SHARDED) {
@@ -98,7 +138,21 @@ __device__ __forceinline__ void nll_rows_body(const T* __restrict__ z, const T* 
     } else {
         loss = nll_log((T)S) + M - L * inv_m;
     }
-    if (live && dz) {
+    if constexpr (kStage) {
+        if (staged && dz) {                   // block-uniform: dz leaves the way z came in — through LDS, coalesced 16-B stores
+            if (live) {
+                const float sf = (float)(nll_exp((T)(mi - M)) / S), uf = (float)(inv_m / ui);
+#pragma unroll
+                for (int k = 0; k < CMAX; ++k)
+                    if (k < c) zst[tid * c + k] = (float)e[k] * sf - (float)ey[k] * uf;
+            }
+            __syncthreads();
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            for (int i = tid; i < ((m * c) >> 2); i += blockDim.x)
+                *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(dz) + 4 * i) = *reinterpret_cast<const f32x4_t*>(zst + 4 * i);
+        }
+    }
+    if (live && dz && !staged) {
         const double scale = nll_exp((T)(mi - M)) / S, inv_u = inv_m / ui;
         if (sizeof(T) == 4) {
             const float sf = (float)scale, uf = (float)inv_u;
