@@ -430,7 +430,8 @@ def gemm_shapes_and_transposes():
     rs = np.random.RandomState(11)
     shapes = [(128, 256, 784), (80, 10, 128), (128, 10, 128), (33, 17, 5), (1, 1, 1), (64, 64, 32),
               (130, 70, 100), (256, 128, 1), (7, 300, 9), (200, 129, 257),
-              (50, 30, 36), (17, 40, 20), (128, 256, 52), (16, 16, 1040)]      # K % 4 == 0 with ragged last chunk / tiles
+              (50, 30, 36), (17, 40, 20), (128, 256, 52), (16, 16, 1040),      # K % 4 == 0 with ragged last chunk / tiles
+              (1024, 256, 784), (512, 256, 788), (300, 520, 1000), (784, 256, 1020)]   # the mid-size (32 x 32 tile) kernel
     for (M, N, K) in shapes:
         a = rs.randn(M, K).astype(np.float32)
         b = rs.randn(K, N).astype(np.float32)
@@ -453,6 +454,61 @@ def gemm_shapes_and_transposes():
     a = rs.randn(37, 19); b = rs.randn(19, 23)
     np.testing.assert_allclose(np.asarray(tn.asarray(a) @ tn.asarray(b)), a @ b, rtol=1e-13, atol=1e-13)
     np.testing.assert_allclose(np.asarray(tn.asarray(a).T @ tn.asarray(a)), a.T @ a, rtol=1e-13, atol=1e-13)
+
+
+def mid_size_gemm_epilogues_vs_numpy():
+    """The 32 x 32-tile latency kernel (bs-512 / bs-1024 MNIST layers) with every epilogue it carries, against float64 numpy:
+    bias + ReLU with the mask in the sign bit (forward), x mask (dX), dW + column sums, and dW with Adam folded in
+    (tnn_dense_bwd_first_adam at 512 rows, extra flat range included)."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(31)
+    rows, n_in, n_out = 512, 784, 256
+    x = rs.rand(rows, n_in).astype(np.float32)
+    w = (rs.randn(n_in, n_out) * 0.05).astype(np.float32)
+    b = rs.randn(n_out).astype(np.float32)
+    X, W, B = tn.asarray(x), tn.asarray(w), tn.asarray(b)
+    out = tn.empty((rows, n_out))
+    lib.gemm_bias_act(0, 0, rows, n_out, n_in, X._ptr, n_in, W._ptr, n_out, B._ptr, _lib.ACT_RELU, 1, out._ptr, n_out, _lib.F32)
+    z = x.astype(np.float64) @ w.astype(np.float64) + b
+    got = np.asarray(out)
+    bound = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64) + np.abs(b)
+    assert (np.abs(np.abs(got) - np.maximum(z, 0)) <= 2e-6 * bound).all()
+    clearly = np.abs(z) > 4e-6 * bound
+    assert (np.signbit(got)[clearly] == (z < 0)[clearly]).all()                          # the ReLU mask rides in the sign bit
+    # dX = (dz W^T) * mask : M = rows, N = n_in, K = n_out
+    dz = (rs.randn(rows, n_out) * 0.1).astype(np.float32)
+    msk = np.where(rs.rand(rows, n_in) < 0.4, np.float32(-0.0), np.float32(1.0)).astype(np.float32)
+    DZ, MK = tn.asarray(dz), tn.asarray(msk)
+    dx = tn.empty((rows, n_in))
+    lib.gemm_mask(0, 1, rows, n_in, n_out, DZ._ptr, n_out, W._ptr, n_out, MK._ptr, n_in, dx._ptr, n_in, _lib.F32)
+    ref = (dz.astype(np.float64) @ w.astype(np.float64).T) * ~np.signbit(msk)
+    np.testing.assert_allclose(np.asarray(dx), ref, rtol=0, atol=1e-5 * np.abs(ref).max())
+    # dW + db, then the same with Adam folded in
+    dw, db = tn.empty((n_in, n_out)), tn.empty((n_out,))
+    lib.gemm_tn_colsum(n_in, n_out, rows, X._ptr, n_in, DZ._ptr, n_out, dw._ptr, n_out, db._ptr, _lib.F32)
+    ref_dw, ref_db = x.astype(np.float64).T @ dz.astype(np.float64), dz.astype(np.float64).sum(0)
+    np.testing.assert_allclose(np.asarray(dw), ref_dw, rtol=0, atol=1e-5 * np.abs(ref_dw).max())
+    np.testing.assert_allclose(np.asarray(db), ref_db, rtol=0, atol=1e-5 * np.abs(ref_db).max())
+    nf = 1000
+    pw, pb, pf = tn.asarray(w), tn.asarray(b), tn.asarray(rs.randn(nf).astype(np.float32))
+    gf = tn.asarray((rs.randn(nf) * 0.1).astype(np.float32))
+    zeros = lambda *sh: tn.zeros(sh)                                                     # noqa: E731
+    mw, vw, mb, vb, mf, vf = zeros(n_in, n_out), zeros(n_in, n_out), zeros(n_out), zeros(n_out), zeros(nf), zeros(nf)
+    pows = tn.asarray(np.array([0.9, 0.999, 0, 0]), dtype=np.float64)
+    dw2, db2 = tn.empty((n_in, n_out)), tn.empty((n_out,))
+    lib.dense_bwd_first_adam(rows, n_in, n_out, X._ptr, DZ._ptr, dw2._ptr, db2._ptr, pw._ptr, mw._ptr, vw._ptr, pb._ptr, mb._ptr,
+                             vb._ptr, pf._ptr, gf._ptr, mf._ptr, vf._ptr, nf, 1e-3, 0.9, 0.999, 1e-8, pows._ptr, _lib.F32)
+    assert np.array_equal(np.asarray(dw2), np.asarray(dw)) and np.array_equal(np.asarray(db2), np.asarray(db))
+    def adam1(p, g):                                                                      # first step from zero moments
+        g = g.astype(np.float64)
+        m, v = 0.1 * g, 0.001 * g * g
+        return p - 1e-3 * (m / 0.1) / (np.sqrt(v / 0.001) + 1e-8)
+    for got_p, p0, g0 in ((pw, w, np.asarray(dw)), (pb, b, np.asarray(db)), (pf, None, None)):
+        if p0 is None:
+            continue
+        np.testing.assert_allclose(np.asarray(got_p), adam1(p0.astype(np.float64), g0), rtol=0, atol=2e-6)
+    assert np.abs(np.asarray(pf)).max() > 0 and np.abs(np.asarray(mf)).max() > 0          # the flat range was updated too
 
 
 def gemm_linearity_property():

@@ -1061,6 +1061,211 @@ int gemm_small(GemmArgs& g, int transA, int transB, float* colsum) {
     return launch_small<16>(g, transA, transB, colsum);
 }
 
+// ------------------------------------------------------------------------------ mid-size latency GEMM
+// Between the 16 x 16 latency kernel above (MNIST layers at 128-256 rows) and the LDS-tiled kernel (>= 256 tiles of 128 x 64):
+// the bs-512 / bs-1024 MNIST step has products of 200-400 MFLOP (1024 x 256 x 784) that are 1024 tiles x 16 waves for the
+// former (14.8 us) and 32-64 tiles + split-K + a reduce launch for the latter.  Same idea as small_tile_fast with a
+// 32 x 32 tile on v_mfma_f32_32x32x2_f32: one workgroup of 8 waves per output tile, the waves split K in 8-deep chunks
+// (4 MFMAs), fragments come straight from global memory through buffer loads (out-of-range -> 0, no exec-mask branches),
+// up to 4 chunks of loads in flight per wave, partial tiles meet in LDS, coalesced epilogue.  Within an 8-deep chunk the
+// lane group g = lane / 32 owns k = 4 g .. 4 g + 3 and MFMA s contracts element s of both groups — a permutation of the
+// contraction index that lets K-contiguous operands arrive as ONE 16-B load per lane and chunk.
+template <bool AKC, bool BKC, bool ADAM>
+__global__ __launch_bounds__(512) void gemm_mid_f32_kernel(GemmArgs g, float* __restrict__ colsum, AdamEpi ad, int n_tiles) {
+    constexpr int WAVES = 8, MAXC = 4;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr uint32_t OOB = 0xffffffffu;
+    if constexpr (ADAM) {
+        if ((int)blockIdx.x >= n_tiles) {               // trailing workgroups: Adam over the other layers' flat range
+            const float ic1 = (float)(1.0 / (1.0 - ad.pows[0])), ic2 = (float)(1.0 / (1.0 - ad.pows[1]));
+            const int64_t nth = (int64_t)(gridDim.x - n_tiles) * blockDim.x;
+            for (int64_t i = (int64_t)(blockIdx.x - n_tiles) * blockDim.x + threadIdx.x; i < ad.fn; i += nth) {
+                float m = ad.fm[i], v = ad.fv[i];
+                ad.fp[i] = adam_apply(ad, ic1, ic2, ad.fg[i], m, v, ad.fp[i]);
+                ad.fm[i] = m;
+                ad.fv[i] = v;
+            }
+            return;
+        }
+    }
+    __shared__ float red[WAVES][16][64];
+    __shared__ float bsum[WAVES][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int block = (int)blockIdx.x;
+    int tm, tn;
+    if (g.xg_m) {
+        const int xcd = block & 7, idx = block >> 3, pm = g.tiles_m / g.xg_m, pn = g.tiles_n / g.xg_n;
+        tm = (xcd % g.xg_m) * pm + idx % pm;
+        tn = (xcd / g.xg_m) * pn + idx / pm;
+    } else {
+        tm = block % g.tiles_m;
+        tn = block / g.tiles_m;
+    }
+    const int64_t m0 = (int64_t)tm * 32, n0 = (int64_t)tn * 32;
+    const int64_t am = m0 + l31, bn = n0 + l31;
+    const bool a_ok = am < g.M, b_ok = bn < g.N;
+    const uint32_t K = (uint32_t)g.K, lda4 = (uint32_t)g.lda * 4u, ldb4 = (uint32_t)g.ldb * 4u;
+    const int nch = (int)((g.K + 7) / 8);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A), 0, (uint32_t)(((AKC ? g.M : g.K) - 1) * g.lda + (AKC ? g.K : g.M)) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.B), 0, (uint32_t)(((BKC ? g.N : g.K) - 1) * g.ldb + (BKC ? g.K : g.N)) * 4u, 0x00020000);
+    const uint32_t a_lane = AKC ? (uint32_t)am * lda4 + (uint32_t)lhi * 16u : (uint32_t)lhi * 4u * lda4 + (uint32_t)am * 4u;
+    const uint32_t b_lane = BKC ? (uint32_t)bn * ldb4 + (uint32_t)lhi * 16u : (uint32_t)lhi * 4u * ldb4 + (uint32_t)bn * 4u;
+    const uint32_t a_chunk = AKC ? 32u : 8u * lda4, b_chunk = BKC ? 32u : 8u * ldb4;
+
+    // epilogue: thread (lane, r0 = tid / 64) finishes accumulator registers r0 and r0 + 8 of every lane slot
+    int64_t e_row[2], e_col;
+    bool e_live[2];
+    float e_pre[2] = {0.f, 0.f}, a_p[2] = {0.f, 0.f}, a_m[2] = {0.f, 0.f}, a_v[2] = {0.f, 0.f};
+    e_col = n0 + l31;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rr = (tid >> 6) + 8 * u;
+        e_row[u] = m0 + (rr & 3) + 8 * (rr >> 2) + 4 * lhi;
+        e_live[u] = e_row[u] < g.M && e_col < g.N;
+        if (e_live[u]) {
+            const int64_t o = e_row[u] * g.ldc + e_col;
+            if (g.epi == EPI_BIAS_ACT) e_pre[u] = g.bias ? g.bias[e_col] : 0.f;
+            else if (g.epi == EPI_MASK) e_pre[u] = g.Y[e_row[u] * g.ldy + e_col];
+            else if (g.beta != 0.f) e_pre[u] = g.C[o];
+            if constexpr (ADAM) { a_p[u] = ad.pw[o]; a_m[u] = ad.mw[o]; a_v[u] = ad.vw[o]; }
+        }
+    }
+    float ab_p = 0.f, ab_m = 0.f, ab_v = 0.f, ic1 = 0.f, ic2 = 0.f;
+    if constexpr (ADAM) {
+        ic1 = (float)(1.0 / (1.0 - ad.pows[0]));
+        ic2 = (float)(1.0 / (1.0 - ad.pows[1]));
+        if (tm == 0 && tid < 32 && n0 + tid < g.N) { ab_p = ad.pb[n0 + tid]; ab_m = ad.mb[n0 + tid]; ab_v = ad.vb[n0 + tid]; }
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bs = 0.f;
+    for (int c0 = wid; c0 < nch; c0 += WAVES * MAXC) {
+        float a[MAXC][4], b[MAXC][4];
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            const uint32_t c = (uint32_t)(c0 + u * WAVES);
+            const uint32_t k = c * 8u + (uint32_t)lhi * 4u;
+            if ((int)c >= nch) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[u][j] = 0.f; b[u][j] = 0.f; }
+                continue;
+            }
+            if constexpr (AKC) {
+                const uint32_t off = (a_ok && k < K) ? a_lane + c * a_chunk : OOB;            // K % 4 == 0: all in or all out
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, off, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[u][j] = __uint_as_float(v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t off = (a_ok && k + j < K) ? a_lane + c * a_chunk + (uint32_t)j * lda4 : OOB;
+                    a[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(a_rsrc, off, 0, 0));
+                }
+            }
+            if constexpr (BKC) {
+                const uint32_t off = (b_ok && k < K) ? b_lane + c * b_chunk : OOB;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, off, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[u][j] = __uint_as_float(v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t off = (b_ok && k + j < K) ? b_lane + c * b_chunk + (uint32_t)j * ldb4 : OOB;
+                    b[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rsrc, off, 0, 0));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], b[u][j], acc, 0, 0, 0);
+            bs += (b[u][0] + b[u][1]) + (b[u][2] + b[u][3]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[r];
+    bsum[wid][lane] = bs;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int rr = (tid >> 6) + 8 * u;
+        float sres = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sres += red[w][rr][lane];
+        if (e_live[u]) {
+            const float val = finish_epilogue(g, sres, e_pre[u]);
+            const int64_t o = e_row[u] * g.ldc + e_col;
+            g.C[o] = val;
+            if constexpr (ADAM) {
+                ad.pw[o] = adam_apply(ad, ic1, ic2, val, a_m[u], a_v[u], a_p[u]);
+                ad.mw[o] = a_m[u];
+                ad.vw[o] = a_v[u];
+            }
+        }
+    }
+    if (colsum != nullptr && tm == 0 && tid < 32 && n0 + tid < g.N) {
+        float sres = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sres += bsum[w][tid] + bsum[w][32 + tid];
+        colsum[n0 + tid] = sres;
+        if constexpr (ADAM) {
+            ad.pb[n0 + tid] = adam_apply(ad, ic1, ic2, sres, ab_m, ab_v, ab_p);
+            ad.mb[n0 + tid] = ab_m;
+            ad.vb[n0 + tid] = ab_v;
+        }
+    }
+}
+
+// the mid-size kernel takes 16-B loads on its K-contiguous operands: alignment, ld % 4 == 0, K % 4 == 0, extents below 2 GiB
+bool mid_ok(const GemmArgs& g, int transA, int transB) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool akc = !transA, bkc = transB != 0;
+    if (akc && !(al(g.A) && g.lda % 4 == 0 && g.K % 4 == 0)) return false;
+    if (bkc && !(al(g.B) && g.ldb % 4 == 0 && g.K % 4 == 0)) return false;
+    const int64_t a_bytes = ((akc ? g.M : g.K) * g.lda) * 4, b_bytes = ((bkc ? g.N : g.K) * g.ldb) * 4;
+    return a_bytes < (int64_t(1) << 31) && b_bytes < (int64_t(1) << 31);
+}
+
+// products the 16 x 16 kernel would take but that are big enough for 32 x 32 tiles to pay: >= 150 MFLOP and >= 192 tiles
+// (measured on the MNIST step: 1024 x 256 x 784 forward 14.8 -> 8.5 us in 256 tiles, 784 x 256 x 1024 / x 512 weight gradient
+// with Adam 17.4 -> 10.9 / 10.4 -> 7.2 us in 200 tiles; the 512-row forward in 128 tiles was no faster: 8.4 vs 8.0 us)
+bool use_mid_path(const GemmArgs& g, int transA, int transB) {
+    static const int mode = getenv("TNN_GEMM_MID") ? atoi(getenv("TNN_GEMM_MID")) : 1;
+    if (!mode) return false;
+    const double flop = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    const int64_t tiles = ((g.M + 31) / 32) * ((g.N + 31) / 32);
+    return flop >= 1.5e8 && tiles >= 192 && mid_ok(g, transA, transB);
+}
+
+void mid_geometry(GemmArgs& g) {
+    g.tiles_m = (int)((g.M + 31) / 32);
+    g.tiles_n = (int)((g.N + 31) / 32);
+    g.splits = 1;
+    g.ws = nullptr;
+    pick_xcd_cut(g);
+}
+
+int gemm_mid(GemmArgs& g, int transA, int transB, float* colsum) {
+    mid_geometry(g);
+    const int tiles = g.tiles_m * g.tiles_n;
+    hipStream_t s = tnn::stream();
+    AdamEpi none = {};
+#define TNN_MID(AKC, BKC) hipLaunchKernelGGL((gemm_mid_f32_kernel<AKC, BKC, false>), tiles, 512, 0, s, g, colsum, none, tiles)
+    if (!transA && !transB) TNN_MID(true, false);
+    else if (!transA && transB) TNN_MID(true, true);
+    else if (transA && !transB) TNN_MID(false, false);
+    else TNN_MID(false, true);
+#undef TNN_MID
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------ f64 (exact mode)
 // Plain LDS-tiled VALU kernel, 64x64 tile, 4x4 micro-tile per thread; not on the measured path.
 struct GemmArgsD {
@@ -1180,7 +1385,8 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     const int64_t a_bytes = (transA ? g.K : g.M) * g.lda * 4, b_bytes = (transB ? g.N : g.K) * g.ldb * 4;
     g.vecA = al(g.A) && g.lda % 4 == 0 && ((transA ? g.M : g.K) % 4 == 0) && a_bytes < (int64_t(1) << 32);
     g.vecB = al(g.B) && g.ldb % 4 == 0 && ((transB ? g.K : g.N) % 4 == 0) && b_bytes < (int64_t(1) << 32);
-    if (use_small_path(g)) return gemm_small(g, transA, transB, colsum);
+    if (use_small_path(g)) return use_mid_path(g, transA, transB) ? gemm_mid(g, transA, transB, colsum)
+                                                                    : gemm_small(g, transA, transB, colsum);
     if (colsum != nullptr) {   // large shapes: the column sum is a separate (HBM-bound, <1 % of the time) pass
         if (int rc = tnn_reduce(TNN_RSUM, g.B, colsum, 1, g.K, g.N, TNN_F32)) return rc;
     }
@@ -1404,9 +1610,11 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
         gw.M = n_in; gw.N = n_out; gw.K = rows; gw.lda = n_in; gw.ldb = n_out; gw.ldc = n_out;
         gw.alpha = 1.f; gw.beta = 0.f; gw.epi = EPI_AXPBY;
         if (use_small_path(gw)) {
-            gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1;
+            const bool mid = use_mid_path(gw, 1, 0);                 // bs >= 512: 32 x 32 tiles (gemm_mid_f32_kernel)
+            if (mid) mid_geometry(gw);
+            else { gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1; }
             const int n_dw = gw.tiles_m * gw.tiles_n;
-            pick_xcd_cut(gw);
+            if (!mid) pick_xcd_cut(gw);
             AdamEpi ad;
             ad.pw = (float*)p_w; ad.mw = (float*)m_w; ad.vw = (float*)v_w;
             ad.pb = (float*)p_b; ad.mb = (float*)m_b; ad.vb = (float*)v_b;
@@ -1416,6 +1624,12 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
             ad.pows = (const double*)pows_f64;
             const int nchunks = (int)((gw.K + 15) / 16);
             hipStream_t s = tnn::stream();
+            if (mid) {
+                const int extra = ad.fn > 0 ? (int)std::min<int64_t>((ad.fn + 511) / 512, 64) : 0;
+                hipLaunchKernelGGL((gemm_mid_f32_kernel<false, false, true>), n_dw + extra, 512, 0, s, gw, (float*)db, ad, n_dw);
+                TNN_LAUNCH_OK();
+                return 0;
+            }
 #define TNN_BWD0(W)                                                                                         \
     do {                                                                                                    \
         const int extra = ad.fn > 0 ? (int)std::min<int64_t>((ad.fn + W * 64 - 1) / (W * 64), 64) : 0;      \
