@@ -257,7 +257,8 @@ class Tensor(object):
         if self._grad is None and not self._grad_zero:
             raise TypeError("unsupported operand type(s) for +=: 'NoneType' and 'DeviceArray' "
                             "(the gradient was dropped by a value assignment; call zero_grad())")
-        g = da.asarray(g)
+        if not isinstance(g, da.DeviceArray):
+            g = da.asarray(g)
         self._home_lent = False                      # see ops.dense_: the arena view may be lent to a fused vjp
         if g.shape != self.shape or g.dtype != self._float_dtype() or g.is_host_scalar:
             if len(g.shape) > len(self.shape) or np.broadcast_shapes(g.shape, self.shape) != self.shape:
@@ -295,19 +296,22 @@ class Tensor(object):
                 order.append(node)
 
         pending = {id(self): seed}
+
+        def lendable(child):
+            """The child's arena view, if this is the first contribution of a lazily-zero, arena-backed leaf."""
+            home = getattr(child, "_grad_home", None)
+            if (home is not None and id(child) not in pending and not child.dependency
+                    and child._grad is None and child._grad_zero):
+                return home
+            return None
+
         for node in reversed(order):
             g = pending.pop(id(node), None)
             if g is None:
                 continue
             node._accumulate(g)
-
-            def lendable(child):
-                """The child's arena view, if this is the first contribution of a lazily-zero, arena-backed leaf."""
-                home = getattr(child, "_grad_home", None)
-                if (home is not None and id(child) not in pending and not child.dependency
-                        and child._grad is None and child._grad_zero):
-                    return home
-                return None
+            if not node.dependency:
+                continue
 
             # a node may offer ALL its edges from one launch (ops.dense_: dW + db + masked dX)
             contribs, fused = None, getattr(node, "_fused_vjp", None)

@@ -1240,7 +1240,8 @@ bool use_mid_path(const GemmArgs& g, int transA, int transB) {
     if (!mode) return false;
     const double flop = 2.0 * (double)g.M * (double)g.N * (double)g.K;
     const int64_t tiles = ((g.M + 31) / 32) * ((g.N + 31) / 32);
-    return flop >= 1.5e8 && tiles >= 192 && mid_ok(g, transA, transB);
+    static const double min_flop = getenv("TNN_GEMM_MID_FLOP") ? atof(getenv("TNN_GEMM_MID_FLOP")) : 1.5e8;
+    return flop >= min_flop && tiles >= 192 && mid_ok(g, transA, transB);
 }
 
 void mid_geometry(GemmArgs& g) {
