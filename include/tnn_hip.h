@@ -271,6 +271,23 @@ TNN_API int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_
                                           const void* y, const void* logit_partials, void* logits, void* dz, void* stats,
                                           void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
                                           void* adam_pows_f64, double b1, double b2);
+/* The data-parallel form for transports whose exchange cannot sit inside a kernel (RCCL — north_star's named transport) and
+ * for peer-to-peer groups sharing one GPU: the shard's statistics are a launch of their own,
+ *   tnn_mlp_head_stats: ONE workgroup sums the partial logits and leaves this rank's {max, sum-exp} (float32) in out_pair
+ *     (exchange = 0; the caller all-gathers the pairs), or exchanges them with the peers over xGMI itself and leaves the MERGED
+ *     pair (exchange = 1, needs tnn_p2p_connect);
+ *   tnn_mlp_head_bwd_tick_ext: tnn_mlp_head_bwd_tick whose workgroups take the batch statistics from stats_pairs
+ *     ([n_pairs][2] float32 {M_q, S_q}: every rank's pair, or one merged pair) and do no cross-row reduction of their own;
+ *     outputs as in the _sharded form (contributions to the global gradients, this rank's share of the loss).
+ * The RCCL step is then forward x 2 | statistics | all-gather | head + hidden backward | first-layer backward | all-reduce |
+ * Adam: 6 launches + 2 collectives instead of 12 + 2. */
+TNN_API int tnn_mlp_head_stats(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* b, const void* y,
+                               const void* logit_partials, void* out_pair_f32, int exchange, int dtype);
+TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
+                                      const void* x, const void* w1, const void* a, const void* w, const void* b,
+                                      const void* y, const void* logit_partials, const void* stats_pairs, int n_pairs,
+                                      void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1,
+                                      void* db1, void* dx, int dtype, void* adam_pows_f64, double b1, double b2);
 /* Forward of the hidden Dense layer in front of the classifier, C = act(A B + bias) like tnn_gemm_bias_act (NN form,
  * core/layers.py:49,98), which ALSO emits the next layer's logits as per-tile partial sums:
  *   head_z[tn][row][c] = sum_{col in [16 tn, 16 tn + 16)} C[row][col] * head_w[col][c]      (head_z: [ceil(N/16)][M][head_c])

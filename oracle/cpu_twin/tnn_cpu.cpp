@@ -661,6 +661,44 @@ int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, 
     return tnn_mlp_head_bwd_tick(rows, n_in, nh, nc, x, w1, a, w, b, y, zpart, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
                                  pows, b1, b2);
 }
+static void twin_logits_from_partials(int64_t rows, int64_t nh, int64_t nc, const void* b, const void* zpart, float* logits) {
+    const int64_t tiles = (nh + 15) / 16;
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < nc; ++c) {
+            float s = 0.f;
+            for (int64_t tn = 0; tn < tiles; ++tn) s += ((const float*)zpart)[(tn * rows + r) * nc + c];
+            logits[r * nc + c] = s + ((const float*)b)[c];
+        }
+}
+int tnn_mlp_head_stats(int64_t rows, int64_t nh, int64_t nc, const void* b, const void* y, const void* zpart, void* out_pair,
+                       int exchange, int dtype) {
+    NEED_INIT();
+    REQ(b && y && zpart && out_pair && dtype == TNN_F32, "cpu twin: tnn_mlp_head_stats needs every buffer, f32");
+    RECORD(tnn_mlp_head_stats(rows, nh, nc, b, y, zpart, out_pair, exchange, dtype));
+    std::vector<float> logits((size_t)(rows * nc));
+    twin_logits_from_partials(rows, nh, nc, b, zpart, logits.data());
+    return tnn_softmax_nll_stats(logits.data(), rows, nc, out_pair, dtype);       // a one-rank exchange is the identity
+}
+int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
+                              const void* a, const void* w, const void* b, const void* y, const void* zpart, const void* pairs,
+                              int n_pairs, void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
+                              void* dx, int dtype, void* pows, double b1, double b2) {
+    NEED_INIT();
+    REQ(x && w1 && zpart && pairs && logits && dz && dw && db && dw1 && db1 && dx && dtype == TNN_F32 && n_pairs >= 1,
+        "cpu twin: tnn_mlp_head_bwd_tick_ext needs every buffer, f32");
+    RECORD(tnn_mlp_head_bwd_tick_ext(rows, m_global, n_in, nh, nc, x, w1, a, w, b, y, zpart, pairs, n_pairs, logits, dz, stats, loss,
+                                     dw, db, dw1, db1, dx, dtype, pows, b1, b2));
+    twin_logits_from_partials(rows, nh, nc, b, zpart, (float*)logits);
+    float merged[2];
+    if (int rc = tnn_lse_merge(pairs, n_pairs, merged, dtype)) return rc;
+    if (stats) { ((float*)stats)[0] = merged[0]; ((float*)stats)[1] = merged[1]; }
+    if (pows) { ((double*)pows)[0] *= b1; ((double*)pows)[1] *= b2; }
+    float loss_tmp = 0.f;
+    if (int rc = tnn_softmax_nll_fwd_bwd(logits, y, rows, nc, m_global, merged, loss ? loss : &loss_tmp, dz, dtype)) return rc;
+    std::vector<float> da((size_t)(rows * nh));
+    if (int rc = tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da.data(), a, dtype)) return rc;
+    return tnn_dense_bwd(rows, n_in, nh, x, da.data(), w1, dw1, db1, dx, x, dtype);
+}
 int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                 const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* hw, int64_t hc,
                                 void* hz, int dtype) {

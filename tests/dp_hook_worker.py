@@ -8,6 +8,10 @@ RCCL runs here through gloo; the launch sequence and the host logic are the same
                   the reference's single-process trajectory tests/golden/traj_D_adam.npz — all-reduce + Adam tail
   mode "Dbucket"  the same with the arena split into one bucket per layer (TNN_BUCKET_BYTES=1)
   mode "Cbucket"  config-C-small (256-256-256 autoencoder, bs 64, sum-of-squares), bucketed, against traj_C_small.npz
+  mode "A"        the bs-128 trajectory split over the ranks (32 rows each at world 4): the shard's head fits the one-launch
+                  form, so the step takes the RCCL-shaped 6-launch structure — statistics as a launch of their own
+                  (tnn_mlp_head_stats), ONE all-gather of the pairs, head + hidden backward merging them
+                  (tnn_mlp_head_bwd_tick_ext), ONE all-reduce with the Adam tail — against traj_A_adam.npz
 """
 
 import ctypes
@@ -63,7 +67,7 @@ def main():
     assert hook(rank, world, ctypes.cast(allreduce, ctypes.c_void_p), ctypes.cast(allgather, ctypes.c_void_p)) == 0
     comm = DeviceCommunicator(rank, world)           # the product's communicator class over tnn_allreduce / tnn_allgather
 
-    name = "C_small" if mode == "Cbucket" else "D_adam"
+    name = "C_small" if mode == "Cbucket" else "A_adam" if mode == "A" else "D_adam"
     cfg, gold = H.load_traj(name)
     w, m = cfg["widths"], cfg["m"]
     assert m % world == 0

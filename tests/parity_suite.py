@@ -405,6 +405,35 @@ def head_and_hidden_backward_one_launch_vs_numpy():
                                        err_msg="%s %s" % (name, tag))
         assert np.asarray(dx)[0, 3] != 0.0 or m == 1                                         # mask = 1 at an exactly-zero input
         np.testing.assert_allclose(np.asarray(pows)[:2], [0.9 ** 2, 0.999 ** 2], rtol=1e-14)
+        # ---- the data-parallel form with the statistics as a launch of their own (RCCL / shared-GPU structure):
+        # tnn_mlp_head_stats leaves this shard's {max, sum-exp}; tnn_mlp_head_bwd_tick_ext merges the pairs it is given.
+        pair = tn.empty((2,))
+        lib.mlp_head_stats(m, Hn, C, B._ptr, Y._ptr, zpart._ptr, pair._ptr, 0, _lib.F32)
+        np.testing.assert_allclose(np.asarray(pair), [z.max(), S], rtol=2e-6)
+        # a second, imaginary rank with m2 rows: its pair enters the merge, its rows the global batch size
+        m2 = 96
+        z2 = rs.randn(m2, C) * 2.0 + 1.0
+        pair2 = np.array([z2.max(), np.exp(z2 - z2.max()).sum()], np.float32)
+        pairs = tn.asarray(np.stack([np.asarray(pair), pair2]).astype(np.float32))
+        loss_s = tn.empty(())
+        for t_ in (logits, dz, dw, db, dw1, db1, dx):
+            t_[...] = 0.0
+        lib.mlp_head_bwd_tick_ext(m, m + m2, n_in, Hn, C, X._ptr, W1._ptr, A._ptr, W._ptr, B._ptr, Y._ptr, zpart._ptr,
+                                  pairs._ptr, 2, logits._ptr, dz._ptr, None, loss_s._ptr, dw._ptr, db._ptr, dw1._ptr,
+                                  db1._ptr, dx._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
+        Mg = max(z.max(), float(pair2[0]))
+        Sg = S * np.exp(z.max() - Mg) + float(pair2[1]) * np.exp(float(pair2[0]) - Mg)
+        eg = np.exp(z - Mg)
+        qg = (eg * y64).sum(1, keepdims=True)
+        dz_g = eg / Sg - (eg * y64 / qg) / (m + m2)
+        share = (np.log(Sg) - np.log(qg)).sum() / (m + m2)
+        np.testing.assert_allclose(float(loss_s), share, rtol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(np.asarray(dz), dz_g, rtol=0, atol=1e-5 * np.abs(dz_g).max(), err_msg=tag)
+        da_g = (dz_g @ w64.T) * ~np.signbit(a)
+        for name, got, ref in (("dw", dw, a64.T @ dz_g), ("db", db, dz_g.sum(0)), ("dw1", dw1, x64.T @ da_g),
+                               ("db1", db1, da_g.sum(0)), ("dx", dx, (da_g @ w164.T) * ~np.signbit(x))):
+            np.testing.assert_allclose(np.asarray(got).reshape(ref.shape), ref, rtol=0, atol=1e-5 * np.abs(ref).max() + 1e-12,
+                                       err_msg="ext %s %s" % (name, tag))
 
 
 def dense_backward_one_launch_vs_numpy():

@@ -214,10 +214,13 @@ struct HeadStats {
 // zc / yc: this thread's three logits / labels of row (t >> 2) (classes sub, sub + 4, sub + 8); one barrier inside.
 // LOSS = false (workgroups that only need dz): no sum of logs, cross-row sums in f32 — a 1280-term DPP tree is good to
 // ~1e-6 relative, dz's tolerance is 1e-5 — which takes the f64 DPP reductions and the logf off their critical path.
-template <int C, bool LOSS = true>
+// EXT: {M, S} of the batch come from memory — ext_n pairs {M_q, S_q} (one per rank of a data-parallel group, or one already
+// merged pair) written by an EARLIER launch (head_stats_kernel + a collective) and merged here; the workgroup then does no
+// cross-row reduction at all, except the sum of logs in the one workgroup that writes the loss.
+template <int C, bool LOSS = true, bool EXT = false>
 __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&yc)[3], const bool slive, const int sub,
                                            const int lane, const int wid, double (*red)[4], HeadStats& o,
-                                           const bool want_loss = true) {
+                                           const bool want_loss = true, const float* ext_pairs = nullptr, const int ext_n = 0) {
     // ---- whole-batch softmax statistics: FOUR threads per row (classes sub, sub + 4, sub + 8), row max / sums by
     // quad-permute DPP; then ONE combined reduction of {max, rescaled sum-exp, sum(log u + max)} over the workgroup
     // (DPP wave reductions + an 8-entry LDS exchange).  Row sums in f32 (10 terms), cross-row sums in f64 — the
@@ -245,6 +248,24 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
     urow += tnn::dpp_move<0xB1, 0xf>(0.f, urow);
     urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
     const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
+    if constexpr (EXT) {
+        float Mx = ext_pairs[0];
+        for (int q = 1; q < ext_n; ++q) Mx = fmaxf(Mx, ext_pairs[2 * q]);
+        float Sx = 0.f;
+        for (int q = 0; q < ext_n; ++q) Sx += ext_pairs[2 * q + 1] * expf(ext_pairs[2 * q] - Mx);
+        double Lx = 0.0;
+        if (LOSS && want_loss) {                                // block-uniform: the loss-writing workgroup only
+            const double wl = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
+            if (lane == 0) red[wid][2] = wl;
+            __syncthreads();
+            Lx = red[lane & 7][2];
+            Lx += tnn::dpp_move<0xB1, 0xf>(0.0, Lx);
+            Lx += tnn::dpp_move<0x4E, 0xf>(0.0, Lx);
+            Lx += tnn::dpp_move<0x141, 0xf>(0.0, Lx);
+        }
+        o.mx = mx; o.urow = urow; o.M = Mx; o.S = (double)Sx; o.L = Lx;
+        return;
+    }
     // A wave holds 16 rows: its {max, sum-exp relative to that max} in f32 (160 terms, DPP tree).  The eight waves' results
     // meet in LDS; every lane then takes entry (lane & 7) and an 8-lane DPP butterfly (quad_perm x 2, row_half_mirror)
     // leaves M, S (and L) in ALL lanes — one exp per lane instead of a serial 8-term loop per thread (measured: the
@@ -311,6 +332,8 @@ struct HeadMArgs {
     int m, rpb;                      // rows (<= 128); da rows per workgroup
     int vec;                         // rows even, zpart / y 16-B aligned: the partial logits are staged with 16-B loads
     int m_global;                    // data-parallel (SH kernels): rows of the GLOBAL batch; the loss written is this rank's share
+    const float* ext_pairs;          // SH == 2: {M_q, S_q} pairs from an earlier launch (head_stats_kernel [+ all-gather])
+    int ext_n;
     const float *a, *w, *b, *y;
     const float* zpart;              // [H / 16][m][C] partial logits from the previous layer's tiles, or NULL
     float *logits, *dz, *stats, *loss, *dw, *db, *da;
@@ -429,7 +452,9 @@ __device__ __forceinline__ HeadGlobal head_exchange(const tnn::p2p::LaunchCtx& c
 // v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
 // CUT (timing builds only, TNN_HEAD_CUT): 0 = the kernel; 1 = stop after the logits, 2 = after the statistics, 3 = after dz.
 // DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
-template <int H, int C, bool PART, int CUT, bool DA, bool SH = false>
+// SH (data parallel): 0 single GPU; 1 the shards' statistics are exchanged inside this launch (head_exchange); 2 they were
+// exchanged before it and arrive through HeadMArgs::ext_pairs
+template <int H, int C, bool PART, int CUT, bool DA, int SH = 0>
 __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, const tnn::p2p::LaunchCtx* ctx = nullptr) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
@@ -528,7 +553,8 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, cons
     }
 
     HeadStats st;
-    head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
+    if constexpr (SH == 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, p.ext_pairs, p.ext_n);
+    else head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
     const float mx = st.mx, urow = st.urow;
@@ -536,13 +562,13 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, cons
     double S = st.S;
     const double L = st.L;
     double inv_m = 1.0 / (double)m;
-    if constexpr (SH) {
+    if constexpr (SH == 1) {
         __shared__ float peer_stats[tnn::p2p::MAXW][2];
         const HeadGlobal gl = head_exchange(*ctx, g == 0, M, (float)S, peer_stats);
         M = gl.M;
         S = (double)gl.S;
-        inv_m = 1.0 / (double)p.m_global;
     }
+    if constexpr (SH != 0) inv_m = 1.0 / (double)p.m_global;
     if constexpr (CUT == 2) {
         p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
         return;
@@ -621,7 +647,7 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, cons
         }
         if (t == 0) {
             // data parallel: this rank's SHARE of the global loss (the all-reduce of the gradient arena sums the shares)
-            if (p.loss) p.loss[0] = SH ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
+            if (p.loss) p.loss[0] = SH != 0 ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
                                        : (float)((double)logf((float)S) + (double)M - L * inv_m);
             if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
             if (p.tick) { p.tick[0] = pw0 * p.b1; p.tick[1] = pw1 * p.b2; }
@@ -663,7 +689,7 @@ struct HeadBwdArgs {
 };
 
 // CUT (timing builds only, TNN_HBW_CUT): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
-template <int H, int C, int CUT = 0, bool SH = false>
+template <int H, int C, int CUT = 0, int SH = 0>
 __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q, tnn::p2p::LaunchCtx ctx) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
@@ -746,19 +772,20 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         return;
     }
     HeadStats st;
-    head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
+    if constexpr (SH == 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, p.ext_pairs, p.ext_n);
+    else head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
     if constexpr (CUT == 2) {
         q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
         return;
     }
     float m_norm = (float)m;
-    if constexpr (SH) {
+    if constexpr (SH == 1) {
         __shared__ float peer_stats[tnn::p2p::MAXW][2];
         const HeadGlobal gl = head_exchange(ctx, false, st.M, (float)st.S, peer_stats);
         st.M = gl.M;
         st.S = (double)gl.S;
-        m_norm = (float)p.m_global;
     }
+    if constexpr (SH != 0) m_norm = (float)p.m_global;
     {
         const float sf = slive ? expf(st.mx - st.M) * __builtin_amdgcn_rcpf((float)st.S) : 0.f;
         const float uf = slive ? __builtin_amdgcn_rcpf(m_norm * st.urow) : 0.f;
@@ -826,6 +853,51 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     }
 }
 
+// The shard's softmax statistics as a launch of its own (data-parallel forms whose exchange is NOT inside the head launch:
+// RCCL, and peer-to-peer groups that share a GPU): ONE workgroup sums the partial logits, reduces {M, S} of its rows and
+//   EXCH = false: leaves the pair in out_pair — the caller all-gathers the ranks' pairs (tnn_allgather) and hands them to
+//                 tnn_mlp_head_bwd_tick_ext, whose workgroups merge them themselves;
+//   EXCH = true : exchanges it with the peers over xGMI right here (the loss kernel's tagged slots and epoch counter: one
+//                 workgroup, so it can advance the counter itself) and leaves the MERGED pair in out_pair.
+template <int C, bool EXCH>
+__global__ __launch_bounds__(512) void head_stats_kernel(HeadMArgs p, float* __restrict__ out_pair, tnn::p2p::LaunchCtx ctx) {
+    constexpr int ROWS = 128, NP = 8;
+    __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];
+    __shared__ double red[8][4];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int srow = t >> 2, sub = t & 3, m = p.m;
+    const bool slive = srow < m;
+    const int sr = min(srow, m - 1);
+    HeadStage<C, NP> stg;
+    head_stage_request<C, NP>(p, t, stg);
+    head_stage_store<C, NP>(p, t, stg, zs, ys);
+    __syncthreads();
+    float zc[3], yc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        zc[i] = zs[sr * C + min(sub + 4 * i, C - 1)];
+        yc[i] = ys[sr * C + min(sub + 4 * i, C - 1)];
+    }
+    HeadStats st;
+    head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
+    float M = st.M, S = (float)st.S;
+    if constexpr (EXCH) {
+        using namespace tnn::p2p;
+        __shared__ float peer_stats[MAXW][2];
+        const Peers& P = ctx.peers;
+        const int W = P.world;
+        const uint32_t ep = *ctx.ag_epoch;
+        if (t < 2 * W) peer_stats[t >> 1][t & 1] = ll_exchange2(P, ep, (t & 1) ? S : M, ctx.dead, ctx.timeout_ticks);
+        __syncthreads();
+        float gm = -INFINITY, gs = 0.f;
+        for (int q = 0; q < W; ++q) gm = fmaxf(gm, peer_stats[q][0]);
+        for (int q = 0; q < W; ++q) gs += peer_stats[q][1] * expf(peer_stats[q][0] - gm);
+        M = gm; S = gs;
+        if (t == 0) *ctx.ag_epoch = ep + 1;
+    }
+    if (t == 0) { out_pair[0] = M; out_pair[1] = S; }
+}
+
 bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype) {
     static const bool off = getenv("TNN_HEAD_MULTI") != nullptr && atoi(getenv("TNN_HEAD_MULTI")) == 0;
     return !off && dtype == TNN_F32 && n_classes == 10 && n_hidden == 128 && rows >= 1 && rows <= 128;
@@ -838,7 +910,7 @@ size_t head_lds_bytes(int64_t m, int64_t H) {
 
 bool g_attr_set = false;
 
-int head_bwd_launch(const char* fn, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
+int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
@@ -856,6 +928,7 @@ int head_bwd_launch(const char* fn, int64_t m_global, int64_t rows, int64_t n_in
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = (int)m_global;
+    p.ext_pairs = ext_pairs; p.ext_n = ext_n;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -866,13 +939,20 @@ int head_bwd_launch(const char* fn, int64_t m_global, int64_t rows, int64_t n_in
     static const int xcd_mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
     q.xcd = xcd_mode;
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
+    if (ext_pairs != nullptr) {          // data parallel, statistics exchanged by an earlier launch / collective
+        TNN_REQUIRE(m_global >= rows && ext_n >= 1 && ext_n <= 64, "%s: m_global < rows or bad pair count", fn);
+        const tnn::p2p::LaunchCtx no_ctx = {};
+        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2>), grid, 512, 0, tnn::stream(), p, q, no_ctx);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
     if (m_global > 0) {                  // data parallel: the exchange of the shards' statistics happens inside the launch
         TNN_REQUIRE(m_global >= rows, "%s: m_global < rows", fn);
         if (int rc = tnn::p2p_refuse_if_failed(fn)) return rc;
         tnn::p2p::LaunchCtx ctx;
         TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "%s: the peer-to-peer transport is not enabled", fn);
         TNN_REQUIRE(grid <= tnn::p2p::BC_ROWS, "%s: %d workgroups exceed the %d hand-over rows", fn, grid, tnn::p2p::BC_ROWS);
-        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, true>), grid, 512, 0, tnn::stream(), p, q, ctx);
+        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 1>), grid, 512, 0, tnn::stream(), p, q, ctx);
         TNN_LAUNCH_OK();
         return 0;
     }
@@ -881,7 +961,7 @@ int head_bwd_launch(const char* fn, int64_t m_global, int64_t rows, int64_t n_in
     const tnn::p2p::LaunchCtx none = {};
     if (getenv("TNN_HBW_OCCUPANCY")) {                  // probe: resident workgroups per CU the runtime computes for this kernel
         int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&mlp_head_bwd_kernel<128, 10, 0, false>), 512, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&mlp_head_bwd_kernel<128, 10, 0, 0>), 512, 0);
         fprintf(stderr, "mlp_head_bwd_kernel: %d workgroups of 512 threads per CU, grid %d\n", nb, grid);
     }
     if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q, none);
@@ -953,6 +1033,7 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = 0;
+    p.ext_pairs = nullptr; p.ext_n = 0;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -976,7 +1057,7 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
-    return head_bwd_launch("tnn_mlp_head_bwd_tick", 0, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y, logit_partials, logits,
+    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, 0, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y, logit_partials, logits,
                            dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
@@ -986,8 +1067,41 @@ int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, 
                                   void* db, void* dw1, void* db1, void* dx, int dtype, void* adam_pows_f64, double b1,
                                   double b2) {
     TNN_REQUIRE(m_global >= 1, "tnn_mlp_head_bwd_tick_sharded: m_global must be the global batch size");
-    return head_bwd_launch("tnn_mlp_head_bwd_tick_sharded", m_global, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y,
+    return head_bwd_launch("tnn_mlp_head_bwd_tick_sharded", nullptr, 0, m_global, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y,
                            logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
+}
+
+int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
+                              const void* x, const void* w1, const void* a, const void* w, const void* b, const void* y,
+                              const void* logit_partials, const void* stats_pairs, int n_pairs, void* logits, void* dz,
+                              void* stats, void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
+                              void* adam_pows_f64, double b1, double b2) {
+    TNN_REQUIRE(stats_pairs != nullptr && m_global >= 1, "tnn_mlp_head_bwd_tick_ext: stats_pairs and m_global are required");
+    return head_bwd_launch("tnn_mlp_head_bwd_tick_ext", (const float*)stats_pairs, n_pairs, m_global, rows, n_in, n_hidden,
+                           n_classes, x, w1, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
+                           adam_pows_f64, b1, b2);
+}
+
+int tnn_mlp_head_stats(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* b, const void* y,
+                       const void* logit_partials, void* out_pair_f32, int exchange, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(b && y && logit_partials && out_pair_f32, "tnn_mlp_head_stats: b, y, logit_partials and out_pair are required");
+    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype), "tnn_mlp_head_stats: ask tnn_mlp_head_fits first");
+    HeadMArgs p = {};
+    p.m = (int)rows;
+    p.b = (const float*)b; p.y = (const float*)y; p.zpart = (const float*)logit_partials;
+    p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
+    if (exchange) {
+        if (int rc = tnn::p2p_refuse_if_failed("tnn_mlp_head_stats")) return rc;
+        tnn::p2p::LaunchCtx ctx;
+        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_mlp_head_stats: the peer-to-peer transport is not enabled");
+        hipLaunchKernelGGL((head_stats_kernel<10, true>), 1, 512, 0, tnn::stream(), p, (float*)out_pair_f32, ctx);
+    } else {
+        const tnn::p2p::LaunchCtx none = {};
+        hipLaunchKernelGGL((head_stats_kernel<10, false>), 1, 512, 0, tnn::stream(), p, (float*)out_pair_f32, none);
+    }
+    TNN_LAUNCH_OK();
+    return 0;
 }
 
 }  // extern "C"

@@ -608,9 +608,45 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     int shared_gpu = 0;
     if (p2p_on) MLP_TRY(tnn_p2p_shared_device(-1, &shared_gpu));
     static const bool merge_shared = getenv("TNN_STEP_MERGE_SHARED") != nullptr && atoi(getenv("TNN_STEP_MERGE_SHARED")) != 0;
-    if (p2p_on && (!shared_gpu || merge_shared) && h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 &&
-        h->w[L - 2] % 16 == 0 && !merge_off)
+    if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0 && !merge_off)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
+    const bool in_kernel_exchange = p2p_on && (!shared_gpu || merge_shared);
+    if (head_multi && !in_kernel_exchange) {
+        // The same structure with the statistics as a launch of their own — for RCCL (north_star's named transport: a
+        // collective cannot sit inside a kernel) and for peer-to-peer groups sharing one GPU:
+        //   forward of the hidden layers (+ partial logits) | tnn_mlp_head_stats: the shard's {max, sum-exp} | their exchange
+        //   (peer-to-peer: inside that launch; otherwise tnn_allgather) | head + hidden layer's backward taking the pairs from
+        //   memory (tnn_mlp_head_bwd_tick_ext; advances Adam's beta powers) | remaining backward | all-reduce + Adam
+        // 6 launches + 2 collectives on RCCL instead of 12 + 2.
+        static const bool ext_off = getenv("TNN_STEP_EXT") != nullptr && atoi(getenv("TNN_STEP_EXT")) == 0;
+        if (!ext_off) {
+            MLP_TRY(mlp_forward(h, x, rows, L - 2));
+            MLP_TRY(tnn_dense_fwd_head_partials(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart, h->dtype));
+            MLP_TRY(tnn_mlp_head_stats(rows, h->w[L - 1], h->w[L], at(h->params, h->b_off[L - 1], h->esz), y, h->zpart,
+                                       h->stats, p2p_on ? 1 : 0, h->dtype));
+            const void* pairs = h->stats;
+            int n_pairs = 1;
+            if (!p2p_on) {
+                MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
+                pairs = h->stats_all;
+                n_pairs = world;
+            }
+            MLP_TRY(tnn_mlp_head_bwd_tick_ext(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
+                                              at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
+                                              at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
+                                              y, h->zpart, pairs, n_pairs, h->act[L - 1], h->dact[L - 1], nullptr, loss_slot,
+                                              at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                              at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
+                                              h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
+            MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 0));
+            return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
+                                      h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);
+        }
+        head_multi = 0;
+    }
     if (head_multi) {
         // xGMI peer-to-peer transport, a GPU per rank (every workgroup of the head launch waits for the merged statistics: all
         // the ranks' launches must be resident together — ranks sharing one GPU deadlock as soon as one launch fills it,
