@@ -728,9 +728,9 @@ def main():
     def sharded_forms_agree(rows_):
         """Data-parallel runs on the peer-to-peer transport with <= 128 rows per rank take the 5-launch sharded step, whose
         multi-workgroup head exchanges the softmax statistics inside its launch — code that only a multi-GPU run exercises
-        across devices.  Before anything is timed, four steps of it are compared with the 8-launch form (exchange in the
-        one-workgroup loss kernel, in use since round 1) from the same parameters and batches; if they disagree (or the
-        new form trips a barrier) every rank stays on the 8-launch form and the line says so."""
+        across devices.  Before anything is timed, four steps of it are compared with the form that exchanges them in a
+        one-workgroup launch of their own (6 launches; what ranks sharing a GPU use) from the same parameters and batches;
+        if they disagree (or the in-kernel exchange trips a barrier) every rank stays on the latter and the line says so."""
         lib = _lib.get()
         cur = ctypes.c_int(0)
         lib.p2p_shared_device(-1, ctypes.byref(cur))
@@ -758,9 +758,10 @@ def main():
         alive = p2p_alive()                            # collective
         ok = all_ranks(local_ok and alive)
         if not ok:
-            lib.p2p_shared_device(1, None)             # every rank: keep the 8-launch form from here on
-        return {"five_launch_vs_eight_launch_losses_agree": ok, "rows_per_rank": rows_,
-                "form_used": "8-launch (ranks share a GPU)" if cur.value else ("5-launch" if ok else "8-launch (fallback)")}
+            lib.p2p_shared_device(1, None)             # every rank: keep the statistics-launch form from here on
+        return {"in_kernel_exchange_agrees_with_statistics_launch": ok, "rows_per_rank": rows_,
+                "form_used": "statistics launch, 6 launches (ranks share a GPU)" if cur.value
+                else ("in-kernel exchange, 5 launches" if ok else "statistics launch, 6 launches (fallback)")}
 
     def p2p_alive():
         st = comm.p2p_status() if comm is not None and hasattr(comm, "p2p_status") else None

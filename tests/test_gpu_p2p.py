@@ -146,10 +146,10 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     assert p2p["replicas_identical"] and p2p["verified_after_run"] and not p2p["barrier_timed_out"] and p2p["graph_captured"]
     assert d["value"] == p2p["value"] > 0
     # before anything was timed the 5-launch sharded step (exchange inside the multi-workgroup head) was compared with the
-    # 8-launch form on this transport (at 64 rows per rank: both ranks' launches fit the one GPU); the timed runs then
-    # stay on the 8-launch form because the ranks share a GPU
+    # form whose statistics are a launch of their own on this transport (at 64 rows per rank: both ranks' launches fit the
+    # one GPU); the timed runs then stay on the latter because the ranks share a GPU
     form = coll["sharded_step_form"]
-    assert form["five_launch_vs_eight_launch_losses_agree"] and form["rows_per_rank"] == 64 and "share" in form["form_used"]
+    assert form["in_kernel_exchange_agrees_with_statistics_launch"] and form["rows_per_rank"] == 64 and "share" in form["form_used"]
     # the sharded step on this transport reproduces the REFERENCE's bs-1024 losses (traj_D_adam, all 5 steps)
     chk = d["parity_vs_reference_fixture"]
     assert chk["ok"] and chk["steps"] == 5 and "traj_D_adam" in chk["fixture"] and chk["max_rel_err"] <= 1e-5
