@@ -1056,8 +1056,9 @@ bool use_small_path(const GemmArgs& g) {
 
 int gemm_small(GemmArgs& g, int transA, int transB, float* colsum) {
     int nchunks = (int)((g.K + 15) / 16);
+    static const int lim8 = getenv("TNN_SMALL_LIM8") ? atoi(getenv("TNN_SMALL_LIM8")) : 48;     // tuning: 8 waves up to this many chunks
     if (nchunks <= 16) return launch_small<4>(g, transA, transB, colsum);
-    if (nchunks <= 48) return launch_small<8>(g, transA, transB, colsum);
+    if (nchunks <= lim8) return launch_small<8>(g, transA, transB, colsum);
     return launch_small<16>(g, transA, transB, colsum);
 }
 
