@@ -160,6 +160,45 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` with NO launcher (the form the driver uses for N = 1): the parent, which never
+    touches the GPU, starts the two ranks itself, relays rank 0's one JSON line and passes the children's status on."""
+    import json
+    env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONDONTWRITEBYTECODE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 1024 and d["config"]["rows_per_rank"] == 512
+    assert d["parity_vs_reference_fixture"]["ok"] and d["exit_code"] == 0
+    assert d["config"]["collectives"]["xgmi_p2p"]["replicas_identical"]
+    assert "note" in d["strong_scaling"]
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_fails_fast_when_a_rank_dies():
+    """One of the self-launched ranks exits right after the rendezvous: the launcher ends the other rank (by PID) and
+    returns a non-zero status well inside the timeout instead of hanging in a collective."""
+    import time
+    env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="5000", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TNN_BENCH_TEST_EXIT_RANK="1", PYTHONDONTWRITEBYTECODE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0
+    assert time.time() - t0 < 240
+    assert "rank 1 exited with code 9" in r.stderr
+
+
+@pytest.mark.gpu
 def test_bench_single_gpu_line_has_the_contract_objects():
     """The driver's N = 1 command: one JSON line with the median-of-repeats protocol, the latency-bound roofline with the
     per-launch event times, the 4096 GEMM roofline, config C's whole step, the drop-in API paths, the strong-scaling

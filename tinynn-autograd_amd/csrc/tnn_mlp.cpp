@@ -59,7 +59,11 @@ struct Mlp {
     void* xT16 = nullptr;            // x^T [w[0], max_rows]
     // measurement hook (tnn_mlp_launch_window): primitive calls of a step are numbered 0, 1, ... in issue order and only
     // those inside [win_lo, win_hi) are executed, so each launch of the step can be replayed and timed on its own
-    int win_lo = 0, win_hi = 1 << 30, call_idx = 0;
+    // No window set (the default): every call runs and the counter only reports launches per step; it is reset at the
+    // top of every public entry point, so it never grows past one step's worth of calls.
+    bool windowed = false;
+    int win_lo = 0, win_hi = 0;
+    int64_t call_idx = 0;
 };
 
 #define MLP_TRY(call)            \
@@ -70,9 +74,9 @@ struct Mlp {
 
 // one primitive call (= one launch for the MNIST-size step) of a training step, subject to the launch window
 #define STEP_CALL(h, call)                                              \
-    do {                                                                \
-        const int idx__ = (h)->call_idx++;                              \
-        if (idx__ >= (h)->win_lo && idx__ < (h)->win_hi) MLP_TRY(call); \
+    do {                                                                                        \
+        const int64_t idx__ = (h)->call_idx++;                                                   \
+        if (!(h)->windowed || (idx__ >= (h)->win_lo && idx__ < (h)->win_hi)) MLP_TRY(call);     \
     } while (0)
 
 inline void* at(char* base, int64_t elem_off, size_t esz) { return base + elem_off * (int64_t)esz; }
@@ -382,6 +386,7 @@ int tnn_mlp_param_offset(void* handle, int layer, int which, int64_t* offset, in
 int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits) {
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_forward"));
+    h->call_idx = 0;
     if (h->bf16) {
         MLP_TRY(mlp16_forward(h, x, rows));
         if (logits) MLP_TRY(tnn_memcpy_d2d(logits, h->act[h->L - 1], (size_t)(rows * h->w[h->L]) * 2));
@@ -393,9 +398,16 @@ int tnn_mlp_forward(void* handle, const void* x, int64_t rows, void* logits) {
     return 0;
 }
 
+static int mlp_forward_stats(Mlp* h, const void* x, int64_t rows, void* stats);
+
 int tnn_mlp_forward_stats(void* handle, const void* x, int64_t rows, void* stats) {
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_forward_stats"));
+    h->call_idx = 0;
+    return mlp_forward_stats(h, x, rows, stats);
+}
+
+static int mlp_forward_stats(Mlp* h, const void* x, int64_t rows, void* stats) {
     if (h->bf16) return mlp16_forward(h, x, rows);
     MLP_TRY(mlp_forward(h, x, rows));
     if (h->loss_kind == 0)
@@ -423,12 +435,20 @@ static int mlp_backward_impl(Mlp* h, const void* x, const void* y, int64_t rows,
 
 int tnn_mlp_backward(void* handle, const void* x, const void* y, int64_t rows, int64_t m_global,
                      const void* stats, void* loss_out) {
+    if (handle) ((Mlp*)handle)->call_idx = 0;
     return mlp_backward_impl((Mlp*)handle, x, y, rows, m_global, stats, loss_out, false);
 }
+
+static int mlp_update(Mlp* h);
 
 int tnn_mlp_update(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) { tnn::set_error("tnn_mlp_update: NULL handle"); return 2; }
+    h->call_idx = 0;
+    return mlp_update(h);
+}
+
+static int mlp_update(Mlp* h) {
     if (h->bf16) return mlp16_update(h);
     if (h->opt_kind == 0)
         STEP_CALL(h, tnn_sgd(h->params, h->grads, h->n_params, h->lr, h->dtype));
@@ -464,7 +484,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // rewrites.
         const int L = h->L;
         void* loss_slot = at(h->grads, h->n_params, h->esz);
-        MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+        MLP_TRY(mlp_forward_stats(h, x, rows, nullptr));
         if (h->loss_kind == 0)
             MLP_TRY(tnn_softmax_nll_fwd_bwd(h->act[L - 1], y, rows, h->w[L], rows, h->stats, loss_slot, h->dact[L - 1], h->dtype));
         else
@@ -487,9 +507,9 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         return 0;
     }
     if (h->loss_kind != 0) {
-        MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
-        MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows, nullptr, loss_out));
-        return tnn_mlp_update(handle);
+        MLP_TRY(mlp_forward_stats(h, x, rows, nullptr));
+        MLP_TRY(mlp_backward_impl(h, x, y, rows, rows, nullptr, loss_out, false));
+        return mlp_update(h);
     }
     // unsharded softmax head: stats + loss + dz in one launch; the loss goes straight to loss_out
     // (e.g. one slot of a per-step loss history) or, by default, to the slot behind the gradient arena
@@ -571,7 +591,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                               at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
                               L > 1 ? h->dact[L - 2] : nullptr, h->dtype));
     MLP_TRY(mlp_backward_layers(h, x, rows, L - 2));
-    return tnn_mlp_update(handle);
+    return mlp_update(h);
 }
 
 static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t rows, void* loss_out);
@@ -591,6 +611,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     //   batch size  ->  C1 in-place all-reduce of grads[0 : n_params + 1] (the loss rides along)  ->  update
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_step_sharded"));
+    h->call_idx = 0;
     int rank = 0, world = 1;
     MLP_TRY(tnn_comm_world(&rank, &world));
     if (h->stats_all_world != world) {
@@ -687,7 +708,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
         return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
                                   h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);
     }
-    MLP_TRY(tnn_mlp_forward_stats(handle, x, rows, nullptr));
+    MLP_TRY(mlp_forward_stats(h, x, rows, nullptr));
     if (h->loss_kind == 0) {
         MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
         MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
@@ -712,17 +733,17 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
             return 0;
         }
         MLP_TRY(tnn_comm_join());
-        MLP_TRY(tnn_mlp_update(handle));
+        MLP_TRY(mlp_update(h));
         if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
         return 0;
     }
-    MLP_TRY(tnn_mlp_backward(handle, x, y, rows, rows * world, h->stats, nullptr));
+    MLP_TRY(mlp_backward_impl(h, x, y, rows, rows * world, h->stats, nullptr, false));
     if (!h->bf16 && h->opt_kind == 1)
         return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
                                   h->eps, h->pows, 1, h->dtype, h->n_params, loss_out);
     // the arenas of a bf16 trainer are fp32 (master weights, gradients, optimizer state)
     MLP_TRY(tnn_allreduce(h->grads, h->n_params + 1, h->bf16 ? TNN_F32 : h->dtype, TNN_RSUM));
-    MLP_TRY(tnn_mlp_update(handle));
+    MLP_TRY(mlp_update(h));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
     return 0;
 }
@@ -734,9 +755,10 @@ int tnn_mlp_launch_window(void* handle, int first, int count, int* calls_in_last
     // tnn_mlp_step went through (executed or skipped) = launches per step.
     Mlp* h = (Mlp*)handle;
     if (!h || (count >= 0 && first < 0)) { tnn::set_error("tnn_mlp_launch_window: bad arguments"); return 2; }
-    if (calls_in_last_step) *calls_in_last_step = h->call_idx;
+    if (calls_in_last_step) *calls_in_last_step = (int)h->call_idx;
+    h->windowed = count >= 0;
     h->win_lo = count < 0 ? 0 : first;
-    h->win_hi = count < 0 ? (1 << 30) : first + count;
+    h->win_hi = count < 0 ? 0 : first + count;
     return 0;
 }
 
