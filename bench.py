@@ -185,8 +185,11 @@ def time_gemms_bf16(widths, rows, reps=10):
     for name, M, N, K, out in shapes:
         key = (M, N, K, out)
         if key not in cache:
-            ops = [(bf16.to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32)),
-                    bf16.to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))) for _ in range(rot)]
+            # one host draw per operand; the other sets are device-side rescalings of it (different bits, same cost)
+            a0 = da.asarray(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+            b0 = da.asarray(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+            ops = [(bf16.to_bf16(a0 * (0.75 ** i)), bf16.to_bf16(b0 * (0.75 ** i))) for i in range(rot)]
+            del a0, b0
             for A, B in ops:
                 bf16.gemm_nt(A, B, out_dtype=out)
             e0, e1 = _lib.Event(), _lib.Event()
@@ -256,6 +259,41 @@ def time_dw_adam_bf16(widths, rows, reps=10):
             "mfma_tflops": round(2.0 * M * N * K / us / 1e6, 1),
             "model": "28 B per parameter (p, m, v read; p, m, v, bf16 copy, bf16 transpose written) + the operands; the "
                      "gradient itself never leaves the accumulators"}
+
+
+def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
+    """configs[4] on the driver's line: the whole bf16 step (8192-wide x 4, 512 rows per GPU, Adam) — single GPU: Adam in
+    the dW epilogues; data-parallel: the sharded-optimizer step (reduce-scatter bf16 dW / Adam on the owned rows /
+    all-gather bf16 W, csrc/tnn_mlp.cpp mlp16_step_zero) — plus, on one GPU, its dominant kernel against the HBM roofline
+    and its GEMMs against the bf16 MFMA peak."""
+    e = FusedRun(WIDTHS_E, 512, "mse", 2, rank, world, comm, force_dp, dtype="bfloat16")
+    re = measure(clock, e, 2, 6, 3, 0.0, 512 * world)
+    gflop = 755.9
+    obj = brief(re, workload="configs[4]: 8192-wide 4-layer MLP, bf16 storage, fp32 accumulate / master weights / Adam "
+                             "state, 512 rows per GPU, sum-of-squares/m", n_gpus=world, algorithmic_gflop_per_step_per_gpu=gflop,
+                mfma_frac_of_whole_step=round(gflop * 1e9 / (re["ms_per_step"] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4))
+    if comm is not None:
+        n = e.trainer.n_params
+        obj["step_form"] = ("sharded optimizer: per layer reduce-scatter(bf16 dW) -> Adam on the owned rows -> all-gather(bf16 W) on "
+                            "the communication stream, overlapping the remaining backward; one small fp32 all-reduce for biases + loss")
+        obj["wire_bytes_per_step_per_gpu"] = int(2 * (world - 1) / max(world, 1) * 2 * n)
+        w16 = np.asarray(e.trainer.weights_bf16())
+        crc = int(np.frombuffer(w16.tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
+        if world > 1:
+            import torch.distributed as dist
+            box = [None] * world
+            dist.all_gather_object(box, crc)
+            obj["replicas_identical_bf16_weights"] = bool(all(c == box[0] for c in box))
+    else:
+        obj["step_form"] = "single GPU: Adam in the epilogue of every dW GEMM (keep_grads off)"
+    del e
+    if comm is None:
+        obj["dw_adam_roofline"] = time_dw_adam_bf16(WIDTHS_E, 512, reps=6)
+        obj["dw_adam_roofline"]["frac_of_step_time"] = round(obj["dw_adam_roofline"]["us"] * 4 / (re["ms_per_step"] * 1e3), 3)
+        g = time_gemms_bf16(WIDTHS_E, 512, reps=6)
+        g.pop("per_gemm", None)
+        obj["gemm_roofline"] = g
+    return obj
 
 
 def load_traffic_table():
@@ -972,6 +1010,37 @@ def main():
         if line is not None:
             line.update(curves)
 
+    # ---------------------------------------------------------------- configs[4] (bf16, 8 GPUs) on the data-parallel line
+    if (comm is not None and getattr(comm, "_rccl", False) and args.workload == "A" and args.path == "fused"
+            and not args.no_extras and args.rows is None and os.environ.get("TNN_BENCH_CONFIG_E", "1") != "0"):
+        # never at the price of the line: a watchdog on EVERY rank emits the line as it stands and ends the process if the
+        # extra measurement does not come back (it is the first time this step form meets real links)
+        limit_e = int(os.environ.get("TNN_BENCH_CONFIG_E_TIMEOUT_S", "180"))
+        state_e = {"note": "did not finish in %d s" % limit_e}
+
+        def stop_e():
+            if line is not None:
+                line["config_E"] = state_e["note"]
+            emit(line)
+            os._exit(exit_code)
+        dog_e = threading.Timer(limit_e, stop_e)
+        dog_e.daemon = True
+        dog_e.start()
+        comm.set_p2p(False)                                  # bandwidth-sized messages: RCCL
+        try:
+            obj_e = config_e_object(clock, rank, world, comm, force_dp)
+        except Exception as exc:                             # noqa: BLE001
+            # the other ranks may be inside a collective of the measurement: no vote is possible — wait for the watchdogs
+            state_e["note"] = "failed on rank %d: %s" % (rank, exc)
+            sys.stderr.write("bench: config_E %s\n" % state_e["note"])
+            time.sleep(limit_e + 30)
+            obj_e = state_e["note"]
+        dog_e.cancel()
+        if transports is not None:
+            comm.set_p2p(transports["used"] == "xgmi-p2p")
+        if line is not None:
+            line["config_E"] = obj_e
+
     # ---------------------------------------------------------------- secondary objects (rank 0, N = 1)
     if line is not None and world == 1 and not args.no_extras:
         if args.workload == "E":
@@ -1001,6 +1070,7 @@ def main():
                                          algorithmic_gflop_per_step=85.8993,
                                          mfma_frac_of_whole_step=round(85.8993e9 / (rc["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
                 del c
+                line["config_E"] = config_e_object(solo)
         if not args.no_cpu_baseline and args.workload != "E":
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
 

@@ -362,6 +362,11 @@ TNN_API int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void
 TNN_API int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                   void* g_out_f32, void* p_master, void* m, void* v, void* w_bf16, void* wT_bf16,
                                   double lr, double b1, double b2, double eps, const void* pows_f64);
+/* Adam on a flat slice of the fp32 master parameters whose gradient arrives as bf16 (the reduce-scattered slice of the
+ * sharded-optimizer step): p / m / v fp32 updated in place, the slice's bf16 working copy refreshed.  pows_f64 already
+ * advanced for this step. */
+TNN_API int tnn_adam_master_g16(void* p_master, const void* g_bf16, void* m, void* v, void* w_bf16, int64_t n, double lr,
+                                double b1, double b2, double eps, const void* pows_f64);
 /* {b1^t, b2^t} *= {b1, b2}: the once-per-step advance of Adam's bias-correction state as a launch of its own */
 TNN_API int tnn_adam_tick(void* pows_f64, double b1, double b2);
 
@@ -409,6 +414,10 @@ TNN_API int tnn_mlp_keep_grads(void* handle, int keep);
 /* after the parameter arena was written from outside (initial weights): refresh derived copies — the bf16
  * working copies W, W^T of a TNN_BF16 trainer; no-op for f32 / f64 */
 TNN_API int tnn_mlp_sync_params(void* handle);
+/* bf16 trainer: the bf16 working copy of the whole parameter arena (arena order, element offsets of
+ * tnn_mlp_param_offset).  In the data-parallel sharded-optimizer step it is the complete, rank-identical copy of the
+ * weights (each rank's fp32 master arena is authoritative for its own rows only). */
+TNN_API int tnn_mlp_bf16_weights(void* handle, void** w_bf16);
 /* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
 TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
 
@@ -431,6 +440,21 @@ TNN_API int tnn_comm_join(void);
 /* wait only for the OLDEST outstanding bucket (buckets complete in issue order): lets the optimizer start on the
  * last layer's parameters while the earlier layers' buckets are still on the links */
 TNN_API int tnn_comm_wait_oldest(void);
+/* Sharded-optimizer exchange for arenas that are bandwidth problems (configs[4]: 268 M parameters).  New relative to
+ * the reference (no communication there); replaces "all-reduce the gradient, every rank runs the same Adam"
+ * (run.py:82-83) by: reduce-scatter the gradient (rank r receives the SUM of slice r), Adam on the OWNED slice only
+ * (core/optimizer.py:67-79), all-gather of the refreshed bf16 weights.  Same bytes on the links as one all-reduce of
+ * the wire dtype, optimizer traffic divided by the world size.
+ * tnn_reduce_scatter: recv[0:n] <- SUM over ranks of send_r[rank*n : (rank+1)*n]; recv may be send + rank*n (in place).
+ * dtype TNN_F32 / TNN_F64 / TNN_BF16.  World 1 without a communicator: a copy. */
+TNN_API int tnn_reduce_scatter(const void* send, void* recv, int64_t n_per_rank, int dtype);
+/* tnn_comm_chain_begin .. tnn_comm_chain_end: every library call in between is enqueued on the COMMUNICATION stream
+ * instead of the library stream, ordered behind everything enqueued on the library stream so far; the library stream
+ * itself continues (the next layer's backward).  chain_end files one "done" event that tnn_comm_wait_oldest /
+ * tnn_comm_join wait for, like a bucket of tnn_allreduce_async.  Without an RCCL communicator (world 1) the chain runs
+ * inline on the library stream. */
+TNN_API int tnn_comm_chain_begin(void);
+TNN_API int tnn_comm_chain_end(void);
 /* C1 and the optimizer in one call (run.py:82-83 with the exchange in between): grads[0:n_reduce] <- SUM over ranks,
  * then tnn_adam_ex(p, grads, m, v, n_params <= n_reduce, ..., advance, scalar_src = grads + scalar_index, scalar_dst).
  * On the peer-to-peer transport (f32, advance == 0) the update is applied by the all-reduce kernel's last stage, so

@@ -104,7 +104,7 @@ template <typename T> T una(int op, T a) {
     return a;
 }
 
-size_t dsize(int dtype) { return dtype == TNN_F32 ? 4 : dtype == TNN_U8 ? 1 : 8; }
+size_t dsize(int dtype) { return dtype == TNN_F32 ? 4 : dtype == TNN_U8 ? 1 : dtype == TNN_BF16 ? 2 : 8; }
 
 #define FLOAT_SWITCH(dtype, fn, ...)                                          \
     switch (dtype) {                                                          \
@@ -817,19 +817,147 @@ int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, 
     return 0;
 }
 
-// ---- bf16 path: GPU only (the twin covers the f32/f64 host logic); same symbols, explicit refusal ----
-#define NO_BF16(name) do { tnn::set_error(name ": the bf16 path has no CPU twin"); return 2; } while (0)
-int tnn_gemm_bf16_nt(int64_t, int64_t, int64_t, const void*, int64_t, const void*, int64_t, void*, int64_t, int,
-                     const void*, int, int, const void*, int64_t) { NO_BF16("tnn_gemm_bf16_nt"); }
-int tnn_transpose_bf16(const void*, void*, int64_t, int64_t) { NO_BF16("tnn_transpose_bf16"); }
-int tnn_cast_bf16(const void*, void*, int64_t, int) { NO_BF16("tnn_cast_bf16"); }
-int tnn_colsum_bf16(const void*, void*, int64_t, int64_t) { NO_BF16("tnn_colsum_bf16"); }
-int tnn_mse_bf16(const void*, const void*, int64_t, int64_t, void*, void*) { NO_BF16("tnn_mse_bf16"); }
-int tnn_adam_master_bf16(void*, const void*, void*, void*, void*, int64_t, double, double, double, double, void*) {
-    NO_BF16("tnn_adam_master_bf16");
+// ---- bf16 path: EMULATION of the device's arithmetic contract (configs[4]) so the product's bf16 trainer host code
+// (csrc/tnn_mlp.cpp: bucket order, reduce-scatter / sharded Adam / all-gather, loss slot) runs at world > 1 without a
+// GPU.  bf16 = the upper 16 bits of an f32, rounded to nearest even on every store (tinynn-autograd_amd/bf16.py
+// round_to_bf16 is the same rule); products accumulate in f32.  The summation ORDER inside a dot product differs from
+// the MFMA's, so twin-vs-device agreement is to f32 round-off, not bit-for-bit.
+typedef uint16_t bf16_t;
+static inline bf16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
 }
-int tnn_gemm_bf16_nt_adam(int64_t, int64_t, int64_t, const void*, int64_t, const void*, int64_t, void*, void*, void*, void*, void*,
-                          void*, double, double, double, double, const void*) { NO_BF16("tnn_gemm_bf16_nt_adam"); }
+static inline float bf2f(bf16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// C[M,N] = A[M,K] B[N,K]^T (core/ops.py:151,157,160 through the K-contiguous copies), epilogues of tnn_gemm_bf16_nt
+int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
+                     int64_t ldc, int c_dtype, const void* bias, int act, int relu_sign, const void* mask_y, int64_t ldy) {
+    NEED_INIT();
+    REQ(A && B && C && M > 0 && N > 0 && K > 0, "tnn_gemm_bf16_nt: bad arguments");
+    REQ(c_dtype == TNN_BF16 || c_dtype == TNN_F32, "tnn_gemm_bf16_nt: c_dtype %d", c_dtype);
+    REQ(!(bias || act) || !mask_y, "tnn_gemm_bf16_nt: bias/activation and mask epilogues are exclusive");
+    RECORD(tnn_gemm_bf16_nt(M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias, act, relu_sign, mask_y, ldy));
+    const bf16_t *a = (const bf16_t*)A, *b = (const bf16_t*)B, *y = (const bf16_t*)mask_y;
+    std::vector<float> arow((size_t)K);
+    for (int64_t i = 0; i < M; ++i) {
+        for (int64_t k = 0; k < K; ++k) arow[k] = bf2f(a[i * lda + k]);
+        for (int64_t j = 0; j < N; ++j) {
+            float acc = 0.f;
+            const bf16_t* bj = b + j * ldb;
+            for (int64_t k = 0; k < K; ++k) acc += arow[k] * bf2f(bj[k]);
+            if (bias || act) {
+                if (bias) acc += ((const float*)bias)[j];
+                if (act == TNN_ACT_RELU) acc = acc < 0.f ? (relu_sign ? -0.0f : 0.f) : fabsf(acc);
+            } else if (y) {
+                if (y[i * ldy + j] & 0x8000u) acc = 0.f;
+            }
+            if (c_dtype == TNN_BF16) ((bf16_t*)C)[i * ldc + j] = f2bf(acc);
+            else ((float*)C)[i * ldc + j] = acc;
+        }
+    }
+    return 0;
+}
+int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols) {
+    NEED_INIT();
+    RECORD(tnn_transpose_bf16(in, out, rows, cols));
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) ((bf16_t*)out)[c * rows + r] = ((const bf16_t*)in)[r * cols + c];
+    return 0;
+}
+int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16) {
+    NEED_INIT();
+    RECORD(tnn_cast_bf16(in, out, n, to_bf16));
+    for (int64_t i = 0; i < n; ++i) {
+        if (to_bf16) ((bf16_t*)out)[i] = f2bf(((const float*)in)[i]);
+        else ((float*)out)[i] = bf2f(((const bf16_t*)in)[i]);
+    }
+    return 0;
+}
+int tnn_colsum_bf16(const void* in, void* out, int64_t rows, int64_t cols) {     // bias gradient, core/ops.py:52-54
+    NEED_INIT();
+    RECORD(tnn_colsum_bf16(in, out, rows, cols));
+    for (int64_t c = 0; c < cols; ++c) {
+        double acc = 0.0;
+        for (int64_t r = 0; r < rows; ++r) acc += (double)bf2f(((const bf16_t*)in)[r * cols + c]);
+        ((float*)out)[c] = (float)acc;
+    }
+    return 0;
+}
+int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out, void* dpred) {
+    NEED_INIT();
+    RECORD(tnn_mse_bf16(pred, y, n, m_global, loss_out, dpred));
+    const double inv_m = 1.0 / (double)m_global;
+    const float two_inv_m = (float)(2.0 * inv_m);
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const float e = bf2f(((const bf16_t*)pred)[i]) - bf2f(((const bf16_t*)y)[i]);
+        acc += (double)e * (double)e;
+        if (dpred) ((bf16_t*)dpred)[i] = f2bf(two_inv_m * e);
+    }
+    ((float*)loss_out)[0] = (float)(acc * inv_m);
+    return 0;
+}
+// core/optimizer.py:67-79 on the fp32 master copy; G16 = the gradient arrives as bf16 (reduce-scattered wire format)
+static void adam_master_rows(bool G16, float* p, const void* g, float* m, float* v, bf16_t* w16, bf16_t* wT16, int64_t rows,
+                             int64_t cols, int64_t ldt, double lr, double b1, double b2, double eps, const double* st) {
+    const float ic1 = (float)(1.0 / (1.0 - st[0])), ic2 = (float)(1.0 / (1.0 - st[1]));
+    const float omb1 = 1.f - (float)b1, omb2 = 1.f - (float)b2, flr = (float)lr, feps = (float)eps;
+    for (int64_t r = 0; r < rows; ++r)
+        for (int64_t c = 0; c < cols; ++c) {
+            const int64_t i = r * cols + c;
+            const float gi = G16 ? bf2f(((const bf16_t*)g)[i]) : ((const float*)g)[i];
+            float mi = m[i], vi = v[i];
+            mi = mi + omb1 * (gi - mi);
+            vi = vi + omb2 * (gi * gi - vi);
+            m[i] = mi;
+            v[i] = vi;
+            const float pi = p[i] + (-flr * (mi * ic1) / (sqrtf(vi * ic2) + feps));
+            p[i] = pi;
+            if (w16) w16[i] = f2bf(pi);
+            if (wT16) wT16[c * ldt + r] = f2bf(pi);
+        }
+}
+int tnn_adam_master_bf16_2d(void* p, const void* g, void* m, void* v, void* w16, void* wT16, int64_t rows, int64_t cols,
+                            double lr, double b1, double b2, double eps, void* pows, int advance) {
+    NEED_INIT();
+    REQ(p && g && m && v && pows, "tnn_adam_master_bf16_2d: NULL argument");
+    RECORD(tnn_adam_master_bf16_2d(p, g, m, v, w16, wT16, rows, cols, lr, b1, b2, eps, pows, advance));
+    double* st = (double*)pows;
+    if (advance) { st[0] *= b1; st[1] *= b2; }
+    adam_master_rows(false, (float*)p, g, (float*)m, (float*)v, (bf16_t*)w16, (bf16_t*)wT16, rows, cols, rows, lr, b1, b2, eps, st);
+    return 0;
+}
+int tnn_adam_master_bf16(void* p, const void* g, void* m, void* v, void* w16, int64_t n, double lr, double b1, double b2,
+                         double eps, void* pows) {
+    return tnn_adam_master_bf16_2d(p, g, m, v, w16, nullptr, 1, n, lr, b1, b2, eps, pows, 1);
+}
+int tnn_adam_master_g16(void* p, const void* g16, void* m, void* v, void* w16, int64_t n, double lr, double b1, double b2,
+                        double eps, const void* pows) {
+    NEED_INIT();
+    REQ(p && g16 && m && v && w16 && pows, "tnn_adam_master_g16: NULL argument");
+    RECORD(tnn_adam_master_g16(p, g16, m, v, w16, n, lr, b1, b2, eps, pows));
+    adam_master_rows(true, (float*)p, g16, (float*)m, (float*)v, (bf16_t*)w16, nullptr, 1, n, 1, lr, b1, b2, eps, (const double*)pows);
+    return 0;
+}
+int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* g_out,
+                          void* p, void* m, void* v, void* w16, void* wT16, double lr, double b1, double b2, double eps,
+                          const void* pows) {
+    NEED_INIT();
+    REQ(p && m && v && pows, "tnn_gemm_bf16_nt_adam: NULL argument");
+    RECORD(tnn_gemm_bf16_nt_adam(M, N, K, A, lda, B, ldb, g_out, p, m, v, w16, wT16, lr, b1, b2, eps, pows));
+    std::vector<float> g((size_t)(M * N));
+    if (int rc = tnn_gemm_bf16_nt(M, N, K, A, lda, B, ldb, g.data(), N, TNN_F32, nullptr, TNN_ACT_NONE, 0, nullptr, 0)) return rc;
+    if (g_out) memcpy(g_out, g.data(), g.size() * 4);
+    adam_master_rows(false, (float*)p, g.data(), (float*)m, (float*)v, (bf16_t*)w16, (bf16_t*)wT16, M, N, M, lr, b1, b2, eps,
+                            (const double*)pows);
+    return 0;
+}
 int tnn_adam_tick(void* pows, double b1, double b2) {
     NEED_INIT();
     REQ(pows != nullptr, "tnn_adam_tick: pows state is NULL");
@@ -837,10 +965,6 @@ int tnn_adam_tick(void* pows, double b1, double b2) {
     ((double*)pows)[0] *= b1;
     ((double*)pows)[1] *= b2;
     return 0;
-}
-int tnn_adam_master_bf16_2d(void*, const void*, void*, void*, void*, void*, int64_t, int64_t, double, double, double,
-                            double, void*, int) {
-    NO_BF16("tnn_adam_master_bf16_2d");
 }
 
 // ---- comm: single-process identity by default.  Multi-process CPU tests either use gloo at the Python layer
@@ -853,6 +977,8 @@ typedef int (*twin_allreduce_fn)(void* buf, int64_t n, int dtype, int rop);
 typedef int (*twin_allgather_fn)(const void* send, void* recv, int64_t n_per_rank, int dtype);
 static twin_allreduce_fn g_hook_allreduce = nullptr;
 static twin_allgather_fn g_hook_allgather = nullptr;
+typedef int (*twin_reduce_scatter_fn)(const void* send, void* recv, int64_t n_per_rank, int dtype);
+static twin_reduce_scatter_fn g_hook_reduce_scatter = nullptr;
 static int g_hook_rank = 0, g_hook_world = 1;
 int tnn_twin_set_collectives(int rank, int world, twin_allreduce_fn ar, twin_allgather_fn ag) {
     REQ(world >= 1 && rank >= 0 && rank < world, "tnn_twin_set_collectives: rank %d / world %d", rank, world);
@@ -863,6 +989,7 @@ int tnn_twin_set_collectives(int rank, int world, twin_allreduce_fn ar, twin_all
     g_comm = ar ? 1 : 0;
     return 0;
 }
+int tnn_twin_set_reduce_scatter(twin_reduce_scatter_fn rs) { g_hook_reduce_scatter = rs; return 0; }
 int tnn_comm_unique_id(void* id) { memset(id, 0, 128); return 0; }
 int tnn_comm_init(int rank, int world, const void*) {
     REQ(world == 1 && rank == 0, "cpu twin: tnn_comm supports world size 1 only");
@@ -880,6 +1007,19 @@ int tnn_allreduce(void* buf, int64_t n, int dtype, int rop) {
 }
 int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) { return tnn_allreduce(buf, n, dtype, rop); }
 int tnn_comm_join(void) { return 0; }
+// the twin has one "stream": a chain runs inline
+int tnn_comm_chain_begin(void) { return 0; }
+int tnn_comm_chain_end(void) { return 0; }
+int tnn_reduce_scatter(const void* s, void* r, int64_t n, int dtype) {
+    REQ(g_comm, "tnn_reduce_scatter: tnn_comm_init() has not been called");
+    if (g_hook_reduce_scatter) {
+        REQ(g_hook_reduce_scatter(s, r, n, dtype) == 0, "tnn_reduce_scatter: the test's collective callback failed");
+        return 0;
+    }
+    REQ(g_hook_world == 1, "tnn_reduce_scatter: no reduce-scatter callback installed");
+    if (r != s) memmove(r, s, (size_t)n * dsize(dtype));
+    return 0;
+}
 int tnn_comm_wait_oldest(void) { return 0; }
 int tnn_allgather(const void* s, void* r, int64_t n, int dtype) {
     REQ(g_comm, "tnn_allgather: tnn_comm_init() has not been called");

@@ -12,6 +12,11 @@ RCCL runs here through gloo; the launch sequence and the host logic are the same
                   form, so the step takes the RCCL-shaped 6-launch structure — statistics as a launch of their own
                   (tnn_mlp_head_stats), ONE all-gather of the pairs, head + hidden backward merging them
                   (tnn_mlp_head_bwd_tick_ext), ONE all-reduce with the Adam tail — against traj_A_adam.npz
+  mode "E"        configs[4] in small: bf16 trainer (512-wide x 2 layers, sum-of-squares, Adam), 64 rows per rank — the
+                  SHARDED-OPTIMIZER step (mlp16_step_zero): per layer reduce-scatter of the bf16 weight gradient, Adam on
+                  the owned rows, all-gather of the bf16 rows; one small all-reduce for biases + loss.  Against
+                  oracle/closed_form.py (float64) on the same bf16-rounded weights and inputs, collective order and sizes
+                  asserted, bf16 weights identical on every rank.
 """
 
 import ctypes
@@ -24,7 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-_NP = {0: np.float32, 1: np.float64, 2: np.int64, 3: np.uint8}
+_NP = {0: np.float32, 1: np.float64, 2: np.int64, 3: np.uint8, 4: np.uint16}   # 4: bf16 bit patterns
 
 
 def main():
@@ -39,7 +44,7 @@ def main():
     from tinynn_autograd_amd.dist import DeviceCommunicator
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    calls = {"allreduce": [], "allgather": 0}
+    calls = {"allreduce": [], "allgather": 0, "seq": []}
 
     def as_array(ptr, n, dtype):
         return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n * np.dtype(_NP[dtype]).itemsize,)).view(_NP[dtype])
@@ -50,22 +55,60 @@ def main():
         t = torch.from_numpy(arr)                                   # shares the twin's memory: reduced in place
         dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MAX, 2: dist.ReduceOp.MIN}[rop])
         calls["allreduce"].append(int(n))
+        calls["seq"].append(("allreduce", int(n), int(dtype)))
         return 0
 
     @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
     def allgather(send, recv, n, dtype):
-        src = torch.from_numpy(as_array(send, n, dtype).copy())
+        src = torch.from_numpy(as_array(send, n, dtype).copy().view(np.uint8))       # bytes: gloo has no 16-bit integers
         parts = [torch.empty_like(src) for _ in range(world)]
         dist.all_gather(parts, src)
-        as_array(recv, n * world, dtype)[...] = np.concatenate([p.numpy() for p in parts])
+        as_array(recv, n * world, dtype)[...] = np.concatenate([p.numpy() for p in parts]).view(_NP[dtype])
         calls["allgather"] += 1
+        calls["seq"].append(("allgather", int(n), int(dtype)))
+        return 0
+
+    def bf16_round(f):
+        u = np.ascontiguousarray(f, dtype=np.float32).view(np.uint32)
+        return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+    @ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int)
+    def reduce_scatter(send, recv, n, dtype):
+        # every rank's whole send buffer travels (test infrastructure, not a bandwidth-optimal collective); slice `rank` is
+        # summed in rank order, rounding to the wire dtype after every addition like a ring of bf16 adds would
+        src = torch.from_numpy(as_array(send, n * world, dtype).copy().view(np.uint8))
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
+        mine = [p.numpy().view(_NP[dtype])[rank * n:(rank + 1) * n] for p in parts]
+        if dtype == 4:
+            acc = (mine[0].astype(np.uint32) << 16).view(np.float32)
+            for q in mine[1:]:
+                acc = (bf16_round(acc + (q.astype(np.uint32) << 16).view(np.float32)).astype(np.uint32) << 16).view(np.float32)
+            out = bf16_round(acc)
+        else:
+            out = mine[0].copy()
+            for q in mine[1:]:
+                out = out + q
+        as_array(recv, n, dtype)[...] = out
+        calls["seq"].append(("reduce_scatter", int(n), int(dtype)))
         return 0
 
     hook = lib.cdll.tnn_twin_set_collectives
     hook.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     hook.restype = ctypes.c_int
     assert hook(rank, world, ctypes.cast(allreduce, ctypes.c_void_p), ctypes.cast(allgather, ctypes.c_void_p)) == 0
+    hook_rs = lib.cdll.tnn_twin_set_reduce_scatter
+    hook_rs.argtypes = [ctypes.c_void_p]
+    hook_rs.restype = ctypes.c_int
+    assert hook_rs(ctypes.cast(reduce_scatter, ctypes.c_void_p)) == 0
     comm = DeviceCommunicator(rank, world)           # the product's communicator class over tnn_allreduce / tnn_allgather
+    if mode == "E":
+        run_config_e_small(tn, comm, calls, rank, world, dist)
+        dist.barrier()
+        hook(0, 1, None, None)
+        hook_rs(None)
+        print("dp_hook_worker %s rank %d/%d ok" % (mode, rank, world))
+        return
 
     name = "C_small" if mode == "Cbucket" else "A_adam" if mode == "A" else "D_adam"
     cfg, gold = H.load_traj(name)
@@ -99,7 +142,64 @@ def main():
     assert all(p == parts[0] for p in parts), "parameters diverged across ranks"
     dist.barrier()
     hook(0, 1, None, None)
+    hook_rs(None)
     print("dp_hook_worker %s rank %d/%d ok" % (mode, rank, world))
+
+
+def run_config_e_small(tn, comm, calls, rank, world, dist):
+    from oracle.closed_form import ClosedFormMLP                 # the checker
+    from tinynn_autograd_amd import bf16
+    from tinynn_autograd_amd.fused import MLPTrainer
+    BF16, F32 = 4, 0
+    widths, rows, lr, steps = [512, 512, 512], 64, 1e-3, 3
+    m = rows * world
+    rs = np.random.RandomState(91)
+    a = np.sqrt(6.0 / 1024)
+    W = [bf16.round_to_bf16(rs.uniform(-a, a, (512, 512)).astype(np.float32)) for _ in range(2)]
+    B = [bf16.round_to_bf16((rs.randn(1, 512) * 0.02).astype(np.float32)) for _ in range(2)]
+    x = bf16.round_to_bf16(rs.rand(m, 512).astype(np.float32))
+    sl = slice(rank * rows, (rank + 1) * rows)
+    trainer = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=lr, dtype="bfloat16", comm=comm)
+    trainer.set_parameters([{"w": W[i], "b": B[i]} for i in range(2)])
+    oracle = ClosedFormMLP(W, B, loss="mse", optimizer="adam", lr=lr)
+    x16 = bf16.to_bf16(x[sl])
+    losses, ref = [], []
+    for s in range(steps):
+        calls["seq"] = []
+        losses.append(float(trainer.step(x16, x16)))
+        ref.append(oracle.step(x, x)[0])
+        # last layer first: reduce-scatter of the bf16 gradient slice, all-gather of the refreshed bf16 rows; then ONE
+        # small fp32 all-reduce carrying both bias gradients and the loss
+        shard = [widths[l] // world * widths[l + 1] for l in range(2)]
+        want = [("reduce_scatter", shard[1], BF16), ("allgather", shard[1], BF16),
+                ("reduce_scatter", shard[0], BF16), ("allgather", shard[0], BF16),
+                ("allreduce", widths[1] + widths[2] + 1, F32)]
+        assert calls["seq"] == want, (calls["seq"], want)
+    # bf16 activations / dz / dW add ~2^-9 relative noise per tensor (same bar as tests/test_gpu_bf16.py)
+    np.testing.assert_allclose(losses, ref, rtol=2e-2)
+    assert losses[-1] < losses[0]
+    w16 = np.asarray(trainer.weights_bf16()).copy()
+    parts = [None] * world
+    dist.all_gather_object(parts, w16.tobytes())
+    assert all(p == parts[0] for p in parts), "bf16 weights diverged across ranks"
+    for l in range(2):
+        got = (np.asarray(trainer.weights_bf16(l)).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        # Adam moves a weight by <= lr per step whatever the gradient's size: three steps of sign-like updates on gradients
+        # that carry bf16 noise stay within a fraction of lr of the float64 trajectory, plus half a bf16 ulp (|w| < 2^-3)
+        err = np.abs(got - oracle.W[l])
+        if rank == 0:
+            print("E layer %d: max %.3g  p99 %.3g  p90 %.3g  median %.3g" % (l, err.max(), np.quantile(err, 0.99), np.quantile(err, 0.9), np.median(err)))
+        # (where a gradient element is smaller than its bf16 noise the update's sign is arbitrary: the device and the oracle
+        # may then move up to lr per step in opposite directions)
+        assert err.max() <= 2 * steps * lr + 2.0 ** -12, (l, err.max())
+        assert np.quantile(err, 0.99) <= 1.0 * lr + 2.0 ** -12, (l, float(np.quantile(err, 0.99)))
+        assert np.median(err) <= 0.1 * lr + 2.0 ** -12, (l, float(np.median(err)))
+        # this rank's fp32 master rows are what its bf16 rows were rounded from
+        r0, r1 = rank * widths[l] // world, (rank + 1) * widths[l] // world
+        own = np.asarray(trainer.param_view(l, "w"))[r0:r1]
+        assert np.array_equal(bf16.round_to_bf16(own), (np.asarray(trainer.weights_bf16(l))[r0:r1].astype(np.uint32) << 16).view(np.float32))
+        bias = np.asarray(trainer.param_view(l, "b"), dtype=np.float64)
+        assert np.abs(bias - oracle.b[l]).max() <= 2 * steps * lr and np.median(np.abs(bias - oracle.b[l])) <= 0.1 * lr
 
 
 if __name__ == "__main__":

@@ -44,7 +44,7 @@ def test_data_parallel_world2_matches_single_process_reference():
     _run_world(2, "dp_worker.py")
 
 
-@pytest.mark.parametrize("mode", ["D", "Dbucket", "Cbucket", "A"])
+@pytest.mark.parametrize("mode", ["D", "Dbucket", "Cbucket", "A", "E"])
 def test_native_sharded_step_world4_over_gloo(mode):
     """The product's C++ data-parallel step (tnn_mlp_step_sharded) at world 4: strong-scaling config D with 1024/4 rows
     per rank against the reference's bs-1024 trajectory — single-collective and bucketed — and the bucketed path on

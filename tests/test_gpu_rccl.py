@@ -70,26 +70,46 @@ def test_sharded_steps_captured_with_rccl_in_graph(comm):
 
 @pytest.mark.gpu
 def test_bf16_trainer_sharded_step_world1(comm):
-    """bf16 storage / fp32 arenas: the sharded step (fp32 gradient arena all-reduced as f32) at world 1 must equal the
-    unsharded step bit for bit."""
+    """bf16 trainer through tnn_mlp_step_sharded at world 1 = the sharded-optimizer step (mlp16_step_zero): reduce-scatter of
+    the bf16 weight gradient / Adam on the owned rows (all of them here) / all-gather of the bf16 rows, each layer's chain on
+    the communication stream.  Against the unsharded step, which keeps the gradient in fp32: the first loss is identical
+    (same forward), afterwards the one extra rounding of dW to bf16 shows (Adam's update is sign-like: |step| <= lr)."""
     from tinynn_autograd_amd import bf16
     from tinynn_autograd_amd.fused import MLPTrainer
     rs = np.random.RandomState(5)
-    widths, m = [256, 256, 256], 128
+    widths, m, lr = [256, 256, 256], 128, 1e-3
     a = np.sqrt(6.0 / 512)
     layers = [{"w": rs.uniform(-a, a, (256, 256)).astype(np.float32), "b": np.zeros((1, 256), np.float32)}
               for _ in range(2)]
     x16 = bf16.to_bf16(rs.rand(m, 256).astype(np.float32))
-    losses = []
-    for c in (None, comm):
-        t = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16", comm=c, force_dp=c is not None)
+    losses, params, w16 = [], [], []
+    for mode in ("plain", "sharded", "sharded_graph"):
+        c = None if mode == "plain" else comm
+        t = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=lr, dtype="bfloat16", comm=c, force_dp=c is not None)
         t.set_parameters(layers)
-        losses.append([float(t.step(x16, x16)) for _ in range(3)])
-        params = np.asarray(t.params)
-        if c is None:
-            ref_params = params
-    assert losses[0] == losses[1]
-    assert np.array_equal(params, ref_params)
+        if mode == "sharded_graph":
+            g = t.capture_steps([(x16, x16)] * 3)
+            losses.append([float(v) for v in np.asarray(g.launch())])
+        else:
+            losses.append([float(t.step(x16, x16)) for _ in range(3)])
+        params.append(np.asarray(t.params).copy())
+        w16.append(np.asarray(t.weights_bf16()).copy())
+        # the bf16 working copy is the rounding of the fp32 master weights
+        assert np.array_equal(bf16.round_to_bf16(params[-1]), (w16[-1].astype(np.uint32) << 16).view(np.float32))
+        # and the next forward sees it (W^T refreshed behind the all-gather)
+        out = np.asarray(t.forward(x16), dtype=np.float64)
+        W = [(np.asarray(t.weights_bf16(l)).astype(np.uint32) << 16).view(np.float32).astype(np.float64) for l in range(2)]
+        B = [np.asarray(t.param_view(l, "b"), dtype=np.float64) for l in range(2)]
+        xs = np.asarray(bf16.to_f32(x16), dtype=np.float64)
+        ref = np.clip(xs @ W[0] + B[0], 0, None)
+        ref = bf16.round_to_bf16(ref.astype(np.float32)).astype(np.float64) @ W[1] + B[1]
+        assert np.abs(out - ref).max() <= 2e-2 * np.abs(ref).max()
+    assert losses[0][0] == losses[1][0]
+    np.testing.assert_allclose(losses[1], losses[0], rtol=2e-3)
+    err = np.abs(params[1] - params[0])
+    assert err.max() <= 2 * 3 * lr and np.median(err) <= 0.1 * lr
+    # eager and captured sharded steps are the same launches
+    assert losses[2] == losses[1] and np.array_equal(params[2], params[1]) and np.array_equal(w16[2], w16[1])
 
 
 @pytest.mark.gpu

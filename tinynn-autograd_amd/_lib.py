@@ -109,6 +109,7 @@ _SIGNATURES = {
     "tnn_adam_master_bf16_2d": [_p, _p, _p, _p, _p, _p, c_int64, c_int64, c_double, c_double, c_double, c_double, _p, c_int],
     "tnn_gemm_bf16_nt_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
     "tnn_adam_tick": [_p, c_double, c_double],
+    "tnn_adam_master_g16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
     "tnn_mlp_create": [c_int, _i64p, c_int64, c_int, c_int, c_double, c_double, c_double, c_double,
                        c_int, POINTER(c_void_p)],
     "tnn_mlp_destroy": [_p],
@@ -126,6 +127,7 @@ _SIGNATURES = {
     "tnn_mlp_keep_grads": [_p, c_int],
     "tnn_mlp_sync_params": [_p],
     "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
+    "tnn_mlp_bf16_weights": [_p, POINTER(c_void_p)],
     "tnn_comm_unique_id": [_p],
     "tnn_comm_init": [c_int, c_int, _p],
     "tnn_comm_destroy": [],
@@ -134,6 +136,9 @@ _SIGNATURES = {
     "tnn_allgather": [_p, _p, c_int64, c_int],
     "tnn_allreduce_async": [_p, c_int64, c_int, c_int],
     "tnn_comm_join": [],
+    "tnn_reduce_scatter": [_p, _p, c_int64, c_int],
+    "tnn_comm_chain_begin": [],
+    "tnn_comm_chain_end": [],
     "tnn_comm_wait_oldest": [],
     "tnn_allreduce_adam": [_p, c_int64, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, c_int, c_int,
                            c_int64, _p],

@@ -27,6 +27,8 @@ struct Rccl {
                               hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
                               hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                                  hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
@@ -72,6 +74,7 @@ int load_rccl() {
     SYM(CommDestroy, "ncclCommDestroy");
     SYM(AllReduce, "ncclAllReduce");
     SYM(AllGather, "ncclAllGather");
+    SYM(ReduceScatter, "ncclReduceScatter");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     return 0;
@@ -92,6 +95,7 @@ int nccl_type(int dtype, ncclDataType_t* t) {
         case TNN_F64: *t = ncclFloat64; return 0;
         case TNN_I64: *t = ncclInt64; return 0;
         case TNN_U8: *t = ncclUint8; return 0;
+        case TNN_BF16: *t = ncclBfloat16; return 0;
     }
     tnn::set_error("tnn_comm: unknown dtype %d", dtype);
     return 2;
@@ -237,6 +241,68 @@ int tnn_allreduce_async(void* buf, int64_t n, int dtype, int rop) {
     return 0;
 }
 
+int tnn_reduce_scatter(const void* send, void* recv, int64_t n_per_rank, int dtype) {
+    TNN_NEED_INIT();
+    if (n_per_rank <= 0) return 0;
+    const size_t esz = dtype == TNN_F64 || dtype == TNN_I64 ? 8 : dtype == TNN_BF16 ? 2 : dtype == TNN_U8 ? 1 : 4;
+    if (R.comm == nullptr) {
+        int rank = 0, world = 1;
+        (void)tnn_comm_world(&rank, &world);
+        TNN_REQUIRE(world == 1, "tnn_reduce_scatter: tnn_comm_init() has not been called");
+        if (recv != send) TNN_CHECK_HIP(hipMemcpyAsync(recv, send, (size_t)n_per_rank * esz, hipMemcpyDeviceToDevice, tnn::stream()));
+        return 0;
+    }
+    ncclDataType_t t;
+    if (int rc = nccl_type(dtype, &t)) return rc;
+    TNN_CHECK_NCCL(R.ReduceScatter(send, recv, (size_t)n_per_rank, t, ncclSum, R.comm, tnn::stream()));
+    return 0;
+}
+
+// A chain = several dependent library calls (reduce-scatter -> optimizer on the owned slice -> all-gather) that run on
+// the communication stream while the library stream goes on with the next layer's backward.  While a chain is open,
+// tnn::stream() IS the communication stream (tnn::set_stream_override).
+static hipEvent_t g_chain_done = nullptr;
+static bool g_chain_open = false, g_chain_inline = false;
+int tnn_comm_chain_begin(void) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(!g_chain_open, "tnn_comm_chain_begin: a chain is already open");
+    g_chain_open = true;
+    g_chain_inline = R.comm == nullptr;
+    if (g_chain_inline) return 0;
+    if (!g_comm_stream) {
+        TNN_CHECK_HIP(hipStreamCreateWithFlags(&g_comm_stream, hipStreamNonBlocking));
+        g_pending = new std::vector<hipEvent_t>();
+    }
+    hipEvent_t produced;
+    if (int rc = take_event(&produced)) { g_chain_open = false; return rc; }
+    const bool ok = hipEventRecord(produced, tnn::stream()) == hipSuccess &&
+                    hipStreamWaitEvent(g_comm_stream, produced, 0) == hipSuccess;
+    give_event(produced);
+    if (!ok || take_event(&g_chain_done)) {
+        g_chain_open = false;
+        tnn::set_error("tnn_comm_chain_begin: ordering the communication stream behind the producer failed");
+        return 1;
+    }
+    tnn::set_stream_override(g_comm_stream);
+    return 0;
+}
+int tnn_comm_chain_end(void) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(g_chain_open, "tnn_comm_chain_end: no chain is open");
+    g_chain_open = false;
+    if (g_chain_inline) return 0;
+    tnn::set_stream_override(nullptr);
+    hipEvent_t done = g_chain_done;
+    g_chain_done = nullptr;
+    if (hipEventRecord(done, g_comm_stream) != hipSuccess) {
+        give_event(done);
+        tnn::set_error("tnn_comm_chain_end: recording the chain-done event failed");
+        return 1;
+    }
+    g_pending->push_back(done);
+    return 0;
+}
+
 int tnn_comm_wait_oldest(void) {
     TNN_NEED_INIT();
     if (!g_pending || g_pending->empty()) return 0;
@@ -267,7 +333,14 @@ int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
     TNN_NEED_INIT();
     if (n_per_rank <= 0) return 0;
     if (tnn::p2p_can_allgather(n_per_rank, dtype)) return tnn::p2p_allgather(send, recv, n_per_rank, dtype);
-    TNN_REQUIRE(R.comm != nullptr, "tnn_allgather: tnn_comm_init() has not been called");
+    if (R.comm == nullptr) {
+        int rank = 0, world = 1;
+        (void)tnn_comm_world(&rank, &world);
+        TNN_REQUIRE(world == 1, "tnn_allgather: tnn_comm_init() has not been called");
+        const size_t esz = dtype == TNN_F64 || dtype == TNN_I64 ? 8 : dtype == TNN_BF16 ? 2 : dtype == TNN_U8 ? 1 : 4;
+        if (recv != send) TNN_CHECK_HIP(hipMemcpyAsync(recv, send, (size_t)n_per_rank * esz, hipMemcpyDeviceToDevice, tnn::stream()));
+        return 0;
+    }
     ncclDataType_t t;
     if (int rc = nccl_type(dtype, &t)) return rc;
     TNN_CHECK_NCCL(R.AllGather(send, recv, (size_t)n_per_rank, t, R.comm, tnn::stream()));

@@ -384,23 +384,35 @@ __global__ __launch_bounds__(64) void sum_partials_f32_kernel(const double* __re
 }
 
 // Adam on the fp32 master copy + refresh of the bf16 working copy (28 B + 2 B per parameter)
-__global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict__ p, const float* __restrict__ g,
+// G16: the gradient itself is bf16 (the reduce-scattered slice of the sharded-optimizer step, tnn_adam_master_g16)
+template <bool G16>
+__global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict__ p, const void* __restrict__ g_,
                                                                float* __restrict__ m, float* __restrict__ v,
                                                                bf16_t* __restrict__ w16, int64_t n, float lr, float b1,
                                                                float b2, float eps, const double* __restrict__ state,
                                                                const int* guard) {
     TNN_GUARD_RETURN(guard);
+    const float* g = reinterpret_cast<const float*>(g_);
+    const bf16_t* g16 = reinterpret_cast<const bf16_t*>(g_);
     const double p1 = state[0], p2 = state[1];
     const float ic1 = (float)(1.0 / (1.0 - p1)), ic2 = (float)(1.0 / (1.0 - p2));
     const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     // 16-B non-temporal streams for everything only the optimizer touches (g, m, v, fp32 master weights); the bf16
     // copy is re-read by the next GEMMs and takes ordinary 8-B stores.  n4 = vectorisable prefix (arenas 16-B aligned).
-    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                           reinterpret_cast<uintptr_t>(v)) & 15) == 0 && (reinterpret_cast<uintptr_t>(w16) & 7) == 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | (reinterpret_cast<uintptr_t>(g_) << (G16 ? 1 : 0)) |
+                           reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(w16) & 7) == 0;
     const int64_t n4 = aligned ? n / 4 : 0;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = tid; i < n4; i += nth) {
-        const f32x4 gi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        f32x4 gi;
+        if constexpr (G16) {
+            const u32x2 gw = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(g16) + i);
+            gi = f32x4{__uint_as_float(gw.x << 16), __uint_as_float(gw.x & 0xffff0000u), __uint_as_float(gw.y << 16),
+                       __uint_as_float(gw.y & 0xffff0000u)};
+        } else {
+            gi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+        }
         f32x4 mi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
         f32x4 vi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
         f32x4 pi = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(256) void adam_master_bf16_kernel(float* __restrict
                                                  (uint32_t)f2bf(pi[2]) | ((uint32_t)f2bf(pi[3]) << 16)};
     }
     for (int64_t i = n4 * 4 + tid; i < n; i += nth) {
-        const float gi = g[i];
+        const float gi = G16 ? bf2f(g16[i]) : g[i];
         float mi = m[i], vi = v[i];
         mi = mi + omb1 * (gi - mi);
         vi = vi + omb2 * (gi * gi - vi);
@@ -712,8 +724,20 @@ int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* 
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam_master_bf16: pows state is NULL");
     hipStream_t s = tnn::stream();
     hipLaunchKernelGGL(adam_advance16_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2, tnn::update_guard());
-    hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid((n + 3) / 4, 256), 256, 0, s, (float*)p_master,
+    hipLaunchKernelGGL(adam_master_bf16_kernel<false>, tnn::stream_grid((n + 3) / 4, 256), 256, 0, s, (float*)p_master,
                        (const float*)g, (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2,
+                       (float)eps, (const double*)pows_f64, tnn::update_guard());
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_adam_master_g16(void* p_master, const void* g_bf16, void* m, void* v, void* w_bf16, int64_t n, double lr, double b1,
+                        double b2, double eps, const void* pows_f64) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    TNN_REQUIRE(p_master && g_bf16 && m && v && w_bf16 && pows_f64, "tnn_adam_master_g16: NULL argument");
+    hipLaunchKernelGGL(adam_master_bf16_kernel<true>, tnn::stream_grid((n + 3) / 4, 256), 256, 0, tnn::stream(),
+                       (float*)p_master, g_bf16, (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2,
                        (float)eps, (const double*)pows_f64, tnn::update_guard());
     TNN_LAUNCH_OK();
     return 0;
@@ -748,7 +772,7 @@ int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void* v, voi
         return 0;
     }
     const int64_t n = rows * cols;
-    hipLaunchKernelGGL(adam_master_bf16_kernel, tnn::stream_grid(n, 256), 256, 0, s, (float*)p_master, (const float*)g,
+    hipLaunchKernelGGL(adam_master_bf16_kernel<false>, tnn::stream_grid(n, 256), 256, 0, s, (float*)p_master, (const float*)g,
                        (float*)m, (float*)v, (bf16_t*)w_bf16, n, (float)lr, (float)b1, (float)b2, (float)eps,
                        (const double*)pows_f64, tnn::update_guard());
     TNN_LAUNCH_OK();

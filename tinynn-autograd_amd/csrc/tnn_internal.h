@@ -6,7 +6,9 @@
 
 namespace tnn {
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
-hipStream_t stream();          // the one library stream (valid after tnn_init)
+hipStream_t stream();          // the one library stream (valid after tnn_init) — or the override below while one is set
+// tnn_comm_chain_begin/_end: launches of the calling thread go to `s` (the communication stream) until reset with nullptr
+void set_stream_override(hipStream_t s);
 bool initialised();
 int num_cus();                 // 256 on MI355X
 // Device word the optimizer-update kernels look at before touching anything: non-zero -> the launch is a no-op

@@ -57,6 +57,12 @@ struct Mlp {
     std::vector<void*> actT16;       // act[l]^T [w[l+1], max_rows]   (dW operand of layer l+1)
     std::vector<void*> dactT16;      // dact[l]^T [w[l+1], max_rows]  (dW operand of layer l)
     void* xT16 = nullptr;            // x^T [w[0], max_rows]
+    // sharded-optimizer step (data-parallel bf16 trainer, mlp16_step_zero): the weight gradients as bf16 in arena order
+    // (wire format of the reduce-scatter) and a contiguous fp32 staging vector [b_0 | ... | b_{L-1} | loss] for the one
+    // small all-reduce of the bias gradients and the loss
+    char* g16 = nullptr;
+    float* bias_g = nullptr;
+    std::vector<int64_t> bias_g_off;
     // measurement hook (tnn_mlp_launch_window): primitive calls of a step are numbered 0, 1, ... in issue order and only
     // those inside [win_lo, win_hi) are executed, so each launch of the step can be replayed and timed on its own
     // No window set (the default): every call runs and the counter only reports launches per step; it is reset at the
@@ -210,6 +216,84 @@ int mlp16_update(Mlp* h) {
     return 0;
 }
 
+// Data-parallel bf16 step with the optimizer SHARDED over the ranks (configs[4]: 268 M parameters, 8 GPUs).  Instead of
+// "all-reduce 1.07 GB of fp32 gradients, every rank runs the same 8.6 GB optimizer pass" (run.py:82-83 taken literally):
+//   per layer, right behind its dW launch and on the communication stream while the library stream goes on with the next
+//   layer's backward:  reduce-scatter of dW_l as bf16 (rank r receives the summed rows [r in/W, (r+1) in/W))  ->  Adam on
+//   those rows of the fp32 master weights (core/optimizer.py:67-79; tnn_adam_master_g16)  ->  all-gather of the refreshed
+//   bf16 rows into every rank's working copy.
+// Bytes on the links per step and rank: 2 (W-1)/W x 2 B per parameter (what ONE bf16 all-reduce moves; the fp32
+// all-reduce moves twice that); optimizer traffic 30 B per parameter / W.  Biases and the loss: one small fp32 all-reduce,
+// replicated Adam.  Each rank's fp32 master / m / v arenas are authoritative for its own rows only; the bf16 working copy
+// (tnn_mlp_bf16_weights) is complete and identical on every rank.  dW is rounded to bf16 once before the sum.
+bool zero_step_fits(const Mlp* h, int world) {
+    if (!h->bf16 || h->opt_kind != 1 || h->loss_kind != 1) return false;
+    for (int l = 0; l < h->L; ++l)
+        if (h->w[l] % world || ((h->w[l] / world) * h->w[l + 1]) % 8) return false;
+    return true;
+}
+
+int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int rank, int world, void* loss_out) {
+    const int L = h->L;
+    if (!h->g16) MLP_TRY(tnn_malloc((size_t)h->arena * 2, (void**)&h->g16));
+    if (!h->bias_g) {
+        int64_t nb = 0;
+        h->bias_g_off.clear();
+        for (int l = 0; l < L; ++l) { h->bias_g_off.push_back(nb); nb += h->w[l + 1]; }
+        h->bias_g_off.push_back(nb);                      // the loss
+        MLP_TRY(tnn_malloc((size_t)(nb + 1) * 4, (void**)&h->bias_g));
+    }
+    const int64_t nb = h->bias_g_off[L];
+    auto f32 = [](void* base, int64_t off) { return (void*)((float*)base + off); };
+    MLP_TRY(mlp16_forward(h, x16, rows));
+    MLP_TRY(tnn_mse_bf16(h->act[L - 1], y16, rows * h->w[L], rows * world, h->bias_g + nb, h->dact[L - 1]));
+    MLP_TRY(tnn_adam_tick(h->pows, h->b1, h->b2));
+    int rc = 0, chains = 0;
+    for (int l = L - 1; l >= 0 && !rc; --l) {
+        const void* in = l == 0 ? x16 : h->act[l - 1];
+        void* inT = l == 0 ? h->xT16 : h->actT16[l - 1];
+        const int64_t wo = h->w_off[l];
+        rc = tnn_transpose_bf16(in, inT, rows, h->w[l]);
+        if (!rc) rc = tnn_transpose_bf16(h->dact[l], h->dactT16[l], rows, h->w[l + 1]);
+        // dz_{l-1} reads the bf16 W_l that this layer's all-gather rewrites: it is enqueued BEFORE the chain opens
+        if (!rc && l > 0)
+            rc = tnn_gemm_bf16_nt(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, wo), h->w[l + 1],
+                                  h->dact[l - 1], h->w[l], TNN_BF16, nullptr, TNN_ACT_NONE, 0, h->act[l - 1], h->w[l]);
+        if (!rc)
+            rc = tnn_gemm_bf16_nt(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows, at16(h->g16, wo), h->w[l + 1],
+                                  TNN_BF16, nullptr, TNN_ACT_NONE, 0, nullptr, 0);
+        if (!rc) rc = tnn_colsum_bf16(h->dact[l], h->bias_g + h->bias_g_off[l], rows, h->w[l + 1]);
+        if (rc) break;
+        const int64_t n_shard = h->w[l] / world * h->w[l + 1], so = wo + (int64_t)rank * n_shard;
+        rc = tnn_comm_chain_begin();
+        if (rc) break;
+        rc = tnn_reduce_scatter(at16(h->g16, wo), at16(h->g16, so), n_shard, TNN_BF16);
+        if (!rc)
+            rc = tnn_adam_master_g16(f32(h->params, so), at16(h->g16, so), f32(h->m, so), f32(h->v, so), at16(h->w16, so),
+                                     n_shard, h->lr, h->b1, h->b2, h->eps, h->pows);
+        if (!rc) rc = tnn_allgather(at16(h->w16, so), at16(h->w16, wo), n_shard, TNN_BF16);
+        const int rc_end = tnn_comm_chain_end();
+        if (!rc) rc = rc_end;
+        ++chains;
+    }
+    // bias gradients + loss: one small all-reduce on the library stream, the same Adam on every rank
+    if (!rc) rc = tnn_allreduce(h->bias_g, nb + 1, TNN_F32, TNN_RSUM);
+    for (int l = 0; l < L && !rc; ++l) {
+        const int64_t bo = h->b_off[l];
+        rc = tnn_adam_master_bf16_2d(f32(h->params, bo), h->bias_g + h->bias_g_off[l], f32(h->m, bo), f32(h->v, bo),
+                                     at16(h->w16, bo), nullptr, 1, h->w[l + 1], h->lr, h->b1, h->b2, h->eps, h->pows, 0);
+    }
+    // W_l^T for the next forward, layer by layer as the chains land (issue order = last layer first)
+    for (int l = L - 1; l >= 0 && !rc && chains > 0; --l, --chains) {
+        rc = tnn_comm_wait_oldest();
+        if (!rc) rc = tnn_transpose_bf16(at16(h->w16, h->w_off[l]), h->wT16[l], h->w[l], h->w[l + 1]);
+    }
+    if (rc) { (void)tnn_comm_join(); return rc; }
+    MLP_TRY(tnn_memcpy_d2d(at(h->grads, h->n_params, 4), h->bias_g + nb, 4));
+    if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, h->bias_g + nb, 4));
+    return 0;
+}
+
 // limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
 bool head_fits_one_workgroup(const Mlp* h, int64_t rows) {
     // classifier heads (<= 16 classes): the one-thread-per-row kernel, up to 1024 rows; wider heads: the LDS image of the
@@ -349,7 +433,7 @@ int tnn_mlp_destroy(void* handle) {
     for (void* p : h->wT16) tnn_free(p);
     for (void* p : h->actT16) tnn_free(p);
     for (void* p : h->dactT16) tnn_free(p);
-    tnn_free(h->w16); tnn_free(h->xT16);
+    tnn_free(h->w16); tnn_free(h->xT16); tnn_free(h->g16); tnn_free(h->bias_g);
     delete h;
     return 0;
 }
@@ -620,6 +704,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
         MLP_TRY(tnn_malloc((size_t)world * 2 * 8, &h->stats_all));
         h->stats_all_world = world;
     }
+    if (zero_step_fits(h, world)) return mlp16_step_zero(h, x, y, rows, rank, world, loss_out);
     int p2p_on = 0;
     MLP_TRY(tnn_p2p_status(nullptr, &p2p_on, nullptr));
     const int L = h->L;
@@ -773,6 +858,13 @@ int tnn_mlp_sync_params(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) { tnn::set_error("tnn_mlp_sync_params: NULL handle"); return 2; }
     return h->bf16 ? mlp16_sync(h) : 0;
+}
+
+int tnn_mlp_bf16_weights(void* handle, void** w16) {
+    Mlp* h = (Mlp*)handle;
+    if (!h || !w16 || !h->bf16) { tnn::set_error("tnn_mlp_bf16_weights: not a bf16 trainer"); return 2; }
+    *w16 = h->w16;
+    return 0;
 }
 
 int tnn_mlp_activation(void* handle, int layer, void** ptr) {

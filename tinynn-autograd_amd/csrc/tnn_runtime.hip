@@ -64,7 +64,9 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-hipStream_t stream() { return g.stream; }
+static thread_local hipStream_t g_stream_override = nullptr;
+hipStream_t stream() { return g_stream_override ? g_stream_override : g.stream; }
+void set_stream_override(hipStream_t s) { g_stream_override = s; }
 bool initialised() { return g.ready; }
 int num_cus() { return g.cus; }
 

@@ -139,6 +139,19 @@ class MLPTrainer(object):
     def get_parameters(self):
         return [{"w": self.param_view(i, "w"), "b": self.param_view(i, "b")} for i in range(self.n_layers)]
 
+    def weights_bf16(self, layer=None):
+        """bf16 trainer: the bf16 working copy of the parameters as raw uint16 bit patterns — the whole arena, or layer
+        `layer`'s [in, out] weight matrix.  In the data-parallel sharded-optimizer step (tnn_mlp_step_sharded on a bf16
+        trainer) this is the complete, rank-identical copy; each rank's fp32 master arena (`params`, `adam_m`, `adam_v`) is
+        then authoritative for its own row slice of every weight matrix only."""
+        p = ctypes.c_void_p()
+        self._lib.mlp_bf16_weights(self._h, ctypes.byref(p))
+        arena = da.from_ptr(p.value, (self.n_params,), np.uint16, self)
+        if layer is None:
+            return arena
+        off, cnt = self._offset(layer, 0)
+        return arena[off:off + cnt].reshape((self.widths[layer], self.widths[layer + 1]))
+
     def activation(self, layer, rows):
         p = ctypes.c_void_p()
         self._lib.mlp_activation(self._h, layer, ctypes.byref(p))
