@@ -837,44 +837,6 @@ def main():
             return bool(int(t.item()))
         return bool(flag)
 
-    def sharded_forms_agree(rows_):
-        """Data-parallel runs on the peer-to-peer transport with <= 128 rows per rank take the 5-launch sharded step, whose
-        multi-workgroup head exchanges the softmax statistics inside its launch — code that only a multi-GPU run exercises
-        across devices.  Before anything is timed, four steps of it are compared with the form that exchanges them in a
-        one-workgroup launch of their own (6 launches; what ranks sharing a GPU use) from the same parameters and batches;
-        if they disagree (or the in-kernel exchange trips a barrier) every rank stays on the latter and the line says so."""
-        lib = _lib.get()
-        cur = ctypes.c_int(0)
-        lib.p2p_shared_device(-1, ctypes.byref(cur))
-        # test hook (ranks sharing one GPU: tests/test_gpu_p2p.py): run the comparison anyway at a row count whose launches
-        # fit the shared GPU together, then put the flag back
-        forced_rows = int(os.environ.get("TNN_BENCH_FORM_CHECK_ROWS", "0"))
-        if forced_rows:
-            rows_ = forced_rows
-        elif cur.value or rows_ > 128:
-            return None                                # already on the 8-launch form / not a shape of the new form
-        out, local_ok = [], True
-        for force_old in (0, 1):
-            lib.p2p_shared_device(force_old, None)
-            try:                                       # whatever happens locally, every rank reaches the votes below
-                fr = FusedRun(widths, rows_, kind, 4, rank, world, comm, False, use_graph=use_graph, seed=77)
-                out.append(np.asarray(fr.chunk.launch() if fr.chunk is not None else [float(fr.trainer.step(*b)) for b in fr.batches],
-                                      dtype=np.float64))
-                del fr
-            except Exception as exc:                   # noqa: BLE001
-                sys.stderr.write("bench: sharded-form check raised on rank %d: %s\n" % (rank, exc))
-                local_ok = False
-                break
-        lib.p2p_shared_device(cur.value, None)
-        local_ok = local_ok and len(out) == 2 and bool(np.allclose(out[0], out[1], rtol=1e-5, atol=0))
-        alive = p2p_alive()                            # collective
-        ok = all_ranks(local_ok and alive)
-        if not ok:
-            lib.p2p_shared_device(1, None)             # every rank: keep the statistics-launch form from here on
-        return {"in_kernel_exchange_agrees_with_statistics_launch": ok, "rows_per_rank": rows_,
-                "form_used": "statistics launch, 6 launches (ranks share a GPU)" if cur.value
-                else ("in-kernel exchange, 5 launches" if ok else "statistics launch, 6 launches (fallback)")}
-
     def p2p_alive():
         st = comm.p2p_status() if comm is not None and hasattr(comm, "p2p_status") else None
         return all_ranks(bool(st and st["enabled"] and not st["dead"]))
@@ -918,9 +880,6 @@ def main():
                 dog.start()
             comm.set_p2p(True)
             try:
-                form_check = sharded_forms_agree(min(rows, 128)) if (args.workload == "A" and world > 1) else None
-                if form_check is not None:
-                    transports["sharded_step_form"] = form_check
                 runner.capture()
                 res_p2p = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
             except Exception as exc:                              # noqa: BLE001 - a peer timeout raises on every rank (comm.check votes)

@@ -262,27 +262,12 @@ TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, 
                                   void* db, void* dw1, void* db1, void* dx, int dtype, void* adam_pows_f64, double b1,
                                   double b2);
 /* The data-parallel form (core/losses.py:26-27 — the softmax spans the GLOBAL batch of m_global rows, this rank holds
- * `rows` of them): the shards' {max, sum-exp} are exchanged over the xGMI peer-to-peer transport INSIDE the launch
- * (workgroup 0 talks to the peers and hands the merged pair to every other workgroup), dz / dw / db / dw1 / db1 / dx are this
- * rank's contributions to the global gradients and *loss its share of the global loss — the all-reduce of the gradient arena
- * (tnn_allreduce_adam) sums both.  Needs tnn_p2p_connect; the sharded step is then 5 launches instead of 8. */
-TNN_API int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
-                                          const void* x, const void* w1, const void* a, const void* w, const void* b,
-                                          const void* y, const void* logit_partials, void* logits, void* dz, void* stats,
-                                          void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
-                                          void* adam_pows_f64, double b1, double b2);
-/* The data-parallel form for transports whose exchange cannot sit inside a kernel (RCCL — north_star's named transport) and
- * for peer-to-peer groups sharing one GPU: the shard's statistics are a launch of their own,
- *   tnn_mlp_head_stats: ONE workgroup sums the partial logits and leaves this rank's {max, sum-exp} (float32) in out_pair
- *     (exchange = 0; the caller all-gathers the pairs), or exchanges them with the peers over xGMI itself and leaves the MERGED
- *     pair (exchange = 1, needs tnn_p2p_connect);
- *   tnn_mlp_head_bwd_tick_ext: tnn_mlp_head_bwd_tick whose workgroups take the batch statistics from stats_pairs
- *     ([n_pairs][2] float32 {M_q, S_q}: every rank's pair, or one merged pair) and do no cross-row reduction of their own;
- *     outputs as in the _sharded form (contributions to the global gradients, this rank's share of the loss).
- * The RCCL step is then forward x 2 | statistics | all-gather | head + hidden backward | first-layer backward | all-reduce |
- * Adam: 6 launches + 2 collectives instead of 12 + 2. */
-TNN_API int tnn_mlp_head_stats(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* b, const void* y,
-                               const void* logit_partials, void* out_pair_f32, int exchange, int dtype);
+ * `rows` of them).  tnn_mlp_head_bwd_tick whose workgroups take the batch statistics from stats_pairs ([n_pairs][2] float32
+ * {M_q, S_q}: every rank's pair, or one already merged pair — written by tnn_dense_fwd_head_partials_stats below [+ the
+ * all-gather of the pairs on RCCL]) and do no cross-row reduction of their own; dz / dw / db / dw1 / db1 / dx are this
+ * rank's contributions to the global gradients and *loss its share of the global loss — the all-reduce of the gradient
+ * arena (tnn_allreduce_adam) sums both.  The data-parallel step is then forward x 2 | [all-gather] | head + hidden
+ * backward | first-layer backward | all-reduce + Adam: 5 launches + the collectives, the same form on every transport. */
 TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
                                       const void* x, const void* w1, const void* a, const void* w, const void* b,
                                       const void* y, const void* logit_partials, const void* stats_pairs, int n_pairs,
@@ -296,6 +281,18 @@ TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_
 TNN_API int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                         int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
                                         const void* head_w, int64_t head_c, void* head_z, int dtype);
+
+/* The same launch in a data-parallel step: the workgroup that finishes LAST (agent-scope arrival counter *ticket_u32, a
+ * device word that is 0 before the first call and returns to 0 at the end of every launch) also reduces this shard's
+ * whole-batch softmax statistics {max, sum-exp} (core/losses.py:25-27) from the partial logits + head_b (classifier bias
+ * [head_c]) and writes them to out_pair_f32[2]; exchange != 0 (needs tnn_p2p_connect): it exchanges the pair with the
+ * peers over xGMI and writes the MERGED pair instead.  y [M, head_c] (labels) rides along for symmetry with the head
+ * kernels' staging.  No statistics launch and nobody waits for a peer inside the head launch that follows.
+ * Shapes of tnn_mlp_head_fits: f32, M <= 128, N == 128, head_c == 10, 16-B aligned operands. */
+TNN_API int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                                              int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
+                                              const void* head_w, int64_t head_c, void* head_z, const void* head_b,
+                                              const void* y, void* ticket_u32, void* out_pair_f32, int exchange, int dtype);
 
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global
@@ -485,13 +482,8 @@ TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);
 TNN_API int tnn_p2p_poll_failed(int* failed);
 /* on != 0: optimizer-update kernels launched from now on become no-ops once the transport's dead word is set (see
  * above); on == 0: back to unconditional updates.  tnn_mlp_step_sharded brackets itself with the pair. */
-/* Ranks of the group share a GPU (one-GPU test boxes)?  set >= 0 stores the answer the host side worked out, current
- * (may be NULL) returns it.  tnn_mlp_step_sharded uses the 5-launch form (statistics exchanged inside the multi-workgroup
- * head launch, every workgroup waiting for the merged pair) only when each rank has a GPU of its own — or when
- * TNN_STEP_MERGE_SHARED=1 vouches that all the ranks' launches fit the shared GPU together. */
-TNN_API int tnn_p2p_shared_device(int set, int* current);
 /* Diagnostics of a timed-out wait, read from the host-pinned mirror without a stream sync: words16[0] = 0, or which
- * wait gave up first (1 collective flag barrier, 2 statistics exchange, 3 hand-over row of the sharded head), [1] the value
+ * wait gave up first (1 collective flag barrier, 2 statistics exchange), [1] the value
  * it expected, [2] the last value it saw, [3] peer / workgroup, [4] flag row / slot parity. */
 TNN_API int tnn_p2p_debug(int* words16);
 TNN_API int tnn_p2p_guard_updates(int on);

@@ -653,14 +653,6 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t nh, int64_t nc, co
         return rc;
     return tnn_dense_bwd(rows, n_in, nh, x, da.data(), w1, dw1, db1, dx, x, dtype);
 }
-int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
-                                  const void* a, const void* w, const void* b, const void* y, const void* zpart, void* logits,
-                                  void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
-                                  void* pows, double b1, double b2) {
-    REQ(m_global == rows, "cpu twin: one-rank group only");      // the peer-to-peer transport needs device IPC
-    return tnn_mlp_head_bwd_tick(rows, n_in, nh, nc, x, w1, a, w, b, y, zpart, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
-                                 pows, b1, b2);
-}
 static void twin_logits_from_partials(int64_t rows, int64_t nh, int64_t nc, const void* b, const void* zpart, float* logits) {
     const int64_t tiles = (nh + 15) / 16;
     for (int64_t r = 0; r < rows; ++r)
@@ -670,14 +662,21 @@ static void twin_logits_from_partials(int64_t rows, int64_t nh, int64_t nc, cons
             logits[r * nc + c] = s + ((const float*)b)[c];
         }
 }
-int tnn_mlp_head_stats(int64_t rows, int64_t nh, int64_t nc, const void* b, const void* y, const void* zpart, void* out_pair,
-                       int exchange, int dtype) {
+int tnn_dense_fwd_head_partials(int64_t, int64_t, int64_t, const void*, int64_t, const void*, int64_t, const void*, int, int, void*,
+                                int64_t, const void*, int64_t, void*, int);
+int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                      const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* head_w,
+                                      int64_t head_c, void* head_z, const void* head_b, const void* y, void* ticket, void* out_pair,
+                                      int exchange, int dtype) {
     NEED_INIT();
-    REQ(b && y && zpart && out_pair && dtype == TNN_F32, "cpu twin: tnn_mlp_head_stats needs every buffer, f32");
-    RECORD(tnn_mlp_head_stats(rows, nh, nc, b, y, zpart, out_pair, exchange, dtype));
-    std::vector<float> logits((size_t)(rows * nc));
-    twin_logits_from_partials(rows, nh, nc, b, zpart, logits.data());
-    return tnn_softmax_nll_stats(logits.data(), rows, nc, out_pair, dtype);       // a one-rank exchange is the identity
+    REQ(head_b && y && ticket && out_pair && dtype == TNN_F32 && M <= 128 && N == 128 && head_c == 10,
+        "cpu twin: tnn_dense_fwd_head_partials_stats needs every buffer, f32, the head's shapes");
+    RECORD(tnn_dense_fwd_head_partials_stats(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z, head_b, y,
+                                             ticket, out_pair, exchange, dtype));
+    if (int rc = tnn_dense_fwd_head_partials(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z, dtype)) return rc;
+    std::vector<float> logits((size_t)(M * head_c));
+    twin_logits_from_partials(M, N, head_c, head_b, head_z, logits.data());
+    return tnn_softmax_nll_stats(logits.data(), M, head_c, out_pair, dtype);      // a one-rank exchange is the identity
 }
 int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
                               const void* a, const void* w, const void* b, const void* y, const void* zpart, const void* pairs,
@@ -1069,7 +1068,6 @@ int tnn_p2p_status(int* c, int* e, int* d) {
 }
 int tnn_p2p_poll_failed(int* f) { if (f) *f = 0; return 0; }
 int tnn_p2p_guard_updates(int) { return 0; }
-int tnn_p2p_shared_device(int, int* cur) { if (cur) *cur = 0; return 0; }
 int tnn_p2p_debug(int* w) { if (w) memset(w, 0, 16 * sizeof(int)); return 0; }
 int tnn_p2p_destroy(void) { g_comm = 0; return 0; }
 

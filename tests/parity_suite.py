@@ -405,11 +405,20 @@ def head_and_hidden_backward_one_launch_vs_numpy():
                                        err_msg="%s %s" % (name, tag))
         assert np.asarray(dx)[0, 3] != 0.0 or m == 1                                         # mask = 1 at an exactly-zero input
         np.testing.assert_allclose(np.asarray(pows)[:2], [0.9 ** 2, 0.999 ** 2], rtol=1e-14)
-        # ---- the data-parallel form with the statistics as a launch of their own (RCCL / shared-GPU structure):
-        # tnn_mlp_head_stats leaves this shard's {max, sum-exp}; tnn_mlp_head_bwd_tick_ext merges the pairs it is given.
-        pair = tn.empty((2,))
-        lib.mlp_head_stats(m, Hn, C, B._ptr, Y._ptr, zpart._ptr, pair._ptr, 0, _lib.F32)
-        np.testing.assert_allclose(np.asarray(pair), [z.max(), S], rtol=2e-6)
+        # ---- the data-parallel form: the LAST workgroup of the forward launch to finish leaves this shard's {max, sum-exp}
+        # (tnn_dense_fwd_head_partials_stats — same activations and partial logits as the plain launch up to the order in
+        # which its 8 waves' K-chunks are summed, and the arrival counter back at 0 so hipGraph replays work);
+        # tnn_mlp_head_bwd_tick_ext merges the pairs it is given.
+        pair, ticket = tn.empty((2,)), tn.asarray(np.zeros(16, np.int64))
+        A2, zpart2 = tn.empty((m, Hn)), tn.zeros((Hn // 16, m, C))
+        for _ in range(3):
+            pair[...] = 0.0
+            lib.dense_fwd_head_partials_stats(m, Hn, n_in, X._ptr, n_in, W1._ptr, Hn, B1._ptr, _lib.ACT_RELU, 1, A2._ptr, Hn,
+                                              W._ptr, C, zpart2._ptr, B._ptr, Y._ptr, ticket._ptr, pair._ptr, 0, _lib.F32)
+            np.testing.assert_allclose(np.asarray(pair), [z.max(), S], rtol=1e-5)
+            assert int(np.asarray(ticket)[0]) == 0
+        np.testing.assert_allclose(np.asarray(A2), a, rtol=0, atol=1e-5 * np.abs(a).max())
+        np.testing.assert_allclose(np.asarray(zpart2), np.asarray(zpart), rtol=0, atol=1e-5 * np.abs(np.asarray(zpart)).max())
         # a second, imaginary rank with m2 rows: its pair enters the merge, its rows the global batch size
         m2 = 96
         z2 = rs.randn(m2, C) * 2.0 + 1.0

@@ -84,7 +84,6 @@ def _run_p2p_workers(world, traj="D_adam"):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), TNN_DEVICE="0", WORLD_SIZE=str(world),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNN_P2P_TIMEOUT_MS="3000",
                    TNN_P2P_TEST_TIMEOUT="1", TNN_P2P_TEST_TRAJ=traj,
-                   TNN_STEP_MERGE_SHARED="1",          # 2 x 64 rows: both ranks' head launches fit the one GPU together
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -110,11 +109,11 @@ def test_p2p_two_processes_share_the_gpu():
 
 @pytest.mark.gpu
 def test_p2p_two_processes_five_launch_step():
-    """The reference's bs-128 trajectory split over two ranks (64 rows each): the 5-launch sharded step, whose
-    multi-workgroup head exchanges the shards' statistics inside the launch (workgroup 0 with the peer, one hand-over row
-    per other workgroup) — eager, replayed from a hipGraph, replicas identical, and the timeout drill.  (Two ranks keep
-    every workgroup of both ranks resident on the one GPU; the driver's N = 8 point has 128 rows per rank on a GPU each —
-    `TNN_P2P_TEST_TRAJ=D_adam` with 8 workers runs that shape on one GPU too, but only by virtue of queue preemption.)"""
+    """The reference's bs-128 trajectory split over two ranks (64 rows each): the 5-launch sharded step — the last
+    workgroup of the hidden layer's forward reduces the shard's softmax statistics and exchanges them with the peer
+    (tnn_dense_fwd_head_partials_stats), the head launch only reads the merged pair — eager, replayed from a hipGraph,
+    replicas identical, and the timeout drill.  One workgroup per rank waits for a peer, so ranks sharing a GPU cannot
+    starve each other (`TNN_P2P_TEST_TRAJ=D_adam` with 8 workers runs the N = 8 shape on one GPU the same way)."""
     _run_p2p_workers(2, "A_adam")
 
 
@@ -126,7 +125,6 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     check, and exactly ONE JSON line on stdout from rank 0."""
     import json
     env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               TNN_BENCH_FORM_CHECK_ROWS="64",         # the pre-timing 5-launch vs 8-launch comparison, at a size that fits one GPU
                PYTHONDONTWRITEBYTECODE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "128",
@@ -145,11 +143,6 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     p2p = coll["xgmi_p2p"]
     assert p2p["replicas_identical"] and p2p["verified_after_run"] and not p2p["barrier_timed_out"] and p2p["graph_captured"]
     assert d["value"] == p2p["value"] > 0
-    # before anything was timed the 5-launch sharded step (exchange inside the multi-workgroup head) was compared with the
-    # form whose statistics are a launch of their own on this transport (at 64 rows per rank: both ranks' launches fit the
-    # one GPU); the timed runs then stay on the latter because the ranks share a GPU
-    form = coll["sharded_step_form"]
-    assert form["in_kernel_exchange_agrees_with_statistics_launch"] and form["rows_per_rank"] == 64 and "share" in form["form_used"]
     # the sharded step on this transport reproduces the REFERENCE's bs-1024 losses (traj_D_adam, all 5 steps)
     chk = d["parity_vs_reference_fixture"]
     assert chk["ok"] and chk["steps"] == 5 and "traj_D_adam" in chk["fixture"] and chk["max_rel_err"] <= 1e-5

@@ -87,11 +87,11 @@ _SIGNATURES = {
     "tnn_mlp_head_fits": [c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
     "tnn_mlp_head_tick": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head_bwd_tick": [c_int64, c_int64, c_int64, c_int64] + [_p] * 16 + [c_int, _p, c_double, c_double],
-    "tnn_mlp_head_bwd_tick_sharded": [c_int64, c_int64, c_int64, c_int64, c_int64] + [_p] * 16 + [c_int, _p, c_double, c_double],
-    "tnn_mlp_head_stats": [c_int64, c_int64, c_int64, _p, _p, _p, _p, c_int, c_int],
     "tnn_mlp_head_bwd_tick_ext": [c_int64, c_int64, c_int64, c_int64, c_int64] + [_p] * 8 + [c_int] + [_p] * 9 + [c_int, _p, c_double, c_double],
     "tnn_dense_fwd_head_partials": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
                                     _p, c_int64, _p, c_int],
+    "tnn_dense_fwd_head_partials_stats": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
+                                          _p, c_int64, _p, _p, _p, _p, _p, c_int, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_dense_bwd_first_adam": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64,
@@ -149,7 +149,6 @@ _SIGNATURES = {
     "tnn_p2p_status": [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
     "tnn_p2p_poll_failed": [POINTER(c_int)],
     "tnn_p2p_debug": [POINTER(c_int)],
-    "tnn_p2p_shared_device": [c_int, POINTER(c_int)],
     "tnn_p2p_guard_updates": [c_int],
     "tnn_p2p_destroy": [],
 }

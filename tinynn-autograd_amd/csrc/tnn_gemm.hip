@@ -20,6 +20,8 @@
 #include <algorithm>
 
 #include "tnn_internal.h"
+#include "tnn_p2p.h"
+#include "tnn_head_stats.h"
 
 namespace {
 
@@ -793,7 +795,9 @@ __device__ __forceinline__ float finish_epilogue(const GemmArgs& g, float acc, f
 //     loop trip made every trip a dependent L2/HBM round trip (fwd0 of the MNIST net: 4 trips per wave);
 //   * the epilogue's operand (bias / ReLU-mask source / old C) is requested up front by the threads that apply it,
 //     instead of after the cross-wave reduction.
-template <bool AKC, bool BKC, int WAVES>
+// SYS_HEADZ: the partial logits leave through write-through (system-scope) stores, because a workgroup of THIS launch
+// on another XCD reads them back (dense_fwd_head_kernel)
+template <bool AKC, bool BKC, int WAVES, bool SYS_HEADZ = false>
 __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __restrict__ colsum, int block,
                                                 float (*red)[4][64], float (*bsum)[64], float* head_lds = nullptr) {
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -924,7 +928,11 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t row = m0 + 4 * grp + q;
-                    if (row < g.M) g.head_z[((int64_t)tn * g.M + row) * g.head_c + i16] = hacc[q];
+                    if (row < g.M) {
+                        float* dst = g.head_z + ((int64_t)tn * g.M + row) * g.head_c + i16;
+                        if constexpr (SYS_HEADZ) tnn::p2p::store_sys(reinterpret_cast<uint32_t*>(dst), __float_as_uint(hacc[q]));
+                        else *dst = hacc[q];
+                    }
                 }
             }
         }
@@ -941,6 +949,36 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, 
     } else {
         small_tile<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum);
     }
+}
+
+// Forward of the hidden layer in front of a classifier head in a DATA-PARALLEL step: the tiles + their partial logits as
+// above, and the workgroup that finishes LAST (an agent-scope ticket drawn after its own partial logits were
+// acknowledged) reduces the shard's whole-batch softmax statistics from all the partials and — on the peer-to-peer
+// transport — exchanges and merges them with the other ranks' (head_tail_stats, tnn_head_stats.h).  The head launch
+// behind this one only READS the pair(s): no statistics launch, no workgroup of the head waiting for a peer, no
+// requirement that the ranks' launches be resident together (core/losses.py:26-27 is why the exchange exists).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, HeadTail ta, tnn::p2p::LaunchCtx ctx) {
+    static_assert(WAVES == 8, "head_tail_stats is written for 512 threads");
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    __shared__ __attribute__((aligned(16))) float head_lds[16 * 20];
+    __shared__ __attribute__((aligned(16))) float zs[128 * 10], ys[128 * 10];
+    __shared__ double dred[8][4];
+    __shared__ int is_last;
+    small_tile_fast<true, false, WAVES, true>(g, nullptr, (int)blockIdx.x, red, bsum, head_lds);
+    if (threadIdx.x < 64) {                                    // wave 0 wrote this tile's partial logits
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(ta.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == gridDim.x - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(ta.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // graph replays start from 0
+            is_last = last;
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    head_tail_stats<10, 8>(ta, ctx, zs, ys, dred);
 }
 
 // Backward of one Dense layer in ONE launch: blocks [0, n_dw) compute dW = X^T dZ (TN) + db = colsum(dZ),
@@ -1704,6 +1742,45 @@ int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, 
     const int64_t total = ((N + 15) / 16) * M * head_c;
     hipLaunchKernelGGL(head_partials_kernel, tnn::stream_grid(total, 256), 256, 0, tnn::stream(), (const float*)C, M, N, ldc,
                        (const float*)head_w, (int)head_c, (float*)head_z);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                      const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* head_w,
+                                      int64_t head_c, void* head_z, const void* head_b, const void* y, void* ticket_u32,
+                                      void* out_pair_f32, int exchange, int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_dense_fwd_head_partials_stats", 0, 0, M, N, K, lda, ldb, ldc)) return rc;
+    TNN_REQUIRE(dtype == TNN_F32 && M >= 1 && M <= 128 && N == 128 && head_c == 10,
+                "tnn_dense_fwd_head_partials_stats: f32, rows <= 128, 128 hidden units, 10 classes (ask tnn_mlp_head_fits)");
+    TNN_REQUIRE(head_w && head_z && head_b && y && ticket_u32 && out_pair_f32,
+                "tnn_dense_fwd_head_partials_stats: head_w, head_z, head_b, y, ticket and out_pair are required");
+    TNN_REQUIRE(act == TNN_ACT_NONE || act == TNN_ACT_RELU, "tnn_dense_fwd_head_partials_stats: activation %d", act);
+    GemmArgs g = {};
+    g.A = (const float*)A; g.B = (const float*)B; g.C = (float*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = 0.f; g.epi = EPI_BIAS_ACT;
+    g.bias = (const float*)bias; g.act = act; g.relu_sign = relu_sign;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    g.vecA = al(A) && lda % 4 == 0 && K % 4 == 0;
+    g.vecB = al(B) && ldb % 4 == 0 && N % 4 == 0;
+    TNN_REQUIRE(small_fast_ok(g, 0, 0), "tnn_dense_fwd_head_partials_stats: operands must be 16-B aligned with K %% 4 == 0");
+    g.head_w = (const float*)head_w; g.head_z = (float*)head_z; g.head_c = (int)head_c;
+    g.tiles_m = (int)((M + 15) / 16);
+    g.tiles_n = (int)(N / 16);
+    g.splits = 1;
+    pick_xcd_cut(g);
+    HeadTail ta;
+    ta.ticket = (unsigned int*)ticket_u32;
+    ta.zpart = (const float*)head_z; ta.bias = (const float*)head_b; ta.y = (const float*)y;
+    ta.out_pair = (float*)out_pair_f32; ta.m = (int)M; ta.exchange = exchange ? 1 : 0;
+    tnn::p2p::LaunchCtx ctx = {};
+    if (exchange) {
+        if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_fwd_head_partials_stats")) return rc;
+        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_head_partials_stats: the peer-to-peer transport is not enabled");
+    }
+    hipLaunchKernelGGL(dense_fwd_head_kernel<8>, dim3((unsigned)(g.tiles_m * g.tiles_n)), 512, 0, tnn::stream(), g, ta, ctx);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -18,6 +18,7 @@
 
 #include "tnn_internal.h"
 #include "tnn_p2p.h"
+#include "tnn_head_stats.h"
 
 namespace {
 
@@ -204,110 +205,6 @@ __global__ __launch_bounds__(kThreads) void mlp_head_kernel(HeadArgs p) {
 }
 
 
-struct HeadStats {
-    bool valid[3];
-    float ec[3], eyc[3];             // exp(z - row max), times the label
-    float mx, urow, M;               // row max, row sum of e * y, batch max
-    double S, L;                     // batch sum-exp (relative to M), sum over rows of log u + row max
-};
-
-// zc / yc: this thread's three logits / labels of row (t >> 2) (classes sub, sub + 4, sub + 8); one barrier inside.
-// LOSS = false (workgroups that only need dz): no sum of logs, cross-row sums in f32 — a 1280-term DPP tree is good to
-// ~1e-6 relative, dz's tolerance is 1e-5 — which takes the f64 DPP reductions and the logf off their critical path.
-// EXT: {M, S} of the batch come from memory — ext_n pairs {M_q, S_q} (one per rank of a data-parallel group, or one already
-// merged pair) written by an EARLIER launch (head_stats_kernel + a collective) and merged here; the workgroup then does no
-// cross-row reduction at all, except the sum of logs in the one workgroup that writes the loss.
-template <int C, bool LOSS = true, bool EXT = false>
-__device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&yc)[3], const bool slive, const int sub,
-                                           const int lane, const int wid, double (*red)[4], HeadStats& o,
-                                           const bool want_loss = true, const float* ext_pairs = nullptr, const int ext_n = 0) {
-    // ---- whole-batch softmax statistics: FOUR threads per row (classes sub, sub + 4, sub + 8), row max / sums by
-    // quad-permute DPP; then ONE combined reduction of {max, rescaled sum-exp, sum(log u + max)} over the workgroup
-    // (DPP wave reductions + an 8-entry LDS exchange).  Row sums in f32 (10 terms), cross-row sums in f64 — the
-    // arithmetic of nll_rows_body (tnn_nll_rows.h) up to summation order.
-    bool (&valid)[3] = o.valid;
-    float (&ec)[3] = o.ec, (&eyc)[3] = o.eyc;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        valid[i] = sub + 4 * i < C;
-        if (valid[i]) mx = zc[i] > mx ? zc[i] : mx;
-    }
-    { float q = tnn::dpp_move<0xB1, 0xf>(-INFINITY, mx); mx = q > mx ? q : mx; }
-    { float q = tnn::dpp_move<0x4E, 0xf>(-INFINITY, mx); mx = q > mx ? q : mx; }
-    float srow_sum = 0.f, urow = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        ec[i] = valid[i] ? expf(zc[i] - mx) : 0.f;
-        eyc[i] = ec[i] * (valid[i] ? yc[i] : 0.f);
-        srow_sum += ec[i];
-        urow += eyc[i];
-    }
-    srow_sum += tnn::dpp_move<0xB1, 0xf>(0.f, srow_sum);
-    srow_sum += tnn::dpp_move<0x4E, 0xf>(0.f, srow_sum);
-    urow += tnn::dpp_move<0xB1, 0xf>(0.f, urow);
-    urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
-    const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
-    if constexpr (EXT) {
-        float Mx = ext_pairs[0];
-        for (int q = 1; q < ext_n; ++q) Mx = fmaxf(Mx, ext_pairs[2 * q]);
-        float Sx = 0.f;
-        for (int q = 0; q < ext_n; ++q) Sx += ext_pairs[2 * q + 1] * expf(ext_pairs[2 * q] - Mx);
-        double Lx = 0.0;
-        if (LOSS && want_loss) {                                // block-uniform: the loss-writing workgroup only
-            const double wl = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
-            if (lane == 0) red[wid][2] = wl;
-            __syncthreads();
-            Lx = red[lane & 7][2];
-            Lx += tnn::dpp_move<0xB1, 0xf>(0.0, Lx);
-            Lx += tnn::dpp_move<0x4E, 0xf>(0.0, Lx);
-            Lx += tnn::dpp_move<0x141, 0xf>(0.0, Lx);
-        }
-        o.mx = mx; o.urow = urow; o.M = Mx; o.S = (double)Sx; o.L = Lx;
-        return;
-    }
-    // A wave holds 16 rows: its {max, sum-exp relative to that max} in f32 (160 terms, DPP tree).  The eight waves' results
-    // meet in LDS; every lane then takes entry (lane & 7) and an 8-lane DPP butterfly (quad_perm x 2, row_half_mirror)
-    // leaves M, S (and L) in ALL lanes — one exp per lane instead of a serial 8-term loop per thread (measured: the
-    // f64 loop + f64 64-lane reductions cost 1.5 us of the head's 4.4).  Across waves S and L are summed in f64 (LOSS).
-    const float wm = tnn::wave_max_dpp(slive ? mx : -INFINITY);
-    const float wsf = tnn::wave_sum_dpp(counts ? srow_sum * expf(mx - wm) : 0.f);
-    const int w8 = lane & 7;
-    if constexpr (!LOSS) {
-        float* redf = reinterpret_cast<float*>(red);            // [8][2] floats in the same LDS words
-        if (lane == 0) { redf[2 * wid] = wm; redf[2 * wid + 1] = wsf; }
-        __syncthreads();
-        const float rm = redf[2 * w8], rs = redf[2 * w8 + 1];
-        float Mf = rm, q;
-        q = tnn::dpp_move<0xB1, 0xf>(-INFINITY, Mf); Mf = q > Mf ? q : Mf;
-        q = tnn::dpp_move<0x4E, 0xf>(-INFINITY, Mf); Mf = q > Mf ? q : Mf;
-        q = tnn::dpp_move<0x141, 0xf>(-INFINITY, Mf); Mf = q > Mf ? q : Mf;
-        float Sf = rm > -INFINITY ? rs * expf(rm - Mf) : 0.f;
-        Sf += tnn::dpp_move<0xB1, 0xf>(0.f, Sf);
-        Sf += tnn::dpp_move<0x4E, 0xf>(0.f, Sf);
-        Sf += tnn::dpp_move<0x141, 0xf>(0.f, Sf);
-        o.mx = mx; o.urow = urow; o.M = Mf; o.S = (double)Sf; o.L = 0.0;
-        return;
-    }
-    double wlog = 0.0;
-    if (want_loss) wlog = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);     // block-uniform branch
-    if (lane == 0) { red[wid][0] = (double)wm; red[wid][1] = (double)wsf; red[wid][2] = wlog; }
-    __syncthreads();
-    const double rm = red[w8][0], rs = red[w8][1];
-    float M = (float)rm, q;
-    q = tnn::dpp_move<0xB1, 0xf>(-INFINITY, M); M = q > M ? q : M;
-    q = tnn::dpp_move<0x4E, 0xf>(-INFINITY, M); M = q > M ? q : M;
-    q = tnn::dpp_move<0x141, 0xf>(-INFINITY, M); M = q > M ? q : M;
-    double S = rm > -INFINITY ? rs * (double)expf((float)rm - M) : 0.0, L = red[w8][2];
-    S += tnn::dpp_move<0xB1, 0xf>(0.0, S);
-    S += tnn::dpp_move<0x4E, 0xf>(0.0, S);
-    S += tnn::dpp_move<0x141, 0xf>(0.0, S);
-    L += tnn::dpp_move<0xB1, 0xf>(0.0, L);
-    L += tnn::dpp_move<0x4E, 0xf>(0.0, L);
-    L += tnn::dpp_move<0x141, 0xf>(0.0, L);
-    o.mx = mx; o.urow = urow; o.M = M; o.S = S; o.L = L;
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // MULTI-WORKGROUP head: the last Dense forward, the whole-batch softmax NLL and the last Dense backward of the
 // single-GPU MNIST-size step in ONE launch WITHOUT serialising on one CU (the single-workgroup kernel above: 14.7 us).
@@ -382,80 +279,15 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
     }
 }
 
-// ---- data-parallel form of the multi-workgroup head: the softmax spans the GLOBAL batch (core/losses.py:26-27), so the
-// shard's {M_r, S_r} have to meet the other ranks' between the statistics and dz — in EVERY workgroup of the launch.
-// Workgroup `lead` (the head's workgroup 0) does the exchange over xGMI (ll_exchange2: one tagged 8-byte store per word and
-// peer, no acknowledgement round trip), merges M = max_r M_r, S = sum_r S_r exp(M_r - M) and hands the pair to every other
-// workgroup through ONE ROW PER WORKGROUP of the uncached region (Header::bc: a workgroup polls only its own row, so the
-// pollers sit on different HBM channels — with all of them on one page the flag stores queue behind the polls, tnn_p2p.h).
-// The tag is the number of all-reduce launches so far + 1 (LaunchCtx::ar_count): every workgroup of this launch reads the
-// same value, and the step's all-reduce advances it before the next step's head runs.  Slots and rows are double-buffered /
-// overwritten safely for the reason given in tnn_p2p.hip (a rank reaches step k + 2 only through step k + 1's barriers).
-// Spins are bounded; on a timeout (or an already dead transport) the statistics stay local — the gradients are then wrong,
-// and the all-reduce + optimizer launch behind this one discards them (the sticky `dead` word).
-struct HeadGlobal {
-    float M, S;
-};
-__device__ __forceinline__ HeadGlobal head_exchange(const tnn::p2p::LaunchCtx& ctx, const bool lead, const float M_loc,
-                                                    const float S_loc, float (*peer_stats)[2]) {
-    using namespace tnn::p2p;
-    const Peers& P = ctx.peers;
-    const int t = threadIdx.x, W = P.world;
-    const uint32_t cnt = *ctx.ar_count, tag = cnt + 1;
-    HeadGlobal out = {M_loc, S_loc};
-    if (lead) {
-        if (t < 2 * W)
-            peer_stats[t >> 1][t & 1] = ll_exchange2(P, cnt, (t & 1) ? S_loc : M_loc, ctx.dead, ctx.timeout_ticks, offsetof(Header, ll2));
-        __syncthreads();
-        const bool dead_now = __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        float gm = -INFINITY, gs = 0.f;
-        for (int q = 0; q < W; ++q) gm = fmaxf(gm, peer_stats[q][0]);
-        for (int q = 0; q < W; ++q) gs += peer_stats[q][1] * expf(peer_stats[q][0] - gm);
-        if (!dead_now) { out.M = gm; out.S = gs; }
-        // hand-over rows of all the other workgroups (a dead transport publishes nothing: the waiters see the dead word)
-        if (!dead_now) {
-            for (int row = t; row < (int)gridDim.x; row += (int)blockDim.x) {
-                uint64_t* dst = reinterpret_cast<uint64_t*>(P.base[P.rank] + offsetof(Header, bc) + (size_t)row * FLAG_ROW);
-                store_sys(dst, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(out.M));
-                store_sys(dst + 1, ((uint64_t)tag << 32) | (uint64_t)__float_as_uint(out.S));
-            }
-        }
-        return out;
-    }
-    if (t < 2) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(P.base[P.rank] + offsetof(Header, bc) + (size_t)blockIdx.x * FLAG_ROW) + t;
-        uint64_t v[1] = {0};
-        uint64_t t0 = 0;
-        uint32_t polls = 0;
-        bool got = false;
-        while (__hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            load_sys(v[0], src);
-            loads_landed(v);
-            if ((uint32_t)(v[0] >> 32) == tag) { got = true; break; }
-            __builtin_amdgcn_s_sleep(2);
-            if ((++polls & 63u) == 0) {
-                const uint64_t now = wall_clock64();
-                if (t0 == 0) t0 = now;
-                if ((int64_t)(now - t0) > ctx.timeout_ticks) { mark_dead(P, ctx.dead, 3, tag, (uint32_t)(v[0] >> 32), blockIdx.x, 0); break; }
-            }
-        }
-        peer_stats[0][t] = got ? __uint_as_float((uint32_t)v[0]) : (t == 0 ? M_loc : S_loc);
-    }
-    __syncthreads();
-    out.M = peer_stats[0][0];
-    out.S = peer_stats[0][1];
-    return out;
-}
-
 // PART: the logits arrive as H / 16 partial sums per element (tnn_dense_fwd_head_partials: the previous layer's 16-column
 // tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
 // v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
 // CUT (timing builds only, TNN_HEAD_CUT): 0 = the kernel; 1 = stop after the logits, 2 = after the statistics, 3 = after dz.
 // DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
-// SH (data parallel): 0 single GPU; 1 the shards' statistics are exchanged inside this launch (head_exchange); 2 they were
-// exchanged before it and arrive through HeadMArgs::ext_pairs
+// SH (data parallel): 0 single GPU; 2 the shards' softmax statistics were reduced (and, on the peer-to-peer transport,
+// exchanged and merged) at the tail of the previous launch (dense_fwd_head_kernel) and arrive through HeadMArgs::ext_pairs
 template <int H, int C, bool PART, int CUT, bool DA, int SH = 0>
-__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, const tnn::p2p::LaunchCtx* ctx = nullptr) {
+__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
     constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
@@ -558,16 +390,10 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g, cons
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
     const float mx = st.mx, urow = st.urow;
-    float M = st.M;
-    double S = st.S;
+    const float M = st.M;
+    const double S = st.S;
     const double L = st.L;
     double inv_m = 1.0 / (double)m;
-    if constexpr (SH == 1) {
-        __shared__ float peer_stats[tnn::p2p::MAXW][2];
-        const HeadGlobal gl = head_exchange(*ctx, g == 0, M, (float)S, peer_stats);
-        M = gl.M;
-        S = (double)gl.S;
-    }
     if constexpr (SH != 0) inv_m = 1.0 / (double)p.m_global;
     if constexpr (CUT == 2) {
         p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
@@ -690,11 +516,11 @@ struct HeadBwdArgs {
 
 // CUT (timing builds only, TNN_HBW_CUT): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
 template <int H, int C, int CUT = 0, int SH = 0>
-__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q, tnn::p2p::LaunchCtx ctx) {
+__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
     if ((int)blockIdx.x < G) {
-        head_block<H, C, true, 0, false, SH>(p, (int)blockIdx.x, &ctx);
+        head_block<H, C, true, 0, false, SH>(p, (int)blockIdx.x);
         return;
     }
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
@@ -779,12 +605,6 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         return;
     }
     float m_norm = (float)m;
-    if constexpr (SH == 1) {
-        __shared__ float peer_stats[tnn::p2p::MAXW][2];
-        const HeadGlobal gl = head_exchange(ctx, false, st.M, (float)st.S, peer_stats);
-        st.M = gl.M;
-        st.S = (double)gl.S;
-    }
     if constexpr (SH != 0) m_norm = (float)p.m_global;
     {
         const float sf = slive ? expf(st.mx - st.M) * __builtin_amdgcn_rcpf((float)st.S) : 0.f;
@@ -853,51 +673,6 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     }
 }
 
-// The shard's softmax statistics as a launch of its own (data-parallel forms whose exchange is NOT inside the head launch:
-// RCCL, and peer-to-peer groups that share a GPU): ONE workgroup sums the partial logits, reduces {M, S} of its rows and
-//   EXCH = false: leaves the pair in out_pair — the caller all-gathers the ranks' pairs (tnn_allgather) and hands them to
-//                 tnn_mlp_head_bwd_tick_ext, whose workgroups merge them themselves;
-//   EXCH = true : exchanges it with the peers over xGMI right here (the loss kernel's tagged slots and epoch counter: one
-//                 workgroup, so it can advance the counter itself) and leaves the MERGED pair in out_pair.
-template <int C, bool EXCH>
-__global__ __launch_bounds__(512) void head_stats_kernel(HeadMArgs p, float* __restrict__ out_pair, tnn::p2p::LaunchCtx ctx) {
-    constexpr int ROWS = 128, NP = 8;
-    __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];
-    __shared__ double red[8][4];
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int srow = t >> 2, sub = t & 3, m = p.m;
-    const bool slive = srow < m;
-    const int sr = min(srow, m - 1);
-    HeadStage<C, NP> stg;
-    head_stage_request<C, NP>(p, t, stg);
-    head_stage_store<C, NP>(p, t, stg, zs, ys);
-    __syncthreads();
-    float zc[3], yc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        zc[i] = zs[sr * C + min(sub + 4 * i, C - 1)];
-        yc[i] = ys[sr * C + min(sub + 4 * i, C - 1)];
-    }
-    HeadStats st;
-    head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
-    float M = st.M, S = (float)st.S;
-    if constexpr (EXCH) {
-        using namespace tnn::p2p;
-        __shared__ float peer_stats[MAXW][2];
-        const Peers& P = ctx.peers;
-        const int W = P.world;
-        const uint32_t ep = *ctx.ag_epoch;
-        if (t < 2 * W) peer_stats[t >> 1][t & 1] = ll_exchange2(P, ep, (t & 1) ? S : M, ctx.dead, ctx.timeout_ticks);
-        __syncthreads();
-        float gm = -INFINITY, gs = 0.f;
-        for (int q = 0; q < W; ++q) gm = fmaxf(gm, peer_stats[q][0]);
-        for (int q = 0; q < W; ++q) gs += peer_stats[q][1] * expf(peer_stats[q][0] - gm);
-        M = gm; S = gs;
-        if (t == 0) *ctx.ag_epoch = ep + 1;
-    }
-    if (t == 0) { out_pair[0] = M; out_pair[1] = S; }
-}
-
 bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype) {
     static const bool off = getenv("TNN_HEAD_MULTI") != nullptr && atoi(getenv("TNN_HEAD_MULTI")) == 0;
     return !off && dtype == TNN_F32 && n_classes == 10 && n_hidden == 128 && rows >= 1 && rows <= 128;
@@ -939,36 +714,24 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, int64_t m
     static const int xcd_mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
     q.xcd = xcd_mode;
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
-    if (ext_pairs != nullptr) {          // data parallel, statistics exchanged by an earlier launch / collective
+    if (ext_pairs != nullptr) {          // data parallel: the statistics come from the tail of the previous launch [+ all-gather]
         TNN_REQUIRE(m_global >= rows && ext_n >= 1 && ext_n <= 64, "%s: m_global < rows or bad pair count", fn);
-        const tnn::p2p::LaunchCtx no_ctx = {};
-        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2>), grid, 512, 0, tnn::stream(), p, q, no_ctx);
-        TNN_LAUNCH_OK();
-        return 0;
-    }
-    if (m_global > 0) {                  // data parallel: the exchange of the shards' statistics happens inside the launch
-        TNN_REQUIRE(m_global >= rows, "%s: m_global < rows", fn);
-        if (int rc = tnn::p2p_refuse_if_failed(fn)) return rc;
-        tnn::p2p::LaunchCtx ctx;
-        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "%s: the peer-to-peer transport is not enabled", fn);
-        TNN_REQUIRE(grid <= tnn::p2p::BC_ROWS, "%s: %d workgroups exceed the %d hand-over rows", fn, grid, tnn::p2p::BC_ROWS);
-        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 1>), grid, 512, 0, tnn::stream(), p, q, ctx);
+        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2>), grid, 512, 0, tnn::stream(), p, q);
         TNN_LAUNCH_OK();
         return 0;
     }
     static const int cut = getenv("TNN_HBW_CUT") ? atoi(getenv("TNN_HBW_CUT")) : 0;        // timing builds
     hipStream_t st = tnn::stream();
-    const tnn::p2p::LaunchCtx none = {};
     if (getenv("TNN_HBW_OCCUPANCY")) {                  // probe: resident workgroups per CU the runtime computes for this kernel
         int nb = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&mlp_head_bwd_kernel<128, 10, 0, 0>), 512, 0);
         fprintf(stderr, "mlp_head_bwd_kernel: %d workgroups of 512 threads per CU, grid %d\n", nb, grid);
     }
-    if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q, none);
-    else if (cut == 2) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 2>), grid, 512, 0, st, p, q, none);
-    else if (cut == 3) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 3>), grid, 512, 0, st, p, q, none);
-    else if (cut == 4) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 4>), grid, 512, 0, st, p, q, none);
-    else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, st, p, q, none);
+    if (cut == 1) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 1>), grid, 512, 0, st, p, q);
+    else if (cut == 2) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 2>), grid, 512, 0, st, p, q);
+    else if (cut == 3) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 3>), grid, 512, 0, st, p, q);
+    else if (cut == 4) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 4>), grid, 512, 0, st, p, q);
+    else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10>), grid, 512, 0, st, p, q);
     TNN_LAUNCH_OK();
     return 0;
 }
@@ -1061,16 +824,6 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
                            dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
-int tnn_mlp_head_bwd_tick_sharded(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
-                                  const void* x, const void* w1, const void* a, const void* w, const void* b, const void* y,
-                                  const void* logit_partials, void* logits, void* dz, void* stats, void* loss, void* dw,
-                                  void* db, void* dw1, void* db1, void* dx, int dtype, void* adam_pows_f64, double b1,
-                                  double b2) {
-    TNN_REQUIRE(m_global >= 1, "tnn_mlp_head_bwd_tick_sharded: m_global must be the global batch size");
-    return head_bwd_launch("tnn_mlp_head_bwd_tick_sharded", nullptr, 0, m_global, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y,
-                           logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
-}
-
 int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
                               const void* x, const void* w1, const void* a, const void* w, const void* b, const void* y,
                               const void* logit_partials, const void* stats_pairs, int n_pairs, void* logits, void* dz,
@@ -1080,28 +833,6 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
     return head_bwd_launch("tnn_mlp_head_bwd_tick_ext", (const float*)stats_pairs, n_pairs, m_global, rows, n_in, n_hidden,
                            n_classes, x, w1, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
                            adam_pows_f64, b1, b2);
-}
-
-int tnn_mlp_head_stats(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* b, const void* y,
-                       const void* logit_partials, void* out_pair_f32, int exchange, int dtype) {
-    TNN_NEED_INIT();
-    TNN_REQUIRE(b && y && logit_partials && out_pair_f32, "tnn_mlp_head_stats: b, y, logit_partials and out_pair are required");
-    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype), "tnn_mlp_head_stats: ask tnn_mlp_head_fits first");
-    HeadMArgs p = {};
-    p.m = (int)rows;
-    p.b = (const float*)b; p.y = (const float*)y; p.zpart = (const float*)logit_partials;
-    p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
-    if (exchange) {
-        if (int rc = tnn::p2p_refuse_if_failed("tnn_mlp_head_stats")) return rc;
-        tnn::p2p::LaunchCtx ctx;
-        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_mlp_head_stats: the peer-to-peer transport is not enabled");
-        hipLaunchKernelGGL((head_stats_kernel<10, true>), 1, 512, 0, tnn::stream(), p, (float*)out_pair_f32, ctx);
-    } else {
-        const tnn::p2p::LaunchCtx none = {};
-        hipLaunchKernelGGL((head_stats_kernel<10, false>), 1, 512, 0, tnn::stream(), p, (float*)out_pair_f32, none);
-    }
-    TNN_LAUNCH_OK();
-    return 0;
 }
 
 }  // extern "C"

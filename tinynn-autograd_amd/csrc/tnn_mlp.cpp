@@ -44,6 +44,7 @@ struct Mlp {
     void* stats = nullptr;           // {M, S} of the last forward_stats
     bool keep_grads = true;          // tnn_mlp_keep_grads: false lets a step consume weight gradients without storing them
     void* zpart = nullptr;           // [w[L-1] / 16][max_rows][w[L]] partial logits (5-launch step, see tnn_mlp_step)
+    void* ticket = nullptr;          // arrival counter of the forward launch whose last workgroup reduces the shard's statistics
     void* stats_all = nullptr;       // [world, 2] gathered shard stats (data-parallel step)
     int stats_all_world = 0;
     std::vector<int64_t> w_off, b_off;
@@ -384,6 +385,8 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     rc |= tnn_malloc(bytes, (void**)&h->v);
     rc |= tnn_malloc(4 * sizeof(double), &h->pows);
     rc |= tnn_malloc(2 * 8, &h->stats);
+    rc |= tnn_malloc(64, &h->ticket);
+    if (!rc) rc |= tnn_memset(h->ticket, 0, 64);
     if (n_layers >= 2 && dtype == TNN_F32)
         rc |= tnn_malloc((size_t)((widths[n_layers - 1] + 15) / 16 * max_rows * widths[n_layers]) * 4, &h->zpart);
     const size_t act_esz = h->bf16 ? 2 : h->esz;
@@ -427,7 +430,7 @@ int tnn_mlp_destroy(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) return 0;
     tnn_free(h->params); tnn_free(h->grads); tnn_free(h->m); tnn_free(h->v);
-    tnn_free(h->pows); tnn_free(h->stats); tnn_free(h->stats_all); tnn_free(h->zpart);
+    tnn_free(h->pows); tnn_free(h->stats); tnn_free(h->ticket); tnn_free(h->stats_all); tnn_free(h->zpart);
     for (void* p : h->act) tnn_free(p);
     for (void* p : h->dact) tnn_free(p);
     for (void* p : h->wT16) tnn_free(p);
@@ -710,74 +713,37 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
     int head_multi = 0;
-    static const bool merge_off = getenv("TNN_STEP_MERGE") != nullptr && atoi(getenv("TNN_STEP_MERGE")) == 0;
-    int shared_gpu = 0;
-    if (p2p_on) MLP_TRY(tnn_p2p_shared_device(-1, &shared_gpu));
-    static const bool merge_shared = getenv("TNN_STEP_MERGE_SHARED") != nullptr && atoi(getenv("TNN_STEP_MERGE_SHARED")) != 0;
-    if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0 && !merge_off)
+    if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
-    // TNN_P2P_EXCHANGE=launch: peer-to-peer groups with a GPU per rank also use the form whose exchange is a launch of its
-    // own (measured with a one-rank group: 32.8-33.3 us/step against 31.5 for the exchange inside the head launch)
-    static const char* exch_env = getenv("TNN_P2P_EXCHANGE");
-    static const bool exch_in_kernel = !(exch_env != nullptr && exch_env[0] == 'l');
-    const bool in_kernel_exchange = p2p_on && exch_in_kernel && (!shared_gpu || merge_shared);
-    if (head_multi && !in_kernel_exchange) {
-        // The same structure with the statistics as a launch of their own — for RCCL (north_star's named transport: a
-        // collective cannot sit inside a kernel) and for peer-to-peer groups sharing one GPU:
-        //   forward of the hidden layers (+ partial logits) | tnn_mlp_head_stats: the shard's {max, sum-exp} | their exchange
-        //   (peer-to-peer: inside that launch; otherwise tnn_allgather) | head + hidden layer's backward taking the pairs from
-        //   memory (tnn_mlp_head_bwd_tick_ext; advances Adam's beta powers) | remaining backward | all-reduce + Adam
-        // 6 launches + 2 collectives on RCCL instead of 12 + 2.
-        static const bool ext_off = getenv("TNN_STEP_EXT") != nullptr && atoi(getenv("TNN_STEP_EXT")) == 0;
-        if (!ext_off) {
-            MLP_TRY(mlp_forward(h, x, rows, L - 2));
-            MLP_TRY(tnn_dense_fwd_head_partials(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
-                                                at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
-                                                at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
-                                                h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart, h->dtype));
-            MLP_TRY(tnn_mlp_head_stats(rows, h->w[L - 1], h->w[L], at(h->params, h->b_off[L - 1], h->esz), y, h->zpart,
-                                       h->stats, p2p_on ? 1 : 0, h->dtype));
-            const void* pairs = h->stats;
-            int n_pairs = 1;
-            if (!p2p_on) {
-                MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
-                pairs = h->stats_all;
-                n_pairs = world;
-            }
-            MLP_TRY(tnn_mlp_head_bwd_tick_ext(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
-                                              at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
-                                              at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
-                                              y, h->zpart, pairs, n_pairs, h->act[L - 1], h->dact[L - 1], nullptr, loss_slot,
-                                              at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
-                                              at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
-                                              h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
-            MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 0));
-            return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
-                                      h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);
-        }
-        head_multi = 0;
-    }
     if (head_multi) {
-        // xGMI peer-to-peer transport, a GPU per rank (every workgroup of the head launch waits for the merged statistics: all
-        // the ranks' launches must be resident together — ranks sharing one GPU deadlock as soon as one launch fills it,
-        // measured with 2 x 128 rows) and a classifier head of the one-launch form — 2L - 1 launches (5 for the MNIST net),
-        // the single-GPU step's structure with the exchange INSIDE the head launch:
-        //   forward of the hidden layers (the last one also emits the partial logits) | head + hidden layer's backward, whose
-        //   workgroup 0 exchanges the shards' {max, sum-exp} with the peers and hands the merged pair to the others
-        //   (tnn_mlp_head_bwd_tick_sharded; it also advances Adam's beta powers) | remaining backward | all-reduce whose
-        //   last stage applies Adam and files the loss
+        // Classifier head of the one-launch form (<= 128 rows per rank: every weak-scaling point, config D at 8 ranks) —
+        // 2L - 1 launches (5 for the MNIST net) + the collectives, ONE form for every transport:
+        //   forward of the hidden layers; the LAST workgroup of the last one to finish also reduces the shard's {max, sum-exp}
+        //   from the partial logits and, on the peer-to-peer transport, exchanges and merges them (tnn_dense_fwd_head_
+        //   partials_stats: no statistics launch, nobody waits for a peer inside the head launch, no residency requirement)
+        //   | RCCL only: tnn_allgather of the pairs | head + hidden layer's backward taking the pair(s) from memory
+        //   (tnn_mlp_head_bwd_tick_ext; advances Adam's beta powers) | remaining backward | all-reduce + Adam
         MLP_TRY(mlp_forward(h, x, rows, L - 2));
-        MLP_TRY(tnn_dense_fwd_head_partials(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
-                                            at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
-                                            at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
-                                            h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart, h->dtype));
-        MLP_TRY(tnn_mlp_head_bwd_tick_sharded(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
-                                              at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
-                                              at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
-                                              y, h->zpart, h->act[L - 1], h->dact[L - 1], h->stats, loss_slot,
-                                              at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
-                                              at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
-                                              h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
+        MLP_TRY(tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                  at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                  at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                  h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                  at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats,
+                                                  p2p_on ? 1 : 0, h->dtype));
+        const void* pairs = h->stats;
+        int n_pairs = 1;
+        if (!p2p_on) {
+            MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
+            pairs = h->stats_all;
+            n_pairs = world;
+        }
+        MLP_TRY(tnn_mlp_head_bwd_tick_ext(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
+                                          at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
+                                          at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
+                                          y, h->zpart, pairs, n_pairs, h->act[L - 1], h->dact[L - 1], nullptr, loss_slot,
+                                          at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                          at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
+                                          h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
         MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 0));
         return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
                                   h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);

@@ -19,16 +19,11 @@ constexpr int THREADS = 512;
 // pollers hit one HBM channel and the flag stores queue behind them (measured: 64 workgroups cost +7 us per
 // all-reduce over one); each workgroup's words therefore get a row of their own, FLAG_ROW bytes apart.
 constexpr int FLAG_ROW = 4096;
-constexpr int BC_ROWS = 1024;     // workgroups of the sharded head launch
 struct Header {                                   // start of every rank's uncached region
     uint8_t flag[2][MAXB][FLAG_ROW];              // [barrier][block] -> uint32_t[MAXW] indexed by source rank
     uint32_t ag_flag[MAXW];                       // [source rank]
     uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
     uint64_t ll[2][MAXW][2];                      // [epoch parity][source rank][word]: (tag << 32) | payload, see ll_exchange2
-    // the multi-workgroup head (tnn_head.hip, sharded form): its own tagged slots (the tags come from a different counter than
-    // the loss kernel's) and one row per workgroup through which workgroup 0 hands the merged {max, sum-exp} to the others
-    uint64_t ll2[2][MAXW][2];
-    uint8_t bc[BC_ROWS][FLAG_ROW];                // row b: uint64_t[2] = (tag << 32) | bits of {M, S}, polled by workgroup b only
 };
 constexpr size_t HEADER_BYTES = (sizeof(Header) + 4095) / 4096 * 4096;
 
@@ -42,8 +37,8 @@ struct Peers {
 
 // A barrier timed out: the sticky device word stops every later wait, the host mirror lets the next host-side call fail
 // loudly (tnn_p2p.hip: p2p_failed) instead of running on partial sums.
-// `why` (non-zero) says which wait gave up — 1: a flag barrier of a collective, 2: the tagged {max, sum-exp} exchange,
-// 3: a workgroup of the sharded head waiting for its hand-over row; tnn_p2p_status reports the word as it is.
+// `why` (non-zero) says which wait gave up — 1: a flag barrier of a collective, 2: the tagged {max, sum-exp} exchange;
+// tnn_p2p_status reports the word as it is.
 // The host mirror is 16 ints: [0] the word, [1..4] what the FIRST wait that gave up was looking at (expected value, last
 // value seen, peer / workgroup, a wait-specific detail) — tnn_p2p_debug reads them without a stream sync.
 __device__ __forceinline__ void mark_dead(const Peers& p, int* dead, int why = 1, uint32_t expected = 0, uint32_t seen = 0,
@@ -56,10 +51,8 @@ __device__ __forceinline__ void mark_dead(const Peers& p, int* dead, int why = 1
 
 struct LaunchCtx {                                // what a kernel embedding an exchange needs
     Peers peers;
-    uint32_t* ag_epoch;                           // epoch of the small all-gather slots (device)
-    const uint32_t* ar_count;                     // all-reduce launches so far (device; advanced by every all-reduce kernel):
-                                                  // the tag source of a MULTI-workgroup exchange, which cannot advance a counter
-                                                  // of its own while other workgroups of the same launch may not have read it
+    uint32_t* ag_epoch;                           // epoch of the small all-gather / tagged-exchange slots (device); only
+                                                  // single-workgroup exchanges use it, so the exchanging kernel advances it itself
     int* dead;
     int64_t timeout_ticks;
 };

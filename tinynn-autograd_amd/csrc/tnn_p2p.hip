@@ -44,14 +44,13 @@ struct State {
     Peers p = {};
     char* own = nullptr;
     void* mapped[MAXW] = {};                      // hipIpcOpenMemHandle results (NULL for self)
-    uint32_t* epoch = nullptr;                    // [MAXB + 2] per-block epochs, the all-gather epoch, the all-reduce launch count
+    uint32_t* epoch = nullptr;                    // [MAXB + 1] per-block epochs, the all-gather / statistics-exchange epoch
                                                   // (local, cached)
     int* dead = nullptr;                          // sticky timeout word (local)
     int* host_dead = nullptr;                     // its host-pinned mirror (hipHostMalloc, mapped): host address
     int64_t max_floats = 0;
     int64_t timeout_ticks = 0;
     int blocks_override = 0;
-    bool shared_device = false;                   // some ranks of the group run on the SAME GPU (tests on one-GPU boxes)
 } S;
 
 __device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
@@ -144,7 +143,6 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
     if (!ok) {                     // timed out (now or earlier): buf, parameters and moments stay as they were
         if (threadIdx.x == 0) {
             epoch[b] = e + 1;
-            if (b == 0) epoch[MAXB + 1] += 1;
         }
         return;
     }
@@ -226,7 +224,6 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
     }
     if (threadIdx.x == 0) {
         epoch[b] = e + 1;
-        if (b == 0) epoch[MAXB + 1] += 1;          // launches so far: the tag source of the sharded head (LaunchCtx::ar_count)
     }
 }
 
@@ -325,7 +322,6 @@ bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
     if (!S.enabled || p2p_failed()) return false;
     ctx->peers = S.p;
     ctx->ag_epoch = S.epoch + MAXB;
-    ctx->ar_count = S.epoch + MAXB + 1;
     ctx->dead = S.dead;
     ctx->timeout_ticks = S.timeout_ticks;
     return true;
@@ -437,18 +433,6 @@ int tnn_p2p_status(int* connected, int* enabled, int* dead) {
             TNN_CHECK_HIP(hipMemcpy(dead, S.dead, sizeof(int), hipMemcpyDeviceToHost));
         }
     }
-    return 0;
-}
-
-int tnn_p2p_shared_device(int set, int* current) {
-    // set >= 0: tell the transport whether ranks of this group share a GPU (the host side knows: dist.py compares the
-    // ranks' host / device pairs).  Kernels in which MANY workgroups of a rank wait for a peer's launch (the sharded
-    // multi-workgroup head) are only safe when every rank's launch can be resident at the same time — on a GPU of its own
-    // always, on a shared one only while all the launches fit it together; tnn_mlp_step_sharded then keeps the form whose
-    // exchange sits in a one-workgroup kernel.  current (may be NULL) receives the flag.
-    TNN_REQUIRE(S.open, "tnn_p2p_shared_device: no peer group");
-    if (set >= 0) S.shared_device = set != 0;
-    if (current) *current = S.shared_device ? 1 : 0;
     return 0;
 }
 

@@ -123,15 +123,6 @@ class DeviceCommunicator(Communicator):
             raise
         self._p2p = True
         self.p2p_bytes = int(max_bytes)
-        # do ranks share a GPU (one-GPU test boxes: TNN_DEVICE=0 for every rank)?  The sharded multi-workgroup head is
-        # only used when every rank has a GPU of its own (tnn_p2p_shared_device)
-        if self.world > 1 and exchange is None:
-            import socket
-            dist = _control_plane()
-            ident = (socket.gethostname(), os.environ.get("TNN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            idents = [None] * self.world
-            dist.all_gather_object(idents, ident)
-            lib.p2p_shared_device(1 if len(set(idents)) < self.world else 0, None)
         return self
 
     def set_p2p(self, on):
