@@ -462,8 +462,13 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(T* __restrict__ p, const
                                                         T* __restrict__ m, T* __restrict__ v,
                                                         int64_t n, T lr, T b1, T b2, T eps,
                                                         const double* __restrict__ state,
-                                                        T* __restrict__ step_out, const int* guard) {
+                                                        T* __restrict__ step_out, const int* guard,
+                                                        const T* __restrict__ scalar_src = nullptr,
+                                                        T* __restrict__ scalar_dst = nullptr) {
     TNN_GUARD_RETURN(guard);
+    // one scalar rides along (the data-parallel trainer files the all-reduced loss into its loss history): no prologue
+    // launch just for a 4-byte copy
+    if (scalar_dst != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *scalar_dst = *scalar_src;
     const double p1 = state[0], p2 = state[1];
     const T inv_c1 = (T)(1.0 / (1.0 - p1)), inv_c2 = (T)(1.0 / (1.0 - p2));
     const T one_m_b1 = T(1) - b1, one_m_b2 = T(1) - b2;
@@ -773,9 +778,12 @@ int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, 
     TNN_REQUIRE(pows_f64 != nullptr, "tnn_adam: pows state is NULL");
     TNN_REQUIRE((scalar_src == nullptr) == (scalar_dst == nullptr), "tnn_adam_ex: scalar_src / scalar_dst go together");
     hipStream_t s = tnn::stream();
-    if (advance || scalar_dst)
-        hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, advance ? b1 : 1.0, advance ? b2 : 1.0,
-                           scalar_src, scalar_dst, dtype == TNN_F64 ? 8 : 4, tnn::update_guard());
+    if (advance) {         // the prologue thread that advances the beta powers also carries the scalar
+        hipLaunchKernelGGL(adam_advance_kernel, 1, 1, 0, s, (double*)pows_f64, b1, b2, scalar_src, scalar_dst,
+                           dtype == TNN_F64 ? 8 : 4, tnn::update_guard());
+        scalar_src = nullptr;
+        scalar_dst = nullptr;
+    }
     if (dtype == TNN_F32) {
         bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                      reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
@@ -784,16 +792,18 @@ int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, double lr, 
         if (vec)
             hipLaunchKernelGGL((adam_kernel<float, 4>), grid, kThreads, 0, s, (float*)p, (const float*)g,
                                (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps,
-                               (const double*)pows_f64, (float*)step_out, tnn::update_guard());
+                               (const double*)pows_f64, (float*)step_out, tnn::update_guard(), (const float*)scalar_src,
+                               (float*)scalar_dst);
         else
             hipLaunchKernelGGL((adam_kernel<float, 1>), grid, kThreads, 0, s, (float*)p, (const float*)g,
                                (float*)m, (float*)v, n, (float)lr, (float)b1, (float)b2, (float)eps,
-                               (const double*)pows_f64, (float*)step_out, tnn::update_guard());
+                               (const double*)pows_f64, (float*)step_out, tnn::update_guard(), (const float*)scalar_src,
+                               (float*)scalar_dst);
     } else if (dtype == TNN_F64) {
         unsigned grid = tnn::stream_grid(n, kThreads);
         hipLaunchKernelGGL((adam_kernel<double, 1>), grid, kThreads, 0, s, (double*)p, (const double*)g,
                            (double*)m, (double*)v, n, lr, b1, b2, eps, (const double*)pows_f64,
-                           (double*)step_out, tnn::update_guard());
+                           (double*)step_out, tnn::update_guard(), (const double*)scalar_src, (double*)scalar_dst);
     } else {
         tnn::set_error("tnn_adam: dtype %d is not a float type", dtype);
         return 2;

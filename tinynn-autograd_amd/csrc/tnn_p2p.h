@@ -57,13 +57,6 @@ struct LaunchCtx {                                // what a kernel embedding an 
     int64_t timeout_ticks;
 };
 
-__device__ __forceinline__ float* recv_of(const Peers& p, int who) {
-    return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES);
-}
-__device__ __forceinline__ float* out_of(const Peers& p, int who) {
-    return reinterpret_cast<float*>(p.base[who] + HEADER_BYTES) + (int64_t)p.world * p.slice_cap;
-}
-
 // Signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine.
 // Everything that crosses a device boundary lives in UNCACHED memory (stores go straight to the fabric, loads come
 // from memory), so no L2 write-back / invalidate is needed — and none is issued: a system-scope release fence is a

@@ -7,16 +7,15 @@
 //     L2, so data written by a peer inside a running kernel is visible without a kernel boundary), exported
 //     once with hipIpcGetMemHandle and mapped by every peer;
 //   * all cross-GPU traffic is PUSHED (posted xGMI writes; nothing waits for a remote read round trip);
-//   * all-reduce = ONE kernel, two-stage: (A) rank r stores its copy of slice p into peer p's recv[r];
-//     barrier; (B) rank r sums recv[0..W) of its own slice IN RANK ORDER and stores the result slice into every
-//     peer's out[]; barrier; (C) out[] -> the caller's buffer.  Each slice is reduced by exactly one rank and
-//     broadcast, so all ranks end up with bit-identical sums (replicas cannot drift apart);
-//     per link and direction: 2 x n/W elements;
-//   * barriers are per-workgroup flag exchanges (block b of every rank works on the same sub-range of every
-//     slice, so only the W "block b"s have to meet): each thread waits for its own stores to be acknowledged, then
-//     relaxed system-scope stores into each peer's flag word and relaxed polls of the local words (tnn_p2p.h has the
-//     reasoning and the measurements).  Flag values grow monotonically from a per-block epoch kept in DEVICE
-//     memory, so the kernel is replayable from a hipGraph with fixed arguments and never needs a reset;
+//   * all-reduce = ONE kernel, two-stage: (A) rank r stores its copy of slice p into peer p's recv slots [r];
+//     (B) rank r sums the W copies of its own slice IN RANK ORDER and stores the result slice into every peer's out
+//     slots; (C) out slots -> the caller's buffer.  Each slice is reduced by exactly one rank and broadcast, so all
+//     ranks end up with bit-identical sums (replicas cannot drift apart); per link and direction: 2 x n/W elements;
+//   * no barriers between the stages (round 3): every payload word travels next to a tag in one 8-byte half of a
+//     16-byte store and the receiver polls the data itself (ll_send / ll_poll below) — one fabric latency per stage
+//     instead of three dependent ones (store-ack wait, flag store -> poll, data load).  Tags grow monotonically from a
+//     per-block launch count kept in DEVICE memory, so the kernel is replayable from a hipGraph with fixed arguments
+//     and never needs a reset; the small all-gather still uses a flag exchange (exchange_flags, tnn_p2p.h);
 //   * (C) can carry the optimizer: the reduced gradient is in registers there, so Adam is applied on the spot;
 //   * spins are bounded by the constant 100 MHz clock: on timeout the kernel sets a sticky `dead` word (device) and
 //     its host-pinned mirror, and from then on NOTHING is consumed: a workgroup whose barrier failed — in this or any
@@ -26,9 +25,10 @@
 //     reads the mirror without a stream sync) and tnn_p2p_status() reports it — a lost peer is a loud error, neither
 //     a hung GPU nor silently diverging replicas.
 //
-// Buffer reuse is safe without extra barriers: a rank enters stage A of call k+1 only after barrier 2 of call k,
-// which every peer signals after its last read of recv[]; out[] of call k+1 is written after barrier 1 of call
-// k+1, which a peer signals only after its kernel k (stage C included) has finished in stream order.
+// Buffer reuse is safe without a handshake: block b of a rank finishes call k only when it has received EVERY out slot of
+// its sub-range, which each peer sends only after reading all its recv slots of that sub-range — so call k+1 may
+// overwrite the recv slots; out slots of call k+1 are written after the writer received the stage-A data of call k+1 from
+// every rank, which a rank sends only after its kernel k (stage C included) has finished in stream order.
 // The small all-gather double-buffers its slots on epoch parity for the same reason.
 #include <string.h>
 
@@ -85,22 +85,91 @@ struct AdamTail {
     float* scalar_dst;
 };
 
+// ---- tagged ("low-latency") slots for the bulk data: every 4-byte payload word travels next to a 4-byte tag in ONE
+// naturally aligned 8-byte half of a 16-byte store, so the receiver polls the DATA itself until every tag is the one it
+// expects.  No store-acknowledgement wait, no flag exchange, no second read per stage: a stage costs one fabric latency
+// end to end where the flag-barrier version of rounds 1-2 paid three dependent ones (ack wait, flag store -> poll, data
+// load).  Wire efficiency is 50 % — irrelevant at 0.94 MB.  A float4 element i of a slice occupies 32 bytes:
+//     {p0, tag, p1, tag | p2, tag, p3, tag}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_load16(u32x4& v, const char* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
+}
+__device__ __forceinline__ void ll_store16(char* ptr, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
+}
+// slot of (source rank src, float4 element i) inside a region: recv half (stage A -> B) or out half (stage B -> C)
+__device__ __forceinline__ size_t ll_recv_off(const Peers& p, int src, int64_t i) {
+    return HEADER_BYTES + (size_t)((int64_t)src * (p.slice_cap / 4) + i) * 32;
+}
+__device__ __forceinline__ size_t ll_out_off(const Peers& p, int src, int64_t i) {
+    return HEADER_BYTES + (size_t)((int64_t)(p.world + src) * (p.slice_cap / 4) + i) * 32;
+}
+__device__ __forceinline__ void ll_send(char* dst, f32x4 v, uint32_t tag) {
+    ll_store16(dst, u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag});
+    ll_store16(dst + 16, u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag});
+}
+// Poll N slots until every live one carries `tag` in all four tag words; false = the transport is (now) dead.
+template <int N>
+__device__ __forceinline__ bool ll_poll(const char* const (&src)[N], const bool (&live)[N], f32x4 (&out)[N], uint32_t tag,
+                                        const Peers& p, int* dead, int64_t timeout_ticks) {
+    uint64_t t0 = 0;
+    uint32_t polls = 0;
+    for (;;) {
+        u32x4 lo[N], hi[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (live[k]) { ll_load16(lo[k], src[k]); ll_load16(hi[k], src[k] + 16); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool ok = true;
+        uint32_t seen = tag;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (!live[k]) continue;
+            asm volatile("" : "+v"(lo[k]), "+v"(hi[k]));          // uses stay behind the wait
+            const bool ready = lo[k][1] == tag && lo[k][3] == tag && hi[k][1] == tag && hi[k][3] == tag;
+            if (!ready) { ok = false; seen = lo[k][1]; }
+            out[k] = f32x4{__uint_as_float(lo[k][0]), __uint_as_float(lo[k][2]), __uint_as_float(hi[k][0]), __uint_as_float(hi[k][2])};
+        }
+        if (ok) return true;
+        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 63u) == 0) {
+            const uint64_t now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if ((int64_t)(now - t0) > timeout_ticks) {
+                mark_dead(p, dead, 1, tag, seen, blockIdx.x, threadIdx.x);
+                return false;
+            }
+        }
+    }
+}
+
 // buf[0:n] <- sum over ranks, in place.  slice = floats per rank slice (multiple of 4, W*slice >= n).
+//   (A) my copy of slice q -> rank q's recv slots [me]         (tagged stores, nothing waits)
+//   (B) poll my recv slots of all W sources, sum IN RANK ORDER, tagged stores of the result into every rank's out slots
+//   (C) poll my out slots of all W slices -> caller's buffer, with Adam applied to the registers when ADAM
+// Tags are the per-workgroup launch count (device memory, hipGraph-replayable); block b of every rank owns the same
+// sub-range of every slice, and a rank's launch k + 1 starts only after its launch k has received EVERY out slot of its
+// sub-range, which each peer sends only after it has read all its recv slots of that sub-range — so launch k + 1 may
+// overwrite both halves without any further handshake.  A missing peer starves stage B on every rank (each sum needs all W
+// copies), nothing reaches any out slot, and no rank updates anything: all or nothing, as before.
 template <bool ADAM>
 __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* __restrict__ buf, int64_t n,
                                                                 int64_t slice, uint32_t* __restrict__ epoch,
                                                                 int* dead, int64_t timeout_ticks, AdamTail t) {
     const int b = blockIdx.x, W = p.world, r = p.rank;
-    const uint32_t e = epoch[b];
+    const uint32_t e = epoch[b], tag = e + 1;
     const int64_t s4 = slice / 4;
     const int64_t per = (s4 + gridDim.x - 1) / gridDim.x;
     const int64_t lo = min((int64_t)b * per, s4), hi = min(lo + per, s4);
-    const int64_t len = hi - lo, cap = p.slice_cap;
+    const int64_t len = hi - lo;
     const int64_t items = len * W;                        // (slice k, element i) pairs of this workgroup
+    bool ok = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 
-    // (A) my copy of slice q -> rank q's recv[r]; slice order starts at my right-hand neighbour so the links
-    // fill evenly.  Loads first (L2 hits: the gradients were just written), then the posted stores.
-    for (int64_t j0 = threadIdx.x; j0 < items; j0 += (int64_t)THREADS * UNROLL) {
+    // (A) slice order starts at my right-hand neighbour so the links fill evenly.  Loads first (L2 hits: the gradients
+    // were just written), then the posted stores.
+    for (int64_t j0 = threadIdx.x; ok && j0 < items; j0 += (int64_t)THREADS * UNROLL) {
         f32x4 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -115,40 +184,40 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             const int64_t j = j0 + (int64_t)u * THREADS;
             if (j < items) {
                 const int q = (r + 1 + (int)(j / len)) % W;
-                store_sys(recv_of(p, q) + (int64_t)r * cap + 4 * (lo + j % len), v[u]);
+                ll_send(p.base[q] + ll_recv_off(p, r, lo + j % len), v[u], tag);
             }
         }
     }
-    bool ok = exchange_flags(p, offsetof(Header, flag) + (size_t)(0 * MAXB + b) * FLAG_ROW, 2 * e + 1, dead, timeout_ticks);
 
-    // (B) reduce my slice in rank order (all W loads in flight, then a fixed-order sum), broadcast the result slice
-    const float* mine = recv_of(p, r);
+    // (B) reduce my slice in rank order (all W slots requested together, then a fixed-order sum), broadcast the result
     for (int64_t i = lo + threadIdx.x; ok && i < hi; i += THREADS) {
-        f32x4 part[MAXW] = {};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < MAXW; ++q)
-            if (q < W) load_sys(part[q], mine + (int64_t)q * cap + 4 * i);
-        loads_landed(part);
-        f32x4 acc = part[0];
+        for (int c = 0; c < MAXW / 8; ++c) {
+            if (8 * c >= W) break;
+            const char* src[8];
+            bool live[8];
+            f32x4 part[8];
 #pragma unroll
-        for (int q = 1; q < MAXW; ++q)
-            if (q < W) acc += part[q];
+            for (int k = 0; k < 8; ++k) {
+                live[k] = 8 * c + k < W;
+                src[k] = p.base[r] + ll_recv_off(p, live[k] ? 8 * c + k : 0, i);
+            }
+            ok = ll_poll<8>(src, live, part, tag, p, dead, timeout_ticks);
+            if (!ok) break;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (live[k]) acc = (c == 0 && k == 0) ? part[k] : acc + part[k];
+        }
+        if (!ok) break;
         for (int k = 0; k < W; ++k) {
             const int q = (r + 1 + k) % W;
-            store_sys(out_of(p, q) + (int64_t)r * cap + 4 * i, acc);
+            ll_send(p.base[q] + ll_out_off(p, r, i), acc, tag);
         }
-    }
-    // a workgroup that lost barrier 1 does not signal barrier 2: no peer can then complete this collective either
-    ok = ok && exchange_flags(p, offsetof(Header, flag) + (size_t)(1 * MAXB + b) * FLAG_ROW, 2 * e + 2, dead, timeout_ticks);
-    if (!ok) {                     // timed out (now or earlier): buf, parameters and moments stay as they were
-        if (threadIdx.x == 0) {
-            epoch[b] = e + 1;
-        }
-        return;
     }
 
-    // (C) gathered result -> caller's buffer (+ the optimizer update when ADAM)
-    const float* res = out_of(p, r);
+    // (C) gathered result -> caller's buffer (+ the optimizer update when ADAM).  A thread that lost a poll (timeout, dead
+    // transport) updates nothing; with a peer missing that is every thread of every rank (see above).
     float ic1 = 0.f, ic2 = 0.f, omb1 = 0.f, omb2 = 0.f;
     if constexpr (ADAM) {
         ic1 = (float)(1.0 / (1.0 - t.pows[0]));
@@ -162,12 +231,15 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
         const float mh = mi * ic1, vh = vi * ic2;
         pi = pi + (-t.lr * mh / (sqrtf(vh) + t.eps));
     };
-    for (int64_t j0 = threadIdx.x; j0 < items; j0 += (int64_t)THREADS * UNROLL) {
+    for (int64_t j0 = threadIdx.x; ok && j0 < items; j0 += (int64_t)THREADS * UNROLL) {
         f32x4 g[UNROLL] = {};
+        const char* gsrc[UNROLL];
+        bool glive[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t j = j0 + (int64_t)u * THREADS;
-            if (j < items) load_sys(g[u], res + (j / len) * cap + 4 * (lo + j % len));
+            glive[u] = j < items;
+            gsrc[u] = p.base[r] + ll_out_off(p, glive[u] ? (int)(j / len) : 0, lo + (glive[u] ? j % len : 0));
         }
         if constexpr (ADAM) {
             // the parameter / moment loads do not depend on the peers: issue them under the same wait
@@ -183,7 +255,8 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
                     vm[u] = *reinterpret_cast<const f32x4*>(t.v + at[u]);
                 }
             }
-            loads_landed(g);
+            ok = ll_poll<UNROLL>(gsrc, glive, g, tag, p, dead, timeout_ticks);
+            if (!ok) break;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int64_t i0 = at[u];
@@ -214,7 +287,8 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
                 }
             }
         } else {
-            loads_landed(g);
+            ok = ll_poll<UNROLL>(gsrc, glive, g, tag, p, dead, timeout_ticks);
+            if (!ok) break;
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 const int64_t j = j0 + (int64_t)u * THREADS;
@@ -355,7 +429,7 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     const int64_t max_floats = max_bytes / 4;
     int64_t cap = (max_floats + world - 1) / world;
     cap = (cap + 3) / 4 * 4;
-    const size_t bytes = HEADER_BYTES + (size_t)2 * world * cap * 4;
+    const size_t bytes = HEADER_BYTES + (size_t)2 * world * cap * 8;      // recv + out halves, every payload word next to its tag
     void* region = nullptr;
     TNN_CHECK_HIP(hipExtMallocWithFlags(&region, bytes, hipDeviceMallocUncached));
     TNN_CHECK_HIP(hipMemset(region, 0, bytes));
