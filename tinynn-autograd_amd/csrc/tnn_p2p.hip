@@ -50,7 +50,7 @@ struct State {
     int* host_dead = nullptr;                     // its host-pinned mirror (hipHostMalloc, mapped): host address
     int64_t max_floats = 0;
     int64_t timeout_ticks = 0;
-    int blocks_override = 0;
+    int grid = MAXB;                              // workgroups of EVERY all-reduce launch (see p2p_allreduce_kernel)
 } S;
 
 __device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
@@ -149,69 +149,73 @@ __device__ __forceinline__ bool ll_poll(const char* const (&src)[N], const bool 
 //   (A) my copy of slice q -> rank q's recv slots [me]         (tagged stores, nothing waits)
 //   (B) poll my recv slots of all W sources, sum IN RANK ORDER, tagged stores of the result into every rank's out slots
 //   (C) poll my out slots of all W slices -> caller's buffer, with Adam applied to the registers when ADAM
-// Tags are the per-workgroup launch count (device memory, hipGraph-replayable); block b of every rank owns the same
-// sub-range of every slice, and a rank's launch k + 1 starts only after its launch k has received EVERY out slot of its
-// sub-range, which each peer sends only after it has read all its recv slots of that sub-range — so launch k + 1 may
-// overwrite both halves without any further handshake.  A missing peer starves stage B on every rank (each sum needs all W
-// copies), nothing reaches any out slot, and no rank updates anything: all or nothing, as before.
+// Slot -> workgroup map: float4 element i of a slice belongs to workgroup (i / 512) % G, thread i % 512, whatever the
+// message size, and the grid is ALWAYS G workgroups — so a slot is only ever written and read on behalf of one workgroup
+// index, and that workgroup's launch count (device memory, advanced by every launch, hipGraph-replayable) is a strictly
+// increasing tag for it: a stale slot can never carry the tag a later call polls for.  A rank's launch k + 1 starts only
+// after its launch k has received EVERY out slot it owns a thread for, which each peer sends only after it has read all its
+// recv slots of that workgroup — so launch k + 1 may overwrite both halves without any further handshake.  A missing peer
+// starves stage B on every rank (each sum needs all W copies), nothing reaches any out slot, and no rank updates anything.
 template <bool ADAM>
 __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* __restrict__ buf, int64_t n,
                                                                 int64_t slice, uint32_t* __restrict__ epoch,
                                                                 int* dead, int64_t timeout_ticks, AdamTail t) {
-    const int b = blockIdx.x, W = p.world, r = p.rank;
-    const uint32_t e = epoch[b], tag = e + 1;
+    const int b = blockIdx.x, G = gridDim.x, W = p.world, r = p.rank;
+    const uint32_t tag = epoch[b] + 1;
     const int64_t s4 = slice / 4;
-    const int64_t per = (s4 + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = min((int64_t)b * per, s4), hi = min(lo + per, s4);
-    const int64_t len = hi - lo;
-    const int64_t items = len * W;                        // (slice k, element i) pairs of this workgroup
+    // this thread's elements of a slice: i_k = (b + k G) 512 + thread, k = 0 .. cnt - 1
+    const int64_t first = (int64_t)b * THREADS + threadIdx.x, stride = (int64_t)G * THREADS;
+    const int cnt = first < s4 ? (int)((s4 - first + stride - 1) / stride) : 0;
+    const int items = cnt * W;                            // (element k, slice) pairs of this thread
     bool ok = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 
     // (A) slice order starts at my right-hand neighbour so the links fill evenly.  Loads first (L2 hits: the gradients
     // were just written), then the posted stores.
-    for (int64_t j0 = threadIdx.x; ok && j0 < items; j0 += (int64_t)THREADS * UNROLL) {
+    for (int j0 = 0; ok && j0 < items; j0 += UNROLL) {
         f32x4 v[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int64_t j = j0 + (int64_t)u * THREADS;
+            const int j = j0 + u;
             if (j < items) {
-                const int q = (r + 1 + (int)(j / len)) % W;
-                v[u] = load_guarded(buf, (int64_t)q * slice + 4 * (lo + j % len), n);
+                const int q = (r + 1 + j % W) % W;
+                v[u] = load_guarded(buf, (int64_t)q * slice + 4 * (first + (j / W) * stride), n);
             }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int64_t j = j0 + (int64_t)u * THREADS;
+            const int j = j0 + u;
             if (j < items) {
-                const int q = (r + 1 + (int)(j / len)) % W;
-                ll_send(p.base[q] + ll_recv_off(p, r, lo + j % len), v[u], tag);
+                const int q = (r + 1 + j % W) % W;
+                ll_send(p.base[q] + ll_recv_off(p, r, first + (j / W) * stride), v[u], tag);
             }
         }
     }
 
-    // (B) reduce my slice in rank order (all W slots requested together, then a fixed-order sum), broadcast the result
-    for (int64_t i = lo + threadIdx.x; ok && i < hi; i += THREADS) {
+    // (B) reduce my slice in rank order (the slots of four sources requested together — eight at once spilled registers —
+    // then a fixed-order sum), broadcast the result
+    for (int k = 0; ok && k < cnt; ++k) {
+        const int64_t i = first + k * stride;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < MAXW / 8; ++c) {
-            if (8 * c >= W) break;
-            const char* src[8];
-            bool live[8];
-            f32x4 part[8];
+        for (int c = 0; c < MAXW / 4; ++c) {
+            if (4 * c >= W) break;
+            const char* src[4];
+            bool live[4];
+            f32x4 part[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                live[k] = 8 * c + k < W;
-                src[k] = p.base[r] + ll_recv_off(p, live[k] ? 8 * c + k : 0, i);
+            for (int x = 0; x < 4; ++x) {
+                live[x] = 4 * c + x < W;
+                src[x] = p.base[r] + ll_recv_off(p, live[x] ? 4 * c + x : 0, i);
             }
-            ok = ll_poll<8>(src, live, part, tag, p, dead, timeout_ticks);
+            ok = ll_poll<4>(src, live, part, tag, p, dead, timeout_ticks);
             if (!ok) break;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (live[k]) acc = (c == 0 && k == 0) ? part[k] : acc + part[k];
+            for (int x = 0; x < 4; ++x)
+                if (live[x]) acc = (c == 0 && x == 0) ? part[x] : acc + part[x];
         }
         if (!ok) break;
-        for (int k = 0; k < W; ++k) {
-            const int q = (r + 1 + k) % W;
+        for (int x = 0; x < W; ++x) {
+            const int q = (r + 1 + x) % W;
             ll_send(p.base[q] + ll_out_off(p, r, i), acc, tag);
         }
     }
@@ -231,24 +235,25 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
         const float mh = mi * ic1, vh = vi * ic2;
         pi = pi + (-t.lr * mh / (sqrtf(vh) + t.eps));
     };
-    for (int64_t j0 = threadIdx.x; ok && j0 < items; j0 += (int64_t)THREADS * UNROLL) {
+    for (int j0 = 0; ok && j0 < items; j0 += UNROLL) {
         f32x4 g[UNROLL] = {};
         const char* gsrc[UNROLL];
         bool glive[UNROLL];
+        int64_t at[UNROLL];                               // element offset in buf (n = nothing to do)
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const int64_t j = j0 + (int64_t)u * THREADS;
+            const int j = j0 + u;
             glive[u] = j < items;
-            gsrc[u] = p.base[r] + ll_out_off(p, glive[u] ? (int)(j / len) : 0, lo + (glive[u] ? j % len : 0));
+            const int q = glive[u] ? j % W : 0;
+            const int64_t i = first + (glive[u] ? j / W : 0) * stride;
+            gsrc[u] = p.base[r] + ll_out_off(p, q, i);
+            at[u] = glive[u] ? (int64_t)q * slice + 4 * i : n;
         }
         if constexpr (ADAM) {
             // the parameter / moment loads do not depend on the peers: issue them under the same wait
             f32x4 pm[UNROLL] = {}, mm[UNROLL] = {}, vm[UNROLL] = {};
-            int64_t at[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int64_t j = j0 + (int64_t)u * THREADS;
-                at[u] = j < items ? (j / len) * slice + 4 * (lo + j % len) : n;
                 if (at[u] + 4 <= t.n_params) {
                     pm[u] = *reinterpret_cast<const f32x4*>(t.p + at[u]);
                     mm[u] = *reinterpret_cast<const f32x4*>(t.m + at[u]);
@@ -290,15 +295,21 @@ __global__ __launch_bounds__(THREADS) void p2p_allreduce_kernel(Peers p, float* 
             ok = ll_poll<UNROLL>(gsrc, glive, g, tag, p, dead, timeout_ticks);
             if (!ok) break;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int64_t j = j0 + (int64_t)u * THREADS;
-                if (j < items) store_guarded(buf, (j / len) * slice + 4 * (lo + j % len), n, g[u]);
-            }
+            for (int u = 0; u < UNROLL; ++u)
+                if (at[u] < n) store_guarded(buf, at[u], n, g[u]);
         }
     }
-    if (threadIdx.x == 0) {
-        epoch[b] = e + 1;
-    }
+    __syncthreads();                                      // every thread has read epoch[b]
+    if (threadIdx.x == 0) epoch[b] = tag;
+}
+
+__global__ __launch_bounds__(MAXB) void p2p_level_tags_kernel(uint32_t* __restrict__ epoch) {
+    __shared__ uint32_t top;
+    if (threadIdx.x == 0) top = 0;
+    __syncthreads();
+    atomicMax(&top, epoch[threadIdx.x]);
+    __syncthreads();
+    epoch[threadIdx.x] = top;
 }
 
 // recv[q][0:words] <- rank q's send[0:words]  (words <= 64), one workgroup
@@ -365,10 +376,10 @@ static int launch_allreduce(float* buf, int64_t n, const AdamTail* tail) {
     const int W = S.p.world;
     int64_t slice = (n + W - 1) / W;
     slice = (slice + 3) / 4 * 4;
-    // one workgroup per 512 float4 of the whole message (measured, 0.94 MB: 16 -> 19.8, 32 -> 12.1, 64 -> 8.4 us)
-    int64_t blocks = S.blocks_override > 0 ? S.blocks_override : (n / 4 + 511) / 512;
-    if (blocks < 1) blocks = 1;
-    if (blocks > MAXB) blocks = MAXB;
+    // ALWAYS the same grid (the slot -> workgroup map and the per-workgroup tags depend on it): S.grid, fixed when the group
+    // is created (TNN_P2P_BLOCKS, default 128: one workgroup per 512 float4 of the 0.94 MB arena) and changed only through
+    // tnn_p2p_tune, which re-levels the tags.  Workgroups without an element of a small message just advance their tag.
+    const int64_t blocks = S.grid;
     if (tail)
         hipLaunchKernelGGL(p2p_allreduce_kernel<true>, dim3((unsigned)blocks), dim3(THREADS), 0, tnn::stream(), S.p, buf,
                            n, slice, S.epoch, S.dead, S.timeout_ticks, *tail);
@@ -459,7 +470,7 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     const double ms = to ? atof(to) : 20000.0;
     S.timeout_ticks = (int64_t)(ms * 1e5);                      // wall_clock64(): 100 MHz
     const char* nb = getenv("TNN_P2P_BLOCKS");
-    S.blocks_override = nb ? atoi(nb) : 0;
+    S.grid = nb && atoi(nb) >= 1 && atoi(nb) <= MAXB ? atoi(nb) : MAXB;
     S.open = true;
     return 0;
 }
@@ -493,7 +504,14 @@ int tnn_p2p_enable(int on) {
 int tnn_p2p_tune(int allreduce_blocks) {
     TNN_REQUIRE(S.open, "tnn_p2p_tune: no peer group");
     TNN_REQUIRE(allreduce_blocks >= 0 && allreduce_blocks <= MAXB, "tnn_p2p_tune: blocks must be in [0, %d]", MAXB);
-    S.blocks_override = allreduce_blocks;          // every rank must use the same value (block b meets block b)
+    // every rank must use the same value (workgroup b of one rank feeds workgroup b of the others).  A different grid maps
+    // slots to different workgroups: level every workgroup's tag at the maximum first, so no stale slot can match
+    const int grid = allreduce_blocks == 0 ? MAXB : allreduce_blocks;
+    if (grid != S.grid) {
+        hipLaunchKernelGGL(p2p_level_tags_kernel, 1, MAXB, 0, tnn::stream(), S.epoch);
+        TNN_LAUNCH_OK();
+        S.grid = grid;
+    }
     return 0;
 }
 
