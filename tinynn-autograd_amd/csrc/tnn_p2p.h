@@ -116,8 +116,10 @@ __device__ __forceinline__ void load_sys(uint32_t& v, const uint32_t* ptr) {
 }
 // Stores into a peer's region carry the same bits (write-through to the fabric at system scope), so they do not
 // depend on how the importing process happened to map the peer's pages; exchange_flags() waits for their acks.
+// (s_nop: wait states of the ">64-bit VMEM store followed by a VALU write of its data registers" hazard, which the
+// compiler cannot insert around inline asm — see ll_store16 in tnn_p2p.hip)
 __device__ __forceinline__ void store_sys(float* ptr, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_sys(uint32_t* ptr, uint32_t v) {
     asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");

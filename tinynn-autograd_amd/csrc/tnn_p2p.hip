@@ -95,8 +95,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ll_load16(u32x4& v, const char* ptr) {
     asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
 }
+// s_nop: a VMEM store of more than 64 bits reads its data VGPRs for a few cycles after issue; the compiler keeps VALU
+// writes away from its OWN stores (a gfx9 hazard it knows) but cannot see through inline asm — without the wait states
+// the v_movs that assemble the NEXT slot overwrote word 0 of this one in some lanes (measured: lanes 12-15 of each row)
 __device__ __forceinline__ void ll_store16(char* ptr, u32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(ptr), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
 }
 // slot of (source rank src, float4 element i) inside a region: recv half (stage A -> B) or out half (stage B -> C)
 __device__ __forceinline__ size_t ll_recv_off(const Peers& p, int src, int64_t i) {
