@@ -115,6 +115,13 @@ TNN_API int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, i
 TNN_API int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg,
                              void* g_out, void* p, void* m, void* v, double lr, double b1, double b2, double eps,
                              const void* pows_f64, int dtype);
+/* The same with the layer's BIAS in the launch (core/ops.py:52-54 + core/optimizer.py:67-79): db [N] = column sums of G
+ * (may be NULL = tnn_gemm_tn_adam), produced by the workgroups of tile row 0 from the operand fragments they stream anyway,
+ * and — when pb / mb / vb [N] are given — Adam applied to the bias right there: no column-reduction launches and no
+ * optimizer launch for the bias.  Shapes the tiled kernel does not take run the launches this replaces. */
+TNN_API int tnn_gemm_tn_adam_bias(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg,
+                                  void* g_out, void* p, void* m, void* v, void* db, void* pb, void* mb, void* vb, double lr,
+                                  double b1, double b2, double eps, const void* pows_f64, int dtype);
 
 /* Backward of one Dense layer y = x w + b given dz = dL/dy (all dense row-major):
  *   dw[n_in,n_out] = x^T dz (core/ops.py:159-160),  db[n_out] = column-sum dz (:52-54),
@@ -299,6 +306,11 @@ TNN_API int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, c
  * (the ops chain sub_ -> pow_(2) -> sum_ -> div_ of core/ops.py:61,121,252,93 in one pass). */
 TNN_API int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t m_global,
                             void* loss_out, void* dpred, int dtype);
+/* The same as the loss launch of a whole training step: loss_out2 (may be NULL) receives the loss too (the step's slot of a
+ * loss history, examples/mnist/run.py:84 — no copy launch), and adam_pows_f64 != NULL: {b1^t, b2^t} *= {b1, b2} by one
+ * thread of the launch (what tnn_adam_tick does as a launch of its own). */
+TNN_API int tnn_mse_fwd_bwd_tick(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out,
+                                 void* loss_out2, void* dpred, int dtype, void* adam_pows_f64, double b1, double b2);
 
 /* SGD: p += -lr * g — core/optimizer.py:46-47 + core/model.py:59-61 */
 TNN_API int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype);

@@ -296,6 +296,19 @@ int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     if (int rc = tnn_gemm_tn_colsum(M, N, K, A, lda, G, ldg, gw, N, nullptr, dtype)) return rc;
     return tnn_adam_ex(p, gw, m, v, M * N, lr, b1, b2, eps, const_cast<void*>(pows), nullptr, dtype, 0, nullptr, nullptr);
 }
+int tnn_gemm_tn_adam_bias(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg, void* g_out,
+                          void* p, void* m, void* v, void* db, void* pb, void* mb, void* vb, double lr, double b1, double b2,
+                          double eps, const void* pows, int dtype) {
+    NEED_INIT();
+    REQ((pb == nullptr) == (mb == nullptr) && (pb == nullptr) == (vb == nullptr) && (pb == nullptr || db != nullptr),
+        "tnn_gemm_tn_adam_bias: pb / mb / vb go together and need db");
+    RECORD(tnn_gemm_tn_adam_bias(M, N, K, A, lda, G, ldg, g_out, p, m, v, db, pb, mb, vb, lr, b1, b2, eps, pows, dtype));
+    if (int rc = tnn_gemm_tn_adam(M, N, K, A, lda, G, ldg, g_out, p, m, v, lr, b1, b2, eps, pows, dtype)) return rc;
+    if (!db) return 0;
+    if (int rc = tnn_reduce(TNN_RSUM, G, db, 1, K, N, dtype)) return rc;
+    if (!pb) return 0;
+    return tnn_adam_ex(pb, db, mb, vb, N, lr, b1, b2, eps, const_cast<void*>(pows), nullptr, dtype, 0, nullptr, nullptr);
+}
 int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, const void* w,
                   void* dw, void* db, void* dx, const void* mask_src, int dtype) {
     NEED_INIT();
@@ -729,6 +742,16 @@ int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t mg, void
         }
         if (loss_out) ((T*)loss_out)[0] = (T)(loss / (double)mg);
     });
+    return 0;
+}
+int tnn_mse_fwd_bwd_tick(const void* pred, const void* y, int64_t n, int64_t mg, void* loss_out, void* loss_out2, void* dpred,
+                         int dtype, void* pows, double b1, double b2) {
+    NEED_INIT();
+    REQ(loss_out != nullptr || loss_out2 == nullptr, "tnn_mse_fwd_bwd_tick: loss_out2 needs loss_out");
+    RECORD(tnn_mse_fwd_bwd_tick(pred, y, n, mg, loss_out, loss_out2, dpred, dtype, pows, b1, b2));
+    if (pows) { ((double*)pows)[0] *= b1; ((double*)pows)[1] *= b2; }
+    if (int rc = tnn_mse_fwd_bwd(pred, y, n, mg, loss_out, dpred, dtype)) return rc;
+    if (loss_out2) memcpy(loss_out2, loss_out, dtype == TNN_F64 ? 8 : 4);
     return 0;
 }
 int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {

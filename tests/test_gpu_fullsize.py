@@ -94,6 +94,55 @@ def test_dw_gemm_with_adam_epilogue_equals_gemm_then_adam():
 
 
 @pytest.mark.gpu
+def test_dw_gemm_with_adam_and_bias_in_one_launch():
+    """tnn_gemm_tn_adam_bias (dW + Adam on W + db + Adam on b from ONE launch: the workgroups of tile row 0 sum the columns of
+    dz from the fragments they stream) against the launches it replaces — tnn_gemm_tn_adam + tnn_reduce + tnn_adam_ex: weights,
+    bias, both moments of each and db bit-identical over two steps (the column sums accumulate in float64 on both sides);
+    tiled shapes (interior + ragged tiles) and the fallback shapes.  tnn_mse_fwd_bwd_tick: loss to both destinations,
+    gradient, and the beta powers advanced once."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(16)
+    for (M, N, K) in ((4096, 4096, 512), (2000, 1100, 96), (784, 256, 128)):
+        a = tn.asarray(rs.uniform(-1, 1, (K, M)).astype(np.float32))
+        gmat = tn.asarray((rs.uniform(-1, 1, (K, N)) * 1e-2).astype(np.float32))
+        p0, pb0 = rs.randn(M, N).astype(np.float32), rs.randn(N).astype(np.float32)
+        res = []
+        for fused in (False, True):
+            P, M_, V_ = tn.asarray(p0), tn.zeros((M, N)), tn.zeros((M, N))
+            PB, MB, VB, DB = tn.asarray(pb0), tn.zeros((N,)), tn.zeros((N,)), tn.zeros((N,))
+            pows = tn.asarray(np.array([1.0, 1.0, 0, 0]), dtype=np.float64)
+            for _ in range(2):
+                lib.adam_tick(pows._ptr, 0.9, 0.999)
+                if fused:
+                    lib.gemm_tn_adam_bias(M, N, K, a._ptr, M, gmat._ptr, N, None, P._ptr, M_._ptr, V_._ptr, DB._ptr, PB._ptr,
+                                          MB._ptr, VB._ptr, 1e-3, 0.9, 0.999, 1e-8, pows._ptr, _lib.F32)
+                else:
+                    lib.gemm_tn_adam(M, N, K, a._ptr, M, gmat._ptr, N, None, P._ptr, M_._ptr, V_._ptr, 1e-3, 0.9, 0.999, 1e-8,
+                                     pows._ptr, _lib.F32)
+                    lib.reduce(_lib.RSUM, gmat._ptr, DB._ptr, 1, K, N, _lib.F32)
+                    lib.adam_ex(PB._ptr, DB._ptr, MB._ptr, VB._ptr, N, 1e-3, 0.9, 0.999, 1e-8, pows._ptr, None, _lib.F32, 0,
+                                None, None)
+            res.append([np.asarray(t) for t in (P, M_, V_, PB, MB, VB, DB)])
+        for name, x0, x1 in zip(("p", "m", "v", "pb", "mb", "vb", "db"), res[0], res[1]):
+            assert np.array_equal(x0, x1), (name, M, N, K, np.abs(x0 - x1).max())
+        ref_db = np.asarray(gmat, dtype=np.float64).sum(0)
+        assert np.abs(res[1][6] - ref_db).max() <= 1e-6 * np.abs(ref_db).max()
+        assert np.abs(res[1][3] - pb0).max() > 5e-4
+    n, mg = 512 * 4096, 512
+    pr, yy = rs.randn(n).astype(np.float32), rs.randn(n).astype(np.float32)
+    PR, YY, DP = tn.asarray(pr), tn.asarray(yy), tn.empty((n,))
+    l1, l2 = tn.empty(()), tn.empty(())
+    pows = tn.asarray(np.array([0.5, 0.25, 0, 0]), dtype=np.float64)
+    lib.mse_fwd_bwd_tick(PR._ptr, YY._ptr, n, mg, l1._ptr, l2._ptr, DP._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
+    e = pr.astype(np.float64) - yy
+    np.testing.assert_allclose(float(l1), (e ** 2).sum() / mg, rtol=1e-6)
+    assert float(l1) == float(l2)
+    np.testing.assert_allclose(np.asarray(DP), (2.0 * e / mg).astype(np.float32), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(np.asarray(pows)[:2], [0.45, 0.24975], rtol=1e-15)
+
+
+@pytest.mark.gpu
 def test_gemm_4096_against_float64_and_linearity():
     rs = np.random.RandomState(5)
     M, N, K = 512, 4096, 4096

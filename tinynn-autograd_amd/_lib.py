@@ -57,6 +57,7 @@ _SIGNATURES = {
                       c_int64, _p, c_int64, c_int],
     "tnn_gemm_tn_colsum": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, _p, c_int],
     "tnn_gemm_tn_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p, c_int],
+    "tnn_gemm_tn_adam_bias": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p, c_int],
     "tnn_dense_bwd": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_ewise_binary": [c_int, _p, _i64p, _p, _i64p, _p, c_int, _i64p, c_int],
     "tnn_ewise_scalar": [c_int, _p, c_double, c_int, _p, c_int64, c_int],
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "tnn_dense_fwd_head_partials_stats": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
                                           _p, c_int64, _p, _p, _p, _p, _p, c_int, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
+    "tnn_mse_fwd_bwd_tick": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_dense_bwd_first_adam": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64,
                                  c_double, c_double, c_double, c_double, _p, c_int],

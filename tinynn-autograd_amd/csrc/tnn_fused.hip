@@ -351,11 +351,14 @@ __global__ __launch_bounds__(1024) void nll_rows_kernel(const T* __restrict__ z,
 
 template <typename TO>
 __global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ partial, int n,
-                                                          TO* __restrict__ out) {
+                                                          TO* __restrict__ out, TO* __restrict__ out2 = nullptr) {
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
     s = tnn::wave_sum(s);
-    if (threadIdx.x == 0) out[0] = (TO)s;
+    if (threadIdx.x == 0) {
+        out[0] = (TO)s;
+        if (out2) out2[0] = (TO)s;               // e.g. the step's slot of a loss history: no copy launch
+    }
 }
 
 // sum((pred-y)^2)/m and its gradient; block partials in f64, combined by sum_partials_kernel
@@ -364,8 +367,16 @@ __global__ __launch_bounds__(kThreads) void mse_fwd_bwd_kernel(const T* __restri
                                                                const T* __restrict__ y, int64_t n,
                                                                double inv_m,
                                                                double* __restrict__ partial,
-                                                               T* __restrict__ dpred) {
+                                                               T* __restrict__ dpred, double* __restrict__ tick = nullptr,
+                                                               double b1 = 1.0, double b2 = 1.0, const int* guard = nullptr) {
     __shared__ double lds[kThreads / 64];
+    // Adam's {b1^t, b2^t} advanced by ONE thread of the step's loss kernel (nothing in this launch reads them; the optimizer
+    // launches behind it do): saves the one-thread launch of tnn_adam_tick
+    if (tick != nullptr && blockIdx.x == 0 && threadIdx.x == 0 &&
+        (guard == nullptr || __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)) {
+        tick[0] *= b1;
+        tick[1] *= b2;
+    }
     double local = 0.0;
     const T two_inv_m = (T)(2.0 * inv_m);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -700,7 +711,13 @@ int tnn_softmax_nll_fused_tick(const void* z, const void* y, int64_t m, int64_t 
 
 int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out,
                     void* dpred, int dtype) {
+    return tnn_mse_fwd_bwd_tick(pred, y, n, m_global, loss_out, nullptr, dpred, dtype, nullptr, 1.0, 1.0);
+}
+
+int tnn_mse_fwd_bwd_tick(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out, void* loss_out2,
+                         void* dpred, int dtype, void* adam_pows_f64, double b1, double b2) {
     TNN_NEED_INIT();
+    TNN_REQUIRE(loss_out != nullptr || loss_out2 == nullptr, "tnn_mse_fwd_bwd_tick: loss_out2 needs loss_out");
     TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_mse_fwd_bwd: dtype %d", dtype);
     TNN_REQUIRE(n > 0 && m_global > 0, "tnn_mse_fwd_bwd: empty batch");
     int64_t nb = tnn::stream_grid(n, kThreads);
@@ -711,14 +728,18 @@ int tnn_mse_fwd_bwd(const void* pred, const void* y, int64_t n, int64_t m_global
     double inv_m = 1.0 / (double)m_global;
     if (dtype == TNN_F32) {
         hipLaunchKernelGGL((mse_fwd_bwd_kernel<float>), (unsigned)nb, kThreads, 0, s, (const float*)pred,
-                           (const float*)y, n, inv_m, (double*)ws, (float*)dpred);
+                           (const float*)y, n, inv_m, (double*)ws, (float*)dpred, (double*)adam_pows_f64, b1, b2,
+                           tnn::update_guard());
         if (loss_out)
-            hipLaunchKernelGGL((sum_partials_kernel<float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)loss_out);
+            hipLaunchKernelGGL((sum_partials_kernel<float>), 1, 64, 0, s, (const double*)ws, (int)nb, (float*)loss_out,
+                               (float*)loss_out2);
     } else {
         hipLaunchKernelGGL((mse_fwd_bwd_kernel<double>), (unsigned)nb, kThreads, 0, s, (const double*)pred,
-                           (const double*)y, n, inv_m, (double*)ws, (double*)dpred);
+                           (const double*)y, n, inv_m, (double*)ws, (double*)dpred, (double*)adam_pows_f64, b1, b2,
+                           tnn::update_guard());
         if (loss_out)
-            hipLaunchKernelGGL((sum_partials_kernel<double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)loss_out);
+            hipLaunchKernelGGL((sum_partials_kernel<double>), 1, 64, 0, s, (const double*)ws, (int)nb, (double*)loss_out,
+                               (double*)loss_out2);
     }
     tnn_free(ws);
     TNN_LAUNCH_OK();

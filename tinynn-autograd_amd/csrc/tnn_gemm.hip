@@ -62,6 +62,10 @@ struct GemmArgs {
     const double* ad_pows;
     const int* ad_guard;
     int staged_c;          // tiled kernel: interior tiles store through an LDS image of the tile (row-major 16-B stores)
+    // tiled TN kernel, CS instantiation (tnn_gemm_tn_adam_bias): the workgroups of tile row 0 also produce the column sums of
+    // B (= the bias gradient, core/ops.py:52-54) from the fragments they stream anyway -> cs_db [N], and apply Adam to the
+    // bias block cs_p / cs_m / cs_v [N] when those are given
+    float *cs_db, *cs_p, *cs_m, *cs_v;
 #ifdef TNN_GEMM_TRACE
     unsigned long long* trace;   // debug build only: [grid][8] timeline words (nullptr = off)
 #endif
@@ -102,7 +106,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 // offsets are computed once before the loop, out-of-range rows read a clamped (valid) address and are
 // zeroed with a select, and only the last, partial K-tile goes through the guarded element-wise loader.
 // VEC = false is the fully guarded element-wise variant for odd shapes / unaligned views.
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC, bool CS = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -313,7 +317,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
             }
         }
     };
+    // CS: per-lane partial column sums of B (lane (l31, lhi) sees k = 8 kk + 4 lhi + j of every K-tile); only the waves that
+    // write them at the end accumulate (tile row 0, wave row 0: wave-uniform).  f64 like every reduction of the library
+    // (tnn_reduce): the float32 result is then the correctly rounded sum whatever the order
+    double cs[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cs[i] = 0.0;
+    const bool do_cs = CS && g.cs_db != nullptr && m0 == 0 && wm == 0 && blockIdx.z == 0;
     auto mfma_chunk = [&](int kk) {
+        if constexpr (CS) {
+            if (do_cs) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    cs[ni] += ((double)bf[kk][ni][0] + (double)bf[kk][ni][1]) + ((double)bf[kk][ni][2] + (double)bf[kk][ni][3]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -463,6 +481,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         if (g.ad_guard != nullptr && *g.ad_guard != 0) return;
         const float ic1 = (float)(1.0 / (1.0 - g.ad_pows[0])), ic2 = (float)(1.0 / (1.0 - g.ad_pows[1]));
         const float omb1 = 1.f - g.ad_b1, omb2 = 1.f - g.ad_b2, lr = g.ad_lr, eps = g.ad_eps;
+        if constexpr (CS) {
+            if (do_cs) {                       // db = column sums of B; Adam on the bias block (core/optimizer.py:67-79)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float sum = (float)(cs[ni] + __shfl_xor(cs[ni], 32, 64));
+                    const int64_t col = n0 + wn * TN + ni * 32 + l31;
+                    if (lhi == 0 && col < g.N) {
+                        g.cs_db[col] = sum;
+                        if (g.cs_p != nullptr) {
+                            float mi = g.cs_m[col], vi = g.cs_v[col];
+                            mi = mi + omb1 * (sum - mi);
+                            vi = vi + omb2 * (sum * sum - vi);
+                            g.cs_m[col] = mi;
+                            g.cs_v[col] = vi;
+                            g.cs_p[col] = g.cs_p[col] + (-lr * (mi * ic1) / (sqrtf(vi * ic2) + eps));
+                        }
+                    }
+                }
+            }
+        }
         constexpr int TS = BN + 4;                                    // LDS row stride of the staged tile (floats)
         if constexpr (BM * TS <= 2 * (A_ELEMS + B_ELEMS) && (BN / 4) <= NT && NT % (BN / 4) == 0) {
             // Interior tiles leave through LDS.  In the accumulator layout a lane owns a ROW and 4 consecutive columns: a 16-B
@@ -1405,6 +1443,13 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
         else                                                                                               \
             hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AKC, BKC, false>), grid, NT, 0, s, g); \
     } while (0)
+    if constexpr (BM == 128 && BN == 64) {
+        if (g.cs_db != nullptr) {                    // tnn_gemm_tn_adam_bias made sure of: TN, vector loads, no split-K
+            hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, false, false, true, true>), grid, NT, 0, s, g);
+            TNN_LAUNCH_OK();
+            return 0;
+        }
+    }
     if (!transA && !transB) TNN_LAUNCH_GEMM(true, false);
     else if (!transA && transB) TNN_LAUNCH_GEMM(true, true);
     else if (transA && !transB) TNN_LAUNCH_GEMM(false, false);
@@ -1554,8 +1599,18 @@ int tnn_gemm_tn_colsum(int64_t M, int64_t N, int64_t K, const void* A, int64_t l
 int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg, void* g_out,
                      void* p, void* m, void* v, double lr, double b1, double b2, double eps, const void* pows_f64,
                      int dtype) {
+    return tnn_gemm_tn_adam_bias(M, N, K, A, lda, G, ldg, g_out, p, m, v, nullptr, nullptr, nullptr, nullptr, lr, b1, b2, eps,
+                                 pows_f64, dtype);
+}
+
+int tnn_gemm_tn_adam_bias(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* G, int64_t ldg, void* g_out,
+                          void* p, void* m, void* v, void* db, void* pb, void* mb, void* vb, double lr, double b1, double b2,
+                          double eps, const void* pows_f64, int dtype) {
     TNN_NEED_INIT();
     if (int rc = check_shapes("tnn_gemm_tn_adam", 1, 0, M, N, K, lda, ldg, N)) return rc;
+    TNN_REQUIRE((pb == nullptr) == (mb == nullptr) && (pb == nullptr) == (vb == nullptr) && (pb == nullptr || db != nullptr),
+                "tnn_gemm_tn_adam_bias: pb / mb / vb go together and need db");
+    TNN_REQUIRE(db == nullptr || ldg == N, "tnn_gemm_tn_adam_bias: the column sum needs a dense G (ldg == N)");
     TNN_REQUIRE(p && m && v && pows_f64, "tnn_gemm_tn_adam: p, m, v and pows are required");
     TNN_REQUIRE(dtype == TNN_F32 || dtype == TNN_F64, "tnn_gemm_tn_adam: dtype %d is not a float type", dtype);
     if (M == 0 || N == 0) return 0;
@@ -1572,7 +1627,16 @@ int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
         g.ad_lr = (float)lr; g.ad_b1 = (float)b1; g.ad_b2 = (float)b2; g.ad_eps = (float)eps;
         g.ad_pows = (const double*)pows_f64;
         g.ad_guard = tnn::update_guard();
-        return gemm_f32(g, 1, 0);                    // >= 128 tiles of 128 x 64: configuration 3, no split-K
+        // db (+ Adam on the bias) from the same launch when the CS instantiation applies: 16-B loads on both operands
+        const bool cs = db != nullptr && al(A) && al(G) && lda % 4 == 0 && M % 4 == 0 && N % 4 == 0 &&
+                        (K * lda) * 4 < (int64_t(1) << 32) && (K * ldg) * 4 < (int64_t(1) << 32);
+        if (cs) { g.cs_db = (float*)db; g.cs_p = (float*)pb; g.cs_m = (float*)mb; g.cs_v = (float*)vb; }
+        if (int rc = gemm_f32(g, 1, 0)) return rc;   // >= 128 tiles of 128 x 64: configuration 3, no split-K
+        if (db != nullptr && !cs) {
+            if (int rc = tnn_reduce(TNN_RSUM, G, db, 1, K, N, dtype)) return rc;
+            if (pb) return tnn_adam_ex(pb, db, mb, vb, N, lr, b1, b2, eps, const_cast<void*>(pows_f64), nullptr, dtype, 0, nullptr, nullptr);
+        }
+        return 0;
     }
     // any other shape / dtype: the two launches this replaces (through a scratch gradient when none is wanted)
     void* scratch = nullptr;
@@ -1582,8 +1646,9 @@ int tnn_gemm_tn_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
         if (tnn_malloc((size_t)(M * N) * esz, &scratch)) return 1;
         gw = scratch;
     }
-    int rc = tnn_gemm_tn_colsum(M, N, K, A, lda, G, ldg, gw, N, nullptr, dtype);
+    int rc = tnn_gemm_tn_colsum(M, N, K, A, lda, G, ldg, gw, N, db, dtype);
     if (!rc) rc = tnn_adam_ex(p, gw, m, v, M * N, lr, b1, b2, eps, const_cast<void*>(pows_f64), nullptr, dtype, 0, nullptr, nullptr);
+    if (!rc && pb) rc = tnn_adam_ex(pb, db, mb, vb, N, lr, b1, b2, eps, const_cast<void*>(pows_f64), nullptr, dtype, 0, nullptr, nullptr);
     if (scratch) tnn_free(scratch);
     return rc;
 }

@@ -569,28 +569,32 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // (tnn_gemm_tn_adam).  The fp32 products are MFMA-bound, so the optimizer's 24 B per parameter ride under them and
         // the separate pass over the arena disappears.  dz_{l-1} is computed BEFORE dW_l: it reads the W_l the epilogue
         // rewrites.
+        // Launches per step: L forward | loss (2; Adam's beta powers advanced by a thread of it, the loss filed to loss_out by
+        // its reduction) | per layer: dz_{l-1} (l > 0) and ONE launch for dW_l + Adam on W_l + db_l + Adam on b_l
+        // (tnn_gemm_tn_adam_bias) — 7 for the two-layer 4096-wide net of configs[2] (15 with the column reductions, bias
+        // optimizer launches, beta-power tick and loss copy as launches of their own).
         const int L = h->L;
         void* loss_slot = at(h->grads, h->n_params, h->esz);
         MLP_TRY(mlp_forward_stats(h, x, rows, nullptr));
-        if (h->loss_kind == 0)
+        if (h->loss_kind == 0) {
             MLP_TRY(tnn_softmax_nll_fwd_bwd(h->act[L - 1], y, rows, h->w[L], rows, h->stats, loss_slot, h->dact[L - 1], h->dtype));
-        else
-            MLP_TRY(tnn_mse_fwd_bwd(h->act[L - 1], y, rows * h->w[L], rows, loss_slot, h->dact[L - 1], h->dtype));
-        MLP_TRY(tnn_adam_tick(h->pows, h->b1, h->b2));
+            MLP_TRY(tnn_adam_tick(h->pows, h->b1, h->b2));
+            if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
+        } else {
+            MLP_TRY(tnn_mse_fwd_bwd_tick(h->act[L - 1], y, rows * h->w[L], rows, loss_slot, loss_out, h->dact[L - 1], h->dtype,
+                                         h->pows, h->b1, h->b2));
+        }
         for (int l = L - 1; l >= 0; --l) {
             const void* in = l == 0 ? x : h->act[l - 1];
             const int64_t wo = h->w_off[l], bo = h->b_off[l];
             if (l > 0)
                 MLP_TRY(tnn_gemm_mask(0, 1, rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at(h->params, wo, 4),
                                       h->w[l + 1], h->act[l - 1], h->w[l], h->dact[l - 1], h->w[l], h->dtype));
-            MLP_TRY(tnn_gemm_tn_adam(h->w[l], h->w[l + 1], rows, in, h->w[l], h->dact[l], h->w[l + 1], nullptr,
-                                     at(h->params, wo, 4), at(h->m, wo, 4), at(h->v, wo, 4), h->lr, h->b1, h->b2, h->eps,
-                                     h->pows, h->dtype));
-            MLP_TRY(tnn_reduce(TNN_RSUM, h->dact[l], at(h->grads, bo, 4), 1, rows, h->w[l + 1], h->dtype));
-            MLP_TRY(tnn_adam_ex(at(h->params, bo, 4), at(h->grads, bo, 4), at(h->m, bo, 4), at(h->v, bo, 4), h->w[l + 1],
-                                h->lr, h->b1, h->b2, h->eps, h->pows, nullptr, h->dtype, 0, nullptr, nullptr));
+            MLP_TRY(tnn_gemm_tn_adam_bias(h->w[l], h->w[l + 1], rows, in, h->w[l], h->dact[l], h->w[l + 1], nullptr,
+                                          at(h->params, wo, 4), at(h->m, wo, 4), at(h->v, wo, 4), at(h->grads, bo, 4),
+                                          at(h->params, bo, 4), at(h->m, bo, 4), at(h->v, bo, 4), h->lr, h->b1, h->b2, h->eps,
+                                          h->pows, h->dtype));
         }
-        if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, loss_slot, h->esz));
         return 0;
     }
     if (h->loss_kind != 0) {
