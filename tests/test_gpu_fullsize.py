@@ -124,8 +124,12 @@ def test_dw_gemm_with_adam_and_bias_in_one_launch():
                     lib.adam_ex(PB._ptr, DB._ptr, MB._ptr, VB._ptr, N, 1e-3, 0.9, 0.999, 1e-8, pows._ptr, None, _lib.F32, 0,
                                 None, None)
             res.append([np.asarray(t) for t in (P, M_, V_, PB, MB, VB, DB)])
+        tiled = M * N >= 2000 * 1100        # the fallback's latency kernel sums dz's columns in float32: equal to round-off
         for name, x0, x1 in zip(("p", "m", "v", "pb", "mb", "vb", "db"), res[0], res[1]):
-            assert np.array_equal(x0, x1), (name, M, N, K, np.abs(x0 - x1).max())
+            if tiled or name in ("p", "m", "v"):
+                assert np.array_equal(x0, x1), (name, M, N, K, np.abs(x0 - x1).max())
+            else:
+                np.testing.assert_allclose(x1, x0, rtol=2e-6, atol=2e-6 * np.abs(x0).max(), err_msg="%s %s" % (name, (M, N, K)))
         ref_db = np.asarray(gmat, dtype=np.float64).sum(0)
         assert np.abs(res[1][6] - ref_db).max() <= 1e-6 * np.abs(ref_db).max()
         assert np.abs(res[1][3] - pb0).max() > 5e-4
