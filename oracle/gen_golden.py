@@ -440,6 +440,10 @@ def epoch_fixture(ref):
     loss_list, sizes, preds, results, margins, _ = run(test_x, test_lab)
     assert loss_list == first[0], "the probe forward changed the training trajectory"
     assert min(margins) > cfg["min_margin"]
+    # pass 3: the same run evaluating the WHOLE candidate pool, near-ties included — what a float64 device run must
+    # reproduce row for row (tests: epoch_loop_float64_all_pool_rows)
+    p_losses, _, p_preds, p_results, p_margins, _ = run(pool_x, pool_lab)
+    assert p_losses == loss_list
     # --- pin the oracle's restatement of the loop
     random_seed(cfg["seed"])
     o_losses, o_preds, o_results = ref_nn.train_epochs(w, train_x, train_y, test_x, test_lab, cfg["num_ep"],
@@ -451,7 +455,10 @@ def epoch_fixture(ref):
                         argmax=np.stack(preds), hit_num=np.array([r["hit_num"] for r in results], dtype=np.int64),
                         total_num=np.array([r["total_num"] for r in results], dtype=np.int64),
                         accuracy=np.array([r["accuracy"] for r in results]), min_top2_margin=np.array(margins),
+                        pool_argmax=np.stack(p_preds), pool_hit_num=np.array([r["hit_num"] for r in p_results], dtype=np.int64),
+                        pool_min_top2_margin=np.array(p_margins),
                         config=np.array(json.dumps(cfg)))
+    print("  epoch (whole pool, %d rows): eval %s, min top-2 margin %.2e" % (len(pool_x), p_results, min(p_margins)))
     print("  epoch: %d steps (batch sizes %s), loss %.4f -> %.4f, eval %s on %d of %d pool rows, min top-2 margin %.2e"
           % (len(loss_list), sorted(set(sizes)), loss_list[0], loss_list[-1], results, len(rows), len(pool_x), min(margins)))
 

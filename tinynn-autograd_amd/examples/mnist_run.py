@@ -81,7 +81,7 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
             batches = [(b.inputs.values, b.targets.values) for b in iterator(train_x, train_y)]   # shuffle drawn here
             if step_trainer is None:
                 model.forward(Tensor(batches[0][0][:1]))   # lazy Dense init from the first batch's width
-                step_trainer = tn.trainer_from_net(net, max_rows=batch_size, lr=lr)
+                step_trainer = tn.trainer_from_net(net, max_rows=batch_size, lr=lr, dtype=tn.get_default_float())
             full = [b for b in batches if b[0].shape[0] == batch_size]
             graph = step_trainer.capture_steps(full)       # the epoch's full batches as ONE hipGraph launch
             loss_list.extend(float(v) for v in np.asarray(graph.launch()))
