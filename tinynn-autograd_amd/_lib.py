@@ -254,6 +254,10 @@ def install_test_twin(path):
     backend_name() == "hip-gfx950".
     """
     global _lib, _is_test_twin
+    import sys
+    da = sys.modules.get(__name__.rsplit(".", 1)[0] + ".device_array")
+    if da is not None:
+        da.trim_cache()               # buffers of the library being replaced
     lib = _Lib(path)
     if lib.kind != 2:
         raise TnnError("install_test_twin: %s is not the CPU test twin" % path)
@@ -276,7 +280,10 @@ def pool_stats():
     lib = get()
     a, b, c = c_int64(0), c_int64(0), c_int64(0)
     lib.pool_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-    return {"live_bytes": a.value, "cached_bytes": b.value, "device_allocs": c.value}
+    import sys
+    da = sys.modules.get(__name__.rsplit(".", 1)[0] + ".device_array")
+    return {"live_bytes": a.value, "cached_bytes": b.value, "device_allocs": c.value,
+            "host_cached_bytes": da._cache_bytes if da is not None else 0}     # part of live_bytes: device_array's free lists
 
 
 def synchronize():
@@ -307,6 +314,9 @@ class Event(object):
             pass
 
 
+capturing = False     # a hipGraph capture is open (Graph.__enter__ .. __exit__)
+
+
 class Graph(object):
     """hipGraph captured from everything enqueued on the library stream inside the `with` block."""
 
@@ -314,10 +324,14 @@ class Graph(object):
         self._h = None
 
     def __enter__(self):
+        global capturing
         get().graph_capture_begin()
+        capturing = True                 # device_array's buffer cache steps aside: the pool tags capture-time buffers
         return self
 
     def __exit__(self, exc_type, exc, tb):
+        global capturing
+        capturing = False
         h = c_void_p()
         try:
             get().graph_capture_end(ctypes.byref(h))

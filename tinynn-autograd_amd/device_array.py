@@ -69,8 +69,36 @@ def _is_scalar_like(x):
     return isinstance(x, (numbers.Number, np.generic)) or (isinstance(x, np.ndarray) and x.ndim == 0)
 
 
+# ---- host-side buffer cache in front of tnn_malloc / tnn_free.  The native pool already recycles HBM, but every
+# tnn_malloc / tnn_free is a ctypes call (~1.5 us each, 18 of them per eager MNIST-size training step, more than its
+# nine kernel launches cost the host).  Freed buffers of an eager step are kept here by size class and handed out again
+# without leaving Python; one stream orders all work, so a recycled buffer is safe to reuse at once (the native pool's own
+# argument).  Buffers allocated while a hipGraph is being captured belong to that graph in the native pool and never enter
+# this cache (own == 2), and nothing is taken from it during a capture.
+_cache = {}                       # size class (bytes) -> [ptr, ...]
+_cache_bytes = 0
+_CACHE_LIMIT = 256 << 20          # beyond this the buffers go back to the native pool
+_CACHE_MAX_BLOCK = 32 << 20       # large buffers are rare and expensive to keep twice
+
+
+def _size_class(nbytes):
+    return (nbytes + 511) & ~511 if nbytes > 0 else 512
+
+
+def trim_cache():
+    """Return every cached buffer to the native pool (tests that audit tnn_pool_stats, shutdown)."""
+    global _cache_bytes
+    lib = _lib._lib
+    for cls, ptrs in _cache.items():
+        for ptr in ptrs:
+            if lib is not None:
+                lib.free(ptr)
+    _cache.clear()
+    _cache_bytes = 0
+
+
 class DeviceArray(object):
-    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "__weakref__")
+    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "_own", "__weakref__")
     __array_priority__ = 1000.0
 
     # ------------------------------------------------------------------ construction
@@ -81,22 +109,34 @@ class DeviceArray(object):
     def _raw(cls, ptr, shape, dtype, base=None, hv=None, t=False):
         self = object.__new__(cls)
         self._ptr = ptr
-        self.shape = tuple(int(s) for s in shape)
-        self.dtype = np.dtype(dtype)
+        self.shape = shape if type(shape) is tuple and all(type(s) is int for s in shape) else tuple(int(s) for s in shape)
+        self.dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
         self._base = base
         self._hv = hv
         self._t = t
+        self._own = 0                # 0: the native pool's (or not owned), 1: recyclable through _cache, 2: graph-owned
         self._tag = None             # free-form marker: RELU_SIGN on a fused Dense+ReLU output; the producer's output array
                                      # on a gradient whose ReLU mask has already been applied (core/ops.py dense_)
         return self
 
     @classmethod
     def _new(cls, shape, dtype):
-        dtype = np.dtype(dtype)
+        global _cache_bytes
+        dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
         nbytes = _prod(shape) * dtype.itemsize
+        sc = _size_class(nbytes)
+        if not _lib.capturing:
+            ptrs = _cache.get(sc)
+            if ptrs:
+                self = cls._raw(ptrs.pop(), shape, dtype)
+                _cache_bytes -= sc
+                self._own = 1
+                return self
         p = ctypes.c_void_p()
-        _lib.get().malloc(max(nbytes, 1), ctypes.byref(p))
-        return cls._raw(p.value, shape, dtype)
+        _lib.get().malloc(sc, ctypes.byref(p))
+        self = cls._raw(p.value, shape, dtype)
+        self._own = 2 if _lib.capturing else 1
+        return self
 
     @classmethod
     def _scalar(cls, value):
@@ -112,8 +152,15 @@ class DeviceArray(object):
         return cls._raw(None, (), _default_float, hv=value)
 
     def __del__(self):
+        global _cache_bytes
         try:
             if self._base is None and self._ptr is not None and _lib._lib is not None:
+                if self._own == 1 and not _lib.capturing:
+                    sc = _size_class(_prod(self.shape) * self.dtype.itemsize)
+                    if sc <= _CACHE_MAX_BLOCK and _cache_bytes + sc <= _CACHE_LIMIT:
+                        _cache.setdefault(sc, []).append(self._ptr)
+                        _cache_bytes += sc
+                        return
                 _lib._lib.free(self._ptr)
         except Exception:
             pass
