@@ -56,8 +56,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
     constexpr int ROWB = g8::ROWB, TILE_B = g8::TILE_B, STAGE_B = g8::STAGE_B, KK = g8::KK;
     constexpr int DJ = 16 / NW;                  // DMA instructions per wave, operand and tile (1 KB each)
     static_assert((NS & (NS - 1)) == 0 && NS >= 2, "stage count must be a power of two");
-    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE_B];        // ONE shared object (a second one makes hipcc
-                                                                             // drain the DMA queue before every ds_read)
+    // ADAM: + 16 KB behind the ring for the transposed bf16 image of half a tile (see the epilogue)
+    __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE_B + (ADAM ? 16384 : 0)];   // ONE shared object (a second one
+                                                                             // makes hipcc drain the DMA queue before every ds_read)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -211,7 +212,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
             const bool interior = m0 + BM <= g.M && n0 + BN <= g.N && g.ldc % 4 == 0 && g.ldt % 4 == 0 &&
                                   ((reinterpret_cast<uintptr_t>(g.ap) | reinterpret_cast<uintptr_t>(g.am) |
                                     reinterpret_cast<uintptr_t>(g.av) | reinterpret_cast<uintptr_t>(gout)) & 15) == 0 &&
-                                  ((reinterpret_cast<uintptr_t>(g.aw16) | reinterpret_cast<uintptr_t>(g.awT16)) & 7) == 0;
+                                  (reinterpret_cast<uintptr_t>(g.aw16) & 7) == 0 && (reinterpret_cast<uintptr_t>(g.awT16) & 15) == 0 &&
+                                  g.ldt % 8 == 0;
             if (interior) {                       // block-uniform
                 float* tile = reinterpret_cast<float*>(lds);
                 __syncthreads();                  // every wave is done with the last stage's fragments
@@ -277,13 +279,39 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
                         if (gout) *reinterpret_cast<f32x4*>(gout + o) = gv;
                     }
                     if (half == 1 && g.awT16 != nullptr) {
+                        // The transposed bf16 copy of this pass' 64 rows leaves through an LDS image [128 columns][64 rows]
+                        // (16 KB behind the ring): written here as 8-B items (4 consecutive rows of one column), read back
+                        // after a barrier as 16-B pieces so that 8 lanes store one whole 128-B segment of a W^T row.  (The
+                        // direct form — every lane an 8-B store into a different W^T row, 16 KB apart — cost 49 of the
+                        // kernel's 370 us for 7 % of its bytes.)  XOR swizzle on the 8-B slot index: row n keeps logical
+                        // slot q at physical slot q ^ ((n >> 2) & 15) — the 16 lanes that write 16 different rows at the
+                        // same q hit 16 different bank pairs.
+                        char* timg = lds + NS * STAGE_B;
+                        const int ral = tid / (BN / 4);                       // this pass' row quad 0..15
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const int w = c >> 1, sh = 16 * (c & 1);
                             const uint32_t lo = ((hp[0][w] >> sh) & 0xffffu) | (((hp[1][w] >> sh) & 0xffffu) << 16);
                             const uint32_t hi = ((hp[2][w] >> sh) & 0xffffu) | (((hp[3][w] >> sh) & 0xffffu) << 16);
-                            *reinterpret_cast<u32x2*>(g.awT16 + (n0 + 4 * cb + c) * g.ldt + m0 + 4 * ra) = u32x2{lo, hi};
+                            const int n = 4 * cb + c;
+                            *reinterpret_cast<u32x2*>(timg + n * 128 + 8 * (ral ^ (cb & 15))) = u32x2{lo, hi};
                         }
+                        __syncthreads();
+                        {
+                            // 128 rows x 8 pieces of 16 B = 1024 pieces, 2 per thread
+#pragma unroll
+                            for (int it = 0; it < 2; ++it) {
+                                const int piece = tid + it * (NW * 64);
+                                const int n = piece >> 3, k = piece & 7;          // physical slots 2k, 2k + 1 of row n
+                                const int key = (n >> 2) & 15;
+                                typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+                                u32x4_ v = *reinterpret_cast<const u32x4_*>(timg + n * 128 + 16 * k);
+                                if (key & 1) v = u32x4_{v[2], v[3], v[0], v[1]};  // odd key: the two logical slots are swapped
+                                const int q0 = (2 * k) ^ (key & ~1);              // first logical slot of the pair
+                                *reinterpret_cast<u32x4_*>(g.awT16 + (n0 + n) * g.ldt + m0 + (stage >> 1) * 64 + 4 * q0) = v;
+                            }
+                        }
+                        if (stage + 1 < 4) __syncthreads();                   // the next pass overwrites the image
                     }
                 }
                 return;
