@@ -67,7 +67,7 @@ WIDTHS_A = [784, 256, 128, 10]
 WIDTHS_C = [4096, 4096, 4096]
 WIDTHS_E = [8192, 8192, 8192, 8192, 8192]
 GLOBAL_BATCH_D = 1024
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 # ------------------------------------------------------------------------------------------------ data / nets
@@ -299,7 +299,7 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
 def load_traffic_table():
     """HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 correction
     + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command; tools/traffic_from_pmc.py)."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(path):
             return json.load(open(path)), os.path.relpath(path, ROOT)
@@ -472,9 +472,10 @@ class FusedRun(Runner):
         else:
             self.trainer = tn.trainer_from_net(build_net(widths), max_rows=rows, loss=kind, optimizer="adam", lr=1e-3,
                                                comm=comm, use_graph=False, force_dp=force_dp)
-            if self.trainer.n_params >= (1 << 22) and comm is None:
-                # large nets (configs[2]): Adam in the dW epilogues, weight gradients not also written to the arena
-                # (tests/test_gpu_fullsize.py: bit-identical parameters and state either way)
+            if comm is None:
+                # single GPU: Adam consumes the weight gradients where they are produced (configs[2]: every dW epilogue;
+                # the MNIST net: the first layer's, the only one its fused step would otherwise write without a reader);
+                # tests/test_gpu_fullsize.py / parity_suite: bit-identical parameters and state either way
                 self.trainer.keep_grads(os.environ.get("TNN_BENCH_KEEP_GRADS", "0") == "1")
         self.chunk, self.segments = None, {}
         self.capture()

@@ -134,7 +134,8 @@ TNN_API int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void*
  * advanced here) on this layer's weights (p_w, m_w, v_w: [n_in, n_out]) and bias (p_b, m_b, v_b: [n_out]) from the
  * gradients just produced, and on one extra flat range of flat_n elements (every other layer's parameters, whose
  * gradients flat_g are already final).  MNIST-size layers: ONE launch — the optimizer costs no launch of its own;
- * other shapes / f64 run the launches this replaces. */
+ * other shapes / f64 run the launches this replaces.  dw may be NULL: the weight gradient is then consumed by Adam without
+ * being stored (tnn_mlp_keep_grads(h, 0)). */
 TNN_API int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* dw,
                                      void* db, void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b,
                                      void* flat_p, const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n,

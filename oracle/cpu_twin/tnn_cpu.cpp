@@ -766,6 +766,9 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
                              void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b, void* flat_p,
                              const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n, double lr, double b1,
                              double b2, double eps, const void* pows, int dtype) {
+    std::vector<char> scratch;                       // dw == NULL: the gradient is consumed without being stored
+    if (!dw && !g_capturing) { scratch.resize((size_t)(n_in * n_out) * (dtype == TNN_F64 ? 8 : 4)); dw = scratch.data(); }
+    REQ(dw != nullptr, "cpu twin: tnn_dense_bwd_first_adam without dw cannot be captured");
     if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
     void* pw = const_cast<void*>(pows);
     if (int rc = tnn_adam_ex(p_w, dw, m_w, v_w, n_in * n_out, lr, b1, b2, eps, pw, nullptr, dtype, 0, nullptr, nullptr)) return rc;

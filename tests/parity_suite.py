@@ -1122,6 +1122,28 @@ def trainer_step_forms_agree_with_the_op_level_model():
             np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
 
 
+def trainer_keep_grads_off_is_bit_identical():
+    """MLPTrainer.keep_grads(False) on the MNIST-size step (what bench.py times on one GPU): the first layer's weight
+    gradient is consumed by Adam in the launch that produces it and not stored — losses, parameters and both moments are
+    bit-identical to the default, every other gradient is still in the arena."""
+    cfg, gold = H.load_traj("A_adam")
+    w = cfg["widths"]
+    runs = []
+    for keep in (True, False):
+        model, _ = H.build_model(cfg)
+        trainer = trainer_from_net(model.net, max_rows=cfg["m"], lr=cfg["lr"]).keep_grads(keep)
+        losses = [float(trainer.step(tn.asarray(x), tn.asarray(y)))
+                  for x, y in H.batches(cfg["data_seed"], 6, cfg["m"], w[0], w[-1], cfg["loss"])]
+        runs.append((losses, np.asarray(trainer.params).copy(), np.asarray(trainer.adam_m).copy(), np.asarray(trainer.adam_v).copy(),
+                     [np.asarray(trainer.grad_view(l, "w")).copy() for l in (1, 2)]))
+    np.testing.assert_allclose(runs[0][0], gold["loss"][:6], rtol=RTOL)
+    assert runs[0][0] == runs[1][0]
+    for k in (1, 2, 3):
+        assert np.array_equal(runs[0][k], runs[1][k])
+    for a, b in zip(runs[0][4], runs[1][4]):
+        assert np.array_equal(a, b)
+
+
 def trainer_checkpoint_resume_is_bit_exact():
     """Train 3 steps, checkpoint (params + Adam state + beta powers), train 3 more; a fresh trainer restored from the
     checkpoint must produce exactly the same 3 losses and parameters."""

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         if constexpr (BM * TS <= 2 * (A_ELEMS + B_ELEMS) && (BN / 4) <= NT && NT % (BN / 4) == 0) {
             // interior tiles leave through LDS too: row-major 16-B stores, a wave instruction covering whole 256-B tile rows
             // instead of 32 rows x 32 B (measured, 128x64 tiles: dW 4096x4096x512 103-105 -> 108-109 TFLOP/s, the M = 512
-            // products +1-3 %; TNN_GEMM_STAGED_C=0 restores the direct stores)
+            // products +1-3 %)
             if (g.staged_c && vec_c && m0 + BM <= g.M && n0 + BN <= g.N) {
                 __syncthreads();
 #pragma unroll
@@ -785,7 +785,7 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
         const int64_t row = m0 + (ln >> 4) * 4 + r, col = n0 + (ln & 15);   // 16x16x4 C/D layout
         if (row < g.M && col < g.N) {
             const float gval = apply_epilogue(g, s, row, col);
-            g.C[row * g.ldc + col] = gval;
+            if (!ADAM || g.C != nullptr) g.C[row * g.ldc + col] = gval;      // ADAM: the gradient itself only on request
             if constexpr (ADAM) {
                 const int64_t i = row * g.ldc + col;
                 ad->pw[i] = adam_apply(*ad, ic1, ic2, gval, a_m, a_v, a_p);
@@ -1126,15 +1126,13 @@ bool use_small_path(const GemmArgs& g) {
     // measured on the MNIST net's layers (whole step, one GPU): bs 256 36 us; bs 512 70 us with the tiled kernel (205 MFLOP in 32
     // tiles of 64 x 64 + split-K + its reduce launch) against 57 us here; bs 1024 77 / 76 us — the switch-over sits at the
     // largest product of the bs-1024 step (2 x 1024 x 784 x 256 = 411 MFLOP)
-    static const double limit = getenv("TNN_GEMM_SMALL_FLOP") ? atof(getenv("TNN_GEMM_SMALL_FLOP")) : 4.2e8;
-    return flop <= limit && tiles <= 8192;
+    return flop <= 4.2e8 && tiles <= 8192;
 }
 
 int gemm_small(GemmArgs& g, int transA, int transB, float* colsum) {
     int nchunks = (int)((g.K + 15) / 16);
-    static const int lim8 = getenv("TNN_SMALL_LIM8") ? atoi(getenv("TNN_SMALL_LIM8")) : 48;     // tuning: 8 waves up to this many chunks
     if (nchunks <= 16) return launch_small<4>(g, transA, transB, colsum);
-    if (nchunks <= lim8) return launch_small<8>(g, transA, transB, colsum);
+    if (nchunks <= 48) return launch_small<8>(g, transA, transB, colsum);
     return launch_small<16>(g, transA, transB, colsum);
 }
 
@@ -1278,7 +1276,7 @@ __global__ __launch_bounds__(512) void gemm_mid_f32_kernel(GemmArgs g, float* __
         if (e_live[u]) {
             const float val = finish_epilogue(g, sres, e_pre[u]);
             const int64_t o = e_row[u] * g.ldc + e_col;
-            g.C[o] = val;
+            if (!ADAM || g.C != nullptr) g.C[o] = val;
             if constexpr (ADAM) {
                 ad.pw[o] = adam_apply(ad, ic1, ic2, val, a_m[u], a_v[u], a_p[u]);
                 ad.mw[o] = a_m[u];
@@ -1313,12 +1311,9 @@ bool mid_ok(const GemmArgs& g, int transA, int transB) {
 // (measured on the MNIST step: 1024 x 256 x 784 forward 14.8 -> 8.5 us in 256 tiles, 784 x 256 x 1024 / x 512 weight gradient
 // with Adam 17.4 -> 10.9 / 10.4 -> 7.2 us in 200 tiles; the 512-row forward in 128 tiles was no faster: 8.4 vs 8.0 us)
 bool use_mid_path(const GemmArgs& g, int transA, int transB) {
-    static const int mode = getenv("TNN_GEMM_MID") ? atoi(getenv("TNN_GEMM_MID")) : 1;
-    if (!mode) return false;
     const double flop = 2.0 * (double)g.M * (double)g.N * (double)g.K;
     const int64_t tiles = ((g.M + 31) / 32) * ((g.N + 31) / 32);
-    static const double min_flop = getenv("TNN_GEMM_MID_FLOP") ? atof(getenv("TNN_GEMM_MID_FLOP")) : 1.5e8;
-    return flop >= min_flop && tiles >= 192 && mid_ok(g, transA, transB);
+    return flop >= 1.5e8 && tiles >= 192 && mid_ok(g, transA, transB);
 }
 
 void mid_geometry(GemmArgs& g) {
@@ -1477,8 +1472,7 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     }
 
     const int cus = tnn::num_cus();
-    static const int staged_mode = getenv("TNN_GEMM_STAGED_C") ? atoi(getenv("TNN_GEMM_STAGED_C")) : 1;
-    g.staged_c = staged_mode;
+    g.staged_c = 1;
     int cfg = -1, splits = 0;
     if (const char* e = getenv("TNN_GEMM_CFG")) cfg = atoi(e);       // tuning override
     if (const char* e = getenv("TNN_GEMM_SPLITK")) splits = atoi(e);
@@ -1742,9 +1736,7 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
     } while (0)
             // measured at bs 128 (8 chunks): 4 waves with two chunks each 21.5 us/step, 8 waves with one chunk each 22.2, 16
             // waves 23.7 — the launch's 784 workgroups cost more per wave than the second load round trip saves
-            // (TNN_BWD0_WAVES overrides for measurements)
-            static const int waves_env = getenv("TNN_BWD0_WAVES") ? atoi(getenv("TNN_BWD0_WAVES")) : 0;
-            const int waves = waves_env ? waves_env : (nchunks <= 16 ? 4 : nchunks <= 48 ? 8 : 16);
+            const int waves = nchunks <= 16 ? 4 : nchunks <= 48 ? 8 : 16;
             if (waves == 4) TNN_BWD0(4);
             else if (waves == 8) TNN_BWD0(8);
             else TNN_BWD0(16);
@@ -1753,11 +1745,11 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
             return 0;
         }
     }
-    // any other shape / dtype: the launches this replaces
-    if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, dw, n_out, db, dtype)) return rc;
+    // any other shape / dtype: the launches this replaces (dw == NULL: through tnn_gemm_tn_adam_bias' scratch gradient)
     void* pows = const_cast<void*>(pows_f64);
-    if (int rc = tnn_adam_ex(p_w, dw, m_w, v_w, n_in * n_out, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr)) return rc;
-    if (int rc = tnn_adam_ex(p_b, db, m_b, v_b, n_out, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr)) return rc;
+    if (int rc = tnn_gemm_tn_adam_bias(n_in, n_out, rows, x, n_in, dz, n_out, dw, p_w, m_w, v_w, db, p_b, m_b, v_b, lr, b1, b2, eps,
+                                       pows, dtype))
+        return rc;
     if (flat_n > 0)
         return tnn_adam_ex(flat_p, flat_g, flat_m, flat_v, flat_n, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr);
     return 0;

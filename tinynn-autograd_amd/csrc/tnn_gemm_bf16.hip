@@ -580,10 +580,9 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     // micro-benchmark does — the register-staged 4-wave kernel looked equal (810 vs 806 TFLOP/s: 134 MB of bf16 weights
     // stay in the 256 MB memory-side cache); in the training step every layer streams its own W / W^T from HBM and the
     // deeper ring wins (whole config-E step: 216 k -> 237 k samples/s; bench.py's per-GEMM table rotates operands for this
-    // reason).  TNN_BF16_KERNEL overrides for measurements: reg | dma8s | dma4s | dma8 | dma4 (8 / 4 waves; s = 2 stages).
-    static const char* env_which = getenv("TNN_BF16_KERNEL");
+    // reason).  Variants: reg | dma8s | dma4s | dma8 | dma4 (8 / 4 waves; s = 2 stages).
     const unsigned tiles = (unsigned)(g.tiles_m * g.tiles_n);
-    const char* which = env_which ? env_which : (tiles >= 2u * (unsigned)tnn::num_cus() ? "dma8s" : "dma8");
+    const char* which = tiles >= 2u * (unsigned)tnn::num_cus() ? "dma8s" : "dma8";
     const bool dma = which[0] == 'd' && which[1] == 'm' && which[2] == 'a';
     const bool swap = g.c_bf16 != 0;          // bf16 outputs: 8-B stores per lane; fp32 outputs: whole 128-B row segments
 #define TNN_DMA_LAUNCH(NW_, NS_)                                                                                         \

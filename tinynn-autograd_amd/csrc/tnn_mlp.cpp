@@ -552,8 +552,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     Mlp* h = (Mlp*)handle;
     MLP_TRY(check_rows(h, rows, "tnn_mlp_step"));
     h->call_idx = 0;
-    static const bool fuse16_off = getenv("TNN_BF16_FUSE_ADAM") != nullptr && atoi(getenv("TNN_BF16_FUSE_ADAM")) == 0;
-    if (h->bf16 && h->opt_kind == 1 && h->loss_kind == 1 && !fuse16_off && !h->keep_grads) {
+    if (h->bf16 && h->opt_kind == 1 && h->loss_kind == 1 && !h->keep_grads) {
         // bf16 trainer, single GPU, weight gradients not wanted in the arena (tnn_mlp_keep_grads(h, 0)): forward | beta
         // powers | backward with Adam in the dW epilogues — no optimizer launch over the weights, no weight-gradient
         // round trip through HBM (8 of the 36 bytes per parameter and step; measured 8192 x 8192 x 512: 385-405 us against
@@ -563,8 +562,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         MLP_TRY(tnn_adam_tick(h->pows, h->b1, h->b2));
         return mlp16_backward(h, x, y, rows, rows, loss_out, false, true);
     }
-    static const bool fuse32_off = getenv("TNN_F32_FUSE_ADAM") != nullptr && atoi(getenv("TNN_F32_FUSE_ADAM")) == 0;
-    if (!h->bf16 && h->dtype == TNN_F32 && h->opt_kind == 1 && !h->keep_grads && !fuse32_off && h->n_params >= (1 << 22)) {
+    if (!h->bf16 && h->dtype == TNN_F32 && h->opt_kind == 1 && !h->keep_grads && h->n_params >= (1 << 22)) {
         // large fp32 nets, single GPU, weight gradients not wanted in the arena: Adam in the epilogue of every dW GEMM
         // (tnn_gemm_tn_adam).  The fp32 products are MFMA-bound, so the optimizer's 24 B per parameter ride under them and
         // the separate pass over the arena disappears.  dz_{l-1} is computed BEFORE dW_l: it reads the W_l the epilogue
@@ -606,7 +604,6 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     // (e.g. one slot of a per-step loss history) or, by default, to the slot behind the gradient arena
     const int L = h->L;
     void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
-    static const bool head_fusion = getenv("TNN_HEAD_FUSION") != nullptr;
     int head_multi = 0;
     if (!h->bf16 && h->opt_kind == 1 && L >= 2)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
@@ -622,8 +619,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                                  at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
                                                  h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
                                                  h->dtype));
-        static const bool merge_off = getenv("TNN_STEP_MERGE") != nullptr && atoi(getenv("TNN_STEP_MERGE")) == 0;
-        if (L >= 3 && h->w[L - 2] % 16 == 0 && !merge_off) {
+        if (L >= 3 && h->w[L - 2] % 16 == 0) {
             // 2L - 2 launches (4 for the MNIST net): the head's launch also carries the backward of the hidden layer in
             // front of it — its tiles derive their slice of that layer's dz from the partial logits themselves
             STEP_CALL(h, tnn_mlp_head_bwd_tick(rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
@@ -643,7 +639,8 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
             MLP_TRY(mlp_backward_layers(h, x, rows, L - 2, 1));
         }
         const int64_t rest = h->w_off[1];
-        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
+        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0],
+                                              h->keep_grads ? at(h->grads, h->w_off[0], h->esz) : nullptr,
                                               at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
                                               at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
                                               at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
@@ -653,7 +650,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                               h->pows, h->dtype));
         return 0;
     }
-    if (!head_fusion && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
+    if (h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
         // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward, the last launch of which also
         // carries the optimizer
         MLP_TRY(mlp_forward(h, x, rows));
@@ -663,7 +660,8 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // launch (its own W / b in the dW epilogue, every other layer's parameters by trailing blocks): 2L + 1 launches
         MLP_TRY(mlp_backward_layers(h, x, rows, -1, 1));
         const int64_t rest = L > 1 ? h->w_off[1] : h->n_params;
-        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0], at(h->grads, h->w_off[0], h->esz),
+        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0],
+                                              h->keep_grads ? at(h->grads, h->w_off[0], h->esz) : nullptr,
                                               at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
                                               at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
                                               at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
@@ -673,8 +671,8 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                               h->pows, h->dtype));
         return 0;
     }
-    // hidden layers forward; then the classifier head (last Dense forward + loss + its backward, one launch when
-    // TNN_HEAD_FUSION is set); then one launch per remaining layer backward; then the optimizer
+    // hidden layers forward; then the classifier head (last Dense forward + loss + its backward: tnn_mlp_head);
+    // then one launch per remaining layer backward; then the optimizer
     MLP_TRY(mlp_forward(h, x, rows, L - 1));
     STEP_CALL(h, tnn_mlp_head(rows, h->w[L - 1], h->w[L], L > 1 ? h->act[L - 2] : x,
                               at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz), y,

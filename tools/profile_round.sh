@@ -1,10 +1,10 @@
 #!/bin/bash
 # One profiling pass of the round on the GPU box (run through gpurun from the repository root):
-#   bash tools/profile_round.sh r02
+#   bash tools/profile_round.sh r03
 # Bench lines, rocprofv3 kernel traces of the same commands, separate --pmc passes (FETCH_SIZE / WRITE_SIZE for the HBM-side
 # traffic, SQ counters for the bf16 GEMM).  Everything lands under gpurun_out/<round>prof/; tools/rocpd_summary.py,
 # tools/rocpd_pmc.py and tools/traffic_from_pmc.py turn the databases into the text files committed under profiles/.
-R=${1:-r02}
+R=${1:-r03}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${R}prof
@@ -14,12 +14,17 @@ run() { echo "== $*" >> $OUT/log.txt; "$@" >> $OUT/log.txt 2>&1; echo "rc=$?" >>
 python3 bench.py --steps 20 --warmup 5 > $OUT/benchA.json 2>> $OUT/log.txt
 python3 bench.py --workload C > $OUT/benchC.json 2>> $OUT/log.txt
 python3 bench.py --workload E > $OUT/benchE.json 2>> $OUT/log.txt
-TNN_FORCE_COMM=1 python3 bench.py --no-extras > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
+TNN_FORCE_COMM=1 python3 bench.py --no-cpu-baseline > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
+python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
+python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
+SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
 
 run rocprofv3 --kernel-trace --stats -d $OUT/ktA -o A -- python3 bench.py --steps 20 --warmup 5
 run rocprofv3 --kernel-trace --stats -d $OUT/ktAstep -o Astep -- python3 bench.py --no-extras --steps 2000 --warmup 64
 run rocprofv3 --kernel-trace --stats -d $OUT/ktC -o C -- python3 bench.py --workload C --no-cpu-baseline
 run rocprofv3 --kernel-trace --stats -d $OUT/ktE -o E -- python3 bench.py --workload E
+# the data-parallel step at world 1 (RCCL leg first, then the peer-to-peer leg) and the single-GPU step: duration + gap per launch
+TNN_FORCE_COMM=1 rocprofv3 --kernel-trace -d $OUT/ktDP -o dp -- python3 bench.py --no-extras --no-cpu-baseline --steps 2000 --warmup 64 >> $OUT/log.txt 2>&1
 
 run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcA_fetch -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcA_write -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
@@ -34,6 +39,12 @@ for d in ktA ktAstep ktC ktE; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_summary.py $db > $OUT/${d}_kernel_stats.txt 2>> $OUT/log.txt
 done
+db=$(find $OUT/ktDP -name "*.db" | head -1)
+if [ -n "$db" ]; then for f in 0.15 0.3 0.5 0.7 0.85; do python3 tools/step_timeline.py $db --frac $f >> $OUT/dp_world1_timeline.txt; done; fi
+db=$(find $OUT/ktAstep -name "*.db" | head -1)
+[ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.5 > $OUT/stepA_timeline.txt 2>> $OUT/log.txt
+db=$(find $OUT/ktC -name "*.db" | head -1)
+[ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.3 > $OUT/stepC_timeline.txt 2>> $OUT/log.txt
 for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcE_fetch pmcE_write pmcbf_sq pmcg32_sq; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_pmc.py $db > $OUT/${d}.txt 2>> $OUT/log.txt
