@@ -55,8 +55,9 @@ class Dense(Layer):
             self.params[name] = tensor
         self.is_init = True
 
-    def forward(self, inputs, relu=False):
-        """relu=True is passed by Net.forward when the next layer is a ReLU: one launch for both (ops.dense_)."""
+    def forward(self, inputs, relu=False, head_w=None, lazy=False):
+        """relu=True is passed by Net.forward when the next layer is a ReLU: one launch for both (ops.dense_); head_w / lazy:
+        the classifier-head arrangements of Net.forward (ops.dense_)."""
         if not self.is_init:
             self._init_parameters(inputs.shape[1])
         self.inputs = inputs                     # kept like the reference does (core/layers.py:48)
@@ -64,7 +65,7 @@ class Dense(Layer):
         if not self.fused:
             out = inputs @ w + b
             return ops.clip(out, 0.0) if relu else out
-        return ops.dense_(inputs, w, b, relu=relu)
+        return ops.dense_(inputs, w, b, relu=relu, head_w=head_w, lazy=lazy)
 
 
 class Activation(Layer):

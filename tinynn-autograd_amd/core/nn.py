@@ -19,15 +19,22 @@ class Net(object):
         its `inputs` attribute (cached but never read by the reference, core/layers.py:67) holds the fused output."""
         from .layers import Dense, ReLU
         layers, i, activations = self.layers, 0, inputs
-        while i < len(layers):
+        n = len(layers)
+        # TRAIN mode, ... Dense -> ReLU -> Dense(classifier): the hidden layer's launch also emits the classifier's logits as
+        # partial sums and the classifier's own GEMM is deferred — the loss node runs forward + loss + backward of the head
+        # in one launch (ops.softmax_nll_); in TEST mode, or if anything else asks for the logits first, nothing changes
+        head = (self._phase == "TRAIN" and n >= 3 and type(layers[-1]) is Dense and layers[-1].fused
+                and type(layers[-2]) is ReLU and type(layers[-3]) is Dense and layers[-3].fused and layers[-1].is_init)
+        while i < n:
             layer = layers[i]
-            nxt = layers[i + 1] if i + 1 < len(layers) else None
+            nxt = layers[i + 1] if i + 1 < n else None
             if type(layer) is Dense and layer.fused and type(nxt) is ReLU:
-                activations = layer.forward(activations, relu=True)
+                activations = layer.forward(activations, relu=True,
+                                            head_w=layers[-1].params["w"] if (head and i == n - 3) else None)
                 nxt.inputs = activations
                 i += 2
             else:
-                activations = layer.forward(activations)
+                activations = layer.forward(activations, lazy=True) if (head and i == n - 1) else layer.forward(activations)
                 i += 1
         return activations
 

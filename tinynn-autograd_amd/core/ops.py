@@ -246,7 +246,7 @@ def clip_(ts, min, max):
 
 
 # ---------------------------------------------------------------------- fused nodes (this package's own)
-def dense_(x, w, b, relu=False):
+def dense_(x, w, b, relu=False, head_w=None, lazy=False):
     """x @ w + b as ONE GEMM with a bias epilogue (core/layers.py:49); the vjps are the NT / TN GEMMs of
     dot_ (core/ops.py:156-160) and the column-sum of add_'s un-broadcast (:49-55).
 
@@ -259,7 +259,12 @@ def dense_(x, w, b, relu=False):
     and, if x is itself a sign-encoded ReLU output, dX = (g W^T) * [z_prev >= 0] from the same launch.  That dX is
     tagged as already masked for x's producer, whose own vjp then skips its mask pass; a gradient that reaches a ReLU
     node untagged (several consumers were summed, or a foreign consumer) is masked there — masking twice is harmless
-    (the mask is idempotent), so the rule never changes a value."""
+    (the mask is idempotent), so the rule never changes a value.
+
+    head_w (Net.forward, hidden layer in front of a classifier head): the launch also emits the NEXT layer's logits as
+    per-tile partial sums (tnn_dense_fwd_head_partials) — they ride on the output array (`_aux`) for the loss node.
+    lazy (Net.forward, the classifier layer itself in TRAIN mode): the GEMM is deferred until the logits are first used
+    (device_array.LazyArray); softmax_nll_ then produces them together with the loss and this layer's backward."""
     xv, wv, bv = x.values, w.values, b.values
     if xv.ndim != 2 or wv.ndim != 2 or xv.shape[1] != wv.shape[0] or bv.size != wv.shape[1]:
         raise ValueError("dense_: shapes %s @ %s + %s do not line up" % (xv.shape, wv.shape, bv.shape))
@@ -270,10 +275,25 @@ def dense_(x, w, b, relu=False):
     xc = xv._as_float(dt)._contig()
     x_relu = x_relu and xc is xv                      # the sign bits must be the producer's own buffer
     xv, wv, bv = xc, wv._as_float(dt)._contig(), bv._as_float(dt)._contig()
-    out = da.empty((m, n), dt)
-    if out.size:
-        _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr,
-                                 _lib.ACT_RELU if relu else _lib.ACT_NONE, 1 if relu else 0, out._ptr, n, out._code())
+    code = da._CODE[dt]
+    if lazy and not relu and m and n and dt == np.float32:
+        def produce(arr, xv=xv, wv=wv, bv=bv):
+            _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_NONE, 0,
+                                     da.DeviceArray._ptr.__get__(arr, da.DeviceArray), n, code)
+        out = da.LazyArray.deferred((m, n), dt, produce)
+    else:
+        lazy = False
+        out = da.empty((m, n), dt)
+        hw = head_w.values if head_w is not None else None
+        if (hw is not None and out.size and dt == np.float32 and hw.dtype == dt and hw.ndim == 2 and hw.shape[0] == n
+                and hw.shape[1] <= 16 and not hw._t and hw._hv is None):
+            zpart = da.empty(((n + 15) // 16, m, hw.shape[1]), dt)
+            _lib.get().dense_fwd_head_partials(m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_RELU if relu else _lib.ACT_NONE,
+                                               1 if relu else 0, out._ptr, n, hw._ptr, hw.shape[1], zpart._ptr, code)
+            out._aux = (zpart, hw)                    # valid for the classifier weights `hw` as they are NOW
+        elif out.size:
+            _lib.get().gemm_bias_act(0, 0, m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr,
+                                     _lib.ACT_RELU if relu else _lib.ACT_NONE, 1 if relu else 0, out._ptr, n, code)
     if relu:
         out._tag = da.RELU_SIGN
 
@@ -364,7 +384,92 @@ def dense_(x, w, b, relu=False):
         return [res[name] for name in edges]
 
     node._fused_vjp = fused_vjp
+    if lazy:
+        node._head = (x, w, b, xv, wv, bv, edges)     # what softmax_nll_ needs to run the head in one launch
     return node
+
+
+def _softmax_head(logits, labels):
+    """The classifier head as ONE launch when the logits are still pending (dense_(lazy=True)) and the shapes are the ones
+    tnn_mlp_head_tick takes: last Dense forward (core/layers.py:49) + whole-batch softmax NLL (core/losses.py:24-32) + the last
+    Dense's backward (core/ops.py:156-160, :52-54, ReLU mask :342-343), i.e. three of the op-level step's launches.  The
+    backward part is SPECULATIVE: its results are handed over when backward() reaches the Dense node with the loss node's own
+    dz (the default seed 1.0); any other seed, a second backward or a foreign consumer recomputes through the ordinary vjps.
+    Returns None when the fusion does not apply."""
+    head = getattr(logits, "_head", None)
+    z = logits._values
+    if head is None or type(z) is not da.LazyArray or not z.pending:
+        return None
+    x, w, b, xv, wv, bv, edges = head
+    y = as_tensor(labels).values
+    m, c = z.shape
+    hdim = wv.shape[0]
+    if (y.shape != z.shape or xv._tag is not da.RELU_SIGN or xv._t or xv._hv is not None or wv._t or bv._t
+            or not _head_fits(m, hdim, c)):
+        return None
+    dt = np.dtype(np.float32)
+    y = y._as_float(dt)._contig()
+    lib = _lib.get()
+    stats, loss, dz = da.empty((2,), dt), da.empty((), dt), da.empty((m, c), dt)
+
+    def dest(t, shape):
+        """The tensor's arena view when its gradient is lazily zero (what the scheduler would lend), else a fresh buffer."""
+        home = getattr(t, "_grad_home", None)
+        if (t.requires_grad and home is not None and t._grad is None and t._grad_zero and not t.dependency
+                and home.size == int(np.prod(shape)) and home.dtype == dt and not home._t and home._hv is None):
+            return home, True
+        return da.empty(shape, dt), False
+    dw, dw_home = dest(w, (hdim, c))
+    db, db_home = dest(b, tuple(b.shape))
+    dx = da.empty((m, hdim), dt) if x.requires_grad else None
+    zpart = None
+    aux = xv._aux
+    if aux is not None and aux[1] is wv and aux[0].shape == (hdim // 16, m, c):
+        zpart = aux[0]
+    lib.mlp_head_tick(m, hdim, c, xv._ptr, wv._ptr, bv._ptr, y._ptr, None if zpart is None else zpart._ptr,
+                      z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, None if dx is None else dx._ptr,
+                      _lib.F32, None, 0.0, 0.0)
+    if dx is not None:
+        dx._tag = xv                                  # already multiplied by x's ReLU mask
+    pre = {"x": (dx, False), "w": (dw, dw_home), "b": (db, db_home)}
+    generic = logits._fused_vjp
+
+    def fused_vjp(g_in, homes):
+        state = logits._head_pre
+        logits._head_pre = None                       # one hand-over; whatever comes later is recomputed
+        if state is not None and g_in is dz:
+            out = []
+            for name, home in zip(edges, homes):
+                arr, wrote_home = pre[name]
+                if wrote_home and home is not arr:    # the arena view is no longer this tensor's to adopt
+                    out = None
+                    break
+                out.append(arr)
+            if out is not None:
+                return out
+        return generic(g_in, homes)
+    logits._head_pre = True
+    logits._fused_vjp = fused_vjp
+
+    def d_logits(g):
+        g = da.asarray(g)
+        if g._hv is not None and float(g._hv) == 1.0:
+            return dz
+        return g * dz
+    return build_unary_ops_tensor(logits, d_logits, loss)
+
+
+_HEAD_FITS = {}
+
+
+def _head_fits(m, hdim, c):
+    key = (m, hdim, c)
+    if key not in _HEAD_FITS:
+        import ctypes
+        fits = ctypes.c_int(0)
+        _lib.get().mlp_head_fits(m, hdim, c, _lib.F32, ctypes.byref(fits))
+        _HEAD_FITS[key] = bool(fits.value)
+    return _HEAD_FITS[key]
 
 
 def sigmoid_(ts):
@@ -379,6 +484,10 @@ def softmax_nll_(logits, labels, comm=None):
 
     With a communicator the {max, sum-exp} pair of every shard is all-gathered and merged, m is the GLOBAL
     batch size, and the returned loss is this shard's share (the shares add up to the global loss)."""
+    if comm is None or comm.world == 1:
+        fused = _softmax_head(logits, labels)
+        if fused is not None:
+            return fused
     z, y = logits.values, as_tensor(labels).values
     dt = z.dtype if z.dtype.kind == "f" else da.get_default_float()
     z, y = z._as_float(dt)._contig(), y._as_float(dt)._contig()

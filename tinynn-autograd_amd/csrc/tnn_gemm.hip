@@ -62,9 +62,9 @@ struct GemmArgs {
     const double* ad_pows;
     const int* ad_guard;
     int staged_c;          // tiled kernel: interior tiles store through an LDS image of the tile (row-major 16-B stores)
-    // tiled TN kernel, CS instantiation (tnn_gemm_tn_adam_bias): the workgroups of tile row 0 also produce the column sums of
-    // B (= the bias gradient, core/ops.py:52-54) from the fragments they stream anyway -> cs_db [N], and apply Adam to the
-    // bias block cs_p / cs_m / cs_v [N] when those are given
+    // tiled TN kernel with EPI_ADAM (tnn_gemm_tn_adam_bias): the workgroups of tile row 0 also produce the column sums of B
+    // (= the bias gradient, core/ops.py:52-54) in their epilogue -> cs_db [N], and apply Adam to the bias block
+    // cs_p / cs_m / cs_v [N] when those are given
     float *cs_db, *cs_p, *cs_m, *cs_v;
 #ifdef TNN_GEMM_TRACE
     unsigned long long* trace;   // debug build only: [grid][8] timeline words (nullptr = off)
@@ -106,7 +106,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 // offsets are computed once before the loop, out-of-range rows read a clamped (valid) address and are
 // zeroed with a select, and only the last, partial K-tile goes through the guarded element-wise loader.
 // VEC = false is the fully guarded element-wise variant for odd shapes / unaligned views.
-template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC, bool CS = false>
+template <int BM, int BN, int BK, int WM, int WN, bool AKC, bool BKC, bool VEC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -317,21 +317,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
             }
         }
     };
-    // CS: per-lane partial column sums of B (lane (l31, lhi) sees k = 8 kk + 4 lhi + j of every K-tile); only the waves that
-    // write them at the end accumulate (tile row 0, wave row 0: wave-uniform).  f64 like every reduction of the library
-    // (tnn_reduce): the float32 result is then the correctly rounded sum whatever the order
-    double cs[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) cs[i] = 0.0;
-    const bool do_cs = CS && g.cs_db != nullptr && m0 == 0 && wm == 0 && blockIdx.z == 0;
     auto mfma_chunk = [&](int kk) {
-        if constexpr (CS) {
-            if (do_cs) {
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    cs[ni] += ((double)bf[kk][ni][0] + (double)bf[kk][ni][1]) + ((double)bf[kk][ni][2] + (double)bf[kk][ni][3]);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -481,25 +467,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         if (g.ad_guard != nullptr && *g.ad_guard != 0) return;
         const float ic1 = (float)(1.0 / (1.0 - g.ad_pows[0])), ic2 = (float)(1.0 / (1.0 - g.ad_pows[1]));
         const float omb1 = 1.f - g.ad_b1, omb2 = 1.f - g.ad_b2, lr = g.ad_lr, eps = g.ad_eps;
-        if constexpr (CS) {
-            if (do_cs) {                       // db = column sums of B; Adam on the bias block (core/optimizer.py:67-79)
+        if (!BKC && g.cs_db != nullptr && m0 == 0 && blockIdx.z == 0) {
+            // Tile row 0 also produces db = column sums of B (= dz, MN-contiguous: the TN form) for its BN columns and applies
+            // Adam to the bias block (core/ops.py:52-54 + core/optimizer.py:67-79).  The K x BN panel was streamed through
+            // this workgroup a moment ago (L2 hits); summing it again HERE, outside the K loop, costs the 64 workgroups of the
+            // row a few microseconds and leaves the MFMA loop alone (a first version added f64 adds on the B fragments
+            // inside the loop's wave-uniform branch: the dW launch went from 162 to 182 us — the interleave pattern of the
+            // loop does not survive extra VALU work).  f64 accumulation like every reduction of the library (tnn_reduce).
+            __shared__ double cs_part[NT / BN][BN];
+            static_assert(NT % BN == 0, "column-sum lanes");
+            const int col = tid % BN, part = tid / BN;
+            const int64_t gcol = n0 + col;
+            double acc_cs = 0.0;
+            if (gcol < g.N)
+                for (int64_t k = part; k < g.K; k += NT / BN) acc_cs += (double)g.B[k * g.ldb + gcol];
+            cs_part[part][col] = acc_cs;
+            __syncthreads();
+            if (part == 0 && gcol < g.N) {
+                double t = 0.0;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const float sum = (float)(cs[ni] + __shfl_xor(cs[ni], 32, 64));
-                    const int64_t col = n0 + wn * TN + ni * 32 + l31;
-                    if (lhi == 0 && col < g.N) {
-                        g.cs_db[col] = sum;
-                        if (g.cs_p != nullptr) {
-                            float mi = g.cs_m[col], vi = g.cs_v[col];
-                            mi = mi + omb1 * (sum - mi);
-                            vi = vi + omb2 * (sum * sum - vi);
-                            g.cs_m[col] = mi;
-                            g.cs_v[col] = vi;
-                            g.cs_p[col] = g.cs_p[col] + (-lr * (mi * ic1) / (sqrtf(vi * ic2) + eps));
-                        }
-                    }
+                for (int q = 0; q < NT / BN; ++q) t += cs_part[q][col];
+                const float sum = (float)t;
+                g.cs_db[gcol] = sum;
+                if (g.cs_p != nullptr) {
+                    float mi = g.cs_m[gcol], vi = g.cs_v[gcol];
+                    mi = mi + omb1 * (sum - mi);
+                    vi = vi + omb2 * (sum * sum - vi);
+                    g.cs_m[gcol] = mi;
+                    g.cs_v[gcol] = vi;
+                    g.cs_p[gcol] = g.cs_p[gcol] + (-lr * (mi * ic1) / (sqrtf(vi * ic2) + eps));
                 }
             }
+            __syncthreads();
         }
         constexpr int TS = BN + 4;                                    // LDS row stride of the staged tile (floats)
         if constexpr (BM * TS <= 2 * (A_ELEMS + B_ELEMS) && (BN / 4) <= NT && NT % (BN / 4) == 0) {
@@ -1438,13 +1437,6 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
         else                                                                                               \
             hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, AKC, BKC, false>), grid, NT, 0, s, g); \
     } while (0)
-    if constexpr (BM == 128 && BN == 64) {
-        if (g.cs_db != nullptr) {                    // tnn_gemm_tn_adam_bias made sure of: TN, vector loads, no split-K
-            hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, false, false, true, true>), grid, NT, 0, s, g);
-            TNN_LAUNCH_OK();
-            return 0;
-        }
-    }
     if (!transA && !transB) TNN_LAUNCH_GEMM(true, false);
     else if (!transA && transB) TNN_LAUNCH_GEMM(true, true);
     else if (transA && !transB) TNN_LAUNCH_GEMM(false, false);
@@ -1621,9 +1613,8 @@ int tnn_gemm_tn_adam_bias(int64_t M, int64_t N, int64_t K, const void* A, int64_
         g.ad_lr = (float)lr; g.ad_b1 = (float)b1; g.ad_b2 = (float)b2; g.ad_eps = (float)eps;
         g.ad_pows = (const double*)pows_f64;
         g.ad_guard = tnn::update_guard();
-        // db (+ Adam on the bias) from the same launch when the CS instantiation applies: 16-B loads on both operands
-        const bool cs = db != nullptr && al(A) && al(G) && lda % 4 == 0 && M % 4 == 0 && N % 4 == 0 &&
-                        (K * lda) * 4 < (int64_t(1) << 32) && (K * ldg) * 4 < (int64_t(1) << 32);
+        // db (+ Adam on the bias) from the same launch: the epilogue of tile row 0 (splits == 1 here)
+        const bool cs = db != nullptr;
         if (cs) { g.cs_db = (float*)db; g.cs_p = (float*)pb; g.cs_m = (float*)mb; g.cs_v = (float*)vb; }
         if (int rc = gemm_f32(g, 1, 0)) return rc;   // >= 128 tiles of 128 x 64: configuration 3, no split-K
         if (db != nullptr && !cs) {

@@ -98,7 +98,7 @@ def trim_cache():
 
 
 class DeviceArray(object):
-    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "_own", "__weakref__")
+    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "_own", "_aux", "__weakref__")
     __array_priority__ = 1000.0
 
     # ------------------------------------------------------------------ construction
@@ -115,6 +115,7 @@ class DeviceArray(object):
         self._hv = hv
         self._t = t
         self._own = 0                # 0: the native pool's (or not owned), 1: recyclable through _cache, 2: graph-owned
+        self._aux = None             # by-product of the producing launch riding along (core/ops.py: the partial logits)
         self._tag = None             # free-form marker: RELU_SIGN on a fused Dense+ReLU output; the producer's output array
                                      # on a gradient whose ReLU mask has already been applied (core/ops.py dense_)
         return self
@@ -642,6 +643,48 @@ def asarray(obj, dtype=None):
     if host.size:
         _lib.get().memcpy_h2d(out._ptr, host.ctypes.data, host.nbytes)
     return out
+
+
+class LazyArray(DeviceArray):
+    """An array whose producing launch is deferred until something first asks for its buffer (`_ptr`).
+
+    Used for ONE thing: the logits of a classifier head in TRAIN mode (core/nn.py, core/ops.py dense_(lazy=True)).  When the
+    loss node gets there first it produces them together with the loss and the head's backward in one launch
+    (ops.softmax_nll_); any other first use — printing, argmax, a custom loss — runs the ordinary GEMM, so the values are the
+    same either way.  The deferral is visible only to code that mutates the producer's inputs IN PLACE between forward()
+    and the first use of the logits (they would be computed from the mutated operands)."""
+    __slots__ = ("_thunk",)
+
+    def _get_ptr(self):
+        thunk = self._thunk
+        if thunk is not None:
+            self._thunk = None
+            thunk(self)
+        return DeviceArray._ptr.__get__(self, DeviceArray)
+
+    def _set_ptr(self, value):
+        DeviceArray._ptr.__set__(self, value)
+
+    _ptr = property(_get_ptr, _set_ptr)
+
+    @classmethod
+    def deferred(cls, shape, dtype, thunk):
+        self = cls._new(shape, dtype)          # the buffer exists; only its content is pending
+        self._thunk = thunk
+        return self
+
+    @property
+    def pending(self):
+        return self._thunk is not None
+
+    def fulfilled_ptr(self):
+        """The buffer for the launch that fulfils the deferral some other way (and ends it)."""
+        self._thunk = None
+        return DeviceArray._ptr.__get__(self, DeviceArray)
+
+    def __del__(self):
+        self._thunk = None
+        DeviceArray.__del__(self)
 
 
 def from_ptr(ptr, shape, dtype, owner):
