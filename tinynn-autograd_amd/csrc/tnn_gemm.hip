@@ -467,26 +467,54 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
         if (g.ad_guard != nullptr && *g.ad_guard != 0) return;
         const float ic1 = (float)(1.0 / (1.0 - g.ad_pows[0])), ic2 = (float)(1.0 / (1.0 - g.ad_pows[1]));
         const float omb1 = 1.f - g.ad_b1, omb2 = 1.f - g.ad_b2, lr = g.ad_lr, eps = g.ad_eps;
-        if (!BKC && g.cs_db != nullptr && m0 == 0 && blockIdx.z == 0) {
-            // Tile row 0 also produces db = column sums of B (= dz, MN-contiguous: the TN form) for its BN columns and applies
+        if (!BKC && g.cs_db != nullptr && blockIdx.z == 0 && (int)(m0 / BM) == (int)(n0 / BN) % g.tiles_m) {
+            // ONE workgroup per tile column (tile row = column index mod tiles_m: spread over the XCDs and over the launch's
+            // duration — with all of them in tile row 0 they sat on two XCDs) also produces db = column sums of B (= dz,
+            // MN-contiguous: the TN form) for its BN columns and applies
             // Adam to the bias block (core/ops.py:52-54 + core/optimizer.py:67-79).  The K x BN panel was streamed through
             // this workgroup a moment ago (L2 hits); summing it again HERE, outside the K loop, costs the 64 workgroups of the
             // row a few microseconds and leaves the MFMA loop alone (a first version added f64 adds on the B fragments
             // inside the loop's wave-uniform branch: the dW launch went from 162 to 182 us — the interleave pattern of the
             // loop does not survive extra VALU work).  f64 accumulation like every reduction of the library (tnn_reduce).
-            __shared__ double cs_part[NT / BN][BN];
-            static_assert(NT % BN == 0, "column-sum lanes");
+            constexpr int C4 = BN / 4, PARTS = NT / C4;            // 16-B loads: thread = (4 columns, one of PARTS row classes)
+            // the partial sums meet in the operand buffers (free after the K loop): NO LDS of their own — 8 KB more per
+            // workgroup took the kernel from 3 to 2 workgroups per CU, for every product of the library (measured: +3 %)
+            static_assert(NT % C4 == 0 && PARTS * BN * 8 <= 2 * (A_ELEMS + B_ELEMS) * 4, "column-sum lanes / LDS");
+            __syncthreads();                                    // every wave is done with the last tile's fragments
+            double (*cs_part)[BN] = reinterpret_cast<double (*)[BN]>(lds);
+            const int c4 = tid % C4, part4 = tid / C4;
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (n0 + 4 * c4 + 3 < g.N && g.vecB) {
+                const float* bp = g.B + n0 + 4 * c4;
+                constexpr int UN = 8;                               // independent loads in flight per thread
+                for (int64_t k0 = part4; k0 < g.K; k0 += (int64_t)PARTS * UN) {
+                    f32x4 v[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; ++u) {
+                        const int64_t k = k0 + (int64_t)u * PARTS;
+                        v[u] = k < g.K ? *reinterpret_cast<const f32x4*>(bp + k * g.ldb) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < UN; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a4[e] += (double)v[u][e];
+                }
+            } else {
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t gc = n0 + 4 * c4 + e;
+                    if (gc < g.N)
+                        for (int64_t k = part4; k < g.K; k += PARTS) a4[e] += (double)g.B[k * g.ldb + gc];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cs_part[part4][4 * c4 + e] = a4[e];
+            __syncthreads();
             const int col = tid % BN, part = tid / BN;
             const int64_t gcol = n0 + col;
-            double acc_cs = 0.0;
-            if (gcol < g.N)
-                for (int64_t k = part; k < g.K; k += NT / BN) acc_cs += (double)g.B[k * g.ldb + gcol];
-            cs_part[part][col] = acc_cs;
-            __syncthreads();
             if (part == 0 && gcol < g.N) {
                 double t = 0.0;
 #pragma unroll
-                for (int q = 0; q < NT / BN; ++q) t += cs_part[q][col];
+                for (int q = 0; q < PARTS; ++q) t += cs_part[q][col];
                 const float sum = (float)t;
                 g.cs_db[gcol] = sum;
                 if (g.cs_p != nullptr) {
