@@ -771,6 +771,70 @@ def epoch_loop_float64_all_pool_rows():
         tn.set_default_float(np.float32)
 
 
+def fused_classifier_head_matches_generic_chain():
+    """Net.forward's TRAIN-mode arrangement for ... Dense -> ReLU -> Dense(10) + SoftmaxCrossEntropyLoss — partial logits from
+    the hidden layer's launch, DEFERRED logits, then last Dense forward + loss + the backward of the last TWO Dense layers in one
+    launch, handed over to backward() — against the literal op chain (Dense(fused=False) + ReLU layers + the 12-op loss):
+    loss, logits, every parameter gradient, and the INTERMEDIATE gradients (the hidden activation's, which the fused launch never
+    stores and a deferred array recomputes on demand; documented deviation: it is the gradient w.r.t. the pre-activation, i.e.
+    already masked).  Also: a non-default seed, a second backward without zero_grad (accumulation), logits read before the loss,
+    and TEST mode — all of which must fall back to the ordinary launches with the same numbers."""
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.nn import Net
+    from tinynn_autograd_amd.core.optimizer import Adam
+    rs = np.random.RandomState(41)
+    m, widths = 96, [64, 48, 128, 10]
+    x = (rs.rand(m, widths[0]) * (rs.rand(m, widths[0]) < 0.4)).astype(np.float32)
+    y = np.eye(10)[rs.randint(0, 10, m)]
+    Ws = [(rs.randn(widths[i], widths[i + 1]) * 0.2).astype(np.float32) for i in range(3)]
+    Bs = [(rs.randn(1, widths[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+
+    def build(fused):
+        layers = []
+        for i in range(3):
+            d = Dense(widths[i + 1], num_in=widths[i], fused=fused)
+            d.params["w"].values = tn.asarray(Ws[i]); d.params["b"].values = tn.asarray(Bs[i])
+            d.params["w"].zero_grad(); d.params["b"].zero_grad()
+            layers.append(d)
+            if i < 2:
+                layers.append(ReLU())
+        net = Net(layers)
+        return net, Model(net=net, loss=SoftmaxCrossEntropyLoss(), optimizer=Adam(lr=1e-3))
+
+    def run(fused, seed=None, twice=False, peek=False, loss_fused=True):
+        net, model = build(fused)
+        model.zero_grad()
+        pred = model.forward(Tensor(x))
+        if peek:
+            first = np.asarray(pred.values).copy()          # forces the deferred logits through the ordinary GEMM
+        loss = SoftmaxCrossEntropyLoss(fused=loss_fused).loss(pred, Tensor(y))
+        loss.backward() if seed is None else loss.backward(seed)
+        if twice:
+            loss.backward()
+        dense = [l for l in net.layers if isinstance(l, Dense)]
+        grads = [np.asarray(l.params[k].grad).copy() for l in dense for k in ("w", "b")]
+        hidden = net.layers[3].inputs                       # fused: the hidden activation; generic: its pre-activation
+        return float(loss.values), np.asarray(pred.values).copy(), grads, np.asarray(hidden.grad).copy()
+
+    ref = run(False, loss_fused=False)
+    for kwargs, scale in ((dict(), 1.0), (dict(peek=True), 1.0), (dict(seed=2.5), 2.5), (dict(twice=True), 2.0)):
+        got = run(True, **kwargs)
+        tag = str(kwargs)
+        np.testing.assert_allclose(got[0], ref[0], rtol=RTOL, err_msg=tag)
+        np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=RTOL * np.abs(ref[1]).max(), err_msg=tag)
+        for g, r in zip(got[2], ref[2]):
+            np.testing.assert_allclose(g.reshape(r.shape), scale * r, rtol=0, atol=2e-5 * scale * np.abs(r).max(), err_msg=tag)
+        np.testing.assert_allclose(got[3], scale * ref[3], rtol=0, atol=2e-5 * scale * np.abs(ref[3]).max(), err_msg=tag)
+    # TEST mode: nothing is deferred
+    net, model = build(True)
+    model.set_phase("TEST")
+    out = model.forward(Tensor(x))
+    assert type(out.values) is tn.DeviceArray
+    np.testing.assert_allclose(np.asarray(out.values), ref[1], rtol=0, atol=RTOL * np.abs(ref[1]).max())
+
+
 def fused_ops_match_generic_chain():
     """softmax_nll_ / dense_ / fused Adam against the literal op chains on the same device."""
     from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss

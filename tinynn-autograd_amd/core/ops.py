@@ -386,6 +386,8 @@ def dense_(x, w, b, relu=False, head_w=None, lazy=False):
     node._fused_vjp = fused_vjp
     if lazy:
         node._head = (x, w, b, xv, wv, bv, edges)     # what softmax_nll_ needs to run the head in one launch
+    elif relu:
+        node._dense_ctx = (x, w, b, xv, wv, bv, edges, x_relu)   # ... and the hidden layer's backward with it
     return node
 
 
@@ -421,18 +423,61 @@ def _softmax_head(logits, labels):
         return da.empty(shape, dt), False
     dw, dw_home = dest(w, (hdim, c))
     db, db_home = dest(b, tuple(b.shape))
-    dx = da.empty((m, hdim), dt) if x.requires_grad else None
     zpart = None
     aux = xv._aux
     if aux is not None and aux[1] is wv and aux[0].shape == (hdim // 16, m, c):
         zpart = aux[0]
-    lib.mlp_head_tick(m, hdim, c, xv._ptr, wv._ptr, bv._ptr, y._ptr, None if zpart is None else zpart._ptr,
-                      z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, None if dx is None else dx._ptr,
-                      _lib.F32, None, 0.0, 0.0)
-    if dx is not None:
-        dx._tag = xv                                  # already multiplied by x's ReLU mask
-    pre = {"x": (dx, False), "w": (dw, dw_home), "b": (db, db_home)}
     generic = logits._fused_vjp
+
+    # ---- with the hidden layer's backward in the same launch (tnn_mlp_head_bwd_tick: the 4-launch trainer's third launch)
+    # when that layer is a fused Dense+ReLU node whose own input carries a ReLU mask: its dz is derived inside the tiles and
+    # never stored, so the gradient handed to the hidden activation is a DEFERRED array (computed by the ordinary vjp only
+    # if somebody reads that intermediate .grad) which the hidden node recognises and answers with the precomputed results
+    hid = getattr(x, "_dense_ctx", None)
+    if (hid is not None and zpart is not None and x.requires_grad and len(x.dependency) == len(hid[6])
+            and hid[7] and hid[3].shape[1] % 16 == 0 and hid[4].dtype == dt and not hid[4]._t and "x" in hid[6]):
+        x0, w1, b1, x0v, w1v, b1v, edges1, _ = hid
+        n_in = x0v.shape[1]
+        dw1, dw1_home = dest(w1, (n_in, hdim))
+        db1, db1_home = dest(b1, tuple(b1.shape))
+        dx0 = da.empty((m, n_in), dt)
+        dx0._tag = x0v
+        lib.mlp_head_bwd_tick(m, n_in, hdim, c, x0v._ptr, w1v._ptr, xv._ptr, wv._ptr, bv._ptr, y._ptr, zpart._ptr,
+                              z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, dw1._ptr, db1._ptr,
+                              dx0._ptr, _lib.F32, None, 0.0, 0.0)
+
+        def hidden_dz(arr, dz=dz, wv=wv, xv=xv):     # only if the intermediate gradient is actually looked at
+            val = da.mul_signmask(dz @ wv.T, xv)
+            _lib.get().memcpy_d2d(da.DeviceArray._ptr.__get__(arr, da.DeviceArray), val._ptr, val.nbytes)
+        dx = da.LazyArray.deferred((m, hdim), dt, hidden_dz)
+        dx._tag = xv
+        pre1 = {"x": (dx0, False), "w": (dw1, dw1_home), "b": (db1, db1_home)}
+        generic1 = x._fused_vjp
+
+        def hidden_vjp(g_in, homes):
+            state = x._head_pre
+            x._head_pre = None
+            if state is not None and g_in is dx:
+                out = []
+                for name, home in zip(edges1, homes):
+                    arr, wrote_home = pre1[name]
+                    if wrote_home and home is not arr:
+                        out = None
+                        break
+                    out.append(arr)
+                if out is not None:
+                    return out
+            return generic1(g_in, homes)
+        x._head_pre = True
+        x._fused_vjp = hidden_vjp
+    else:
+        dx = da.empty((m, hdim), dt) if x.requires_grad else None
+        lib.mlp_head_tick(m, hdim, c, xv._ptr, wv._ptr, bv._ptr, y._ptr, None if zpart is None else zpart._ptr,
+                          z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, None if dx is None else dx._ptr,
+                          _lib.F32, None, 0.0, 0.0)
+        if dx is not None:
+            dx._tag = xv                              # already multiplied by x's ReLU mask
+    pre = {"x": (dx, False), "w": (dw, dw_home), "b": (db, db_home)}
 
     def fused_vjp(g_in, homes):
         state = logits._head_pre
