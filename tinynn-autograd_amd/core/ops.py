@@ -10,6 +10,8 @@ Extra fused nodes used by this package's own layers/losses (parity-tested agains
 `dense_` (GEMM + bias epilogue), `sigmoid_`, `softmax_nll_` (whole-batch softmax NLL).
 """
 
+import math
+
 import numpy as np
 
 from .. import _lib
@@ -418,7 +420,7 @@ def _softmax_head(logits, labels):
         """The tensor's arena view when its gradient is lazily zero (what the scheduler would lend), else a fresh buffer."""
         home = getattr(t, "_grad_home", None)
         if (t.requires_grad and home is not None and t._grad is None and t._grad_zero and not t.dependency
-                and home.size == int(np.prod(shape)) and home.dtype == dt and not home._t and home._hv is None):
+                and home.size == math.prod(shape) and home.dtype == dt and not home._t and home._hv is None):
             return home, True
         return da.empty(shape, dt), False
     dw, dw_home = dest(w, (hdim, c))

@@ -50,11 +50,7 @@ def _i64arr(values):
     return (ctypes.c_int64 * len(values))(*values)
 
 
-def _prod(shape):
-    n = 1
-    for s in shape:
-        n *= int(s)
-    return n
+_prod = math.prod
 
 
 def _dense_strides(shape):
@@ -109,7 +105,7 @@ class DeviceArray(object):
     def _raw(cls, ptr, shape, dtype, base=None, hv=None, t=False):
         self = object.__new__(cls)
         self._ptr = ptr
-        self.shape = shape if type(shape) is tuple and all(type(s) is int for s in shape) else tuple(int(s) for s in shape)
+        self.shape = tuple(map(int, shape))
         self.dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
         self._base = base
         self._hv = hv
