@@ -71,6 +71,15 @@ def test_sharded_trainer_on_p2p_world1_matches_reference_fixture():
         comm.close()
 
 
+@pytest.mark.gpu
+def test_p2p_eight_processes_the_n8_point():
+    """configs[3] as the driver's N = 8 run shards it — global batch 1024, 128 rows per rank — with EIGHT ranks on the box's
+    one GPU: the 5-launch sharded step (statistics reduced and exchanged by the last workgroup of the forward launch, tagged
+    all-reduce with the Adam tail) reproduces the reference's bs-1024 trajectory, replicas identical, timeout drill green.
+    Only one workgroup per rank ever waits for a peer outside the all-reduce, so the ranks cannot starve each other."""
+    _run_p2p_workers(8, "D_adam")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
