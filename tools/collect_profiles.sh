@@ -1,0 +1,24 @@
+#!/bin/bash
+# Copy the summaries of one profiling pass (gpurun_out/<round>prof/, produced by tools/profile_round.sh) into profiles/ under
+# the round's prefix:  bash tools/collect_profiles.sh r03
+R=${1:-r03}
+S=gpurun_out/${R}prof
+D=profiles
+cp $S/benchA.json $D/${R}_benchA.json
+cp $S/benchA_dp_world1.json $D/${R}_benchA_dp_world1.json
+cp $S/benchC.json $D/${R}_benchC.json
+cp $S/benchE.json $D/${R}_benchE.json
+cp $S/ktA_kernel_stats.txt $D/${R}_benchA_kernel_stats.txt
+cp $S/ktAstep_kernel_stats.txt $D/${R}_benchA_step_kernel_stats.txt
+cp $S/ktC_kernel_stats.txt $D/${R}_benchC_kernel_stats.txt
+cp $S/ktE_kernel_stats.txt $D/${R}_benchE_kernel_stats.txt
+for w in A C E; do cat $S/pmc${w}_fetch.txt $S/pmc${w}_write.txt > $D/${R}_bench${w}_pmc.txt; done
+cp $S/pmcbf_sq.txt $D/${R}_gemm_bf16_pmc.txt
+cp $S/pmcg32_sq.txt $D/${R}_gemm_f32_pmc.txt
+cp $S/traffic.json $D/${R}_traffic.json
+cp $S/dp_world1_timeline.txt $D/${R}_dp_world1_timeline.txt
+cp $S/stepA_timeline.txt $D/${R}_stepA_timeline.txt
+cp $S/p2p_latency.txt $D/${R}_p2p_latency.txt
+cp $S/dw_adam_bf16.txt $D/${R}_dw_adam_bf16.txt
+cp $S/gemm_f32_sweep.txt $D/${R}_gemm_f32_sweep.txt
+ls -la $D/${R}_*
