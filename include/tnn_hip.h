@@ -354,6 +354,15 @@ TNN_API int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16);   
 TNN_API int tnn_colsum_bf16(const void* in, void* out_f32, int64_t rows, int64_t cols);    /* bias gradient */
 TNN_API int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32,
                          void* dpred);
+/* ... as the loss launch of a whole step: loss_out2 (may be NULL) receives the loss too (no copy launch) and, with
+ * adam_pows_f64 != NULL, one thread advances {b1^t, b2^t} (tnn_adam_tick without its launch). */
+TNN_API int tnn_mse_bf16_tick(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32,
+                              void* loss_out2_f32, void* dpred, void* adam_pows_f64, double b1, double b2);
+/* The bias of one bf16 Dense layer in ONE launch: db_f32 [cols] = column sums of dz (bf16 [rows, cols], core/ops.py:52-54)
+ * and, when p_master / m / v [cols] are given, Adam on the fp32 master bias (core/optimizer.py:67-79, pows already advanced)
+ * + its bf16 copy w_bf16 (may be NULL).  Replaces tnn_colsum_bf16 (two launches at this size) + tnn_adam_master_bf16_2d. */
+TNN_API int tnn_bias_bf16_adam(const void* dz, int64_t rows, int64_t cols, void* db_f32, void* p_master, void* m, void* v,
+                               void* w_bf16, double lr, double b1, double b2, double eps, const void* pows_f64);
 /* Adam on the fp32 master parameters (same maths as tnn_adam) that also refreshes the bf16 working copy */
 TNN_API int tnn_adam_master_bf16(void* p_master, const void* g, void* m, void* v, void* w_bf16, int64_t n,
                                  double lr, double b1, double b2, double eps, void* pows_f64);

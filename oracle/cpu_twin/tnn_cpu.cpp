@@ -928,6 +928,17 @@ int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, v
     ((float*)loss_out)[0] = (float)(acc * inv_m);
     return 0;
 }
+int tnn_mse_bf16_tick(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out, void* loss_out2, void* dpred,
+                      void* pows, double b1, double b2) {
+    NEED_INIT();
+    REQ(loss_out != nullptr || loss_out2 == nullptr, "tnn_mse_bf16_tick: loss_out2 needs loss_out");
+    RECORD(tnn_mse_bf16_tick(pred, y, n, m_global, loss_out, loss_out2, dpred, pows, b1, b2));
+    if (pows) { ((double*)pows)[0] *= b1; ((double*)pows)[1] *= b2; }
+    float tmp = 0.f;
+    if (int rc = tnn_mse_bf16(pred, y, n, m_global, loss_out ? loss_out : &tmp, dpred)) return rc;
+    if (loss_out2) memcpy(loss_out2, loss_out, 4);
+    return 0;
+}
 // core/optimizer.py:67-79 on the fp32 master copy; G16 = the gradient arrives as bf16 (reduce-scattered wire format)
 static void adam_master_rows(bool G16, float* p, const void* g, float* m, float* v, bf16_t* w16, bf16_t* wT16, int64_t rows,
                              int64_t cols, int64_t ldt, double lr, double b1, double b2, double eps, const double* st) {
@@ -968,6 +979,16 @@ int tnn_adam_master_g16(void* p, const void* g16, void* m, void* v, void* w16, i
     REQ(p && g16 && m && v && w16 && pows, "tnn_adam_master_g16: NULL argument");
     RECORD(tnn_adam_master_g16(p, g16, m, v, w16, n, lr, b1, b2, eps, pows));
     adam_master_rows(true, (float*)p, g16, (float*)m, (float*)v, (bf16_t*)w16, nullptr, 1, n, 1, lr, b1, b2, eps, (const double*)pows);
+    return 0;
+}
+int tnn_bias_bf16_adam(const void* dz, int64_t rows, int64_t cols, void* db, void* p, void* m, void* v, void* w16, double lr,
+                       double b1, double b2, double eps, const void* pows) {
+    NEED_INIT();
+    REQ(dz && db && rows > 0, "tnn_bias_bf16_adam: dz and db are required");
+    RECORD(tnn_bias_bf16_adam(dz, rows, cols, db, p, m, v, w16, lr, b1, b2, eps, pows));
+    if (int rc = tnn_colsum_bf16(dz, db, rows, cols)) return rc;
+    if (p) adam_master_rows(false, (float*)p, db, (float*)m, (float*)v, (bf16_t*)w16, nullptr, 1, cols, 1, lr, b1, b2, eps,
+                            (const double*)pows);
     return 0;
 }
 int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* g_out,

@@ -107,6 +107,8 @@ _SIGNATURES = {
     "tnn_cast_bf16": [_p, _p, c_int64, c_int],
     "tnn_colsum_bf16": [_p, _p, c_int64, c_int64],
     "tnn_mse_bf16": [_p, _p, c_int64, c_int64, _p, _p],
+    "tnn_mse_bf16_tick": [_p, _p, c_int64, c_int64, _p, _p, _p, _p, c_double, c_double],
+    "tnn_bias_bf16_adam": [_p, c_int64, c_int64, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
     "tnn_adam_master_bf16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
     "tnn_adam_master_bf16_2d": [_p, _p, _p, _p, _p, _p, c_int64, c_int64, c_double, c_double, c_double, c_double, _p, c_int],
     "tnn_gemm_bf16_nt_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],

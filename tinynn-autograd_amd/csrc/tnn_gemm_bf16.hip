@@ -340,28 +340,18 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
         out[i] = bf2f(in[i]);
 }
 
-// column sums of a bf16 [R, C] matrix into f32 (bias gradient); block = 64 columns x 4 row lanes, f32 accumulate
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ in, float* __restrict__ out,
-                                                          int64_t R, int64_t C, int64_t rows_per_slice) {
-    __shared__ float lds[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t c = (int64_t)blockIdx.x * 64 + tx;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per_slice;
-    int64_t r1 = r0 + rows_per_slice;
-    if (r1 > R) r1 = R;
-    float acc = 0.f;
-    if (c < C)
-        for (int64_t r = r0 + ty; r < r1; r += 4) acc += bf2f(in[r * C + c]);
-    lds[ty][tx] = acc;
-    __syncthreads();
-    if (ty == 0 && c < C) out[(int64_t)blockIdx.y * C + c] = (lds[0][tx] + lds[1][tx]) + (lds[2][tx] + lds[3][tx]);
-}
-
 // sum((pred - y)^2) / m and dpred = 2 (pred - y) / m on bf16 tensors (f32 math, f64 block partials)
 __global__ __launch_bounds__(256) void mse_bf16_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ y,
                                                        int64_t n, double inv_m, double* __restrict__ partial,
-                                                       bf16_t* __restrict__ dpred) {
+                                                       bf16_t* __restrict__ dpred, double* __restrict__ tick = nullptr,
+                                                       double tb1 = 1.0, double tb2 = 1.0, const int* guard = nullptr) {
     __shared__ double lds[4];
+    // Adam's {b1^t, b2^t} advanced by one thread of the step's loss launch (nothing in this launch reads them)
+    if (tick != nullptr && blockIdx.x == 0 && threadIdx.x == 0 &&
+        (guard == nullptr || __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)) {
+        tick[0] *= tb1;
+        tick[1] *= tb2;
+    }
     double local = 0.0;
     const float two_inv_m = (float)(2.0 * inv_m);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -376,11 +366,14 @@ __global__ __launch_bounds__(256) void mse_bf16_kernel(const bf16_t* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = ((lds[0] + lds[1]) + (lds[2] + lds[3])) * inv_m;
 }
 __global__ __launch_bounds__(64) void sum_partials_f32_kernel(const double* __restrict__ partial, int n,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, float* __restrict__ out2 = nullptr) {
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
     s = tnn::wave_sum(s);
-    if (threadIdx.x == 0) out[0] = (float)s;
+    if (threadIdx.x == 0) {
+        out[0] = (float)s;
+        if (out2) out2[0] = (float)s;
+    }
 }
 
 // Adam on the fp32 master copy + refresh of the bf16 working copy (28 B + 2 B per parameter)
@@ -541,6 +534,64 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
         }
     }
 }
+// Bias of one bf16 Dense layer in ONE launch: db = column sums of dz (bf16 [R, C], core/ops.py:52-54, f32 accumulation like
+// colsum_bf16_kernel) and, when p != NULL, Adam on the fp32 master bias + refresh of its bf16 copy (core/optimizer.py:67-79).
+// Block = 64 columns x all rows: thread (4 columns, one of 16 row lanes), 8-B loads, the lanes meet in LDS.  Replaces the
+// two column-reduction launches + the bias optimizer launch of the bf16 step (3 x ~5-10 us per layer for 32 KB of output).
+__global__ __launch_bounds__(256) void bias_bf16_kernel(const bf16_t* __restrict__ dz, int64_t R, int64_t C,
+                                                        float* __restrict__ db, float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ w16, float lr, float b1,
+                                                        float b2, float eps, const double* __restrict__ state,
+                                                        const int* guard) {
+    __shared__ float part[16][64 + 4];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * cq;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 + 3 < C && C % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 7) == 0) {
+        constexpr int UN = 8;
+        for (int64_t r0 = rl; r0 < R; r0 += 16 * UN) {
+            u32x2 q[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t r = r0 + 16 * u;
+                q[u] = r < R ? *reinterpret_cast<const u32x2*>(dz + r * C + c0) : u32x2{0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                a[0] += __uint_as_float(q[u].x << 16); a[1] += __uint_as_float(q[u].x & 0xffff0000u);
+                a[2] += __uint_as_float(q[u].y << 16); a[3] += __uint_as_float(q[u].y & 0xffff0000u);
+            }
+        }
+    } else {
+        for (int e = 0; e < 4; ++e)
+            if (c0 + e < C)
+                for (int64_t r = rl; r < R; r += 16) a[e] += bf2f(dz[r * C + c0 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[rl][4 * cq + e] = a[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        if (c < C) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += part[q][threadIdx.x];
+            db[c] = s;
+            if (p != nullptr && (guard == nullptr || __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)) {
+                const float ic1 = (float)(1.0 / (1.0 - state[0])), ic2 = (float)(1.0 / (1.0 - state[1]));
+                float mi = m[c], vi = v[c];
+                mi = mi + (1.f - b1) * (s - mi);
+                vi = vi + (1.f - b2) * (s * s - vi);
+                m[c] = mi;
+                v[c] = vi;
+                const float pi = p[c] + (-lr * (mi * ic1) / (sqrtf(vi * ic2) + eps));
+                p[c] = pi;
+                if (w16 != nullptr) w16[c] = f2bf(pi);
+            }
+        }
+    }
+}
+
 __global__ void adam_advance16_kernel(double* __restrict__ state, double b1, double b2, const int* guard) {
     TNN_GUARD_RETURN(guard);
     state[0] *= b1;
@@ -669,48 +720,44 @@ int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16) {
 }
 
 int tnn_colsum_bf16(const void* in, void* out_f32, int64_t rows, int64_t cols) {
+    // one launch, the summation order of tnn_bias_bf16_adam (so a step that fuses the bias optimizer in and one that does
+    // not produce the same bits)
+    return tnn_bias_bf16_adam(in, rows, cols, out_f32, nullptr, nullptr, nullptr, nullptr, 0.0, 0.0, 0.0, 0.0, nullptr);
+}
+
+int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32, void* dpred) {
+    return tnn_mse_bf16_tick(pred, y, n, m_global, loss_out_f32, nullptr, dpred, nullptr, 1.0, 1.0);
+}
+
+int tnn_bias_bf16_adam(const void* dz, int64_t rows, int64_t cols, void* db_f32, void* p_master, void* m, void* v, void* w_bf16,
+                       double lr, double b1, double b2, double eps, const void* pows_f64) {
     TNN_NEED_INIT();
     if (cols <= 0) return 0;
-    const int64_t strips = (cols + 63) / 64;
-    int64_t slices = 1;
-    const int64_t cap = (int64_t)tnn::num_cus() * 4;
-    if (strips < cap && rows >= 256) {
-        slices = cap / strips;
-        if (slices > rows / 64) slices = rows / 64;
-        if (slices > 64) slices = 64;
-        if (slices < 1) slices = 1;
-    }
-    const int64_t rps = (rows + slices - 1) / slices;
-    slices = (rows + rps - 1) / rps;
-    if (slices == 1) {
-        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)strips, 1), 256, 0, tnn::stream(), (const bf16_t*)in,
-                           (float*)out_f32, rows, cols, rps);
-        TNN_LAUNCH_OK();
-        return 0;
-    }
-    void* ws = nullptr;
-    if (tnn_malloc((size_t)(slices * cols) * sizeof(float), &ws)) return 1;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)strips, (unsigned)slices), 256, 0, tnn::stream(),
-                       (const bf16_t*)in, (float*)ws, rows, cols, rps);
-    int rc = tnn_reduce(TNN_RSUM, ws, out_f32, 1, slices, cols, TNN_F32);
-    tnn_free(ws);
-    if (rc) return rc;
+    TNN_REQUIRE(dz && db_f32 && rows > 0, "tnn_bias_bf16_adam: dz and db are required");
+    TNN_REQUIRE((p_master == nullptr) == (m == nullptr) && (p_master == nullptr) == (v == nullptr) &&
+                    (p_master == nullptr || pows_f64 != nullptr),
+                "tnn_bias_bf16_adam: p / m / v / pows go together");
+    hipLaunchKernelGGL(bias_bf16_kernel, dim3((unsigned)((cols + 63) / 64)), 256, 0, tnn::stream(), (const bf16_t*)dz, rows, cols,
+                       (float*)db_f32, (float*)p_master, (float*)m, (float*)v, (bf16_t*)w_bf16, (float)lr, (float)b1, (float)b2,
+                       (float)eps, (const double*)pows_f64, tnn::update_guard());
     TNN_LAUNCH_OK();
     return 0;
 }
 
-int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32, void* dpred) {
+int tnn_mse_bf16_tick(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32, void* loss_out2_f32,
+                      void* dpred, void* adam_pows_f64, double b1, double b2) {
     TNN_NEED_INIT();
     TNN_REQUIRE(n > 0 && m_global > 0, "tnn_mse_bf16: empty batch");
+    TNN_REQUIRE(loss_out_f32 != nullptr || loss_out2_f32 == nullptr, "tnn_mse_bf16_tick: loss_out2 needs loss_out");
     int64_t nb = tnn::stream_grid(n, 256);
     if (nb > 1024) nb = 1024;
     void* ws = nullptr;
     if (tnn_malloc((size_t)nb * sizeof(double), &ws)) return 1;
     hipLaunchKernelGGL(mse_bf16_kernel, (unsigned)nb, 256, 0, tnn::stream(), (const bf16_t*)pred, (const bf16_t*)y, n,
-                       1.0 / (double)m_global, (double*)ws, (bf16_t*)dpred);
+                       1.0 / (double)m_global, (double*)ws, (bf16_t*)dpred, (double*)adam_pows_f64, b1, b2, tnn::update_guard());
     if (loss_out_f32)
         hipLaunchKernelGGL(sum_partials_f32_kernel, 1, 64, 0, tnn::stream(), (const double*)ws, (int)nb,
-                           (float*)loss_out_f32);
+                           (float*)loss_out_f32, (float*)loss_out2_f32);
     tnn_free(ws);
     TNN_LAUNCH_OK();
     return 0;

@@ -153,14 +153,17 @@ int mlp16_forward(Mlp* h, const void* x16, int64_t rows) {
 // fused_adam: single-GPU step — Adam consumes dW_l in the GEMM's epilogue (tnn_gemm_bf16_nt_adam; the beta powers were
 // advanced by the caller).  dz_{l-1} is then computed BEFORE dW_l, because it reads the bf16 W_l that the epilogue rewrites.
 int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64_t m_global, void* loss_out,
-                   bool bucket = false, bool fused_adam = false) {
+                   bool bucket = false, bool fused_adam = false, bool tick = false) {
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, 4);
     if (h->loss_kind != 1) {
         tnn::set_error("bf16 trainer: only the sum-of-squares loss is implemented");
         return 2;
     }
-    MLP_TRY(tnn_mse_bf16(h->act[L - 1], y16, rows * h->w[L], m_global, loss_slot, h->dact[L - 1]));
+    // tick: one thread of the loss launch advances Adam's beta powers, its reduction files the loss to loss_out too
+    MLP_TRY(tnn_mse_bf16_tick(h->act[L - 1], y16, rows * h->w[L], m_global, loss_slot, tick ? loss_out : nullptr, h->dact[L - 1],
+                              tick ? h->pows : nullptr, h->b1, h->b2));
+    if (tick) loss_out = nullptr;
     for (int l = L - 1; l >= 0; --l) {
         const void* in = l == 0 ? x16 : h->act[l - 1];
         void* inT = l == 0 ? h->xT16 : h->actT16[l - 1];
@@ -181,10 +184,9 @@ int mlp16_backward(Mlp* h, const void* x16, const void* y16, int64_t rows, int64
             MLP_TRY(tnn_gemm_bf16_nt_adam(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows,
                                           h->keep_grads ? f32(h->grads, wo) : nullptr, f32(h->params, wo), f32(h->m, wo),
                                           f32(h->v, wo), at16(h->w16, wo), h->wT16[l], h->lr, h->b1, h->b2, h->eps, h->pows));
-            MLP_TRY(tnn_colsum_bf16(h->dact[l], f32(h->grads, bo), rows, h->w[l + 1]));
-            MLP_TRY(tnn_adam_master_bf16_2d(f32(h->params, bo), f32(h->grads, bo), f32(h->m, bo), f32(h->v, bo),
-                                            at16(h->w16, bo), nullptr, 1, h->w[l + 1], h->lr, h->b1, h->b2, h->eps,
-                                            h->pows, 0));
+            // db_l + Adam on b_l in one launch
+            MLP_TRY(tnn_bias_bf16_adam(h->dact[l], rows, h->w[l + 1], f32(h->grads, bo), f32(h->params, bo), f32(h->m, bo),
+                                       f32(h->v, bo), at16(h->w16, bo), h->lr, h->b1, h->b2, h->eps, h->pows));
             continue;
         }
         MLP_TRY(tnn_gemm_bf16_nt(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows,
@@ -247,8 +249,8 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
     const int64_t nb = h->bias_g_off[L];
     auto f32 = [](void* base, int64_t off) { return (void*)((float*)base + off); };
     MLP_TRY(mlp16_forward(h, x16, rows));
-    MLP_TRY(tnn_mse_bf16(h->act[L - 1], y16, rows * h->w[L], rows * world, h->bias_g + nb, h->dact[L - 1]));
-    MLP_TRY(tnn_adam_tick(h->pows, h->b1, h->b2));
+    MLP_TRY(tnn_mse_bf16_tick(h->act[L - 1], y16, rows * h->w[L], rows * world, h->bias_g + nb, nullptr, h->dact[L - 1], h->pows,
+                              h->b1, h->b2));
     int rc = 0, chains = 0;
     for (int l = L - 1; l >= 0 && !rc; --l) {
         const void* in = l == 0 ? x16 : h->act[l - 1];
@@ -263,7 +265,8 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
         if (!rc)
             rc = tnn_gemm_bf16_nt(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows, at16(h->g16, wo), h->w[l + 1],
                                   TNN_BF16, nullptr, TNN_ACT_NONE, 0, nullptr, 0);
-        if (!rc) rc = tnn_colsum_bf16(h->dact[l], h->bias_g + h->bias_g_off[l], rows, h->w[l + 1]);
+        if (!rc) rc = tnn_bias_bf16_adam(h->dact[l], rows, h->w[l + 1], h->bias_g + h->bias_g_off[l], nullptr, nullptr, nullptr,
+                                         nullptr, h->lr, h->b1, h->b2, h->eps, nullptr);
         if (rc) break;
         const int64_t n_shard = h->w[l] / world * h->w[l + 1], so = wo + (int64_t)rank * n_shard;
         rc = tnn_comm_chain_begin();
@@ -559,8 +562,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // 450-495 for GEMM + optimizer).  With the gradient ALSO stored the fused launch is slower than the two (517 us):
         // keep_grads stays on the separate launches.
         MLP_TRY(mlp16_forward(h, x, rows));
-        MLP_TRY(tnn_adam_tick(h->pows, h->b1, h->b2));
-        return mlp16_backward(h, x, y, rows, rows, loss_out, false, true);
+        return mlp16_backward(h, x, y, rows, rows, loss_out, false, true, true);
     }
     if (!h->bf16 && h->dtype == TNN_F32 && h->opt_kind == 1 && !h->keep_grads && h->n_params >= (1 << 22)) {
         // large fp32 nets, single GPU, weight gradients not wanted in the arena: Adam in the epilogue of every dW GEMM
