@@ -203,3 +203,47 @@ def test_bf16_trainer_fused_step_equals_separate_launches(monkeypatch):
             assert np.array_equal(got[k], runs[0][k]), k
     for l in range(3):
         assert np.array_equal(runs[1][4][l], runs[0][4][l])              # stored gradients of the default step
+
+
+@pytest.mark.gpu
+def test_bias_launch_and_bf16_gradient_adam_vs_numpy():
+    """tnn_bias_bf16_adam (db = column sums of a bf16 dz + Adam on the fp32 master bias + its bf16 copy, one launch) and
+    tnn_adam_master_g16 (Adam on a slice whose gradient arrives as bf16: the reduce-scattered slice of the sharded-optimizer
+    step) against float64 numpy; ragged column counts and an unaligned view take the element-wise path."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(77)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for rows, cols in ((512, 8192), (100, 70), (64, 4)):
+        dz = bf16.round_to_bf16((rs.randn(rows, cols) * 1e-2).astype(np.float32))
+        DZ = bf16.to_bf16(dz)
+        p0, m0, v0 = rs.randn(cols).astype(np.float32), (rs.randn(cols) * 1e-3).astype(np.float32), (rs.rand(cols) * 1e-5).astype(np.float32)
+        P, M, V, DB = tn.asarray(p0), tn.asarray(m0), tn.asarray(v0), tn.zeros((cols,))
+        W16 = tn.empty((cols,), np.uint16)
+        pows = tn.asarray(np.array([b1 ** 3, b2 ** 3, 0, 0]), dtype=np.float64)
+        lib.bias_bf16_adam(DZ._ptr, rows, cols, DB._ptr, P._ptr, M._ptr, V._ptr, W16._ptr, lr, b1, b2, eps, pows._ptr)
+        g = dz.astype(np.float64).sum(0)
+        np.testing.assert_allclose(np.asarray(DB), g, rtol=0, atol=2e-6 * np.abs(dz).sum(0).max())
+        gd = np.asarray(DB, dtype=np.float64)                        # the update is checked on the device's own sums
+        ob1, ob2 = float(np.float32(1) - np.float32(b1)), float(np.float32(1) - np.float32(b2))   # the kernels' float32 1 - beta
+        m1 = m0 + ob1 * (gd - m0)
+        v1 = v0 + ob2 * (gd * gd - v0)
+        p1 = p0 - lr * (m1 / (1 - b1 ** 3)) / (np.sqrt(v1 / (1 - b2 ** 3)) + eps)
+        np.testing.assert_allclose(np.asarray(M), m1, rtol=0, atol=2e-6 * np.abs(m1).max())
+        np.testing.assert_allclose(np.asarray(V), v1, rtol=0, atol=2e-6 * np.abs(v1).max())
+        np.testing.assert_allclose(np.asarray(P), p1, rtol=0, atol=2e-6 * np.abs(p1).max())
+        assert np.array_equal(np.asarray(bf16.to_f32(W16)), bf16.round_to_bf16(np.asarray(P)))
+    for n in (8192 * 16, 1000, 7):
+        g = bf16.round_to_bf16((rs.randn(n) * 1e-2).astype(np.float32))
+        p0, m0, v0 = rs.randn(n).astype(np.float32), (rs.randn(n) * 1e-3).astype(np.float32), (rs.rand(n) * 1e-5).astype(np.float32)
+        P, M, V, G16, W16 = tn.asarray(p0), tn.asarray(m0), tn.asarray(v0), bf16.to_bf16(g), tn.empty((n,), np.uint16)
+        pows = tn.asarray(np.array([b1 ** 2, b2 ** 2, 0, 0]), dtype=np.float64)
+        lib.adam_master_g16(P._ptr, G16._ptr, M._ptr, V._ptr, W16._ptr, n, lr, b1, b2, eps, pows._ptr)
+        gd = g.astype(np.float64)
+        m1 = m0 + ob1 * (gd - m0)
+        v1 = v0 + ob2 * (gd * gd - v0)
+        p1 = p0 - lr * (m1 / (1 - b1 ** 2)) / (np.sqrt(v1 / (1 - b2 ** 2)) + eps)
+        np.testing.assert_allclose(np.asarray(M), m1, rtol=0, atol=2e-6 * np.abs(m1).max())
+        np.testing.assert_allclose(np.asarray(V), v1, rtol=0, atol=2e-6 * np.abs(v1).max())
+        np.testing.assert_allclose(np.asarray(P), p1, rtol=0, atol=2e-6 * np.abs(p1).max())
+        assert np.array_equal(np.asarray(bf16.to_f32(W16)), bf16.round_to_bf16(np.asarray(P)))
