@@ -248,6 +248,101 @@ def clip_(ts, min, max):
 
 
 # ---------------------------------------------------------------------- fused nodes (this package's own)
+class _DenseVjp(object):
+    """The vjps of one ops.dense_ node (see dense_): per-edge forms for schedulers that ask edge by edge (the reference's
+    own recursion), `fused_vjp` for Tensor.backward, which offers all edges at once."""
+    __slots__ = ("x", "w", "b", "xv", "wv", "bv", "out", "m", "k", "n", "dt", "relu", "x_relu", "edges", "shared")
+
+    def __init__(self, x, w, b, xv, wv, bv, out, m, k, n, dt, relu, x_relu):
+        self.x, self.w, self.b, self.xv, self.wv, self.bv, self.out = x, w, b, xv, wv, bv, out
+        self.m, self.k, self.n, self.dt, self.relu, self.x_relu = m, k, n, dt, relu, x_relu
+        self.edges = ()
+        self.shared = []              # [(g object, db)] computed together with dW, waiting for the bias vjp
+
+    def dz_of(self, g_in):
+        """Gradient w.r.t. the pre-activation: g itself, or g * [z >= 0] for the fused ReLU unless a consumer's dX
+        launch applied that mask already."""
+        g = da.asarray(g_in)
+        if not self.relu or g._tag is self.out:
+            return g
+        return da.mul_signmask(g, self.out)
+
+    def d_x(self, g):
+        return self.dz_of(g) @ self.wv.T
+
+    def _dw_db(self, g_in, dest):
+        m, k, n, dt, b = self.m, self.k, self.n, self.dt, self.b
+        g = self.dz_of(g_in)
+        if g.shape != (m, n) or g.dtype != dt or g._hv is not None or not g.size:
+            return None
+        g = g._contig()
+        dw = dest if dest is not None else da.empty((k, n), dt)
+        db = None
+        if b.requires_grad:
+            home = getattr(b, "_grad_home", None)
+            if (home is not None and b._grad is None and b._grad_zero and not getattr(b, "_home_lent", False)
+                    and home.size == n and home.dtype == dt):
+                db = home                            # the bias' own arena view: lent out once per backward
+                b._home_lent = True
+            else:
+                db = da.empty(tuple(b.shape), dt)
+        _lib.get().gemm_tn_colsum(k, n, m, self.xv._ptr, k, g._ptr, n, dw._ptr, n, db._ptr if db is not None else None,
+                                  dw._code())
+        if db is not None:
+            del self.shared[:]
+            self.shared.append((g_in, db))
+        return dw
+
+    def d_w(self, g):
+        dw = self._dw_db(g, None)
+        return dw if dw is not None else self.xv.T @ self.dz_of(g)
+
+    def d_w_into(self, g, dest):
+        if dest.shape != (self.k, self.n) or dest.dtype != self.dt or dest._t or dest._hv is not None:
+            return self.d_w(g)
+        dw = self._dw_db(g, dest)
+        return dw if dw is not None else self.d_w(g)
+
+    d_w.into = d_w_into               # Tensor.backward: the first contribution of a lazily-zero leaf goes to its arena view
+
+    def d_b(self, g):
+        if self.shared and self.shared[0][0] is g:
+            return self.shared.pop()[1]
+        return _unbroadcast(self.dz_of(g), self.b.shape)
+
+    def fused_vjp(self, g_in, homes):
+        """All edges from ONE tnn_dense_bwd launch.  homes[i]: the arena view of edge i's tensor when the scheduler
+        lends it (first contribution of a lazily-zero leaf), else None.  Returns None to decline (odd gradients)."""
+        m, k, n, dt, edges = self.m, self.k, self.n, self.dt, self.edges
+        g = da.asarray(g_in)
+        if g.shape != (m, n) or g.dtype != dt or g._hv is not None or g._t or not g.size:
+            return None
+        if "x" in edges and not self.x_relu:
+            return None                               # dX without a mask epilogue: the per-edge GEMMs
+        g = self.dz_of(g)._contig()
+        xv = self.xv
+        res = {}
+        dw = db = dx = None
+        for name, home in zip(edges, homes):
+            if name == "w":
+                ok = home is not None and home.shape == (k, n) and home.dtype == dt and not home._t and home._hv is None
+                dw = home if ok else da.empty((k, n), dt)
+                res["w"] = dw
+            elif name == "b":
+                ok = home is not None and home.size == n and home.dtype == dt and not home._t and home._hv is None
+                db = home if ok else da.empty(tuple(self.b.shape), dt)
+                res["b"] = db
+            else:
+                dx = da.empty((m, k), dt)
+                dx._tag = xv                          # already multiplied by x's ReLU mask
+                res["x"] = dx
+        if dw is None:
+            dw = da.empty((k, n), dt)                 # w frozen: the launch still needs somewhere to write
+        _lib.get().dense_bwd(m, k, n, xv._ptr, g._ptr, self.wv._ptr, dw._ptr, db._ptr if db is not None else None,
+                             dx._ptr if dx is not None else None, xv._ptr if dx is not None else None, dw._code())
+        return [res[name] for name in edges]
+
+
 def dense_(x, w, b, relu=False, head_w=None, lazy=False):
     """x @ w + b as ONE GEMM with a bias epilogue (core/layers.py:49); the vjps are the NT / TN GEMMs of
     dot_ (core/ops.py:156-160) and the column-sum of add_'s un-broadcast (:49-55).
@@ -299,92 +394,11 @@ def dense_(x, w, b, relu=False, head_w=None, lazy=False):
     if relu:
         out._tag = da.RELU_SIGN
 
-    def dz_of(g_in):
-        """Gradient w.r.t. the pre-activation: g itself, or g * [z >= 0] for the fused ReLU unless a consumer's dX
-        launch applied that mask already."""
-        g = da.asarray(g_in)
-        if not relu or g._tag is out:
-            return g
-        return da.mul_signmask(g, out)
-
-    # ---- per-edge vjps (used when the scheduler cannot offer all edges at once, e.g. the reference's own recursion)
-    shared = []                       # [(g object, db)] computed together with dW, waiting for the bias vjp
-
-    def d_x(g):
-        return dz_of(g) @ wv.T
-
-    def _dw_db(g_in, dest):
-        g = dz_of(g_in)
-        if g.shape != (m, n) or g.dtype != dt or g._hv is not None or not g.size:
-            return None
-        g = g._contig()
-        dw = dest if dest is not None else da.empty((k, n), dt)
-        db = None
-        if b.requires_grad:
-            home = getattr(b, "_grad_home", None)
-            if (home is not None and b._grad is None and b._grad_zero and not getattr(b, "_home_lent", False)
-                    and home.size == n and home.dtype == dt):
-                db = home                            # the bias' own arena view: lent out once per backward
-                b._home_lent = True
-            else:
-                db = da.empty(tuple(b.shape), dt)
-        _lib.get().gemm_tn_colsum(k, n, m, xv._ptr, k, g._ptr, n, dw._ptr, n, db._ptr if db is not None else None,
-                                  dw._code())
-        if db is not None:
-            del shared[:]
-            shared.append((g_in, db))
-        return dw
-
-    def d_w(g):
-        dw = _dw_db(g, None)
-        return dw if dw is not None else xv.T @ dz_of(g)
-
-    def d_w_into(g, dest):
-        if dest.shape != (k, n) or dest.dtype != dt or dest._t or dest._hv is not None:
-            return d_w(g)
-        dw = _dw_db(g, dest)
-        return dw if dw is not None else d_w(g)
-    d_w.into = d_w_into
-
-    def d_b(g):
-        if shared and shared[0][0] is g:
-            return shared.pop()[1]
-        return _unbroadcast(dz_of(g), b.shape)
-
-    parents = [(x, d_x), (w, d_w), (b, d_b)]
-    node = _make_node(x.__class__, out, parents)
-    edges = [name for name, t in (("x", x), ("w", w), ("b", b)) if t.requires_grad]
-
-    def fused_vjp(g_in, homes):
-        """All edges from ONE tnn_dense_bwd launch.  homes[i]: the arena view of edge i's tensor when the scheduler
-        lends it (first contribution of a lazily-zero leaf), else None.  Returns None to decline (odd gradients)."""
-        g = da.asarray(g_in)
-        if g.shape != (m, n) or g.dtype != dt or g._hv is not None or g._t or not g.size:
-            return None
-        if "x" in edges and not x_relu:
-            return None                               # dX without a mask epilogue: the per-edge GEMMs
-        g = dz_of(g)._contig()
-        res = {}
-        dw = db = dx = None
-        for name, home in zip(edges, homes):
-            if name == "w":
-                ok = home is not None and home.shape == (k, n) and home.dtype == dt and not home._t and home._hv is None
-                dw = home if ok else da.empty((k, n), dt)
-                res["w"] = dw
-            elif name == "b":
-                ok = home is not None and home.size == n and home.dtype == dt and not home._t and home._hv is None
-                db = home if ok else da.empty(tuple(b.shape), dt)
-                res["b"] = db
-            else:
-                dx = da.empty((m, k), dt)
-                dx._tag = xv                          # already multiplied by x's ReLU mask
-                res["x"] = dx
-        if dw is None:
-            dw = da.empty((k, n), dt)                 # w frozen: the launch still needs somewhere to write
-        _lib.get().dense_bwd(m, k, n, xv._ptr, g._ptr, wv._ptr, dw._ptr, db._ptr if db is not None else None,
-                             dx._ptr if dx is not None else None, xv._ptr if dx is not None else None, dw._code())
-        return [res[name] for name in edges]
-
+    # the vjps live on ONE context object (bound methods) instead of eight closures per call: the op-level step is host-bound
+    ctx = _DenseVjp(x, w, b, xv, wv, bv, out, m, k, n, dt, relu, x_relu)
+    node = _make_node(x.__class__, out, [(x, ctx.d_x), (w, ctx.d_w), (b, ctx.d_b)])
+    edges = ctx.edges = [name for name, t in (("x", x), ("w", w), ("b", b)) if t.requires_grad]
+    fused_vjp = ctx.fused_vjp
     node._fused_vjp = fused_vjp
     if lazy:
         node._head = (x, w, b, xv, wv, bv, edges)     # what softmax_nll_ needs to run the head in one launch

@@ -320,13 +320,18 @@ class Tensor(object):
             for j, dep in enumerate(node.dependency):
                 child, fn = dep["tensor"], dep["grad_fn"]
                 key = id(child)
-                into = getattr(fn, "into", None)
                 if contribs is not None:
                     contrib = contribs[j]
-                elif into is not None and lendable(child) is not None:
-                    contrib = into(g, child._grad_home)
                 else:
-                    contrib = fn(g)
+                    # a vjp may offer a form that writes straight into the leaf's arena view (`fn.into`; for a bound
+                    # method the attribute sits on the function, so it is bound to the same object here)
+                    into = getattr(fn, "into", None)
+                    if into is not None and lendable(child) is not None:
+                        owner = getattr(fn, "__self__", None)
+                        contrib = (into(owner, g, child._grad_home) if owner is not None
+                                   else into(g, child._grad_home))
+                    else:
+                        contrib = fn(g)
                 if key in pending:
                     pending[key] = pending[key] + contrib
                 else:
