@@ -10,7 +10,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p, POINTER
 
-_HERE = os.path.dirname(os.path.abspath(__file__))
+import sys
+
+# the package directory — taken from the package, not from __file__: this module may run from its compiled copy under
+# _compiled/ (_host_build.py)
+_HERE = os.path.dirname(os.path.abspath(sys.modules[__name__.rpartition(".")[0]].__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtnn_hip.so")
 
 # dtype / op codes (must mirror include/tnn_hip.h)
