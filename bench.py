@@ -1023,6 +1023,8 @@ def main():
                 paths["note"] = ("the same step on the drop-in Tensor/ops/Dense/ReLU/SoftmaxCrossEntropyLoss/Adam/Model API: one "
                                  "launch per op issued from Python (eager) / the same loop body recorded with tn.capture, 16 steps on "
                                  "their resident batches per hipGraph, and replayed (graph)")
+                paths["host_modules"] = ("compiled ahead of time from the .py sources (tinynn-autograd_amd/_host_build.py)"
+                                         if tn.host_modules_compiled() else "interpreted")
                 line["paths"] = paths
                 c = FusedRun(WIDTHS_C, 512, "mse", 2, use_graph=use_graph)
                 rc = measure(solo, c, 3, 20, 3, 0.0, 512)
