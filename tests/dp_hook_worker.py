@@ -6,7 +6,9 @@ RCCL runs here through gloo; the launch sequence and the host logic are the same
 
   mode "D"        strong-scaling config D: global batch 1024, 1024/W rows per rank, softmax loss, against
                   the reference's single-process trajectory tests/golden/traj_D_adam.npz — all-reduce + Adam tail
-  mode "Dbucket"  the same with the arena split into one bucket per layer (TNN_BUCKET_BYTES=1)
+                  (256 rows per rank at world 4: the row-blocked form of the one-launch head, two blocks of 128 rows)
+  mode "Dbucket"  the same on the generic path (TNN_HEAD_ROW_BLOCKS=0) with the arena split into one bucket per layer
+                  (TNN_BUCKET_BYTES=1)
   mode "Cbucket"  config-C-small (256-256-256 autoencoder, bs 64, sum-of-squares), bucketed, against traj_C_small.npz
   mode "A"        the bs-128 trajectory split over the ranks (32 rows each at world 4): the shard's head fits the one-launch
                   form, so the step takes the RCCL-shaped 6-launch structure — statistics as a launch of their own

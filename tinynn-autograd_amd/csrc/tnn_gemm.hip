@@ -1833,8 +1833,8 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
                                       void* out_pair_f32, int exchange, int dtype) {
     TNN_NEED_INIT();
     if (int rc = check_shapes("tnn_dense_fwd_head_partials_stats", 0, 0, M, N, K, lda, ldb, ldc)) return rc;
-    TNN_REQUIRE(dtype == TNN_F32 && M >= 1 && M <= 128 && N == 128 && head_c == 10,
-                "tnn_dense_fwd_head_partials_stats: f32, rows <= 128, 128 hidden units, 10 classes (ask tnn_mlp_head_fits)");
+    TNN_REQUIRE(dtype == TNN_F32 && M >= 1 && M <= 1024 && N == 128 && head_c == 10,
+                "tnn_dense_fwd_head_partials_stats: f32, rows <= 1024, 128 hidden units, 10 classes");
     TNN_REQUIRE(head_w && head_z && head_b && y && ticket_u32 && out_pair_f32,
                 "tnn_dense_fwd_head_partials_stats: head_w, head_z, head_b, y, ticket and out_pair are required");
     TNN_REQUIRE(act == TNN_ACT_NONE || act == TNN_ACT_RELU, "tnn_dense_fwd_head_partials_stats: activation %d", act);

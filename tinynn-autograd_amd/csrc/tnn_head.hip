@@ -16,6 +16,10 @@
 #include "tnn_p2p.h"
 #include "tnn_head_stats.h"
 
+#ifndef TNN_HEAD_PREFETCH
+#define TNN_HEAD_PREFETCH 1
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   * da: thread (column j, row group) with W[j][:] in registers and dz rows broadcast from LDS; dW: 8 x C outputs per
 //     workgroup, 4 row-quarters per output summed with two quad-permute DPP steps.
 struct HeadMArgs {
-    int m, rpb;                      // rows (<= 128); da rows per workgroup
+    int m, rpb;                      // rows (<= 128; SH == 2: any number, walked in blocks of 128); da rows per workgroup
     int vec;                         // rows even, zpart / y 16-B aligned: the partial logits are staged with 16-B loads
     int m_global;                    // data-parallel (SH kernels): rows of the GLOBAL batch; the loss written is this rank's share
     const float* ext_pairs;          // SH == 2: {M_q, S_q} pairs from an earlier launch (head_stats_kernel [+ all-gather])
@@ -62,34 +66,46 @@ template <int C, int NP>
 struct HeadStage {
     f32x4 v[NP], yv;
 };
+// mb / row0: the row block staged (rows [row0, row0 + mb) of the p.m rows the partial array was written for).
 template <int C, int NP>
-__device__ __forceinline__ void head_stage_request(const HeadMArgs& p, const int t, HeadStage<C, NP>& h) {
-    const int n = p.m * C;
+__device__ __forceinline__ void head_stage_request(const HeadMArgs& p, const int t, HeadStage<C, NP>& h, const int mb, const int row0) {
+    const int n = mb * C, stride = p.m * C, base = row0 * C;
     if (p.vec && t < (n >> 2)) {
 #pragma unroll
-        for (int tn = 0; tn < NP; ++tn) h.v[tn] = *reinterpret_cast<const f32x4*>(p.zpart + (size_t)tn * n + 4 * t);
-        h.yv = *reinterpret_cast<const f32x4*>(p.y + 4 * t);
+        for (int tn = 0; tn < NP; ++tn) h.v[tn] = *reinterpret_cast<const f32x4*>(p.zpart + (size_t)tn * stride + base + 4 * t);
+        h.yv = *reinterpret_cast<const f32x4*>(p.y + base + 4 * t);
     }
 }
 template <int C, int NP>
-__device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t, const HeadStage<C, NP>& h, float* zs, float* ys) {
+__device__ __forceinline__ f32x4 head_stage_bias(const HeadMArgs& p, const int t) {
+    // the bias of this thread's four staged elements — the same for every row block (a block starts at a multiple of C floats)
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (p.vec) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = p.b[(4 * t + i) % C];
+    }
+    return b;
+}
+template <int C, int NP>
+__device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t, const HeadStage<C, NP>& h, float* zs, float* ys,
+                                                 const int mb, const int row0, const f32x4 bias4) {
     static_assert(NP == 8, "the partial-sum tree is written for 8 tiles");
-    const int n = p.m * C;
+    const int n = mb * C, stride = p.m * C, base = row0 * C;
     if (p.vec) {
         if (t < (n >> 2)) {
             f32x4 s = ((h.v[0] + h.v[1]) + (h.v[2] + h.v[3])) + ((h.v[4] + h.v[5]) + (h.v[6] + h.v[7]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] += p.b[(4 * t + i) % C];
+            s += bias4;
             *reinterpret_cast<f32x4*>(zs + 4 * t) = s;
             *reinterpret_cast<f32x4*>(ys + 4 * t) = h.yv;
         }
     } else {
+#pragma unroll 1                                   // the rare path (odd row count): keep its registers off the kernel's budget
         for (int e = t; e < n; e += 512) {
             float u[NP];
 #pragma unroll
-            for (int tn = 0; tn < NP; ++tn) u[tn] = p.zpart[(size_t)tn * n + e];
+            for (int tn = 0; tn < NP; ++tn) u[tn] = p.zpart[(size_t)tn * stride + base + e];
             zs[e] = (((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]))) + p.b[e % C];
-            ys[e] = p.y[e];
+            ys[e] = p.y[base + e];
         }
     }
 }
@@ -102,10 +118,12 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
 // DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
 // SH (data parallel): 0 single GPU; 2 the shards' softmax statistics were reduced (and, on the peer-to-peer transport,
 // exchanged and merged) at the tail of the previous launch (dense_fwd_head_kernel) and arrive through HeadMArgs::ext_pairs
-template <int H, int C, bool PART, int CUT, bool DA, int SH = 0>
+// RB (with SH == 2 only): the rows are walked in blocks of 128 (any number of rows); without it one block, as before
+template <int H, int C, bool PART, int CUT, bool DA, int SH = 0, bool RB = false>
 __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
+    static_assert(!RB || (SH == 2 && PART && !DA && CUT == 0), "row blocks exist in the form that takes the statistics from memory only");
     constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
     __shared__ float zs[ROWS * ZS];                // logits (MFMA form only); odd row stride: conflict-free with lane = row
     __shared__ __attribute__((aligned(16))) float ws[H * WS];      // W, rows padded to 12 (columns >= C hold 0)
@@ -113,51 +131,88 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     __shared__ __attribute__((aligned(16))) float dzT[C * TS];     // dz^T [c][row]: the dW / db phases read 4 rows at a time
     __shared__ __attribute__((aligned(16))) float asT[JPB * TS];   // a[:, 8g : 8g + 8]^T [j][row] for this workgroup's dW rows
     __shared__ double red[8][4];
+    __shared__ __attribute__((aligned(16))) float zst[PART ? ROWS * C : 4], yst[PART ? ROWS * C : 4];   // staged logits / labels
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
     const int r = t & (ROWS - 1), kq = t >> 7;     // da phase: column r, row group kq
     const int srow = t >> 2, sub = t & 3;          // statistics: row srow, classes sub, sub + 4, sub + 8
-    const int m = p.m;
-    const bool slive = srow < m;
+    // SH == 2 (statistics from memory: nothing couples the rows inside this launch any more): ANY number of rows, taken in
+    // blocks of 128 whose contributions to dW / db / the loss are accumulated in registers; otherwise one block
+    const int nb = RB ? (p.m + ROWS - 1) / ROWS : 1;
 
-    // ---- every global read of the kernel is requested here, before the first use, in as few vector-memory
+    // ---- the loads that do not depend on the row block
+    constexpr int WV = H * C / 4;                                       // float4 pieces of W (320)
+    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+    if (t < WV) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
+    // Adam's beta powers: read NOW (a dependent global round trip at the very end of workgroup 0 cost 1.3 us of the launch)
+    double pw0 = 0.0, pw1 = 0.0;
+    if (g == 0 && t == 0 && p.tick) { pw0 = p.tick[0]; pw1 = p.tick[1]; }
+
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PART) bias4 = head_stage_bias<C, NP>(p, t);
+    float dws0 = 0.f, dws1 = 0.f;                  // this thread's dW partial sums (threads < JPB * C * 4)
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};            // workgroup 0, wave 7: db partial sums
+    double Lsum = 0.0;
+    float M = 0.f;
+    double S = 0.0;
+    // row blocks: the global reads of block rb + 1 are requested as soon as block rb's staged values sit in LDS (a block's
+    // chain of loads -> LDS -> statistics -> products is ~1 us of dependent latency plus the loads' own 1.5-2 us, which this hides)
+    HeadStage<C, NP> stg_nx;
+    f32x4 asl_nx = {0.f, 0.f, 0.f, 0.f};
+    constexpr bool PF = TNN_HEAD_PREFETCH;
+    if constexpr (RB && PF) {
+        const int m0b = min(ROWS, p.m);
+        head_stage_request<C, NP>(p, t, stg_nx, m0b, 0);
+        asl_nx = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m0b - 1) * H + g * JPB + 4 * (t & 1));
+    }
+    for (int rb = 0; rb < nb; ++rb) {
+    int row0 = rb * ROWS;
+    // opaque to the optimiser: otherwise every global address of the block is strength-reduced into a loop-carried 64-bit
+    // register pair (~50 VGPRs, the kernel drops to one workgroup per CU)
+    if constexpr (RB) asm volatile("" : "+s"(row0));
+    const int m = RB ? min(ROWS, p.m - row0) : p.m;
+    const float* const a_rb = p.a + (size_t)row0 * H;
+    const bool slive = srow < m;
+    if (rb) __syncthreads();                       // every LDS image of the previous block has been consumed
+    int tt = t;                                    // the thread index as the block's global addresses see it (opaque, see row0)
+    if constexpr (RB) asm volatile("" : "+v"(tt));
+
+    // ---- every global read of the block is requested here, before the first use, in as few vector-memory
     // instructions as possible; no exec-mask branches around loads: rows beyond m read a clamped (valid) address and
     // are neutralised in the arithmetic (their dz is 0, so whatever they loaded never reaches an output).
     const int sr = min(srow, m - 1);
     float zc[3] = {0.f, 0.f, 0.f}, yc[3];
-    __shared__ __attribute__((aligned(16))) float zst[PART ? ROWS * C : 4], yst[PART ? ROWS * C : 4];   // staged logits / labels
     HeadStage<C, NP> stg;
     f32x4 av[PART ? 1 : KC];
     if constexpr (PART) {
-        head_stage_request<C, NP>(p, t, stg);
+        if constexpr (RB && PF) stg = stg_nx;
+        else head_stage_request<C, NP>(p, tt, stg, m, row0);
     } else {
-        const float* arow = p.a + (size_t)min(16 * wid + i16, m - 1) * H + 4 * grp;
+        const float* arow = a_rb + (size_t)min(16 * wid + i16, m - 1) * H + 4 * grp;
 #pragma unroll
         for (int c = 0; c < KC; ++c) av[c] = *reinterpret_cast<const f32x4*>(arow + 16 * c);
     }
     if constexpr (!PART) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
+        for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)(row0 + sr) * C + min(sub + 4 * i, C - 1)];
     }
-    constexpr int WV = H * C / 4;                                       // float4 pieces of W (320)
-    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
-    if (t < WV) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
     float am[2] = {0.f, 0.f};
     const int r0 = g * p.rpb, rend = min(m, r0 + p.rpb);
     if constexpr (DA) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
+        for (int i = 0; i < 2; ++i) am[i] = a_rb[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
     }
-    const f32x4 asl = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
-    // Adam's beta powers: read NOW (a dependent global round trip at the very end of workgroup 0 cost 1.3 us of the launch)
-    double pw0 = 0.0, pw1 = 0.0;
-    if (g == 0 && t == 0 && p.tick) { pw0 = p.tick[0]; pw1 = p.tick[1]; }
+    f32x4 asl;
+    if constexpr (RB && PF) asl = asl_nx;
+    else asl = *reinterpret_cast<const f32x4*>(a_rb + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
 
     // ---- W and the dW slice of a -> LDS (visible after the first barrier below)
-    if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
-    if (t < WV) {
+    if (rb == 0) {
+        if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
+        if (t < WV) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
+            for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
+        }
     }
     if (t < 2 * ROWS) {
 #pragma unroll
@@ -165,7 +220,15 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
 
     if constexpr (PART) {
-        head_stage_store<C, NP>(p, t, stg, zst, yst);
+        head_stage_store<C, NP>(p, t, stg, zst, yst, m, row0, bias4);
+        if constexpr (RB && PF) {
+            // the staged values are in LDS, their registers are free: the next block's reads travel from here on
+            if (rb + 1 < nb) {
+                const int m1 = min(ROWS, p.m - row0 - ROWS);
+                head_stage_request<C, NP>(p, tt, stg_nx, m1, row0 + ROWS);
+                asl_nx = *reinterpret_cast<const f32x4*>(a_rb + (size_t)(ROWS + min((tt & 255) >> 1, m1 - 1)) * H + g * JPB + 4 * (tt & 1));
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -206,13 +269,13 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
     const float mx = st.mx, urow = st.urow;
-    const float M = st.M;
-    const double S = st.S;
-    const double L = st.L;
+    M = st.M;
+    S = st.S;
+    Lsum += st.L;
     double inv_m = 1.0 / (double)m;
     if constexpr (SH != 0) inv_m = 1.0 / (double)p.m_global;
     if constexpr (CUT == 2) {
-        p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
+        p.da[(size_t)g * 512 + t] = (float)(S + st.L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
         return;
     }
     float dzc[3];
@@ -262,46 +325,52 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     // The first version read a[row][j] and dz[row][c] element by element: 64 LDS reads per thread, 0.7 us.
     if (t < JPB * C * 4) {                                      // 320 threads = 5 whole waves
         const int q = t & 3, o = t >> 2, jl = o / C, c = o - jl * C;
-        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < ROWS / 16; ++i) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(asT + jl * TS + 16 * i + 4 * q);
             const f32x4 d4 = *reinterpret_cast<const f32x4*>(dzT + c * TS + 16 * i + 4 * q);
-            s0 = fmaf(a4[0], d4[0], s0); s1 = fmaf(a4[1], d4[1], s1);
-            s0 = fmaf(a4[2], d4[2], s0); s1 = fmaf(a4[3], d4[3], s1);
+            dws0 = fmaf(a4[0], d4[0], dws0); dws1 = fmaf(a4[1], d4[1], dws1);
+            dws0 = fmaf(a4[2], d4[2], dws0); dws1 = fmaf(a4[3], d4[3], dws1);
         }
-        float s = s0 + s1;
+    }
+    if (g == 0 && wid == 7) {                                   // db[c] = sum_r dz[r][c]: lane (c, row quarter)
+        const int c = min(lane & 15, C - 1), rq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) dbacc += *reinterpret_cast<const f32x4*>(dzT + c * TS + 32 * rq + 4 * i);
+    }
+    if (g == G - 1 && slive) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (valid[i]) {
+                if (p.logits) p.logits[(size_t)(row0 + srow) * C + sub + 4 * i] = zc[i];
+                if (p.dz) p.dz[(size_t)(row0 + srow) * C + sub + 4 * i] = dzc[i];
+            }
+    }
+    }   // row blocks
+
+    if (t < JPB * C * 4) {
+        const int q = t & 3, o = t >> 2, jl = o / C, c = o - jl * C;
+        float s = dws0 + dws1;
         s += tnn::dpp_move<0xB1, 0xf>(0.f, s);
         s += tnn::dpp_move<0x4E, 0xf>(0.f, s);
         if (q == 0) p.dw[(size_t)(g * JPB + jl) * C + c] = s;
     }
     if constexpr (CUT == 5) return;
     if (g == 0) {
-        if (wid == 7) {                                         // db[c] = sum_r dz[r][c]: lane (c, row quarter)
-            const int c = min(lane & 15, C - 1), rq = lane >> 4;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < ROWS / 16; ++i) acc += *reinterpret_cast<const f32x4*>(dzT + c * TS + 32 * rq + 4 * i);
-            float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (wid == 7) {
+            float s = (dbacc[0] + dbacc[1]) + (dbacc[2] + dbacc[3]);
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
             if (lane < C) p.db[lane] = s;
         }
         if (t == 0) {
             // data parallel: this rank's SHARE of the global loss (the all-reduce of the gradient arena sums the shares)
-            if (p.loss) p.loss[0] = SH != 0 ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
-                                       : (float)((double)logf((float)S) + (double)M - L * inv_m);
+            const double inv_all = 1.0 / (double)(SH != 0 ? p.m_global : p.m);
+            if (p.loss) p.loss[0] = SH != 0 ? (float)((((double)logf((float)S) + (double)M) * (double)p.m - Lsum) * inv_all)
+                                       : (float)((double)logf((float)S) + (double)M - Lsum * inv_all);
             if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
             if (p.tick) { p.tick[0] = pw0 * p.b1; p.tick[1] = pw1 * p.b2; }
         }
-    }
-    if (g == G - 1 && slive) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (valid[i]) {
-                if (p.logits) p.logits[(size_t)srow * C + sub + 4 * i] = zc[i];
-                if (p.dz) p.dz[(size_t)srow * C + sub + 4 * i] = dzc[i];
-            }
     }
 }
 
@@ -331,12 +400,12 @@ struct HeadBwdArgs {
 };
 
 // CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
-template <int H, int C, int CUT = 0, int SH = 0>
-__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
+template <int H, int C, int CUT = 0, int SH = 0, bool RB = false>
+__global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
     if ((int)blockIdx.x < G) {
-        head_block<H, C, true, 0, false, SH>(p, (int)blockIdx.x);
+        head_block<H, C, true, 0, false, SH, RB>(p, (int)blockIdx.x);
         return;
     }
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
@@ -348,9 +417,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
     const int srow = t >> 2, sub = t & 3;
-    const int m = p.m;
-    const bool slive = srow < m;
-    const int sr = min(srow, m - 1);
+    const int mt = p.m;                                              // all rows of this call
     const int n_dw = q.tiles_in * TH;
     const int blk = (int)blockIdx.x - G;
     const bool is_dw = blk < n_dw;
@@ -364,7 +431,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
             tn = (xcd >> 1) * (TH / 4) + idx / pm;
         } else { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
     } else {
-        const int b2 = blk - n_dw, tr = (m + 15) / 16;
+        const int b2 = blk - n_dw, tr = (mt + 15) / 16;
         if (q.xcd && tr % 2 == 0 && q.tiles_in % 4 == 0 && n_dw % 8 == 0) {
             const int xcd = b2 & 7, idx = b2 >> 3, pm = tr / 2;
             tm = (xcd & 1) * pm + idx % pm;
@@ -372,36 +439,65 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         } else { tm = b2 % tr; tn = b2 / tr; }
     }
     const int m0 = tm * 16, n0 = tn * 16;
+    // SH == 2 (statistics from memory): any number of rows in blocks of 128.  A dW tile contracts over ALL rows — it walks the
+    // blocks and keeps accumulating; a dx tile lives in ONE block (its 16 rows) and derives only that block's dz
+    const int nb = RB ? (mt + ROWS - 1) / ROWS : 1;
+    const int rb_lo = (RB && !is_dw) ? m0 / ROWS : 0, rb_hi = is_dw ? nb : rb_lo + 1;
+    const int m0l = is_dw ? m0 : m0 - rb_lo * ROWS;                  // dx: first tile row inside its block
 
-    // ---- every global read, up front.  The dz1 slice of a tile is itself a 16x16x4 MFMA product
+    // ---- the loads that do not depend on the row block, up front.  The dz1 slice of a tile is itself a 16x16x4 MFMA product
     //   P[row][unit] = sum_c dz[row][c] W2[unit][c]    (K = 12: 10 classes + 2 zero columns, 3 MFMAs per wave)
     // dW tile: wave w takes rows 16 w .. 16 w + 15 x units n0 .. n0 + 15; dx tile: rows m0 .. m0 + 15 x units 16 w .. 16 w + 15.
     // Lane (i16, grp) supplies B[k = grp][n = i16] = W2[unit i16][class 4 s + grp] and receives P[row 4 grp + r][unit i16],
     // r = 0..3 — for the dW tile that IS the B fragment of the tile product (b[j] = dz1[16 w + 4 grp + j][n0 + i16]).
-    HeadStage<C, NP> stg;
-    head_stage_request<C, NP>(p, t, stg);
     const int urow = (is_dw ? n0 : 16 * wid) + i16;                  // this lane's hidden unit
-    const int prow0 = (is_dw ? 16 * wid : m0) + 4 * grp;             // first of this lane's 4 panel rows
-    float w2f[3], a1m[4];
+    const int prow0 = (is_dw ? 16 * wid : m0l) + 4 * grp;            // first of this lane's 4 panel rows (inside the block)
+    float w2f[3];
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) w2f[s3] = p.w[(size_t)urow * C + min(4 * s3 + grp, C - 1)];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) a1m[r] = p.a[(size_t)min(prow0 + r, m - 1) * H + urow];
-    float af[4] = {0.f, 0.f, 0.f, 0.f};          // dW: x fragment
     f32x4 bf = {0.f, 0.f, 0.f, 0.f};             // dx: W1 fragment
     float e_pre = 0.f;                           // dx: mask source
     const int e_r = (t >> 6) & 3, e_ln = t & 63;
-    if (is_dw) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = q.x[(size_t)min(16 * wid + 4 * grp + j, m - 1) * n_in + m0 + i16];
-    } else {
+    if (!is_dw) {
         bf = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + i16) * H + 16 * wid + 4 * grp);
-        if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, m - 1) * n_in + n0 + (e_ln & 15)];
+        if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, mt - 1) * n_in + n0 + (e_ln & 15)];
     }
     if (grp >= 2) w2f[2] = 0.f;                  // classes 10, 11 do not exist (the clamped address read class 9)
     static_assert(C == 10, "the zero columns of the K = 12 product are written for 10 classes");
 
-    head_stage_store<C, NP>(p, t, stg, zs, ys);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bs = 0.f;
+    const f32x4 bias4 = head_stage_bias<C, NP>(p, t);
+    // the global reads of one row block: staged logits / labels, the mask source rows of a1, (dW) the x fragment
+    HeadStage<C, NP> stg_nx;
+    float a1m_nx[4], af_nx[4] = {0.f, 0.f, 0.f, 0.f};
+    auto request_block = [&](const int rb) {
+        int row0 = rb * ROWS, tt = t;
+        if constexpr (RB) { asm volatile("" : "+s"(row0)); asm volatile("" : "+v"(tt)); }   // see head_block: keeps the addresses out of loop-carried registers
+        const int m = RB ? min(ROWS, mt - row0) : mt;
+        head_stage_request<C, NP>(p, tt, stg_nx, m, row0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1m_nx[r] = p.a[(size_t)(row0 + min(prow0 + r, m - 1)) * H + urow];
+        if (is_dw) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af_nx[j] = q.x[(size_t)(row0 + min(16 * wid + 4 * grp + j, m - 1)) * n_in + m0 + i16];
+        }
+    };
+    constexpr bool PF = RB && TNN_HEAD_PREFETCH;
+    if (PF) request_block(rb_lo);
+    for (int rb = rb_lo; rb < rb_hi; ++rb) {
+    if (!PF) request_block(rb);
+    const int row0 = rb * ROWS;
+    const int m = RB ? min(ROWS, mt - row0) : mt;                    // rows of this block
+    const bool slive = srow < m;
+    const int sr = min(srow, m - 1);
+    if (rb > rb_lo) __syncthreads();             // the staged logits of the previous block have been read by every wave
+    float a1m[4], af[4];                         // af: the dW tile's x fragment
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { a1m[r] = a1m_nx[r]; af[r] = af_nx[r]; }
+    head_stage_store<C, NP>(p, t, stg_nx, zs, ys, m, row0, bias4);
+    // the staged values are in LDS, their registers are free: the next block's reads travel while this one is worked on
+    if (PF && rb + 1 < rb_hi) request_block(rb + 1);
     __syncthreads();
     float zc[3], yc[3];
 #pragma unroll
@@ -431,7 +527,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         if (sub >= 2) dzr[srow * WS + 8 + sub] = 0.f;
     }
     // dW tile: wave w reads back only the 16 rows it wrote itself (srow = 16 w + lane / 4) — no workgroup barrier, the
-    // LDS queue of a wave is in order; dx tile: the 16 rows of the tile were written by wave tm
+    // LDS queue of a wave is in order; dx tile: the 16 rows of the tile were written by wave m0l / 16
     if (is_dw) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
     else __syncthreads();
     if constexpr (CUT == 3) {
@@ -441,14 +537,12 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
 
     f32x4 pz = {0.f, 0.f, 0.f, 0.f};
     {
-        const float* drow = dzr + ((is_dw ? 16 * wid : m0) + i16) * WS + grp;          // A[m = i16][k = grp] = dz[row][4 s + grp]
+        const float* drow = dzr + ((is_dw ? 16 * wid : m0l) + i16) * WS + grp;         // A[m = i16][k = grp] = dz[row][4 s + grp]
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(drow[4 * s3], w2f[s3], pz, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) pz[r] = (__float_as_uint(a1m[r]) >> 31) ? 0.f : pz[r];   // rows >= m: dz = 0 there
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float bs = 0.f;
     if (is_dw) {
         if constexpr (CUT == 4) {
             q.dx[(size_t)(blk % 64) * 512 + t] = pz[0] + pz[1] + pz[2] + pz[3] + af[0] + af[1] + af[2] + af[3];
@@ -456,7 +550,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], pz[j], acc, 0, 0, 0);
-        bs = (pz[0] + pz[1]) + (pz[2] + pz[3]);
+        bs += (pz[0] + pz[1]) + (pz[2] + pz[3]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pan[(4 * grp + r) * PS + 16 * wid + i16] = pz[r];
@@ -469,6 +563,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[j], acc, 0, 0, 0);
     }
+    }   // row blocks
 #pragma unroll
     for (int r = 0; r < 4; ++r) redm[wid][r][lane] = acc[r];
     bsum[wid][lane] = bs;
@@ -479,7 +574,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         for (int w = 0; w < 8; ++w) s += redm[w][e_r][e_ln];
         const int row = m0 + (e_ln >> 4) * 4 + e_r, col = n0 + (e_ln & 15);           // 16x16x4 C/D layout
         if (is_dw) q.dw1[(size_t)row * H + col] = s;
-        else if (row < m) q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+        else if (row < mt) q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
     }
     if (is_dw && tm == 0 && t < 16) {
         float s = 0.f;
@@ -502,7 +597,10 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, int64_t m
     TNN_REQUIRE(x && w1 && a && w && b && y && logit_partials && dw && db && dw1 && db1 && dx,
                 "%s: x, w1, a, w, b, y, logit_partials, dw, db, dw1, db1 and dx are required", fn);
     auto al = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
-    TNN_REQUIRE(head_multi_fits(rows, n_hidden, n_classes, dtype) && n_in % 16 == 0 && al(a) && al(w) && al(w1),
+    // rows: <= 128 when the workgroups reduce the statistics themselves; with the statistics taken from memory (ext_pairs)
+    // nothing couples the rows inside the launch and they are walked in blocks of 128 (<= 1024: 8 blocks)
+    TNN_REQUIRE(head_multi_fits(ext_pairs ? (rows <= 1024 ? 1 : rows) : rows, n_hidden, n_classes, dtype) && n_in % 16 == 0 &&
+                    al(a) && al(w) && al(w1),
                 "%s: this head does not fit the merged form (tnn_mlp_head_fits, n_in %% 16 == 0, 16-B aligned a / w / w1)", fn);
     HeadMArgs p;
     p.m = (int)rows;
@@ -524,7 +622,8 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, int64_t m
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
     if (ext_pairs != nullptr) {          // data parallel: the statistics come from the tail of the previous launch [+ all-gather]
         TNN_REQUIRE(m_global >= rows && ext_n >= 1 && ext_n <= 64, "%s: m_global < rows or bad pair count", fn);
-        hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2>), grid, 512, 0, tnn::stream(), p, q);
+        if (rows > 128) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2, true>), grid, 512, 0, tnn::stream(), p, q);
+        else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2>), grid, 512, 0, tnn::stream(), p, q);
         TNN_LAUNCH_OK();
         return 0;
     }

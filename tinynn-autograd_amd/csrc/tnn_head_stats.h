@@ -117,7 +117,7 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
 // zpart [NP][m][C]: every tile column's share of the logits, written by the workgroups of THIS launch with system-scope
 // (write-through) stores; the caller has established that all of them have landed (an agent-scope ticket, see
 // dense_fwd_head_kernel) — they are read back here with cache-bypassing loads because this XCD's L2 may hold nothing
-// (or stale lines) of what the other XCDs wrote.  512 threads: four per row, rows <= 128.
+// (or stale lines) of what the other XCDs wrote.  512 threads: four per row, 128 rows at a time.
 //   out_pair <- {M_r, S_r} of this shard, or, with `exchange`, the pair merged over all ranks of the peer-to-peer group
 //   (tagged 8-byte stores, one link latency: ll_exchange2 on the loss kernel's slots and epoch counter — ONE workgroup per
 //   launch runs this, so it may advance the counter itself).
@@ -136,47 +136,59 @@ __device__ __forceinline__ void head_tail_stats(const HeadTail& ta, const tnn::p
     using namespace tnn::p2p;
     static_assert(NP == 8, "the partial-sum tree is written for 8 tiles");
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int m = ta.m, n = m * C;
-    const bool vec = (m % 2 == 0) && ((reinterpret_cast<uintptr_t>(ta.y) | reinterpret_cast<uintptr_t>(ta.zpart)) & 15) == 0;
-    if (vec) {
-        if (t < (n >> 2)) {
-            f32x4 v[NP];
-#pragma unroll
-            for (int tn = 0; tn < NP; ++tn) load_sys(v[tn], ta.zpart + (size_t)tn * n + 4 * t);
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(ta.y + 4 * t);
-            loads_landed(v);
-            f32x4 s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] += ta.bias[(4 * t + i) % C];
-            *reinterpret_cast<f32x4*>(zs + 4 * t) = s;
-            *reinterpret_cast<f32x4*>(ys + 4 * t) = yv;
-        }
-    } else {
-        for (int e = t; e < n; e += 512) {
-            uint32_t u[NP];
-#pragma unroll
-            for (int tn = 0; tn < NP; ++tn) load_sys(u[tn], reinterpret_cast<const uint32_t*>(ta.zpart) + (size_t)tn * n + e);
-            loads_landed(u);
-            float f[NP];
-#pragma unroll
-            for (int tn = 0; tn < NP; ++tn) f[tn] = __uint_as_float(u[tn]);
-            zs[e] = (((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) + ta.bias[e % C];
-            ys[e] = ta.y[e];
-        }
-    }
-    __syncthreads();
+    const int mt = ta.m, stride = mt * C;
+    const bool vec = (mt % 2 == 0) && ((reinterpret_cast<uintptr_t>(ta.y) | reinterpret_cast<uintptr_t>(ta.zpart)) & 15) == 0;
     const int srow = t >> 2, sub = t & 3;
-    const bool slive = srow < m;
-    const int sr = min(srow, m - 1);
-    float zc[3], yc[3];
+    // more than 128 rows (the large-batch single-GPU step, config D's per-rank batch at 2 / 4 ranks): blocks of 128 rows, one
+    // after the other, their {max, sum-exp} merged as the ranks' pairs are
+    float M = -INFINITY, S = 0.f;
+    for (int row0 = 0; row0 < mt; row0 += 128) {
+        const int m = min(128, mt - row0), n = m * C, base = row0 * C;
+        if (row0) __syncthreads();
+        if (vec) {
+            if (t < (n >> 2)) {
+                f32x4 v[NP];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        zc[i] = zs[sr * C + min(sub + 4 * i, C - 1)];
-        yc[i] = ys[sr * C + min(sub + 4 * i, C - 1)];
+                for (int tn = 0; tn < NP; ++tn) load_sys(v[tn], ta.zpart + (size_t)tn * stride + base + 4 * t);
+                const f32x4 yv = *reinterpret_cast<const f32x4*>(ta.y + base + 4 * t);
+                loads_landed(v);
+                f32x4 s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += ta.bias[(4 * t + i) % C];
+                *reinterpret_cast<f32x4*>(zs + 4 * t) = s;
+                *reinterpret_cast<f32x4*>(ys + 4 * t) = yv;
+            }
+        } else {
+            for (int e = t; e < n; e += 512) {
+                uint32_t u[NP];
+#pragma unroll
+                for (int tn = 0; tn < NP; ++tn) load_sys(u[tn], reinterpret_cast<const uint32_t*>(ta.zpart) + (size_t)tn * stride + base + e);
+                loads_landed(u);
+                float f[NP];
+#pragma unroll
+                for (int tn = 0; tn < NP; ++tn) f[tn] = __uint_as_float(u[tn]);
+                zs[e] = (((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]))) + ta.bias[e % C];
+                ys[e] = ta.y[base + e];
+            }
+        }
+        __syncthreads();
+        const bool slive = srow < m;
+        const int sr = min(srow, m - 1);
+        float zc[3], yc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            zc[i] = zs[sr * C + min(sub + 4 * i, C - 1)];
+            yc[i] = ys[sr * C + min(sub + 4 * i, C - 1)];
+        }
+        HeadStats st;
+        head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
+        if (row0 == 0) { M = st.M; S = (float)st.S; }
+        else {
+            const float nm = fmaxf(M, st.M);
+            S = S * expf(M - nm) + (float)st.S * expf(st.M - nm);
+            M = nm;
+        }
     }
-    HeadStats st;
-    head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
-    float M = st.M, S = (float)st.S;
     if (ta.exchange) {
         __shared__ float peer_stats[MAXW][2];
         const Peers& P = ctx.peers;

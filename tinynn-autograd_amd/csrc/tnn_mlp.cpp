@@ -298,6 +298,17 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
     return 0;
 }
 
+// The merged head + hidden-backward launch with the softmax statistics taken from memory (tnn_mlp_head_bwd_tick_ext behind
+// tnn_dense_fwd_head_partials_stats): nothing couples the rows inside that launch, so it walks them in blocks of 128 — the
+// 2L - 2 launch step for per-rank batches of 129 .. 384 rows (bs 256 on one GPU, config D at 4 ranks).  The blocks are
+// walked one after the other inside each workgroup (~6 us per block over the whole step), so from four blocks on the
+// 7-launch form below is faster (measured: 256 rows 29.5 vs 35.4 us, 512 rows 42.1 vs 41.4, 1024 rows 64 vs 53)
+bool head_fits_row_blocks(const Mlp* h, int64_t rows) {
+    const int L = h->L;
+    return h->dtype == TNN_F32 && !h->bf16 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 1] == 128 &&
+           h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= 384 && h->zpart != nullptr;
+}
+
 // limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
 bool head_fits_one_workgroup(const Mlp* h, int64_t rows) {
     // classifier heads (<= 16 classes): the one-thread-per-row kernel, up to 1024 rows; wider heads: the LDS image of the
@@ -652,6 +663,39 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                               h->pows, h->dtype));
         return 0;
     }
+    static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
+    if (row_blocks && head_fits_row_blocks(h, rows)) {
+        // 129 .. 384 rows, 2L - 2 launches (4 for the MNIST net) like the <= 128-row step: the LAST workgroup of the hidden
+        // layer's forward reduces the whole-batch {max, sum-exp} (block by block), the merged head launch reads the pair
+        // and walks the rows in blocks of 128 (dW / db / loss accumulated in registers), the first layer's backward carries
+        // the optimizer.  (Before: 7 launches — three forward, a one-workgroup loss, three backward: 35.4 us at 256 rows.)
+        MLP_TRY(mlp_forward(h, x, rows, L - 2));
+        STEP_CALL(h, tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                       at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                       at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                       h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                       at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats, 0,
+                                                       h->dtype));
+        STEP_CALL(h, tnn_mlp_head_bwd_tick_ext(rows, rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
+                                               at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
+                                               at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
+                                               y, h->zpart, h->stats, 1, h->act[L - 1], h->dact[L - 1], nullptr, loss_dst,
+                                               at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                               at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
+                                               h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
+        MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 1));
+        const int64_t rest = h->w_off[1];
+        STEP_CALL(h, tnn_dense_bwd_first_adam(rows, h->w[0], h->w[1], x, h->dact[0],
+                                              h->keep_grads ? at(h->grads, h->w_off[0], h->esz) : nullptr,
+                                              at(h->grads, h->b_off[0], h->esz), at(h->params, h->w_off[0], h->esz),
+                                              at(h->m, h->w_off[0], h->esz), at(h->v, h->w_off[0], h->esz),
+                                              at(h->params, h->b_off[0], h->esz), at(h->m, h->b_off[0], h->esz),
+                                              at(h->v, h->b_off[0], h->esz), at(h->params, rest, h->esz),
+                                              at(h->grads, rest, h->esz), at(h->m, rest, h->esz),
+                                              at(h->v, rest, h->esz), h->n_params - rest, h->lr, h->b1, h->b2, h->eps,
+                                              h->pows, h->dtype));
+        return 0;
+    }
     if (h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
         // forward | loss (+ Adam's beta powers advanced by its thread 0) | backward, the last launch of which also
         // carries the optimizer
@@ -719,6 +763,8 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     int head_multi = 0;
     if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
+    static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
+    if (!head_multi && row_blocks && head_fits_row_blocks(h, rows)) head_multi = 1;     // 129 .. 384 rows per rank: blocks of 128
     if (head_multi) {
         // Classifier head of the one-launch form (<= 128 rows per rank: every weak-scaling point, config D at 8 ranks) —
         // 2L - 1 launches (5 for the MNIST net) + the collectives, ONE form for every transport:
