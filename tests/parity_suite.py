@@ -445,6 +445,60 @@ def head_and_hidden_backward_one_launch_vs_numpy():
                                        err_msg="ext %s %s" % (name, tag))
 
 
+def head_row_blocks_vs_numpy():
+    """More than 128 rows through the two launches that carry the statistics through memory: the tail of
+    tnn_dense_fwd_head_partials_stats reduces {max, sum-exp} block by block (up to 1024 rows) and tnn_mlp_head_bwd_tick_ext
+    walks the rows in blocks of 128 — full blocks, a ragged last block, a one-row last block, an odd row count (the
+    element-wise staging path), eight blocks — against float64 numpy."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(31)
+    Hn, C, n_in = 128, 10, 48
+    for m in (256, 200, 129, 384, 333, 1024):
+        pre0 = rs.randn(m, n_in).astype(np.float32)
+        x = np.where(pre0 < 0, np.float32(-0.0), np.abs(pre0)).astype(np.float32)
+        w1 = (rs.randn(n_in, Hn) * 0.2).astype(np.float32)
+        b1v = rs.randn(Hn).astype(np.float32)
+        w = (rs.randn(Hn, C) * 0.3).astype(np.float32)
+        b = rs.randn(C).astype(np.float32)
+        y = np.eye(C, dtype=np.float32)[rs.randint(0, C, m)]
+        X, W1, B1, W, B, Y = (tn.asarray(v) for v in (x, w1, b1v, w, b, y))
+        A, zpart = tn.empty((m, Hn)), tn.zeros((Hn // 16, m, C))
+        pair, ticket = tn.empty((2,)), tn.asarray(np.zeros(16, np.int64))
+        tag = "rows=%d" % m
+        for _ in range(2):
+            pair[...] = 0.0
+            lib.dense_fwd_head_partials_stats(m, Hn, n_in, X._ptr, n_in, W1._ptr, Hn, B1._ptr, _lib.ACT_RELU, 1, A._ptr, Hn,
+                                              W._ptr, C, zpart._ptr, B._ptr, Y._ptr, ticket._ptr, pair._ptr, 0, _lib.F32)
+            a = np.asarray(A).copy()
+            a64, w64, y64, x64, w164 = (v.astype(np.float64) for v in (a, w, y, x, w1))
+            z = a64 @ w64 + b
+            S = np.exp(z - z.max()).sum()
+            np.testing.assert_allclose(np.asarray(pair), [z.max(), S], rtol=1e-5, err_msg=tag)
+            assert int(np.asarray(ticket)[0]) == 0
+        ref_a = np.maximum(x64 @ w164 + b1v, 0.0)
+        np.testing.assert_allclose(np.abs(a), ref_a, rtol=0, atol=1e-5 * ref_a.max(), err_msg=tag)
+        logits, dz, loss = tn.zeros((m, C)), tn.zeros((m, C)), tn.empty(())
+        dw, db = tn.zeros((Hn, C)), tn.zeros((C,))
+        dw1, db1, dx = tn.zeros((n_in, Hn)), tn.zeros((Hn,)), tn.zeros((m, n_in))
+        pows = tn.asarray(np.array([0.9, 0.999, 0, 0]), dtype=np.float64)
+        lib.mlp_head_bwd_tick_ext(m, m, n_in, Hn, C, X._ptr, W1._ptr, A._ptr, W._ptr, B._ptr, Y._ptr, zpart._ptr,
+                                  pair._ptr, 1, logits._ptr, dz._ptr, None, loss._ptr, dw._ptr, db._ptr, dw1._ptr,
+                                  db1._ptr, dx._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
+        e = np.exp(z - z.max())
+        q = (e * y64).sum(1, keepdims=True)
+        ref_dz = e / S - (e * y64 / q) / m
+        ref_da = (ref_dz @ w64.T) * ~np.signbit(a)
+        np.testing.assert_allclose(float(loss), (np.log(S) - np.log(q)).sum() / m, rtol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(np.asarray(logits), z, rtol=0, atol=1e-5 * np.abs(z).max(), err_msg=tag)
+        for name, got, ref in (("dz", dz, ref_dz), ("dw", dw, a64.T @ ref_dz), ("db", db, ref_dz.sum(0)),
+                               ("dw1", dw1, x64.T @ ref_da), ("db1", db1, ref_da.sum(0)),
+                               ("dx", dx, (ref_da @ w164.T) * ~np.signbit(x))):
+            np.testing.assert_allclose(np.asarray(got).reshape(ref.shape), ref, rtol=0, atol=1e-5 * np.abs(ref).max() + 1e-12,
+                                       err_msg="%s %s" % (name, tag))
+        np.testing.assert_allclose(np.asarray(pows)[:2], [0.9 ** 2, 0.999 ** 2], rtol=1e-14)
+
+
 def dense_backward_one_launch_vs_numpy():
     import ctypes
     from tinynn_autograd_amd import _lib

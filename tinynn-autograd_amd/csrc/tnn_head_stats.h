@@ -142,23 +142,50 @@ __device__ __forceinline__ void head_tail_stats(const HeadTail& ta, const tnn::p
     // more than 128 rows (the large-batch single-GPU step, config D's per-rank batch at 2 / 4 ranks): blocks of 128 rows, one
     // after the other, their {max, sum-exp} merged as the ranks' pairs are
     float M = -INFINITY, S = 0.f;
+    // vec path: the partials of TWO blocks are requested before the first wait (their round trips through the memory side —
+    // ~2 us each at system scope — overlap), the third block's as soon as the first one's registers are free
+    // (system-scope loads the COMPILER can see — buffer loads with the sc0 sc1 cache-policy bits — because they are carried
+    // across loop iterations: a register copy the compiler inserts behind an inline-asm load reads the register before the
+    // data has landed; measured, rows = 384 gave NaN statistics)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    f32x4 cur[NP], nxt[NP], ycur = {0.f, 0.f, 0.f, 0.f}, ynxt = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ta.zpart), 0,
+                                                                        (uint32_t)(NP * stride) * 4u, 0x00020000);
+    auto issue = [&](f32x4 (&v)[NP], f32x4& yv, const int row0) {
+        const int n = min(128, mt - row0) * C, base = row0 * C;
+        if (t < (n >> 2)) {
+#pragma unroll
+            for (int tn = 0; tn < NP; ++tn)
+                v[tn] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, (uint32_t)(base + 4 * t) * 4u,
+                                                                                        (uint32_t)(tn * stride) * 4u, 17));
+            yv = *reinterpret_cast<const f32x4*>(ta.y + base + 4 * t);
+        }
+    };
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};           // the bias of this thread's four staged elements: the same for every block
+    if (vec) {
+        issue(cur, ycur, 0);
+        if (mt > 128) issue(nxt, ynxt, 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = ta.bias[(4 * t + i) % C];
+    }
     for (int row0 = 0; row0 < mt; row0 += 128) {
         const int m = min(128, mt - row0), n = m * C, base = row0 * C;
         if (row0) __syncthreads();
         if (vec) {
             if (t < (n >> 2)) {
-                f32x4 v[NP];
-#pragma unroll
-                for (int tn = 0; tn < NP; ++tn) load_sys(v[tn], ta.zpart + (size_t)tn * stride + base + 4 * t);
-                const f32x4 yv = *reinterpret_cast<const f32x4*>(ta.y + base + 4 * t);
-                loads_landed(v);
-                f32x4 s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s[i] += ta.bias[(4 * t + i) % C];
+                f32x4 s = ((cur[0] + cur[1]) + (cur[2] + cur[3])) + ((cur[4] + cur[5]) + (cur[6] + cur[7]));
+                s += bias4;
                 *reinterpret_cast<f32x4*>(zs + 4 * t) = s;
-                *reinterpret_cast<f32x4*>(ys + 4 * t) = yv;
+                *reinterpret_cast<f32x4*>(ys + 4 * t) = ycur;
+            }
+            if (row0 + 128 < mt) {
+#pragma unroll
+                for (int tn = 0; tn < NP; ++tn) cur[tn] = nxt[tn];
+                ycur = ynxt;
+                if (row0 + 256 < mt) issue(nxt, ynxt, row0 + 256);
             }
         } else {
+#pragma unroll 1
             for (int e = t; e < n; e += 512) {
                 uint32_t u[NP];
 #pragma unroll
