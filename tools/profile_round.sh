@@ -18,6 +18,9 @@ TNN_FORCE_COMM=1 python3 bench.py --no-cpu-baseline > $OUT/benchA_dp_world1.json
 python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
 python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
 SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
+bash tools/probes/rows_sweep.sh > $OUT/rows_sweep.txt 2>> $OUT/log.txt
+python3 tools/probes/eager_phases.py > $OUT/eager_phases.txt 2>> $OUT/log.txt
+TNN_HOST_COMPILED=0 python3 tools/probes/eager_phases.py >> $OUT/eager_phases.txt 2>> $OUT/log.txt
 
 run rocprofv3 --kernel-trace --stats -d $OUT/ktA -o A -- python3 bench.py --steps 20 --warmup 5
 run rocprofv3 --kernel-trace --stats -d $OUT/ktAstep -o Astep -- python3 bench.py --no-extras --steps 2000 --warmup 64
@@ -25,6 +28,8 @@ run rocprofv3 --kernel-trace --stats -d $OUT/ktC -o C -- python3 bench.py --work
 run rocprofv3 --kernel-trace --stats -d $OUT/ktE -o E -- python3 bench.py --workload E
 # the data-parallel step at world 1 (RCCL leg first, then the peer-to-peer leg) and the single-GPU step: duration + gap per launch
 TNN_FORCE_COMM=1 rocprofv3 --kernel-trace -d $OUT/ktDP -o dp -- python3 bench.py --no-extras --no-cpu-baseline --steps 2000 --warmup 64 >> $OUT/log.txt 2>&1
+
+run rocprofv3 --kernel-trace -d $OUT/kt256 -o r256 -- python3 bench.py --rows 256 --no-extras --no-cpu-baseline --steps 2000 --warmup 64
 
 run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcA_fetch -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcA_write -o A -- python3 bench.py --no-extras --steps 200 --warmup 20
@@ -45,6 +50,8 @@ db=$(find $OUT/ktAstep -name "*.db" | head -1)
 [ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.5 > $OUT/stepA_timeline.txt 2>> $OUT/log.txt
 db=$(find $OUT/ktC -name "*.db" | head -1)
 [ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.3 > $OUT/stepC_timeline.txt 2>> $OUT/log.txt
+db=$(find $OUT/kt256 -name "*.db" | head -1)
+[ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.5 > $OUT/step256_timeline.txt 2>> $OUT/log.txt
 for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcE_fetch pmcE_write pmcbf_sq pmcg32_sq; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_pmc.py $db > $OUT/${d}.txt 2>> $OUT/log.txt
