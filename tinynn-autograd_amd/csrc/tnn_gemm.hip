@@ -1507,9 +1507,13 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
     // to 9 % faster.  (The TN weight-gradient shape shows no such preference: 128 x 64 stays.)
     const int64_t t64x128 = ((g.M + 63) / 64) * ((g.N + 127) / 128);
     if (cfg == 3 && !getenv("TNN_GEMM_CFG") && !transA && g.M <= 1024 && t64x128 >= cus / 2 && t64x128 <= 2 * cus) cfg = 1;
+    // (Round 3, measured and not kept: the same 128 x 64 / 64 x 128 tiles with EIGHT waves of 32 x 32 — two per SIMD, so one
+    // wave's MFMAs can cover the other's barrier and wait states.  Plain products on one box: TN 156 us against 162 (64 x 128)
+    // and 172 (128 x 64), NN 146 against 148, NT 144-147 against 143; inside config C's step, where the TN launches carry the
+    // Adam epilogue, 0.739-0.745 ms against 0.736 for the four-wave 128 x 64 tile.)
     if (splits <= 0) {
         splits = 1;
-        int64_t tiles = (cfg == 3 || cfg == 5) ? t128x64 : cfg == 2 ? t64 : cfg == 0 ? ((g.M + 127) / 128) * ((g.N + 127) / 128)
+        int64_t tiles = cfg == 3 ? t128x64 : cfg == 2 ? t64 : cfg == 0 ? ((g.M + 127) / 128) * ((g.N + 127) / 128)
                                                               : ((g.M + 63) / 64) * ((g.N + 127) / 128);
         if (tiles < cus) {
             // fewer tiles than CUs: split K until every CU has a workgroup, keeping >= 8 K-tiles (256 deep)
@@ -1526,8 +1530,6 @@ int gemm_f32(GemmArgs& g, int transA, int transB, float* colsum = nullptr) {
         case 1: return launch_cfg<64, 128, 32, 2, 2>(g, transA, transB, splits);
         case 2: return launch_cfg<64, 64, 32, 2, 2>(g, transA, transB, splits);
         case 3: return launch_cfg<128, 64, 32, 2, 2>(g, transA, transB, splits);
-        case 4: return launch_cfg<64, 128, 32, 2, 4>(g, transA, transB, splits);     // experiment: 8 waves of 32 x 32
-        case 5: return launch_cfg<128, 64, 32, 4, 2>(g, transA, transB, splits);
     }
     tnn::set_error("tnn_gemm: unknown tile configuration %d", cfg);
     return 2;
