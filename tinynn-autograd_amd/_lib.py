@@ -15,7 +15,8 @@ import sys
 # the package directory — taken from the package, not from __file__: this module may run from its compiled copy under
 # _compiled/ (_host_build.py)
 _HERE = os.path.dirname(os.path.abspath(sys.modules[__name__.rpartition(".")[0]].__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtnn_hip.so")
+# TNN_LIB_PATH: another build of the same library (same-box A/B timing of kernel variants, tools/probes/)
+LIB_PATH = os.environ.get("TNN_LIB_PATH") or os.path.join(_HERE, "lib", "libtnn_hip.so")
 
 # dtype / op codes (must mirror include/tnn_hip.h)
 F32, F64, I64, U8, BF16 = 0, 1, 2, 3, 4
