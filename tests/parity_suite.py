@@ -1151,6 +1151,21 @@ def fused_dense_relu_node_matches_generic_chain():
     for name, got, ref in zip(("a", "out", "dx", "dw1", "db1", "dw2", "db2"), *results):
         np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * max(np.abs(ref).max(), 1e-6), err_msg=name)
     assert np.abs(results[0][2][3]).max() > 0                     # row 3: z == 0 keeps its gradient
+    # the INTERMEDIATE gradient (documented deviation): with one fused consumer the hidden activation's .grad is
+    # the upstream gradient already multiplied by the ReLU mask; the reference's ReLU-output tensor holds it unmasked
+    inter = []
+    for fused in (True, False):
+        x = Tensor(xh, requires_grad=True)
+        w1, b1 = Tensor(w1h, requires_grad=True), Tensor(b1h, requires_grad=True)
+        w2, b2 = Tensor(w2h, requires_grad=True), Tensor(b2h, requires_grad=True)
+        a = ops.dense_(x, w1, b1, relu=True) if fused else ops.clip(x @ w1 + b1, 0.0)
+        out = ops.dense_(a, w2, b2) if fused else a @ w2 + b2
+        (out * out).sum().backward()
+        inter.append((np.asarray(a.grad), np.asarray(a.values), np.asarray(x.grad)))
+    mask = ~np.signbit(inter[0][1])
+    assert (~mask).any() and mask.any()
+    np.testing.assert_allclose(inter[0][0], inter[1][0] * mask, rtol=0, atol=2e-5 * np.abs(inter[1][0]).max())
+    np.testing.assert_allclose(inter[0][2], inter[1][2], rtol=0, atol=2e-5 * np.abs(inter[1][2]).max())
     # Net.forward fuses Dense -> ReLU pairs and nothing else; one tnn_dense_bwd launch per layer in backward
     np.random.seed(2)
     net = Net([Dense(h, num_in=k), ReLU(), Dense(h, num_in=h), ReLU(), Dense(c, num_in=h)])
