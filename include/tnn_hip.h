@@ -275,7 +275,9 @@ TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, 
  * all-gather of the pairs on RCCL]) and do no cross-row reduction of their own; dz / dw / db / dw1 / db1 / dx are this
  * rank's contributions to the global gradients and *loss its share of the global loss — the all-reduce of the gradient
  * arena (tnn_allreduce_adam) sums both.  The data-parallel step is then forward x 2 | [all-gather] | head + hidden
- * backward | first-layer backward | all-reduce + Adam: 5 launches + the collectives, the same form on every transport. */
+ * backward | first-layer backward | all-reduce + Adam: 5 launches + the collectives, the same form on every transport.
+ * rows <= 1024 here (nothing couples the rows inside the launch once the statistics come from memory: they are walked in
+ * blocks of 128); with m_global == rows and one pair it is also the single-GPU step for batches of more than 128 rows. */
 TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
                                       const void* x, const void* w1, const void* a, const void* w, const void* b,
                                       const void* y, const void* logit_partials, const void* stats_pairs, int n_pairs,
@@ -290,13 +292,14 @@ TNN_API int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const v
                                         int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
                                         const void* head_w, int64_t head_c, void* head_z, int dtype);
 
-/* The same launch in a data-parallel step: the workgroup that finishes LAST (agent-scope arrival counter *ticket_u32, a
- * device word that is 0 before the first call and returns to 0 at the end of every launch) also reduces this shard's
+/* The same launch in a data-parallel step: the workgroup that finishes LAST (agent-scope arrival counters in ticket_u32 —
+ * 128 bytes of device memory, zero before the first call; every launch leaves the counters at zero — one counter up to
+ * 128 rows; beyond, one per block of 128 rows plus one for the blocks' pairs, which are staged behind them) also reduces this shard's
  * whole-batch softmax statistics {max, sum-exp} (core/losses.py:25-27) from the partial logits + head_b (classifier bias
  * [head_c]) and writes them to out_pair_f32[2]; exchange != 0 (needs tnn_p2p_connect): it exchanges the pair with the
  * peers over xGMI and writes the MERGED pair instead.  y [M, head_c] (labels) rides along for symmetry with the head
  * kernels' staging.  No statistics launch and nobody waits for a peer inside the head launch that follows.
- * Shapes of tnn_mlp_head_fits: f32, M <= 128, N == 128, head_c == 10, 16-B aligned operands. */
+ * f32, M <= 1024, N == 128, head_c == 10, 16-B aligned operands. */
 TNN_API int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                               int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
                                               const void* head_w, int64_t head_c, void* head_z, const void* head_b,

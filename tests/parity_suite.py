@@ -1223,16 +1223,16 @@ def trainer_step_forms_agree_with_the_op_level_model():
       [30, 64, 32, 128, 10]  4 layers: two more launches around the merged one
       [30, 20, 128, 10]      hidden input width not a multiple of 16: head and hidden backward stay separate launches
       [30, 48, 64, 10]       a head the one-launch form does not take (64 hidden units): the 7-launch step
-    and batches of 129 .. 384 rows on the row-blocked form of the same launches."""
+    and batches of 129 .. 512 rows on the row-blocked form of the same launches."""
     from tinynn_autograd_amd.core.model import Model
     from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
     from tinynn_autograd_amd.core.optimizer import Adam
     rs = np.random.RandomState(12)
     cases = [(w, r) for w in ([40, 128, 10], [30, 48, 128, 10], [30, 64, 32, 128, 10], [30, 20, 128, 10], [30, 48, 64, 10])
              for r in (128, 37)]
-    # 129 .. 384 rows: the same 2L - 2 launches, the merged launch walking the rows in blocks of 128 (full blocks, a ragged
-    # last block, a one-row last block, three blocks); beyond that, and for [40, 128, 10] / [30, 20, 128, 10], the 7-launch form
-    cases += [(w, r) for w in ([30, 48, 128, 10], [30, 64, 32, 128, 10]) for r in (256, 200, 129, 384, 385)]
+    # 129 .. 512 rows: the same 2L - 2 launches, the merged launch walking the rows in blocks of 128 (full blocks, a ragged
+    # last block, a one-row last block, four blocks); beyond that, and for [40, 128, 10] / [30, 20, 128, 10], the 7-launch form
+    cases += [(w, r) for w in ([30, 48, 128, 10], [30, 64, 32, 128, 10]) for r in (256, 200, 129, 512, 513)]
     cases += [([40, 128, 10], 256), ([30, 20, 128, 10], 200)]
     for widths, rows in cases:
         if True:

@@ -862,14 +862,8 @@ __device__ __forceinline__ float finish_epilogue(const GemmArgs& g, float acc, f
 //     instead of after the cross-wave reduction.
 // SYS_HEADZ: the partial logits leave through write-through (system-scope) stores, because a workgroup of THIS launch
 // on another XCD reads them back (dense_fwd_head_kernel)
-template <bool AKC, bool BKC, int WAVES, bool SYS_HEADZ = false>
-__device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __restrict__ colsum, int block,
-                                                float (*red)[4][64], float (*bsum)[64], float* head_lds = nullptr) {
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    constexpr uint32_t OOB = 0xffffffffu;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i16 = lane & 15, grp = lane >> 4;
-    int tm, tn;
+// tile of workgroup `block` of the latency kernels: one rectangle of the tile grid per XCD (pick_xcd_cut) or column-major
+__device__ __forceinline__ void small_tile_coords(const GemmArgs& g, const int block, int& tm, int& tn) {
     if (g.xg_m) {
         const int xcd = block & 7, idx = block >> 3, pm = g.tiles_m / g.xg_m, pn = g.tiles_n / g.xg_n;
         tm = (xcd % g.xg_m) * pm + idx % pm;
@@ -878,6 +872,17 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
         tm = block % g.tiles_m;
         tn = block / g.tiles_m;
     }
+}
+
+template <bool AKC, bool BKC, int WAVES, bool SYS_HEADZ = false>
+__device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __restrict__ colsum, int block,
+                                                float (*red)[4][64], float (*bsum)[64], float* head_lds = nullptr) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr uint32_t OOB = 0xffffffffu;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    int tm, tn;
+    small_tile_coords(g, block, tm, tn);
     const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
     const int64_t am = m0 + i16, bn = n0 + i16;
     const bool a_ok = am < g.M, b_ok = bn < g.N;
@@ -1032,18 +1037,53 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
     __shared__ double dred[8][4];
     __shared__ int is_last;
     small_tile_fast<true, false, WAVES, true>(g, nullptr, (int)blockIdx.x, red, bsum, head_lds);
+    // Shards of more than 128 rows: every 128-row block has its own arrival counter (ticket[1 + rb], the block's 8 tile rows x
+    // all tile columns), so the blocks' statistics are reduced in parallel, each by the workgroup that finishes the block; the
+    // pairs meet through memory (system scope) behind a second counter (ticket[0]) whose last arrival merges them in block
+    // order.  Up to 128 rows: one counter, one pair, as before.
+    using namespace tnn::p2p;
+    int tm, tn;
+    small_tile_coords(g, (int)blockIdx.x, tm, tn);
+    const int nb = (ta.m + 127) / 128, rb = nb > 1 ? tm >> 3 : 0;
+    const unsigned cnt = nb > 1 ? (unsigned)(min(8, g.tiles_m - 8 * rb) * g.tiles_n) : gridDim.x;
+    unsigned int* const ctr = ta.ticket + (nb > 1 ? 1 + rb : 0);
+    float* const pairs = reinterpret_cast<float*>(ta.ticket + 16);          // [8][2] behind the 16 counters
     if (threadIdx.x < 64) {                                    // wave 0 wrote this tile's partial logits
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
-            const unsigned prev = __hip_atomic_fetch_add(ta.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = prev == gridDim.x - 1 ? 1 : 0;
-            if (last) __hip_atomic_store(ta.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // graph replays start from 0
+            const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == cnt - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // graph replays start from 0
             is_last = last;
         }
     }
     __syncthreads();
     if (!is_last) return;
-    head_tail_stats<10, 8>(ta, ctx, zs, ys, dred);
+    float M, S;
+    head_tail_stats<10, 8>(ta, 128 * rb, min(ta.m, 128 * rb + 128), zs, ys, dred, M, S);
+    if (nb > 1) {
+        __syncthreads();                                       // is_last is about to be reused
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(pairs + 2 * rb, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(pairs + 2 * rb + 1, S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned prev = __hip_atomic_fetch_add(ta.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == (unsigned)nb - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(ta.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = last;
+        }
+        __syncthreads();
+        if (!is_last) return;
+        M = -INFINITY; S = 0.f;
+        for (int q = 0; q < nb; ++q) {                         // block order: the same sum whichever block finished last
+            const float mq = __hip_atomic_load(pairs + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const float sq = __hip_atomic_load(pairs + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const float nm = fmaxf(M, mq);
+            S = S * expf(M - nm) + sq * expf(mq - nm);
+            M = nm;
+        }
+    }
+    head_tail_finish(ta, ctx, M, S);
 }
 
 // Backward of one Dense layer in ONE launch: blocks [0, n_dw) compute dW = X^T dZ (TN) + db = colsum(dZ),

@@ -130,17 +130,18 @@ struct HeadTail {
     int m, exchange;
 };
 
+// {max, sum-exp} over rows [row_lo, row_hi) of the shard (all threads return the same pair)
 template <int C, int NP>
-__device__ __forceinline__ void head_tail_stats(const HeadTail& ta, const tnn::p2p::LaunchCtx& ctx, float* zs, float* ys,
-                                                double (*red)[4]) {
+__device__ __forceinline__ void head_tail_stats(const HeadTail& ta, const int row_lo, const int row_hi, float* zs, float* ys,
+                                                double (*red)[4], float& M_out, float& S_out) {
     using namespace tnn::p2p;
     static_assert(NP == 8, "the partial-sum tree is written for 8 tiles");
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int mt = ta.m, stride = mt * C;
-    const bool vec = (mt % 2 == 0) && ((reinterpret_cast<uintptr_t>(ta.y) | reinterpret_cast<uintptr_t>(ta.zpart)) & 15) == 0;
+    const int mt = row_hi, stride = ta.m * C;        // mt: end of the row range; stride: the partial array's tile stride
+    const bool vec = (ta.m % 2 == 0) && (row_hi % 2 == 0) && ((reinterpret_cast<uintptr_t>(ta.y) | reinterpret_cast<uintptr_t>(ta.zpart)) & 15) == 0;
     const int srow = t >> 2, sub = t & 3;
-    // more than 128 rows (the large-batch single-GPU step, config D's per-rank batch at 2 / 4 ranks): blocks of 128 rows, one
-    // after the other, their {max, sum-exp} merged as the ranks' pairs are
+    // a range of more than 128 rows: blocks of 128 rows, one after the other, their {max, sum-exp} merged as the ranks' pairs are
+    // (the forward launch gives every 128-row block to the workgroup that finishes it LAST, so ranges are one block there)
     float M = -INFINITY, S = 0.f;
     // vec path: the partials of TWO blocks are requested before the first wait (their round trips through the memory side —
     // ~2 us each at system scope — overlap), the third block's as soon as the first one's registers are free
@@ -163,14 +164,14 @@ __device__ __forceinline__ void head_tail_stats(const HeadTail& ta, const tnn::p
     };
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};           // the bias of this thread's four staged elements: the same for every block
     if (vec) {
-        issue(cur, ycur, 0);
-        if (mt > 128) issue(nxt, ynxt, 128);
+        issue(cur, ycur, row_lo);
+        if (mt > row_lo + 128) issue(nxt, ynxt, row_lo + 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias4[i] = ta.bias[(4 * t + i) % C];
     }
-    for (int row0 = 0; row0 < mt; row0 += 128) {
+    for (int row0 = row_lo; row0 < mt; row0 += 128) {
         const int m = min(128, mt - row0), n = m * C, base = row0 * C;
-        if (row0) __syncthreads();
+        if (row0 > row_lo) __syncthreads();
         if (vec) {
             if (t < (n >> 2)) {
                 f32x4 s = ((cur[0] + cur[1]) + (cur[2] + cur[3])) + ((cur[4] + cur[5]) + (cur[6] + cur[7]));
@@ -209,13 +210,22 @@ __device__ __forceinline__ void head_tail_stats(const HeadTail& ta, const tnn::p
         }
         HeadStats st;
         head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
-        if (row0 == 0) { M = st.M; S = (float)st.S; }
+        if (row0 == row_lo) { M = st.M; S = (float)st.S; }
         else {
             const float nm = fmaxf(M, st.M);
             S = S * expf(M - nm) + (float)st.S * expf(st.M - nm);
             M = nm;
         }
     }
+    M_out = M;
+    S_out = S;
+}
+
+// The shard's pair is complete in every thread of ONE workgroup: on the peer-to-peer transport exchange and merge it with the
+// other ranks' (tagged 8-byte stores, one link latency), then leave it in out_pair for the head launch.
+__device__ __forceinline__ void head_tail_finish(const HeadTail& ta, const tnn::p2p::LaunchCtx& ctx, float M, float S) {
+    using namespace tnn::p2p;
+    const int t = threadIdx.x;
     if (ta.exchange) {
         __shared__ float peer_stats[MAXW][2];
         const Peers& P = ctx.peers;

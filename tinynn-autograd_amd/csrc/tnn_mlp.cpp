@@ -300,13 +300,16 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
 
 // The merged head + hidden-backward launch with the softmax statistics taken from memory (tnn_mlp_head_bwd_tick_ext behind
 // tnn_dense_fwd_head_partials_stats): nothing couples the rows inside that launch, so it walks them in blocks of 128 — the
-// 2L - 2 launch step for per-rank batches of 129 .. 384 rows (bs 256 on one GPU, config D at 4 ranks).  The blocks are
-// walked one after the other inside each workgroup (~6 us per block over the whole step), so from four blocks on the
-// 7-launch form below is faster (measured: 256 rows 29.5 vs 35.4 us, 512 rows 42.1 vs 41.4, 1024 rows 64 vs 53)
+// 2L - 2 launch step for per-rank batches of 129 .. 512 rows (bs 256 / 512 on one GPU, config D at 2 / 4 ranks).  The
+// statistics of the blocks are reduced in parallel (one finishing workgroup per block at the tail of the forward launch),
+// the blocks of the merged launch are walked one after the other inside each workgroup (~2 us per block), so from eight
+// blocks on the 7-launch form below is faster (measured: 256 rows 29.3 vs 35.4 us, 512 rows 38.9 vs 41.5, 1024 rows 55.0
+// vs 52.7; TNN_HEAD_ROW_BLOCKS_MAX moves the limit, TNN_HEAD_ROW_BLOCKS=0 turns the form off)
 bool head_fits_row_blocks(const Mlp* h, int64_t rows) {
     const int L = h->L;
+    static const int64_t row_blocks_max = getenv("TNN_HEAD_ROW_BLOCKS_MAX") ? atoll(getenv("TNN_HEAD_ROW_BLOCKS_MAX")) : 512;
     return h->dtype == TNN_F32 && !h->bf16 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 1] == 128 &&
-           h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= 384 && h->zpart != nullptr;
+           h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= row_blocks_max && h->zpart != nullptr;
 }
 
 // limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
@@ -399,8 +402,8 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     rc |= tnn_malloc(bytes, (void**)&h->v);
     rc |= tnn_malloc(4 * sizeof(double), &h->pows);
     rc |= tnn_malloc(2 * 8, &h->stats);
-    rc |= tnn_malloc(64, &h->ticket);
-    if (!rc) rc |= tnn_memset(h->ticket, 0, 64);
+    rc |= tnn_malloc(256, &h->ticket);          // 16 arrival counters + the row blocks' {max, sum-exp} pairs (tnn_dense_fwd_head_partials_stats)
+    if (!rc) rc |= tnn_memset(h->ticket, 0, 256);
     if (n_layers >= 2 && dtype == TNN_F32)
         rc |= tnn_malloc((size_t)((widths[n_layers - 1] + 15) / 16 * max_rows * widths[n_layers]) * 4, &h->zpart);
     const size_t act_esz = h->bf16 ? 2 : h->esz;
@@ -665,8 +668,8 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     }
     static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
     if (row_blocks && head_fits_row_blocks(h, rows)) {
-        // 129 .. 384 rows, 2L - 2 launches (4 for the MNIST net) like the <= 128-row step: the LAST workgroup of the hidden
-        // layer's forward reduces the whole-batch {max, sum-exp} (block by block), the merged head launch reads the pair
+        // 129 .. 512 rows, 2L - 2 launches (4 for the MNIST net) like the <= 128-row step: the LAST workgroup of the hidden
+        // layer's forward reduces the whole-batch {max, sum-exp} (every block by its own finisher), the merged head launch reads the pair
         // and walks the rows in blocks of 128 (dW / db / loss accumulated in registers), the first layer's backward carries
         // the optimizer.  (Before: 7 launches — three forward, a one-workgroup loss, three backward: 35.4 us at 256 rows.)
         MLP_TRY(mlp_forward(h, x, rows, L - 2));
@@ -764,7 +767,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
     static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
-    if (!head_multi && row_blocks && head_fits_row_blocks(h, rows)) head_multi = 1;     // 129 .. 384 rows per rank: blocks of 128
+    if (!head_multi && row_blocks && head_fits_row_blocks(h, rows)) head_multi = 1;     // 129 .. 512 rows per rank: blocks of 128
     if (head_multi) {
         // Classifier head of the one-launch form (<= 128 rows per rank: every weak-scaling point, config D at 8 ranks) —
         // 2L - 1 launches (5 for the MNIST net) + the collectives, ONE form for every transport:
