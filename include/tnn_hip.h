@@ -277,7 +277,9 @@ TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, 
  * arena (tnn_allreduce_adam) sums both.  The data-parallel step is then forward x 2 | [all-gather] | head + hidden
  * backward | first-layer backward | all-reduce + Adam: 5 launches + the collectives, the same form on every transport.
  * rows <= 1024 here (nothing couples the rows inside the launch once the statistics come from memory: they are walked in
- * blocks of 128); with m_global == rows and one pair it is also the single-GPU step for batches of more than 128 rows. */
+ * blocks of 128); with m_global == rows it is also the single-GPU step for batches of more than 128 rows.  n_pairs < 0:
+ * logit_partials holds the WHOLE logits [rows, n_classes] without the bias and stats_pairs -n_pairs pairs
+ * (tnn_dense_fwd_rows_head_stats). */
 TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
                                       const void* x, const void* w1, const void* a, const void* w, const void* b,
                                       const void* y, const void* logit_partials, const void* stats_pairs, int n_pairs,
@@ -304,6 +306,19 @@ TNN_API int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, c
                                               int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
                                               const void* head_w, int64_t head_c, void* head_z, const void* head_b,
                                               const void* y, void* ticket_u32, void* out_pair_f32, int exchange, int dtype);
+
+/* The hidden layer's forward in front of a classifier head for batches of more than 128 rows on ONE GPU, row-panel form
+ * (core/layers.py:49,97-98 + the first half of core/losses.py:24-27): C = relu(A B + bias) as above, and because a
+ * workgroup owns 16 whole rows it also finishes their logits and their softmax statistics:
+ *   head_z_full [M, head_c] = C head_w            (WITHOUT head_b: tnn_mlp_head_bwd_tick_ext adds it, as it does to partials)
+ *   pairs_f32 [ceil(M / 16)][2] = {max, sum-exp relative to it} of (C head_w + head_b) over each 16-row panel
+ * to be handed to tnn_mlp_head_bwd_tick_ext as logit_partials / stats_pairs with n_pairs = -ceil(M / 16) (negative: whole
+ * logits instead of H / 16 partial sums).  No arrival counter and no re-read of partial logits at the tail of the launch.
+ * f32, M <= 1024, N == 128, head_c == 10, act == TNN_ACT_RELU, A 16-B aligned with lda and K multiples of 4. */
+TNN_API int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                                          int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
+                                          const void* head_w, int64_t head_c, void* head_z_full, const void* head_b,
+                                          void* pairs_f32, int dtype);
 
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global

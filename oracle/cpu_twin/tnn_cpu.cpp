@@ -691,15 +691,50 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
     twin_logits_from_partials(M, N, head_c, head_b, head_z, logits.data());
     return tnn_softmax_nll_stats(logits.data(), M, head_c, out_pair, dtype);      // a one-rank exchange is the identity
 }
+int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                  const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* head_w,
+                                  int64_t head_c, void* head_z_full, const void* head_b, void* pairs, int dtype) {
+    NEED_INIT();
+    REQ(head_w && head_z_full && head_b && pairs && dtype == TNN_F32 && M >= 1 && M <= 1024 && N == 128 && head_c == 10 && act == TNN_ACT_RELU,
+        "cpu twin: tnn_dense_fwd_rows_head_stats needs every buffer, f32, the head's shapes, a ReLU layer");
+    RECORD(tnn_dense_fwd_rows_head_stats(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z_full, head_b,
+                                         pairs, dtype));
+    if (int rc = tnn_gemm_bias_act(0, 0, M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, dtype)) return rc;
+    float* z = (float*)head_z_full;
+    for (int64_t r = 0; r < M; ++r)
+        for (int64_t c = 0; c < head_c; ++c) {
+            float s = 0.f;
+            for (int64_t col = 0; col < N; ++col) s += ((const float*)C)[r * ldc + col] * ((const float*)head_w)[col * head_c + c];
+            z[r * head_c + c] = s;                                  // the classifier bias is added by the head launch
+        }
+    for (int64_t p0 = 0; p0 < M; p0 += 16) {                        // one {max, sum-exp} pair per 16-row panel
+        const int64_t p1 = p0 + 16 < M ? p0 + 16 : M;
+        float mx = -INFINITY;
+        for (int64_t r = p0; r < p1; ++r)
+            for (int64_t c = 0; c < head_c; ++c) mx = std::max(mx, z[r * head_c + c] + ((const float*)head_b)[c]);
+        double se = 0.0;
+        for (int64_t r = p0; r < p1; ++r)
+            for (int64_t c = 0; c < head_c; ++c) se += std::exp((double)(z[r * head_c + c] + ((const float*)head_b)[c]) - (double)mx);
+        ((float*)pairs)[2 * (p0 / 16)] = mx;
+        ((float*)pairs)[2 * (p0 / 16) + 1] = (float)se;
+    }
+    return 0;
+}
 int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
                               const void* a, const void* w, const void* b, const void* y, const void* zpart, const void* pairs,
                               int n_pairs, void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                               void* dx, int dtype, void* pows, double b1, double b2) {
     NEED_INIT();
-    REQ(x && w1 && zpart && pairs && logits && dz && dw && db && dw1 && db1 && dx && dtype == TNN_F32 && n_pairs >= 1,
+    REQ(x && w1 && zpart && pairs && logits && dz && dw && db && dw1 && db1 && dx && dtype == TNN_F32 && n_pairs != 0,
         "cpu twin: tnn_mlp_head_bwd_tick_ext needs every buffer, f32");
     RECORD(tnn_mlp_head_bwd_tick_ext(rows, m_global, n_in, nh, nc, x, w1, a, w, b, y, zpart, pairs, n_pairs, logits, dz, stats, loss,
                                      dw, db, dw1, db1, dx, dtype, pows, b1, b2));
+    if (n_pairs < 0) {                                              // whole logits without the bias (tnn_dense_fwd_rows_head_stats)
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t c = 0; c < nc; ++c)
+                ((float*)logits)[r * nc + c] = ((const float*)zpart)[r * nc + c] + ((const float*)b)[c];
+        n_pairs = -n_pairs;
+    } else
     twin_logits_from_partials(rows, nh, nc, b, zpart, (float*)logits);
     float merged[2];
     if (int rc = tnn_lse_merge(pairs, n_pairs, merged, dtype)) return rc;

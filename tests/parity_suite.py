@@ -497,6 +497,34 @@ def head_row_blocks_vs_numpy():
             np.testing.assert_allclose(np.asarray(got).reshape(ref.shape), ref, rtol=0, atol=1e-5 * np.abs(ref).max() + 1e-12,
                                        err_msg="%s %s" % (name, tag))
         np.testing.assert_allclose(np.asarray(pows)[:2], [0.9 ** 2, 0.999 ** 2], rtol=1e-14)
+        # ---- the single-GPU forward in its row-panel form (tnn_dense_fwd_rows_head_stats): the activations, the WHOLE logits
+        # without the bias, one {max, sum-exp} pair per 16-row panel; tnn_mlp_head_bwd_tick_ext then takes n_pairs < 0
+        n_pan = (m + 15) // 16
+        A3, zfull, pairs3 = tn.empty((m, Hn)), tn.zeros((m, C)), tn.zeros((n_pan, 2))
+        lib.dense_fwd_rows_head_stats(m, Hn, n_in, X._ptr, n_in, W1._ptr, Hn, B1._ptr, _lib.ACT_RELU, 1, A3._ptr, Hn,
+                                      W._ptr, C, zfull._ptr, B._ptr, pairs3._ptr, _lib.F32)
+        a3 = np.asarray(A3)
+        np.testing.assert_allclose(a3, a, rtol=0, atol=1e-5 * np.abs(a).max(), err_msg=tag)
+        assert np.array_equal(np.signbit(a3), np.signbit(a)) or np.abs(a3[np.signbit(a3) != np.signbit(a)]).max() < 1e-5
+        z3 = a3.astype(np.float64) @ w64
+        np.testing.assert_allclose(np.asarray(zfull), z3, rtol=0, atol=1e-5 * np.abs(z3).max(), err_msg=tag)
+        zb3 = z3 + b
+        got_pairs = np.asarray(pairs3)
+        for pnl in range(n_pan):
+            blk = zb3[16 * pnl:16 * pnl + 16]
+            np.testing.assert_allclose(got_pairs[pnl], [blk.max(), np.exp(blk - blk.max()).sum()], rtol=1e-5,
+                                       err_msg="%s panel %d" % (tag, pnl))
+        for t_ in (logits, dz, dw, db, dw1, db1, dx):
+            t_[...] = 0.0
+        lib.mlp_head_bwd_tick_ext(m, m, n_in, Hn, C, X._ptr, W1._ptr, A3._ptr, W._ptr, B._ptr, Y._ptr, zfull._ptr,
+                                  pairs3._ptr, -n_pan, logits._ptr, dz._ptr, None, loss._ptr, dw._ptr, db._ptr, dw1._ptr,
+                                  db1._ptr, dx._ptr, _lib.F32, pows._ptr, 0.9, 0.999)
+        np.testing.assert_allclose(float(loss), (np.log(S) - np.log(q)).sum() / m, rtol=1e-5, err_msg=tag)
+        for name, got, ref in (("dz", dz, ref_dz), ("dw", dw, a64.T @ ref_dz), ("db", db, ref_dz.sum(0)),
+                               ("dw1", dw1, x64.T @ ref_da), ("db1", db1, ref_da.sum(0)),
+                               ("dx", dx, (ref_da @ w164.T) * ~np.signbit(x))):
+            np.testing.assert_allclose(np.asarray(got).reshape(ref.shape), ref, rtol=0, atol=2e-5 * np.abs(ref).max() + 1e-12,
+                                       err_msg="row panels %s %s" % (name, tag))
 
 
 def dense_backward_one_launch_vs_numpy():
@@ -1223,16 +1251,16 @@ def trainer_step_forms_agree_with_the_op_level_model():
       [30, 64, 32, 128, 10]  4 layers: two more launches around the merged one
       [30, 20, 128, 10]      hidden input width not a multiple of 16: head and hidden backward stay separate launches
       [30, 48, 64, 10]       a head the one-launch form does not take (64 hidden units): the 7-launch step
-    and batches of 129 .. 512 rows on the row-blocked form of the same launches."""
+    and batches of 129 .. 1024 rows on the row-blocked form of the same launches."""
     from tinynn_autograd_amd.core.model import Model
     from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
     from tinynn_autograd_amd.core.optimizer import Adam
     rs = np.random.RandomState(12)
     cases = [(w, r) for w in ([40, 128, 10], [30, 48, 128, 10], [30, 64, 32, 128, 10], [30, 20, 128, 10], [30, 48, 64, 10])
              for r in (128, 37)]
-    # 129 .. 512 rows: the same 2L - 2 launches, the merged launch walking the rows in blocks of 128 (full blocks, a ragged
-    # last block, a one-row last block, four blocks); beyond that, and for [40, 128, 10] / [30, 20, 128, 10], the 7-launch form
-    cases += [(w, r) for w in ([30, 48, 128, 10], [30, 64, 32, 128, 10]) for r in (256, 200, 129, 512, 513)]
+    # 129 .. 1024 rows: the same 2L - 2 launches, the merged launch walking the rows in blocks of 128 (full blocks, a ragged
+    # last block, a one-row last block, four and eight blocks); beyond that, and for [40, 128, 10] / [30, 20, 128, 10], the 7-launch form
+    cases += [(w, r) for w in ([30, 48, 128, 10], [30, 64, 32, 128, 10]) for r in (256, 200, 129, 512, 1000)]
     cases += [([40, 128, 10], 256), ([30, 20, 128, 10], 200)]
     for widths, rows in cases:
         if True:

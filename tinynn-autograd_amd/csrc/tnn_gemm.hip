@@ -1086,6 +1086,151 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
     head_tail_finish(ta, ctx, M, S);
 }
 
+// Forward of the hidden layer in front of a classifier head for batches of MORE than 128 rows on one GPU, ROW-PANEL form:
+// a workgroup owns 16 whole rows — its 8 waves take the 8 column tiles of the 128 hidden units, each over the whole K — so
+// the classifier's logits of those rows (8 partial products summed through LDS) and the rows' softmax statistics are
+// finished INSIDE the workgroup: no arrival counter, no system-scope re-read of partial logits at the tail of the launch
+// (2.3 us per 128-row block in dense_fwd_head_kernel, measured).  Outputs: the activations (bias + ReLU, sign-encoded
+// zeros), zfull [M][10] = the logits WITHOUT the classifier bias (the head launch adds it, as it does to summed partials),
+// pairs [ceil(M / 16)][2] = {max, sum-exp relative to it} of each 16-row panel — the head launch merges them.
+struct RowPanelArgs {
+    const float *A, *B, *bias;       // A [M][lda] (K-contiguous), B [K][ldb] (128 columns), bias [128]
+    float* C;                        // [M][ldc]
+    int64_t lda, ldb, ldc;
+    int M, K, relu_sign;
+    const float *head_w, *head_b;    // [128][10], [10]
+    float *zfull, *pairs;
+};
+
+__global__ __launch_bounds__(512) void dense_fwd_rowpanel_head_kernel(RowPanelArgs g) {
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr uint32_t OOB = 0xffffffffu;
+    constexpr int C = 10;
+    __shared__ __attribute__((aligned(16))) float tile_s[8][16 * 20];     // each wave's finished 16 x 16 tile, 16-B aligned rows
+    __shared__ float zred[8][16 * 16];                                    // partial logits [wave][row][class slot]
+    __shared__ float wred[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int m0 = 16 * (int)blockIdx.x, n0 = 16 * wid;
+    const uint32_t K = (uint32_t)g.K, lda4 = (uint32_t)g.lda * 4u, ldb4 = (uint32_t)g.ldb * 4u;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.A), 0, (uint32_t)(((int64_t)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(g.B), 0, (uint32_t)(((int64_t)(g.K - 1) * g.ldb + 128) * 4), 0x00020000);
+    const uint32_t b_lane = (uint32_t)grp * 4u * ldb4 + (uint32_t)(n0 + i16) * 4u;  // + 16 rows per chunk
+
+    // epilogue operands, requested first
+    const float e_bias = g.bias ? g.bias[n0 + i16] : 0.f;
+    float head_pre[4] = {0.f, 0.f, 0.f, 0.f};                 // head_w[n0 + 4 grp + j][class i16]: the B fragment of the logits product
+    if (i16 < C) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) head_pre[j] = g.head_w[(n0 + 4 * grp + j) * C + i16];
+    }
+    const int zrow = tid >> 4, zcls = tid & 15;               // threads < 256: logit (row, class slot)
+    const float zb = (tid < 256 && zcls < C) ? g.head_b[zcls] : 0.f;
+
+    // K loop in super-blocks of 256: the 16 rows of A go through LDS once per workgroup (all eight waves need the same rows),
+    // and a wave requests ALL its B fragments of the super-block before the first MFMA (64 dword loads in flight, one round
+    // trip) — with 16 / 32 / 64 workgroups in the launch it is one workgroup's latency that the launch takes.
+    constexpr int KB = 256, CH = KB / 16, AS = KB + 4;
+    __shared__ __attribute__((aligned(16))) float a_s[16 * AS];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < g.K; kb += KB) {
+        float b[CH][4];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const uint32_t k = (uint32_t)kb + (uint32_t)c * 16u + (uint32_t)grp * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t boff = (k + j < K) ? b_lane + (uint32_t)(kb / 16 + c) * 16u * ldb4 + (uint32_t)j * ldb4 : OOB;
+                b[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b_rsrc, boff, 0, 0));
+            }
+        }
+        // A[16 rows][kb .. kb + 256): 1024 pieces of 16 B, two per thread (rows beyond M / columns beyond K: zero-filled)
+        u32x4_t av[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = tid + i * 512, row = piece >> 6, c4 = piece & 63;
+            const uint32_t k = (uint32_t)kb + (uint32_t)c4 * 4u;
+            const uint32_t aoff = (m0 + row < g.M && k < K) ? (uint32_t)(m0 + row) * lda4 + k * 4u : OOB;
+            av[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff, 0, 0);
+        }
+        if (kb) __syncthreads();                              // the previous super-block's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = tid + i * 512, row = piece >> 6, c4 = piece & 63;
+            *reinterpret_cast<u32x4_t*>(a_s + row * AS + 4 * c4) = av[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_s + i16 * AS + 16 * c + 4 * grp);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b[c][j], acc, 0, 0, 0);
+        }
+    }
+
+    // epilogue: acc[r] = out[row 4 grp + r][col i16] of this wave's tile (16x16x4 C/D layout)
+    float* ts = tile_s[wid];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v = acc[r] + e_bias;
+        if (g.relu_sign) v = v < 0.f ? -0.0f : fabsf(v);
+        else v = v < 0.f ? 0.f : v;
+        const int row = m0 + 4 * grp + r;
+        if (row < g.M) g.C[(int64_t)row * g.ldc + n0 + i16] = v;
+        ts[(4 * grp + r) * 20 + i16] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        // this wave's share of the logits: out[16 rows][its 16 units] x head_w[those units][classes] (a sign-encoded zero,
+        // -0.0, contributes -0 * w = 0)
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ts + i16 * 20 + 4 * grp);        // out[row i16][unit 4 grp + j]
+        f32x4 hacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], head_pre[j], hacc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zred[wid][(4 * grp + q) * 16 + i16] = hacc[q];          // [row 4 grp + q][class i16]
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const float* zr = &zred[0][zrow * 16 + zcls];
+        const float z_nb = ((zr[0] + zr[256]) + (zr[512] + zr[768])) + ((zr[1024] + zr[1280]) + (zr[1536] + zr[1792]));
+        const int grow = m0 + zrow;
+        const bool valid = zcls < C && grow < g.M;
+        if (valid) g.zfull[(int64_t)grow * C + zcls] = z_nb;
+        const float z = z_nb + zb;                            // what the head launch reconstructs: (sum of "partials") + bias
+        // row statistics over the 16 lanes of a DPP row (quad swaps, half-row mirror, row mirror: every lane ends with the total)
+        float mx = valid ? z : -INFINITY, w;
+        w = tnn::dpp_move<0xB1, 0xf>(-INFINITY, mx); mx = w > mx ? w : mx;
+        w = tnn::dpp_move<0x4E, 0xf>(-INFINITY, mx); mx = w > mx ? w : mx;
+        w = tnn::dpp_move<0x141, 0xf>(-INFINITY, mx); mx = w > mx ? w : mx;
+        w = tnn::dpp_move<0x140, 0xf>(-INFINITY, mx); mx = w > mx ? w : mx;
+        float se = valid ? expf(z - mx) : 0.f;
+        se += tnn::dpp_move<0xB1, 0xf>(0.f, se);
+        se += tnn::dpp_move<0x4E, 0xf>(0.f, se);
+        se += tnn::dpp_move<0x141, 0xf>(0.f, se);
+        se += tnn::dpp_move<0x140, 0xf>(0.f, se);
+        // the wave's four rows (lanes with class slot 0 speak for their row), then the four waves through LDS
+        const bool speaks = zcls == 0 && grow < g.M;
+        const float wm = tnn::wave_max_dpp(speaks ? mx : -INFINITY);
+        const float ws = tnn::wave_sum_dpp(speaks ? se * expf(mx - wm) : 0.f);
+        if (lane == 0) { wred[wid][0] = wm; wred[wid][1] = ws; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float M = wred[0][0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) M = fmaxf(M, wred[q][0]);
+        float S = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S += wred[q][0] > -INFINITY ? wred[q][1] * expf(wred[q][0] - M) : 0.f;
+        g.pairs[2 * blockIdx.x] = M;
+        g.pairs[2 * blockIdx.x + 1] = S;
+    }
+}
+
 // Backward of one Dense layer in ONE launch: blocks [0, n_dw) compute dW = X^T dZ (TN) + db = colsum(dZ),
 // blocks [n_dw, n_dw + n_dx) compute dX = (dZ W^T) * mask (NT, sign-bit mask epilogue).  The two products
 // only share their input dZ, so they are independent grids fused to save a kernel boundary.
@@ -1906,6 +2051,30 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
         TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_head_partials_stats: the peer-to-peer transport is not enabled");
     }
     hipLaunchKernelGGL(dense_fwd_head_kernel<8>, dim3((unsigned)(g.tiles_m * g.tiles_n)), 512, 0, tnn::stream(), g, ta, ctx);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                  const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* head_w,
+                                  int64_t head_c, void* head_z_full, const void* head_b, void* pairs_f32, int dtype) {
+    TNN_NEED_INIT();
+    if (int rc = check_shapes("tnn_dense_fwd_rows_head_stats", 0, 0, M, N, K, lda, ldb, ldc)) return rc;
+    TNN_REQUIRE(dtype == TNN_F32 && M >= 1 && M <= 1024 && N == 128 && head_c == 10 && K >= 1,
+                "tnn_dense_fwd_rows_head_stats: f32, 1 <= rows <= 1024, 128 hidden units, 10 classes");
+    TNN_REQUIRE(A && B && C && head_w && head_z_full && head_b && pairs_f32,
+                "tnn_dense_fwd_rows_head_stats: A, B, C, head_w, head_z_full, head_b and pairs are required");
+    TNN_REQUIRE(act == TNN_ACT_RELU, "tnn_dense_fwd_rows_head_stats: the hidden layer in front of the head is a ReLU layer (activation %d)", act);
+    TNN_REQUIRE((reinterpret_cast<uintptr_t>(A) & 15) == 0 && lda % 4 == 0 && K % 4 == 0 &&
+                    (M - 1) * lda + K < (int64_t)1 << 30 && (K - 1) * ldb + 128 < (int64_t)1 << 30,
+                "tnn_dense_fwd_rows_head_stats: A must be 16-B aligned with lda and K multiples of 4, operands below 4 GiB");
+    RowPanelArgs g;
+    g.A = (const float*)A; g.B = (const float*)B; g.bias = (const float*)bias; g.C = (float*)C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.M = (int)M; g.K = (int)K; g.relu_sign = relu_sign;
+    g.head_w = (const float*)head_w; g.head_b = (const float*)head_b;
+    g.zfull = (float*)head_z_full; g.pairs = (float*)pairs_f32;
+    hipLaunchKernelGGL(dense_fwd_rowpanel_head_kernel, dim3((unsigned)((M + 15) / 16)), 512, 0, tnn::stream(), g);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -47,6 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct HeadMArgs {
     int m, rpb;                      // rows (<= 128; SH == 2: any number, walked in blocks of 128); da rows per workgroup
     int vec;                         // rows even, zpart / y 16-B aligned: the partial logits are staged with 16-B loads
+    int nparts;                      // tiles of zpart that exist: H / 16 partial sums, or 1 = whole logits (bias still to be added)
     int m_global;                    // data-parallel (SH kernels): rows of the GLOBAL batch; the loss written is this rank's share
     const float* ext_pairs;          // SH == 2: {M_q, S_q} pairs from an earlier launch (head_stats_kernel [+ all-gather])
     int ext_n;
@@ -72,7 +73,10 @@ __device__ __forceinline__ void head_stage_request(const HeadMArgs& p, const int
     const int n = mb * C, stride = p.m * C, base = row0 * C;
     if (p.vec && t < (n >> 2)) {
 #pragma unroll
-        for (int tn = 0; tn < NP; ++tn) h.v[tn] = *reinterpret_cast<const f32x4*>(p.zpart + (size_t)tn * stride + base + 4 * t);
+        for (int tn = 0; tn < NP; ++tn) {
+            h.v[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (tn < p.nparts) h.v[tn] = *reinterpret_cast<const f32x4*>(p.zpart + (size_t)tn * stride + base + 4 * t);   // uniform
+        }
         h.yv = *reinterpret_cast<const f32x4*>(p.y + base + 4 * t);
     }
 }
@@ -103,7 +107,7 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
         for (int e = t; e < n; e += 512) {
             float u[NP];
 #pragma unroll
-            for (int tn = 0; tn < NP; ++tn) u[tn] = p.zpart[(size_t)tn * stride + base + e];
+            for (int tn = 0; tn < NP; ++tn) u[tn] = tn < p.nparts ? p.zpart[(size_t)tn * stride + base + e] : 0.f;
             zs[e] = (((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]))) + p.b[e % C];
             ys[e] = p.y[base + e];
         }
@@ -588,7 +592,7 @@ bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtyp
     return dtype == TNN_F32 && n_classes == 10 && n_hidden == 128 && rows >= 1 && rows <= 128;
 }
 
-int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
+int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whole_logits, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
@@ -610,6 +614,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, int64_t m
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = (int)m_global;
     p.ext_pairs = ext_pairs; p.ext_n = ext_n;
+    p.nparts = whole_logits ? 1 : 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -674,6 +679,7 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = 0;
     p.ext_pairs = nullptr; p.ext_n = 0;
+    p.nparts = 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
     p.tick = (double*)adam_pows_f64; p.b1 = b1; p.b2 = b2;
@@ -688,7 +694,7 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
-    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, 0, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y, logit_partials, logits,
+    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, false, 0, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y, logit_partials, logits,
                            dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
@@ -698,7 +704,9 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
                               void* stats, void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
                               void* adam_pows_f64, double b1, double b2) {
     TNN_REQUIRE(stats_pairs != nullptr && m_global >= 1, "tnn_mlp_head_bwd_tick_ext: stats_pairs and m_global are required");
-    return head_bwd_launch("tnn_mlp_head_bwd_tick_ext", (const float*)stats_pairs, n_pairs, m_global, rows, n_in, n_hidden,
+    // n_pairs < 0: logit_partials holds WHOLE logits [rows][classes] without the bias (tnn_dense_fwd_rows_head_stats) and
+    // there are -n_pairs pairs
+    return head_bwd_launch("tnn_mlp_head_bwd_tick_ext", (const float*)stats_pairs, n_pairs < 0 ? -n_pairs : n_pairs, n_pairs < 0, m_global, rows, n_in, n_hidden,
                            n_classes, x, w1, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
                            adam_pows_f64, b1, b2);
 }

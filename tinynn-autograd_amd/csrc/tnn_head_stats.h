@@ -53,10 +53,18 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
     urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
     const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
     if constexpr (EXT) {
-        float Mx = ext_pairs[0];
-        for (int q = 1; q < ext_n; ++q) Mx = fmaxf(Mx, ext_pairs[2 * q]);
-        float Sx = 0.f;
-        for (int q = 0; q < ext_n; ++q) Sx += ext_pairs[2 * q + 1] * expf(ext_pairs[2 * q] - Mx);
+        // merge of the pairs, one per lane (ext_n <= 64: the ranks' pairs, or one per 16-row panel of the row-panel forward —
+        // a serial loop of 64 dependent expf per call cost the 1024-row step 80 us): wave-wide DPP max, then the rescaled sum
+        float Mx, Sx;
+        if (ext_n == 1) {                                       // one already merged pair (uniform branch)
+            Mx = ext_pairs[0];
+            Sx = ext_pairs[1];
+        } else {
+            const bool has = lane < ext_n;
+            const float mq = has ? ext_pairs[2 * lane] : -INFINITY, sq = has ? ext_pairs[2 * lane + 1] : 0.f;
+            Mx = tnn::wave_max_dpp(mq);
+            Sx = tnn::wave_sum_dpp(has ? sq * expf(mq - Mx) : 0.f);
+        }
         double Lx = 0.0;
         if (LOSS && want_loss) {                                // block-uniform: the loss-writing workgroup only
             const double wl = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);

@@ -298,18 +298,20 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
     return 0;
 }
 
-// The merged head + hidden-backward launch with the softmax statistics taken from memory (tnn_mlp_head_bwd_tick_ext behind
-// tnn_dense_fwd_head_partials_stats): nothing couples the rows inside that launch, so it walks them in blocks of 128 — the
-// 2L - 2 launch step for per-rank batches of 129 .. 512 rows (bs 256 / 512 on one GPU, config D at 2 / 4 ranks).  The
-// statistics of the blocks are reduced in parallel (one finishing workgroup per block at the tail of the forward launch),
-// the blocks of the merged launch are walked one after the other inside each workgroup (~2 us per block), so from eight
-// blocks on the 7-launch form below is faster (measured: 256 rows 29.3 vs 35.4 us, 512 rows 38.9 vs 41.5, 1024 rows 55.0
-// vs 52.7; TNN_HEAD_ROW_BLOCKS_MAX moves the limit, TNN_HEAD_ROW_BLOCKS=0 turns the form off)
-bool head_fits_row_blocks(const Mlp* h, int64_t rows) {
+// The merged head + hidden-backward launch with the softmax statistics taken from memory (tnn_mlp_head_bwd_tick_ext):
+// nothing couples the rows inside that launch, so it walks them in blocks of 128 — the 2L - 2 launch step for batches of more
+// than 128 rows.  One GPU (129 .. 1024 rows): the hidden layer's forward in its row-panel form (tnn_dense_fwd_rows_head_stats:
+// a workgroup owns 16 whole rows and finishes their logits and statistics itself).  Data parallel (129 .. 512 rows per rank,
+// config D at 2 / 4 ranks): the tiled forward whose tail reduces the statistics per 128-row block behind arrival counters
+// (tnn_dense_fwd_head_partials_stats) — the exchange needs ONE pair per rank.  Measured, same box, us per step at 256 / 512 /
+// 1024 rows: row-panel forward 28.4 / 37.1 / 51.4, counter tail 30.0 / 40.0 / 57.6, the 7-launch form below 35.5 / 41.4 / 52.8
+// (tools/probes/rows_sweep.sh; TNN_HEAD_ROW_BLOCKS_MAX moves the upper limits, TNN_HEAD_ROW_BLOCKS=0 turns the form off).
+bool head_fits_row_blocks(const Mlp* h, int64_t rows, bool sharded) {
     const int L = h->L;
-    static const int64_t row_blocks_max = getenv("TNN_HEAD_ROW_BLOCKS_MAX") ? atoll(getenv("TNN_HEAD_ROW_BLOCKS_MAX")) : 512;
+    static const int64_t env_max = getenv("TNN_HEAD_ROW_BLOCKS_MAX") ? atoll(getenv("TNN_HEAD_ROW_BLOCKS_MAX")) : 0;
+    const int64_t row_blocks_max = env_max > 0 ? env_max : (sharded ? 512 : 1024);
     return h->dtype == TNN_F32 && !h->bf16 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 1] == 128 &&
-           h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= row_blocks_max && h->zpart != nullptr;
+           h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= row_blocks_max && rows <= 1024 && h->zpart != nullptr;
 }
 
 // limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
@@ -401,7 +403,7 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     rc |= tnn_malloc(bytes, (void**)&h->m);
     rc |= tnn_malloc(bytes, (void**)&h->v);
     rc |= tnn_malloc(4 * sizeof(double), &h->pows);
-    rc |= tnn_malloc(2 * 8, &h->stats);
+    rc |= tnn_malloc(64 * 2 * 8, &h->stats);        // {max, sum-exp}: one pair, or one per 16-row panel (<= 64) of the row-panel forward
     rc |= tnn_malloc(256, &h->ticket);          // 16 arrival counters + the row blocks' {max, sum-exp} pairs (tnn_dense_fwd_head_partials_stats)
     if (!rc) rc |= tnn_memset(h->ticket, 0, 256);
     if (n_layers >= 2 && dtype == TNN_F32)
@@ -667,22 +669,35 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         return 0;
     }
     static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
-    if (row_blocks && head_fits_row_blocks(h, rows)) {
-        // 129 .. 512 rows, 2L - 2 launches (4 for the MNIST net) like the <= 128-row step: the LAST workgroup of the hidden
-        // layer's forward reduces the whole-batch {max, sum-exp} (every block by its own finisher), the merged head launch reads the pair
+    if (row_blocks && head_fits_row_blocks(h, rows, false)) {
+        // 129 .. 1024 rows, 2L - 2 launches (4 for the MNIST net) like the <= 128-row step: the hidden layer's forward leaves the
+        // whole-batch {max, sum-exp} as pairs in memory, the merged head launch reads them
         // and walks the rows in blocks of 128 (dW / db / loss accumulated in registers), the first layer's backward carries
         // the optimizer.  (Before: 7 launches — three forward, a one-workgroup loss, three backward: 35.4 us at 256 rows.)
         MLP_TRY(mlp_forward(h, x, rows, L - 2));
-        STEP_CALL(h, tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+        // one GPU: the hidden layer's forward in its row-panel form — a workgroup owns 16 whole rows, finishes their logits and
+        // their softmax statistics itself and leaves one {max, sum-exp} pair per panel (no arrival counter, no re-read of
+        // partial logits at the tail of the launch); the merged launch merges the pairs (n_pairs < 0: whole logits)
+        static const bool row_panels = !(getenv("TNN_HEAD_ROW_PANELS") && atoi(getenv("TNN_HEAD_ROW_PANELS")) == 0);
+        const int n_panels = (int)((rows + 15) / 16);
+        if (row_panels && h->w[L - 2] % 4 == 0)
+            STEP_CALL(h, tnn_dense_fwd_rows_head_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
                                                        at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
                                                        at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
                                                        h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
-                                                       at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats, 0,
-                                                       h->dtype));
+                                                       at(h->params, h->b_off[L - 1], h->esz), h->stats, h->dtype));
+        else
+            STEP_CALL(h, tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                           at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                           at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                           h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                           at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats, 0,
+                                                           h->dtype));
         STEP_CALL(h, tnn_mlp_head_bwd_tick_ext(rows, rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
                                                at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
                                                at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
-                                               y, h->zpart, h->stats, 1, h->act[L - 1], h->dact[L - 1], nullptr, loss_dst,
+                                               y, h->zpart, h->stats, (row_panels && h->w[L - 2] % 4 == 0) ? -n_panels : 1,
+                                               h->act[L - 1], h->dact[L - 1], nullptr, loss_dst,
                                                at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
                                                at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
                                                h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
@@ -767,7 +782,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
     static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
-    if (!head_multi && row_blocks && head_fits_row_blocks(h, rows)) head_multi = 1;     // 129 .. 512 rows per rank: blocks of 128
+    if (!head_multi && row_blocks && head_fits_row_blocks(h, rows, true)) head_multi = 1;     // 129 .. 512 rows per rank: blocks of 128
     if (head_multi) {
         // Classifier head of the one-launch form (<= 128 rows per rank: every weak-scaling point, config D at 8 ranks) —
         // 2L - 1 launches (5 for the MNIST net) + the collectives, ONE form for every transport:
