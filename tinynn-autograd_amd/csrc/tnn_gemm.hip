@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(512) void dense_fwd_rowpanel_head_kernel(RowPanelAr
     // trip) — with 16 / 32 / 64 workgroups in the launch it is one workgroup's latency that the launch takes.
     constexpr int KB = 256, CH = KB / 16, AS = KB + 4;
     __shared__ __attribute__((aligned(16))) float a_s[16 * AS];
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 accq[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // independent MFMA chains
     for (int kb = 0; kb < g.K; kb += KB) {
         float b[CH][4];
 #pragma unroll
@@ -1166,9 +1166,10 @@ __global__ __launch_bounds__(512) void dense_fwd_rowpanel_head_kernel(RowPanelAr
         for (int c = 0; c < CH; ++c) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(a_s + i16 * AS + 16 * c + 4 * grp);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b[c][j], acc, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) accq[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b[c][j], accq[j], 0, 0, 0);
         }
     }
+    const f32x4 acc = (accq[0] + accq[1]) + (accq[2] + accq[3]);
 
     // epilogue: acc[r] = out[row 4 grp + r][col i16] of this wave's tile (16x16x4 C/D layout)
     float* ts = tile_s[wid];

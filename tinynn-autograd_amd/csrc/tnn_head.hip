@@ -154,6 +154,8 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
 
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (PART) bias4 = head_stage_bias<C, NP>(p, t);
+    float ext_ms[2] = {0.f, 0.f};                  // SH == 2: the batch's {max, sum-exp}, merged once for all row blocks
+    if constexpr (SH == 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
     float dws0 = 0.f, dws1 = 0.f;                  // this thread's dW partial sums (threads < JPB * C * 4)
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};            // workgroup 0, wave 7: db partial sums
     double Lsum = 0.0;
@@ -268,7 +270,7 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
 
     HeadStats st;
-    if constexpr (SH == 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, p.ext_pairs, p.ext_n);
+    if constexpr (SH == 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, ext_ms, 0);
     else head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
@@ -472,6 +474,8 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     const f32x4 bias4 = head_stage_bias<C, NP>(p, t);
+    float ext_ms[2] = {0.f, 0.f};                // SH == 2: the batch's {max, sum-exp}, merged once for all row blocks
+    if constexpr (SH == 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
     // the global reads of one row block: staged logits / labels, the mask source rows of a1, (dW) the x fragment
     HeadStage<C, NP> stg_nx;
     float a1m_nx[4], af_nx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs
         return;
     }
     HeadStats st;
-    if constexpr (SH == 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, p.ext_pairs, p.ext_n);
+    if constexpr (SH == 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, ext_ms, 0);
     else head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
     if constexpr (CUT == 2) {
         q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;

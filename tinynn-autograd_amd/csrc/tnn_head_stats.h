@@ -15,6 +15,21 @@ struct HeadStats {
     double S, L;                     // batch sum-exp (relative to M), sum over rows of log u + row max
 };
 
+// Merge of ext_n {max, sum-exp} pairs from memory, one per lane (ext_n <= 64: the ranks' pairs, or one per 16-row panel of the
+// row-panel forward — a serial loop of 64 dependent expf per call cost the 1024-row step 80 us): wave-wide DPP max, then the
+// rescaled sum; every wave computes the same pair.
+__device__ __forceinline__ void head_merge_pairs(const float* pairs, const int n, const int lane, float& M, float& S) {
+    if (n == 1) {                                               // one already merged pair (uniform branch)
+        M = pairs[0];
+        S = pairs[1];
+        return;
+    }
+    const bool has = lane < n;
+    const float mq = has ? pairs[2 * lane] : -INFINITY, sq = has ? pairs[2 * lane + 1] : 0.f;
+    M = tnn::wave_max_dpp(mq);
+    S = tnn::wave_sum_dpp(has ? sq * expf(mq - M) : 0.f);
+}
+
 // zc / yc: this thread's three logits / labels of row (t >> 2) (classes sub, sub + 4, sub + 8); one barrier inside.
 // LOSS = false (workgroups that only need dz): no sum of logs, cross-row sums in f32 — a 1280-term DPP tree is good to
 // ~1e-6 relative, dz's tolerance is 1e-5 — which takes the f64 DPP reductions and the logf off their critical path.
@@ -53,18 +68,11 @@ __device__ __forceinline__ void head_stats(const float (&zc)[3], const float (&y
     urow += tnn::dpp_move<0x4E, 0xf>(0.f, urow);
     const bool counts = slive && sub == 0;                      // one lane per row feeds the cross-row sums
     if constexpr (EXT) {
-        // merge of the pairs, one per lane (ext_n <= 64: the ranks' pairs, or one per 16-row panel of the row-panel forward —
-        // a serial loop of 64 dependent expf per call cost the 1024-row step 80 us): wave-wide DPP max, then the rescaled sum
+        // the batch's pair: merged by the caller once per workgroup (head_merge_pairs) and handed over in ext_pairs[0..1] of
+        // a two-float array in registers (ext_n is then 0), or merged here
         float Mx, Sx;
-        if (ext_n == 1) {                                       // one already merged pair (uniform branch)
-            Mx = ext_pairs[0];
-            Sx = ext_pairs[1];
-        } else {
-            const bool has = lane < ext_n;
-            const float mq = has ? ext_pairs[2 * lane] : -INFINITY, sq = has ? ext_pairs[2 * lane + 1] : 0.f;
-            Mx = tnn::wave_max_dpp(mq);
-            Sx = tnn::wave_sum_dpp(has ? sq * expf(mq - Mx) : 0.f);
-        }
+        if (ext_n == 0) { Mx = ext_pairs[0]; Sx = ext_pairs[1]; }
+        else head_merge_pairs(ext_pairs, ext_n, lane, Mx, Sx);
         double Lx = 0.0;
         if (LOSS && want_loss) {                                // block-uniform: the loss-writing workgroup only
             const double wl = tnn::wave_sum_dpp(counts ? (double)logf(urow) + (double)mx : 0.0);
