@@ -304,7 +304,7 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
 // a workgroup owns 16 whole rows and finishes their logits and statistics itself).  Data parallel (129 .. 512 rows per rank,
 // config D at 2 / 4 ranks): the tiled forward whose tail reduces the statistics per 128-row block behind arrival counters
 // (tnn_dense_fwd_head_partials_stats) — the exchange needs ONE pair per rank.  Measured, same box, us per step at 256 / 512 /
-// 1024 rows: row-panel forward 28.4 / 37.1 / 51.4, counter tail 30.0 / 40.0 / 57.6, the 7-launch form below 35.5 / 41.4 / 52.8
+// 1024 rows: row-panel forward 26.9 / 34.7 / 45.5, counter tail 29.6 / 38.6 / 54.8, the 7-launch form below 35.4 / 41.4 / 52.7
 // (tools/probes/rows_sweep.sh; TNN_HEAD_ROW_BLOCKS_MAX moves the upper limits, TNN_HEAD_ROW_BLOCKS=0 turns the form off).
 bool head_fits_row_blocks(const Mlp* h, int64_t rows, bool sharded) {
     const int L = h->L;
