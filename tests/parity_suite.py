@@ -866,8 +866,18 @@ def fused_classifier_head_matches_generic_chain():
     from tinynn_autograd_amd.core.model import Model
     from tinynn_autograd_amd.core.nn import Net
     from tinynn_autograd_amd.core.optimizer import Adam
+    for m in (96, 300):                                          # 300 rows: the row-panel forward + the row-blocked merged launch
+        _fused_classifier_head_case(m)
+
+
+def _fused_classifier_head_case(m):
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.nn import Net
+    from tinynn_autograd_amd.core.optimizer import Adam
     rs = np.random.RandomState(41)
-    m, widths = 96, [64, 48, 128, 10]
+    widths = [64, 48, 128, 10]
     x = (rs.rand(m, widths[0]) * (rs.rand(m, widths[0]) < 0.4)).astype(np.float32)
     y = np.eye(10)[rs.randint(0, 10, m)]
     Ws = [(rs.randn(widths[i], widths[i + 1]) * 0.2).astype(np.float32) for i in range(3)]

@@ -55,7 +55,7 @@ class Dense(Layer):
             self.params[name] = tensor
         self.is_init = True
 
-    def forward(self, inputs, relu=False, head_w=None, lazy=False):
+    def forward(self, inputs, relu=False, head_w=None, lazy=False, head_b=None):
         """relu=True is passed by Net.forward when the next layer is a ReLU: one launch for both (ops.dense_); head_w / lazy:
         the classifier-head arrangements of Net.forward (ops.dense_)."""
         if not self.is_init:
@@ -65,7 +65,7 @@ class Dense(Layer):
         if not self.fused:
             out = inputs @ w + b
             return ops.clip(out, 0.0) if relu else out
-        return ops.dense_(inputs, w, b, relu=relu, head_w=head_w, lazy=lazy)
+        return ops.dense_(inputs, w, b, relu=relu, head_w=head_w, lazy=lazy, head_b=head_b)
 
 
 class Activation(Layer):

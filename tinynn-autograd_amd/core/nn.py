@@ -29,8 +29,9 @@ class Net(object):
             layer = layers[i]
             nxt = layers[i + 1] if i + 1 < n else None
             if type(layer) is Dense and layer.fused and type(nxt) is ReLU:
-                activations = layer.forward(activations, relu=True,
-                                            head_w=layers[-1].params["w"] if (head and i == n - 3) else None)
+                feeds_head = head and i == n - 3
+                activations = layer.forward(activations, relu=True, head_w=layers[-1].params["w"] if feeds_head else None,
+                                            head_b=layers[-1].params["b"] if feeds_head else None)
                 nxt.inputs = activations
                 i += 2
             else:

@@ -343,7 +343,7 @@ class _DenseVjp(object):
         return [res[name] for name in edges]
 
 
-def dense_(x, w, b, relu=False, head_w=None, lazy=False):
+def dense_(x, w, b, relu=False, head_w=None, lazy=False, head_b=None):
     """x @ w + b as ONE GEMM with a bias epilogue (core/layers.py:49); the vjps are the NT / TN GEMMs of
     dot_ (core/ops.py:156-160) and the column-sum of add_'s un-broadcast (:49-55).
 
@@ -359,7 +359,9 @@ def dense_(x, w, b, relu=False, head_w=None, lazy=False):
     (the mask is idempotent), so the rule never changes a value.
 
     head_w (Net.forward, hidden layer in front of a classifier head): the launch also emits the NEXT layer's logits as
-    per-tile partial sums (tnn_dense_fwd_head_partials) — they ride on the output array (`_aux`) for the loss node.
+    per-tile partial sums (tnn_dense_fwd_head_partials) — they ride on the output array (`_aux`) for the loss node.  More than
+    128 rows (head_b, the classifier's bias, is then needed too): the row-panel launch instead (tnn_dense_fwd_rows_head_stats:
+    whole logits without the bias + one {max, sum-exp} pair per 16 rows).
     lazy (Net.forward, the classifier layer itself in TRAIN mode): the GEMM is deferred until the logits are first used
     (device_array.LazyArray); softmax_nll_ then produces them together with the loss and this layer's backward."""
     xv, wv, bv = x.values, w.values, b.values
@@ -382,7 +384,15 @@ def dense_(x, w, b, relu=False, head_w=None, lazy=False):
         lazy = False
         out = da.empty((m, n), dt)
         hw = head_w.values if head_w is not None else None
-        if (hw is not None and out.size and dt == np.float32 and hw.dtype == dt and hw.ndim == 2 and hw.shape[0] == n
+        hb = head_b.values if head_b is not None else None
+        if (hw is not None and 128 < m <= 1024 and relu and n == 128 and k % 4 == 0 and dt == np.float32 and hw.dtype == dt
+                and hw.shape == (128, 10) and not hw._t and hw._hv is None and hb is not None and hb.dtype == dt
+                and hb.size == 10 and not hb._t and hb._hv is None):
+            zfull, pairs = da.empty((m, 10), dt), da.empty(((m + 15) // 16, 2), dt)
+            _lib.get().dense_fwd_rows_head_stats(m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_RELU, 1, out._ptr, n,
+                                                 hw._ptr, 10, zfull._ptr, hb._ptr, pairs._ptr, code)
+            out._aux = (zfull, hw, pairs, hb)         # valid for the classifier weights / bias as they are NOW
+        elif (hw is not None and out.size and m <= 128 and dt == np.float32 and hw.dtype == dt and hw.ndim == 2 and hw.shape[0] == n
                 and hw.shape[1] <= 16 and not hw._t and hw._hv is None):
             zpart = da.empty(((n + 15) // 16, m, hw.shape[1]), dt)
             _lib.get().dense_fwd_head_partials(m, n, k, xv._ptr, k, wv._ptr, n, bv._ptr, _lib.ACT_RELU if relu else _lib.ACT_NONE,
@@ -422,8 +432,12 @@ def _softmax_head(logits, labels):
     y = as_tensor(labels).values
     m, c = z.shape
     hdim = wv.shape[0]
+    aux = xv._aux
+    # more than 128 rows: only with what the row-panel forward left behind (whole logits + panel statistics for THESE weights)
+    rows_form = (m > 128 and aux is not None and len(aux) == 4 and aux[1] is wv and aux[3] is bv
+                 and aux[0].shape == (m, c) and hdim == 128 and c == 10)
     if (y.shape != z.shape or xv._tag is not da.RELU_SIGN or xv._t or xv._hv is not None or wv._t or bv._t
-            or not _head_fits(m, hdim, c)):
+            or not (rows_form or (m <= 128 and _head_fits(m, hdim, c)))):
         return None
     dt = np.dtype(np.float32)
     y = y._as_float(dt)._contig()
@@ -440,8 +454,9 @@ def _softmax_head(logits, labels):
     dw, dw_home = dest(w, (hdim, c))
     db, db_home = dest(b, tuple(b.shape))
     zpart = None
-    aux = xv._aux
-    if aux is not None and aux[1] is wv and aux[0].shape == (hdim // 16, m, c):
+    if rows_form:
+        zpart = aux[0]
+    elif aux is not None and aux[1] is wv and aux[0].shape == (hdim // 16, m, c):
         zpart = aux[0]
     generic = logits._fused_vjp
 
@@ -458,9 +473,15 @@ def _softmax_head(logits, labels):
         db1, db1_home = dest(b1, tuple(b1.shape))
         dx0 = da.empty((m, n_in), dt)
         dx0._tag = x0v
-        lib.mlp_head_bwd_tick(m, n_in, hdim, c, x0v._ptr, w1v._ptr, xv._ptr, wv._ptr, bv._ptr, y._ptr, zpart._ptr,
-                              z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, dw1._ptr, db1._ptr,
-                              dx0._ptr, _lib.F32, None, 0.0, 0.0)
+        if rows_form:
+            pairs = aux[2]
+            lib.mlp_head_bwd_tick_ext(m, m, n_in, hdim, c, x0v._ptr, w1v._ptr, xv._ptr, wv._ptr, bv._ptr, y._ptr, zpart._ptr,
+                                      pairs._ptr, -pairs.shape[0], z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr,
+                                      db._ptr, dw1._ptr, db1._ptr, dx0._ptr, _lib.F32, None, 0.0, 0.0)
+        else:
+            lib.mlp_head_bwd_tick(m, n_in, hdim, c, x0v._ptr, w1v._ptr, xv._ptr, wv._ptr, bv._ptr, y._ptr, zpart._ptr,
+                                  z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, dw1._ptr, db1._ptr,
+                                  dx0._ptr, _lib.F32, None, 0.0, 0.0)
 
         def hidden_dz(arr, dz=dz, wv=wv, xv=xv):     # only if the intermediate gradient is actually looked at
             val = da.mul_signmask(dz @ wv.T, xv)
@@ -486,6 +507,8 @@ def _softmax_head(logits, labels):
             return generic1(g_in, homes)
         x._head_pre = True
         x._fused_vjp = hidden_vjp
+    elif rows_form:
+        return None                                   # the one-launch head without the hidden backward exists for <= 128 rows only
     else:
         dx = da.empty((m, hdim), dt) if x.requires_grad else None
         lib.mlp_head_tick(m, hdim, c, xv._ptr, wv._ptr, bv._ptr, y._ptr, None if zpart is None else zpart._ptr,
