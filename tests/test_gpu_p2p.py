@@ -162,22 +162,27 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
 
 
 @pytest.mark.gpu
-def test_bench_gpus_2_launches_its_own_ranks():
-    """`python3 bench.py --gpus 2 ...` with NO launcher (the form the driver uses for N = 1): the parent, which never
-    touches the GPU, starts the two ranks itself, relays rank 0's one JSON line and passes the children's status on."""
+@pytest.mark.parametrize("gpus", [2, 4])
+def test_bench_gpus_2_launches_its_own_ranks(gpus):
+    """`python3 bench.py --gpus N ...` with NO launcher (the form the driver uses for N = 1): the parent, which never
+    touches the GPU, starts the ranks itself, relays rank 0's one JSON line and passes the children's status on.  N = 2 / 4:
+    512 / 256 rows per rank — the data-parallel 5-launch step whose merged head launch walks the rows in blocks of 128 and
+    whose forward tail reduces the statistics per block before the exchange."""
     import json
     env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0",
                PYTHONDONTWRITEBYTECODE="1")
+    if gpus > 2:
+        env["TNN_BENCH_CONFIG_E"] = "0"                 # four 8192-wide bf16 trainers on one GPU: covered at N = 2
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong"
-    assert d["config"]["global_batch"] == 1024 and d["config"]["rows_per_rank"] == 512
+    assert d["n_gpus"] == gpus and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 1024 and d["config"]["rows_per_rank"] == 1024 // gpus
     assert d["parity_vs_reference_fixture"]["ok"] and d["exit_code"] == 0
     assert d["config"]["collectives"]["xgmi_p2p"]["replicas_identical"]
     assert "note" in d["strong_scaling"]
