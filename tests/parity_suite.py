@@ -1300,6 +1300,49 @@ def trainer_step_forms_agree_with_the_op_level_model():
             np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
 
 
+def trainer_row_blocks_random_batch_sizes():
+    """The 4-launch step for batches of more than 128 rows (row-panel forward + row-blocked merged launch) at a dozen random
+    batch sizes in 129 .. 1024 — odd ones included, which take the element-wise staging paths — against the op-level Model
+    built WITHOUT any fusion (Dense(fused=False) layers, the 12-op loss): losses of two steps and the parameters after them."""
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.nn import Net
+    from tinynn_autograd_amd.core.optimizer import Adam
+    rs = np.random.RandomState(77)
+    widths = [36, 48, 128, 10]
+    sizes = sorted(set([129, 1024, 255, 257] + list(rs.randint(130, 1024, 8))))
+    for rows in sizes:
+        Ws = [(rs.randn(widths[i], widths[i + 1]) * 0.2).astype(np.float32) for i in range(3)]
+        Bs = [(rs.randn(1, widths[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+
+        def build(fused):
+            layers = []
+            for i in range(3):
+                d = Dense(widths[i + 1], num_in=widths[i], fused=fused)
+                d.params["w"].values = tn.asarray(Ws[i]); d.params["b"].values = tn.asarray(Bs[i])
+                d.params["w"].zero_grad(); d.params["b"].zero_grad()
+                layers.append(d)
+                if i < 2:
+                    layers.append(ReLU())
+            return Net(layers)
+        ref_net = build(False)
+        loss_layer = SoftmaxCrossEntropyLoss(fused=False)
+        model = Model(net=ref_net, loss=loss_layer, optimizer=Adam(lr=1e-3))
+        trainer = trainer_from_net(build(True), max_rows=int(rows), loss="softmax_nll", optimizer="adam", lr=1e-3)
+        for step in range(2):
+            x = (rs.rand(rows, widths[0]) * (rs.rand(rows, widths[0]) < 0.5)).astype(np.float32)
+            y = np.eye(10, dtype=np.float32)[rs.randint(0, 10, rows)]
+            model.zero_grad()
+            out = loss_layer.loss(model.forward(Tensor(x)), Tensor(y))
+            out.backward()
+            model.step()
+            tl = float(trainer.step(tn.asarray(x), tn.asarray(y)))
+            np.testing.assert_allclose(tl, float(out.values), rtol=2e-5, err_msg="rows=%d step %d" % (rows, step))
+        flat = np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
+        np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg="rows=%d" % rows)
+
+
 def trainer_keep_grads_off_is_bit_identical():
     """MLPTrainer.keep_grads(False) on the MNIST-size step (what bench.py times on one GPU): the first layer's weight
     gradient is consumed by Adam in the launch that produces it and not stored — losses, parameters and both moments are
