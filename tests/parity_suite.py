@@ -1300,6 +1300,49 @@ def trainer_step_forms_agree_with_the_op_level_model():
             np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
 
 
+def eager_step_leaves_no_reference_cycles():
+    """An op-level training step must be freed by reference counting alone: a cycle among its tensors (one existed: hidden
+    activation -> its wrapped vjp -> the classifier's vjp -> its input tensor) parks the step's device buffers until the
+    cycle collector runs — 620 extra device allocations and +40 MB over 100 000 eager steps on the GPU box."""
+    import gc
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.nn import Net
+    from tinynn_autograd_amd.core.optimizer import Adam
+    rs = np.random.RandomState(3)
+    for widths, rows in (([20, 32, 128, 10], 24), ([20, 32, 128, 10], 200), ([20, 16, 12, 5], 24)):
+        np.random.seed(1)
+        layers = []
+        for i in range(3):
+            layers.append(Dense(widths[i + 1], num_in=widths[i]))
+            if i < 2:
+                layers.append(ReLU())
+        loss_layer = SoftmaxCrossEntropyLoss()
+        model = Model(net=Net(layers), loss=loss_layer, optimizer=Adam(lr=1e-3))
+        x = Tensor(rs.rand(rows, widths[0]).astype(np.float32))
+        y = Tensor(np.eye(widths[-1], dtype=np.float32)[rs.randint(0, widths[-1], rows)])
+
+        def step():
+            model.zero_grad()
+            out = loss_layer.loss(model.forward(x), y)
+            out.backward()
+            model.step()
+        for _ in range(3):
+            step()
+        gc.collect()
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            for _ in range(5):
+                step()
+            found = gc.collect()
+        finally:
+            if was:
+                gc.enable()
+        assert found == 0, "%d objects of 5 steps (%s, %d rows) were only reachable by the cycle collector" % (found, widths, rows)
+
+
 def trainer_row_blocks_random_batch_sizes():
     """The 4-launch step for batches of more than 128 rows (row-panel forward + row-blocked merged launch) at a dozen random
     batch sizes in 129 .. 1024 — odd ones included, which take the element-wise staging paths — against the op-level Model

@@ -11,6 +11,7 @@ Extra fused nodes used by this package's own layers/losses (parity-tested agains
 """
 
 import math
+import weakref
 
 import numpy as np
 
@@ -251,10 +252,12 @@ def clip_(ts, min, max):
 class _DenseVjp(object):
     """The vjps of one ops.dense_ node (see dense_): per-edge forms for schedulers that ask edge by edge (the reference's
     own recursion), `fused_vjp` for Tensor.backward, which offers all edges at once."""
-    __slots__ = ("x", "w", "b", "xv", "wv", "bv", "out", "m", "k", "n", "dt", "relu", "x_relu", "edges", "shared")
+    __slots__ = ("b", "xv", "wv", "bv", "out", "m", "k", "n", "dt", "relu", "x_relu", "edges", "shared")
 
-    def __init__(self, x, w, b, xv, wv, bv, out, m, k, n, dt, relu, x_relu):
-        self.x, self.w, self.b, self.xv, self.wv, self.bv, self.out = x, w, b, xv, wv, bv, out
+    def __init__(self, b, xv, wv, bv, out, m, k, n, dt, relu, x_relu):
+        # arrays, not the input tensors (only the bias tensor, a leaf, for its arena view): a vjp that held its node's input
+        # TENSOR closed a reference cycle through the speculative head (x -> its wrapped vjp -> the classifier's vjp -> x)
+        self.b, self.xv, self.wv, self.bv, self.out = b, xv, wv, bv, out
         self.m, self.k, self.n, self.dt, self.relu, self.x_relu = m, k, n, dt, relu, x_relu
         self.edges = ()
         self.shared = []              # [(g object, db)] computed together with dW, waiting for the bias vjp
@@ -405,7 +408,7 @@ def dense_(x, w, b, relu=False, head_w=None, lazy=False, head_b=None):
         out._tag = da.RELU_SIGN
 
     # the vjps live on ONE context object (bound methods) instead of eight closures per call: the op-level step is host-bound
-    ctx = _DenseVjp(x, w, b, xv, wv, bv, out, m, k, n, dt, relu, x_relu)
+    ctx = _DenseVjp(b, xv, wv, bv, out, m, k, n, dt, relu, x_relu)
     node = _make_node(x.__class__, out, [(x, ctx.d_x), (w, ctx.d_w), (b, ctx.d_b)])
     edges = ctx.edges = [name for name, t in (("x", x), ("w", w), ("b", b)) if t.requires_grad]
     fused_vjp = ctx.fused_vjp
@@ -491,7 +494,11 @@ def _softmax_head(logits, labels):
         pre1 = {"x": (dx0, False), "w": (dw1, dw1_home), "b": (db1, db1_home)}
         generic1 = x._fused_vjp
 
+        x_ref = weakref.ref(x)                        # not x itself: x._fused_vjp -> this closure -> x would be a cycle that
+                                                      # keeps the whole step's graph (and its buffers) alive until the cycle GC
+
         def hidden_vjp(g_in, homes):
+            x = x_ref()
             state = x._head_pre
             x._head_pre = None
             if state is not None and g_in is dx:
@@ -518,7 +525,10 @@ def _softmax_head(logits, labels):
             dx._tag = xv                              # already multiplied by x's ReLU mask
     pre = {"x": (dx, False), "w": (dw, dw_home), "b": (db, db_home)}
 
+    logits_ref = weakref.ref(logits)                  # see x_ref above
+
     def fused_vjp(g_in, homes):
+        logits = logits_ref()
         state = logits._head_pre
         logits._head_pre = None                       # one hand-over; whatever comes later is recomputed
         if state is not None and g_in is dz:
