@@ -1300,6 +1300,34 @@ def trainer_step_forms_agree_with_the_op_level_model():
             np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
 
 
+def graph_released_while_another_capture_is_open():
+    """A captured function whose last reference dies in the MIDDLE of another capture (garbage collection during a
+    re-capture does this): its destruction must not touch the capturing stream — tnn_graph_destroy used to synchronise it,
+    which invalidated the open capture ("operation failed due to a previous error during capture") — and the graph recorded
+    meanwhile must replay correctly."""
+    a = tn.asarray(np.arange(8, dtype=np.float32))
+    out1 = tn.zeros((8,))
+    holder = {}
+
+    def first():
+        out1[...] = a * 2.0
+        return out1
+    holder["old"] = tn.capture(first, warmup=1)
+    holder["old"]()
+    out2 = tn.zeros((8,))
+
+    def second():
+        tmp = a + 1.0
+        holder.pop("old", None)                   # the first graph dies here, inside the second capture
+        out2[...] = tmp * 3.0
+        return out2
+    again = tn.capture(second, warmup=0)
+    out2[...] = 0.0
+    again()
+    np.testing.assert_allclose(np.asarray(out2), (np.arange(8) + 1.0) * 3.0)
+    np.testing.assert_allclose(np.asarray(out1), np.arange(8) * 2.0)
+
+
 def eager_step_leaves_no_reference_cycles():
     """An op-level training step must be freed by reference counting alone: a cycle among its tensors (one existed: hidden
     activation -> its wrapped vjp -> the classifier's vjp -> its input tensor) parks the step's device buffers until the

@@ -42,6 +42,7 @@ struct State {
     uint64_t next_graph_id = 1;
     GraphRec* capturing = nullptr;
     std::unordered_map<uint64_t, GraphRec*> graphs;
+    std::vector<GraphRec*> destroy_later;             // graphs released while another capture was open (tnn_graph_destroy)
 };
 State g;
 
@@ -282,6 +283,8 @@ int tnn_event_destroy(void* ev) {
     return 0;
 }
 
+static int graph_destroy_now(GraphRec* r);
+
 int tnn_graph_capture_begin(void) {
     TNN_NEED_INIT();
     std::lock_guard<std::mutex> lk(g.mu);
@@ -308,7 +311,14 @@ int tnn_graph_capture_end(void** graph_exec) {
         r = g.capturing;
         g.capturing = nullptr;
     }
-    TNN_CHECK_HIP(hipStreamEndCapture(g.stream, &r->graph));
+    const hipError_t e_end = hipStreamEndCapture(g.stream, &r->graph);
+    std::vector<GraphRec*> later;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        later.swap(g.destroy_later);
+    }
+    for (GraphRec* d : later) graph_destroy_now(d);           // graphs whose owners died while this capture was open
+    TNN_CHECK_HIP(e_end);
     TNN_CHECK_HIP(hipGraphInstantiate(&r->exec, r->graph, nullptr, nullptr, 0));
     *graph_exec = (void*)r;
     return 0;
@@ -325,6 +335,19 @@ int tnn_graph_launch(void* graph_exec) {
 int tnn_graph_destroy(void* graph_exec) {
     if (!graph_exec || !g.ready) return 0;
     GraphRec* r = (GraphRec*)graph_exec;
+    {
+        // While ANOTHER capture is open (a garbage-collected graph object dying in the middle of a re-capture) the stream
+        // must not be synchronised — that invalidates the open capture: the destruction waits for tnn_graph_capture_end.
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.capturing != nullptr && g.capturing != r) {
+            g.destroy_later.push_back(r);
+            return 0;
+        }
+    }
+    return graph_destroy_now(r);
+}
+
+static int graph_destroy_now(GraphRec* r) {
     hipStreamSynchronize(g.stream);
     std::lock_guard<std::mutex> lk(g.mu);
     if (r->exec) hipGraphExecDestroy(r->exec);
