@@ -1300,6 +1300,30 @@ def trainer_step_forms_agree_with_the_op_level_model():
             np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
 
 
+def trainer_captured_steps_of_mixed_batch_sizes():
+    """One hipGraph holding seven training steps at seven batch sizes (128, a ragged 37, 256, 512, 129, 1024, 128 — every form
+    of the step: 4 launches, row-panel forward + row blocks, a one-row last block) replayed twice, against an eager trainer fed
+    the same fourteen batches: losses and parameters bit-identical."""
+    rs = np.random.RandomState(0)
+    widths = [40, 48, 128, 10]
+
+    def mk(rows):
+        x = (rs.rand(rows, widths[0]) * (rs.rand(rows, widths[0]) < 0.4)).astype(np.float32)
+        y = np.eye(10, dtype=np.float32)[rs.randint(0, 10, rows)]
+        return tn.asarray(x), tn.asarray(y)
+    batches = [mk(r) for r in (128, 37, 256, 512, 129, 1024, 128)]
+    cfg = dict(widths=widths, seed=5, opt="adam", lr=1e-3, loss="softmax_nll")
+    trainers = []
+    for _ in range(2):
+        model, _ = H.build_model(cfg)
+        trainers.append(trainer_from_net(model.net, max_rows=1024, loss="softmax_nll", optimizer="adam", lr=1e-3, use_graph=False))
+    graph = trainers[0].capture_steps(batches)
+    got = np.concatenate([np.asarray(graph.launch()).copy(), np.asarray(graph.launch()).copy()])
+    ref = np.asarray([float(trainers[1].step(x, y)) for x, y in batches + batches], np.float32)
+    assert np.array_equal(got, ref), (got, ref)
+    assert np.array_equal(np.asarray(trainers[0].params), np.asarray(trainers[1].params))
+
+
 def graph_released_while_another_capture_is_open():
     """A captured function whose last reference dies in the MIDDLE of another capture (garbage collection during a
     re-capture does this): its destruction must not touch the capturing stream — tnn_graph_destroy used to synchronise it,
