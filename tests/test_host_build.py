@@ -19,7 +19,8 @@ PROBE = ("import sys, warnings; sys.path.insert(0, %r)\n"
 
 
 def _probe(root, **env):
-    e = dict(os.environ, **env)
+    e = dict(os.environ, TNN_HOST_COMPILED="1")          # whatever mode the test session itself runs in
+    e.update(env)
     out = subprocess.run([sys.executable, "-c", PROBE % root], env=e, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = dict(l.split(" ", 1) if " " in l else (l, "") for l in out.stdout.strip().splitlines())
