@@ -21,6 +21,7 @@ What `value` is:
             strong_scaling  the config-D point of THIS N (N = 1: bs 1024 on one GPU = `--workload A --rows 1024`), and at
                             N > 1 the single-GPU bs-1024 step measured on rank 0 of the same run
             weak_scaling    128 rows per rank (global batch 128 N)
+            batch_sizes     (N = 1) the same net at 256 and 512 rows on the one GPU — the per-rank batches of N = 4 / 2
           so both curves can be drawn from the driver's N = 1/2/4/8 lines.
   Transports at N > 1: RCCL (north_star's named transport) is timed FIRST, the xGMI peer-to-peer path second; both are
   reported unconditionally under config.collectives.  `value` is the peer-to-peer run when that transport passed its
@@ -949,6 +950,15 @@ def main():
             curves["strong_scaling"] = brief(r1, global_batch=GLOBAL_BATCH_D, rows_per_rank=GLOBAL_BATCH_D,
                                              launches_per_step=d1.launches_per_step(), note=strong_note)
             del d1
+            if not args.no_extras and args.rows is None:
+                # the same net at the batch sizes in between (the per-rank batches of the strong curve at N = 4 / 2)
+                between = {}
+                for rows_b in (256, 512):
+                    rb_run = FusedRun(widths, rows_b, kind, 32, 0, 1, None, False, use_graph=use_graph)
+                    between[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
+                                                 launches_per_step=rb_run.launches_per_step())
+                    del rb_run
+                curves["batch_sizes"] = between
         elif other_rows != rows:
             other = FusedRun(widths, other_rows, kind, 64 if other_rows <= 256 else 32, rank, world, comm, False,
                              use_graph=use_graph)
