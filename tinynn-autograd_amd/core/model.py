@@ -14,6 +14,8 @@
 (core/model.py:18-35).
 """
 
+import weakref
+
 import numpy as np
 
 from .. import device_array as da
@@ -31,6 +33,7 @@ class Model(object):
         self._param_arena = None
         self._grad_arena = None
         self._arena_tensors = None
+        self._pending_first = None   # (x, dz, w, rows, n_in, n_out): the first Dense layer's backward, deferred to step()
 
     def forward(self, inputs):
         return self.net.forward(inputs)
@@ -84,10 +87,24 @@ class Model(object):
         total = sum(t.values.size for t in tensors)
         params, grads = da.empty((total,), dt), da.zeros((total,), dt)
         off = 0
+        # The FIRST Dense layer's two gradient views can be declared pending (device_array.LazyArray): with a fused Adam on
+        # one GPU its backward launch is deferred to step(), where ONE launch computes dW / db and applies the optimizer to
+        # the whole arena (tnn_dense_bwd_first_adam — the whole-step trainer's last launch); anything that looks at those
+        # gradients first (a read, gradient clipping, a second backward) runs the ordinary backward launch instead.
+        first = self._first_dense_params(tensors) if (dt == np.float32 and self.comm is None
+                                                      and hasattr(self.optimizer, "apply_with_first_layer")) else ()
+        self._pending_first = None
         for t in tensors:
             n = t.values.size
             pv = params[off:off + n].reshape(t.shape)
-            gv = grads[off:off + n].reshape(t.shape)
+            if any(t is f for f in first):
+                gv = da.LazyArray.view(grads, off, t.shape)
+                t._defer_first = weakref.ref(self)
+            else:
+                gv = grads[off:off + n].reshape(t.shape)
+                t._defer_first = None
+            # the loss launch of a step may advance Adam's powers for it (ops._softmax_head, Adam.take_tick)
+            t._tick_optimizer = weakref.ref(self.optimizer) if (first and hasattr(self.optimizer, "take_tick")) else None
             pv[...] = t.values
             had_grad = t._grad is not None
             if had_grad:
@@ -99,11 +116,68 @@ class Model(object):
             off += n
         self._param_arena, self._grad_arena, self._arena_tensors = params, grads, tensors
 
+    def _first_dense_params(self, tensors):
+        """(w, b) of the net's first layer when that is a Dense whose parameters head the arena, else ()."""
+        from .layers import Dense
+        layers = getattr(self.net, "layers", None)
+        if not layers or type(layers[0]) is not Dense or not layers[0].fused or len(tensors) < 2:
+            return ()
+        w, b = layers[0].params.get("w"), layers[0].params.get("b")
+        if w is None or b is None or tensors[0] is not w or tensors[1] is not b or w.values.ndim != 2:
+            return ()
+        return (w, b)
+
+    def _defer_first_backward(self, x, dz, w, dw_home, db_home, rows, n_in, n_out):
+        """Called by the first Dense layer's vjp (ops._DenseVjp.fused_vjp) instead of launching: remember the operands, mark
+        the two arena views pending.  Returns False to decline (the vjp then launches as usual)."""
+        ts = self._arena_tensors
+        if (ts is None or self.comm is not None or dw_home is not ts[0]._grad_home or db_home is not ts[1]._grad_home
+                or self._pending_first is not None):
+            return False
+        self._pending_first = (x, dz, w, rows, n_in, n_out)
+        me = weakref.ref(self)
+
+        def materialise(_arr, me=me):
+            model = me()
+            if model is not None:
+                model._run_pending_first()
+        dw_home.defer(materialise)
+        db_home.defer(materialise)
+        return True
+
+    def _run_pending_first(self):
+        """The deferred launch after all: dW and db of the first layer into their arena views (tnn_dense_bwd)."""
+        pend, self._pending_first = self._pending_first, None
+        ts = self._arena_tensors
+        if pend is None or ts is None:
+            return
+        x, dz, w, rows, n_in, n_out = pend
+        dw, db = ts[0]._grad_home, ts[1]._grad_home
+        from .. import _lib
+        _lib.get().dense_bwd(rows, n_in, n_out, x._ptr, dz._ptr, w._ptr, dw.fulfilled_ptr(), db.fulfilled_ptr(), None, None,
+                             dz._code())
+
     # ------------------------------------------------------------------ the training step
     def step(self):
         params = self.net.get_parameters()
         if self.use_arena:
             self._bind_arenas()
+        pend = self._pending_first
+        if pend is not None:
+            ts = self._arena_tensors
+            if (ts is not None and ts[0]._grad_home.pending and ts[1]._grad_home.pending
+                    and all(t._grad is t._grad_home for t in ts)):
+                x, dz, _w, rows, n_in, n_out = pend
+                if self.optimizer.apply_with_first_layer(self._param_arena, self._grad_arena, rows, n_in, n_out, x, dz):
+                    # ONE launch: the first layer's backward + the optimizer over the whole arena
+                    self._pending_first = None
+                    ts[0]._grad_home.drop()
+                    ts[1]._grad_home.drop()
+                    for t in ts:
+                        t.values = t._values_home            # same post-state as `param += step`: grad dropped
+                    return
+            if self._pending_first is not None:
+                self._run_pending_first()
         all_grads = [{k: p.grad for k, p in layer.items()} for layer in params]
 
         if self.comm is not None and self.comm.world > 1:
@@ -156,6 +230,7 @@ class Model(object):
                 layer[key] += step[key]
 
     def zero_grad(self):
+        self._pending_first = None                   # (Tensor.zero_grad drops the pending marks of the two arena views)
         for layer in self.net.get_parameters():
             for p in layer.values():
                 if p is not None:

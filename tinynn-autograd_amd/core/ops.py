@@ -341,6 +341,12 @@ class _DenseVjp(object):
                 res["x"] = dx
         if dw is None:
             dw = da.empty((k, n), dt)                 # w frozen: the launch still needs somewhere to write
+        if dx is None and edges == ["w", "b"] and type(dw) is da.LazyArray and type(db) is da.LazyArray:
+            # the model's FIRST layer writing into its arena views: the launch can wait for the optimizer (core/model.py)
+            owner = getattr(self.b, "_defer_first", None)
+            owner = owner() if owner is not None else None
+            if owner is not None and owner._defer_first_backward(xv, g, self.wv, dw, db, m, k, n):
+                return [dw, db]
         _lib.get().dense_bwd(m, k, n, xv._ptr, g._ptr, self.wv._ptr, dw._ptr, db._ptr if db is not None else None,
                              dx._ptr if dx is not None else None, xv._ptr if dx is not None else None, dw._code())
         return [res[name] for name in edges]
@@ -476,15 +482,21 @@ def _softmax_head(logits, labels):
         db1, db1_home = dest(b1, tuple(b1.shape))
         dx0 = da.empty((m, n_in), dt)
         dx0._tag = x0v
+        # Adam's bias-correction powers for the coming step are advanced by one thread of this launch when the classifier's
+        # parameters belong to a Model whose optimizer asks for it (once per optimizer step: Adam.take_tick)
+        opt = getattr(w, "_tick_optimizer", None)
+        opt = opt() if opt is not None else None
+        tick = opt.take_tick() if opt is not None else None
+        pows, tb1, tb2 = tick if tick is not None else (None, 0.0, 0.0)
         if rows_form:
             pairs = aux[2]
             lib.mlp_head_bwd_tick_ext(m, m, n_in, hdim, c, x0v._ptr, w1v._ptr, xv._ptr, wv._ptr, bv._ptr, y._ptr, zpart._ptr,
                                       pairs._ptr, -pairs.shape[0], z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr,
-                                      db._ptr, dw1._ptr, db1._ptr, dx0._ptr, _lib.F32, None, 0.0, 0.0)
+                                      db._ptr, dw1._ptr, db1._ptr, dx0._ptr, _lib.F32, pows, tb1, tb2)
         else:
             lib.mlp_head_bwd_tick(m, n_in, hdim, c, x0v._ptr, w1v._ptr, xv._ptr, wv._ptr, bv._ptr, y._ptr, zpart._ptr,
                                   z.fulfilled_ptr(), dz._ptr, stats._ptr, loss._ptr, dw._ptr, db._ptr, dw1._ptr, db1._ptr,
-                                  dx0._ptr, _lib.F32, None, 0.0, 0.0)
+                                  dx0._ptr, _lib.F32, pows, tb1, tb2)
 
         def hidden_dz(arr, dz=dz, wv=wv, xv=xv):     # only if the intermediate gradient is actually looked at
             val = da.mul_signmask(dz @ wv.T, xv)

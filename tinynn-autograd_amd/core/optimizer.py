@@ -84,6 +84,7 @@ class Adam(BaseOptimizer):
         self._m = 0
         self._v = 0
         self._pows = None      # device double[4]: {b1^(t-1), b2^(t-1), ticket, pad}
+        self._ticked = False   # the powers have ALREADY been advanced for the coming step (by the loss launch, see take_tick)
 
     def _compute_step(self, grad):
         self._t += 1
@@ -100,8 +101,45 @@ class Adam(BaseOptimizer):
             return False
         self._t += 1
         self._ensure_state(grads)
-        _lib.get().adam(params._ptr, grads._ptr, self._m._ptr, self._v._ptr, grads.size, self.lr, self._b1, self._b2,
-                        self._eps, self._pows._ptr, None, grads._code())
+        if self._ticked:                             # the loss launch advanced the powers for this step
+            _lib.get().adam_ex(params._ptr, grads._ptr, self._m._ptr, self._v._ptr, grads.size, self.lr, self._b1, self._b2,
+                               self._eps, self._pows._ptr, None, grads._code(), 0, None, None)
+            self._ticked = False
+        else:
+            _lib.get().adam(params._ptr, grads._ptr, self._m._ptr, self._v._ptr, grads.size, self.lr, self._b1, self._b2,
+                            self._eps, self._pows._ptr, None, grads._code())
+        return True
+
+    def take_tick(self):
+        """For the loss launch of a training step (ops._softmax_head): (powers pointer, b1, b2) if that launch should advance
+        the bias-correction powers for the coming step — once per optimizer step, however many losses are evaluated in
+        between — else None.  The whole-step trainer does the same in its head launch; it is what lets the step's LAST launch
+        carry the optimizer (apply_with_first_layer) without a launch or an arrival counter for the advance."""
+        if not self.fused or self._pows is None or self._ticked:
+            return None
+        self._ticked = True
+        return self._pows._ptr, self._b1, self._b2
+
+    def apply_with_first_layer(self, params, grads, rows, n_in, n_out, x, dz):
+        """The backward of the model's FIRST Dense layer (deferred by Model, core/model.py) and the Adam step over the whole
+        arena in ONE launch (tnn_dense_bwd_first_adam): dW = x^T dz and db = column sums of dz are written to the head of
+        `grads` (the layer's arena views) and consumed in the same launch.  Returns False if this optimizer cannot."""
+        if not (self.fused and _flat_pair_ok(params, grads)) or grads.dtype != np.float32:
+            return False
+        self._ensure_state(grads)
+        lib = _lib.get()
+        if not self._ticked:                         # no loss launch advanced the powers: a launch of its own
+            lib.adam_tick(self._pows._ptr, self._b1, self._b2)
+        self._t += 1
+        self._ticked = False
+        esz = grads.dtype.itemsize
+        nw, nb = n_in * n_out, n_out
+        rest = nw + nb
+        pp, gp, mp, vp = params._ptr, grads._ptr, self._m._ptr, self._v._ptr
+        lib.dense_bwd_first_adam(rows, n_in, n_out, x._ptr, dz._ptr, gp, gp + nw * esz, pp, mp, vp, pp + nw * esz,
+                                 mp + nw * esz, vp + nw * esz, pp + rest * esz, gp + rest * esz, mp + rest * esz,
+                                 vp + rest * esz, grads.size - rest, self.lr, self._b1, self._b2, self._eps,
+                                 self._pows._ptr, grads._code())
         return True
 
     def _ensure_state(self, grad):
@@ -114,8 +152,13 @@ class Adam(BaseOptimizer):
         lib = _lib.get()
         self._ensure_state(grad)
         step = da.empty(grad.shape, grad.dtype)
-        lib.adam(None, grad._ptr, self._m._ptr, self._v._ptr, grad.size, self.lr, self._b1, self._b2,
-                 self._eps, self._pows._ptr, step._ptr, grad._code())
+        if self._ticked:                             # see take_tick
+            lib.adam_ex(None, grad._ptr, self._m._ptr, self._v._ptr, grad.size, self.lr, self._b1, self._b2,
+                        self._eps, self._pows._ptr, step._ptr, grad._code(), 0, None, None)
+            self._ticked = False
+        else:
+            lib.adam(None, grad._ptr, self._m._ptr, self._v._ptr, grad.size, self.lr, self._b1, self._b2,
+                     self._eps, self._pows._ptr, step._ptr, grad._code())
         return step
 
 

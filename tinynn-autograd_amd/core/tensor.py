@@ -251,6 +251,9 @@ class Tensor(object):
         self._grad_zero = True
         self._grad_shared = False
         self._home_lent = False
+        home = self._grad_home
+        if home is not None and type(home) is da.LazyArray:
+            home.drop()                              # a deferred backward launch (core/model.py) is not wanted any more
 
     def _accumulate(self, g):
         """self.grad += g (core/tensor.py:163) with broadcasting of g to self.shape."""

@@ -644,7 +644,8 @@ def asarray(obj, dtype=None):
 class LazyArray(DeviceArray):
     """An array whose producing launch is deferred until something first asks for its buffer (`_ptr`).
 
-    Used for ONE thing: the logits of a classifier head in TRAIN mode (core/nn.py, core/ops.py dense_(lazy=True)).  When the
+    Used for two things: the gradient views of a Model's arena (`view` / `defer`, see core/model.py) and, first, the logits of
+    a classifier head in TRAIN mode (core/nn.py, core/ops.py dense_(lazy=True)).  When the
     loss node gets there first it produces them together with the loss and the head's backward in one launch
     (ops.softmax_nll_); any other first use — printing, argmax, a custom loss — runs the ordinary GEMM, so the values are the
     same either way.  The deferral is visible only to code that mutates the producer's inputs IN PLACE between forward()
@@ -668,6 +669,23 @@ class LazyArray(DeviceArray):
         self = cls._new(shape, dtype)          # the buffer exists; only its content is pending
         self._thunk = thunk
         return self
+
+    @classmethod
+    def view(cls, base, offset, shape):
+        """A view of `shape` over base's buffer from element `offset` on whose content may be declared pending (`defer`):
+        the gradient views of a Model's arena (core/model.py) — the launch that fills them can then wait for the optimizer."""
+        ptr = DeviceArray._ptr.__get__(base, DeviceArray) if type(base) is not DeviceArray else base._ptr
+        self = cls._raw(ptr + offset * base.dtype.itemsize, shape, base.dtype, base=base)
+        self._thunk = None
+        return self
+
+    def defer(self, thunk):
+        """Declare the content pending: `thunk(self)` runs before the first access to the buffer (or never, see drop)."""
+        self._thunk = thunk
+
+    def drop(self):
+        """Forget a pending producer (the content is about to be overwritten or is no longer wanted)."""
+        self._thunk = None
 
     @property
     def pending(self):
