@@ -1324,6 +1324,74 @@ def trainer_captured_steps_of_mixed_batch_sizes():
     assert np.array_equal(np.asarray(trainers[0].params), np.asarray(trainers[1].params))
 
 
+def deferred_first_layer_backward_semantics():
+    """Model.step() on one GPU with a fused Adam runs the FIRST Dense layer's backward and the optimizer in one launch — the
+    backward launch is deferred at backward() time, the loss launch advances Adam's powers.  Every way of using the API in
+    between must give the parameters of a model built WITHOUT any fusion (Dense(fused=False), the 12-op loss, Adam(fused=False)):
+    plain steps; gradients read between backward and step; two backward calls before one step (accumulation); a backward whose
+    gradients are thrown away by zero_grad; the loss evaluated twice before the step; a non-default seed; a step with no
+    backward at all in front of it (zero gradients)."""
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
+    from tinynn_autograd_amd.core.model import Model
+    from tinynn_autograd_amd.core.nn import Net
+    from tinynn_autograd_amd.core.optimizer import Adam
+    rs = np.random.RandomState(9)
+    widths, rows = [24, 32, 128, 10], 48
+    Ws = [(rs.randn(widths[i], widths[i + 1]) * 0.2).astype(np.float32) for i in range(3)]
+    Bs = [(rs.randn(1, widths[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    data = [((rs.rand(rows, widths[0]) * (rs.rand(rows, widths[0]) < 0.5)).astype(np.float32),
+             np.eye(10, dtype=np.float32)[rs.randint(0, 10, rows)]) for _ in range(4)]
+
+    def build(fused):
+        layers = []
+        for i in range(3):
+            d = Dense(widths[i + 1], num_in=widths[i], fused=fused)
+            d.params["w"].values = tn.asarray(Ws[i]); d.params["b"].values = tn.asarray(Bs[i])
+            d.params["w"].zero_grad(); d.params["b"].zero_grad()
+            layers.append(d)
+            if i < 2:
+                layers.append(ReLU())
+        loss_layer = SoftmaxCrossEntropyLoss(fused=fused)
+        return Model(net=Net(layers), loss=loss_layer, optimizer=Adam(lr=1e-3, fused=fused)), loss_layer
+
+    def scenario(model, loss_layer, name):
+        def fwd_loss(i):
+            x, y = data[i % len(data)]
+            return loss_layer.loss(model.forward(Tensor(x)), Tensor(y))
+        first = model.net.layers[0].params
+        for i in range(3):
+            model.zero_grad()
+            if name == "plain":
+                fwd_loss(i).backward()
+            elif name == "read":
+                fwd_loss(i).backward()
+                float(np.asarray(first["w"].grad).sum()) + float(np.asarray(first["b"].grad).sum())
+            elif name == "accumulate":
+                fwd_loss(i).backward()
+                fwd_loss(i + 1).backward()
+            elif name == "discard":
+                fwd_loss(i + 2).backward()
+                model.zero_grad()
+                fwd_loss(i).backward()
+            elif name == "two_losses":
+                fwd_loss(i + 1)                       # evaluated, never differentiated
+                fwd_loss(i).backward()
+            elif name == "seed":
+                fwd_loss(i).backward(0.5)
+            elif name == "no_backward":
+                if i != 1:
+                    fwd_loss(i).backward()
+            model.step()
+        return np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
+
+    for name in ("plain", "read", "accumulate", "discard", "two_losses", "seed", "no_backward"):
+        got = scenario(*build(True), name)
+        ref = scenario(*build(False), name)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=0.1 * 1e-3, err_msg=name)       # Adam: SURVEY H1
+        assert np.isfinite(got).all(), name
+
+
 def graph_released_while_another_capture_is_open():
     """A captured function whose last reference dies in the MIDDLE of another capture (garbage collection during a
     re-capture does this): its destruction must not touch the capturing stream — tnn_graph_destroy used to synchronise it,
