@@ -1391,6 +1391,40 @@ def deferred_first_layer_backward_semantics():
         np.testing.assert_allclose(got, ref, rtol=0, atol=0.1 * 1e-3, err_msg=name)       # Adam: SURVEY H1
         assert np.isfinite(got).all(), name
 
+    # a hipGraph that holds forward + loss + backward but NOT the step (gradients inspected after every replay): the deferred
+    # launch must be inside the graph, and the advance of Adam's powers by the loss launch must not accumulate over replays
+    model, loss_layer = build(True)
+    x_stage, y_stage = Tensor(data[0][0]), Tensor(data[0][1])
+    for i in range(2):                                    # warm-up: arenas bound, optimizer state created
+        model.zero_grad()
+        loss_layer.loss(model.forward(x_stage), y_stage).backward()
+        model.step()
+    pows_before = np.asarray(model.optimizer._pows).copy()
+
+    def partial():
+        model.zero_grad()
+        out = loss_layer.loss(model.forward(x_stage), y_stage)
+        out.backward()
+        return out
+    replay = tn.capture(partial, warmup=0)
+    ref_model, ref_loss = build(False)
+    for i in range(2):
+        ref_model.zero_grad()
+        ref_loss.loss(ref_model.forward(Tensor(data[0][0])), Tensor(data[0][1])).backward()
+        ref_model.step()
+    first = model.net.layers[0].params
+    for i in range(3):
+        xb, yb = data[(i + 1) % len(data)]
+        x_stage.values[...] = tn.asarray(xb); y_stage.values[...] = tn.asarray(yb)
+        replay()
+        ref_model.zero_grad()
+        ref_loss.loss(ref_model.forward(Tensor(xb)), Tensor(yb)).backward()
+        for k in ("w", "b"):
+            r = np.asarray(ref_model.net.layers[0].params[k].grad)
+            np.testing.assert_allclose(np.asarray(first[k].grad), r, rtol=0, atol=2e-5 * np.abs(r).max(),
+                                       err_msg="replayed first-layer gradient %s, replay %d" % (k, i))
+    np.testing.assert_allclose(np.asarray(model.optimizer._pows)[:2], pows_before[:2], rtol=1e-12)
+
 
 def graph_released_while_another_capture_is_open():
     """A captured function whose last reference dies in the MIDDLE of another capture (garbage collection during a

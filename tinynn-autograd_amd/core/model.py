@@ -21,6 +21,18 @@ import numpy as np
 from .. import device_array as da
 
 
+_PENDING = weakref.WeakSet()      # models with a deferred first-layer backward
+
+
+def settle_pending():
+    """End of a hipGraph capture (graph.py): a backward whose first-layer launch is still deferred belongs INTO the graph —
+    the step that would have absorbed it is outside the captured function."""
+    for model in list(_PENDING):
+        if model._pending_first is not None:
+            model._run_pending_first()
+    _PENDING.clear()
+
+
 class Model(object):
 
     def __init__(self, net, loss, optimizer, comm=None, use_arena=True):
@@ -135,6 +147,7 @@ class Model(object):
                 or self._pending_first is not None):
             return False
         self._pending_first = (x, dz, w, rows, n_in, n_out)
+        _PENDING.add(self)
         me = weakref.ref(self)
 
         def materialise(_arr, me=me):

@@ -13,6 +13,7 @@ ADDS to the parameters (core/model.py:59-61).  All state lives in HBM.
 """
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -67,6 +68,20 @@ class SGD(BaseOptimizer):
         return True
 
 
+_TICKED = weakref.WeakSet()       # Adam instances whose powers a loss launch has advanced for a step that has not run yet
+
+
+def settle_ticks():
+    """End of a hipGraph capture (graph.py): a captured function that evaluated a loss but did NOT contain the optimizer step
+    would advance the powers on every replay while the step runs outside — take the advance back inside the graph and let
+    the step advance them itself.  (A captured WHOLE step has consumed its tick: nothing to do.)"""
+    for opt in list(_TICKED):
+        if opt._ticked and opt._pows is not None:
+            _lib.get().adam_tick(opt._pows._ptr, 1.0 / opt._b1, 1.0 / opt._b2)
+            opt._ticked = False
+    _TICKED.clear()
+
+
 def _flat_pair_ok(params, grads):
     return (isinstance(params, da.DeviceArray) and isinstance(grads, da.DeviceArray) and params.shape == grads.shape
             and params.dtype == grads.dtype and params.dtype.kind == "f" and params.ndim == 1
@@ -118,6 +133,7 @@ class Adam(BaseOptimizer):
         if not self.fused or self._pows is None or self._ticked:
             return None
         self._ticked = True
+        _TICKED.add(self)
         return self._pows._ptr, self._b1, self._b2
 
     def apply_with_first_layer(self, params, grads, rows, n_in, n_out, x, dz):

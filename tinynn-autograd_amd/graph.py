@@ -30,6 +30,11 @@ class CapturedFunction(object):
         self._graph = _lib.Graph()
         with self._graph:
             self.outputs = fn()          # recorded, not executed
+            # work the op-level fusions left for a step that is NOT part of fn (a deferred first-layer backward, an advance
+            # of Adam's powers by the loss launch) is settled inside the graph; a captured whole step leaves nothing
+            from .core import model as _model, optimizer as _optimizer
+            _model.settle_pending()
+            _optimizer.settle_ticks()
 
     def __call__(self):
         self._graph.launch()
