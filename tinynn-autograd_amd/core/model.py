@@ -143,9 +143,10 @@ class Model(object):
         """Called by the first Dense layer's vjp (ops._DenseVjp.fused_vjp) instead of launching: remember the operands, mark
         the two arena views pending.  Returns False to decline (the vjp then launches as usual)."""
         ts = self._arena_tensors
-        if (ts is None or self.comm is not None or dw_home is not ts[0]._grad_home or db_home is not ts[1]._grad_home
-                or self._pending_first is not None):
+        if ts is None or self.comm is not None or dw_home is not ts[0]._grad_home or db_home is not ts[1]._grad_home:
             return False
+        if self._pending_first is not None and (dw_home.pending or db_home.pending):
+            return False                             # an earlier backward is still outstanding (not dropped by zero_grad)
         self._pending_first = (x, dz, w, rows, n_in, n_out)
         _PENDING.add(self)
         me = weakref.ref(self)
@@ -190,7 +191,10 @@ class Model(object):
                         t.values = t._values_home            # same post-state as `param += step`: grad dropped
                     return
             if self._pending_first is not None:
-                self._run_pending_first()
+                if ts is not None and (ts[0]._grad_home.pending or ts[1]._grad_home.pending):
+                    self._run_pending_first()
+                else:
+                    self._pending_first = None       # its gradients were dropped (Tensor.zero_grad): nothing to run
         all_grads = [{k: p.grad for k, p in layer.items()} for layer in params]
 
         if self.comm is not None and self.comm.world > 1:
