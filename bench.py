@@ -1030,9 +1030,9 @@ def main():
                     r = OpsRun(widths, rows, kind, 16, graph=graph)
                     paths[name] = brief(measure(solo, r, 20, 200, 3, args.min_ms, rows))
                     del r
-                paths["note"] = ("the same step on the drop-in Tensor/ops/Dense/ReLU/SoftmaxCrossEntropyLoss/Adam/Model API: one "
-                                 "launch per op issued from Python (eager) / the same loop body recorded with tn.capture, 16 steps on "
-                                 "their resident batches per hipGraph, and replayed (graph)")
+                paths["note"] = ("the same step on the drop-in Tensor/ops/Dense/ReLU/SoftmaxCrossEntropyLoss/Adam/Model API (the "
+                                 "reference's loop body, 4 launches per step like the trainer): issued from Python op by op (eager) / "
+                                 "recorded with tn.capture, 16 steps on their resident batches per hipGraph, and replayed (graph)")
                 paths["host_modules"] = ("compiled ahead of time from the .py sources (tinynn-autograd_amd/_host_build.py)"
                                          if tn.host_modules_compiled() else "interpreted")
                 line["paths"] = paths
