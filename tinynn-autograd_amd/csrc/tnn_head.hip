@@ -16,10 +16,6 @@
 #include "tnn_p2p.h"
 #include "tnn_head_stats.h"
 
-#ifndef TNN_HEAD_PREFETCH
-#define TNN_HEAD_PREFETCH 1
-#endif
-
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -67,9 +63,437 @@ template <int C, int NP>
 struct HeadStage {
     f32x4 v[NP], yv;
 };
+template <int C, int NP>
+__device__ __forceinline__ void head_stage_request(const HeadMArgs& p, const int t, HeadStage<C, NP>& h) {
+    const int n = p.m * C;
+    if (p.vec && t < (n >> 2)) {
+#pragma unroll
+        for (int tn = 0; tn < NP; ++tn) h.v[tn] = *reinterpret_cast<const f32x4*>(p.zpart + (size_t)tn * n + 4 * t);
+        h.yv = *reinterpret_cast<const f32x4*>(p.y + 4 * t);
+    }
+}
+template <int C, int NP>
+__device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t, const HeadStage<C, NP>& h, float* zs, float* ys) {
+    static_assert(NP == 8, "the partial-sum tree is written for 8 tiles");
+    const int n = p.m * C;
+    if (p.vec) {
+        if (t < (n >> 2)) {
+            f32x4 s = ((h.v[0] + h.v[1]) + (h.v[2] + h.v[3])) + ((h.v[4] + h.v[5]) + (h.v[6] + h.v[7]));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += p.b[(4 * t + i) % C];
+            *reinterpret_cast<f32x4*>(zs + 4 * t) = s;
+            *reinterpret_cast<f32x4*>(ys + 4 * t) = h.yv;
+        }
+    } else {
+        for (int e = t; e < n; e += 512) {
+            float u[NP];
+#pragma unroll
+            for (int tn = 0; tn < NP; ++tn) u[tn] = p.zpart[(size_t)tn * n + e];
+            zs[e] = (((u[0] + u[1]) + (u[2] + u[3])) + ((u[4] + u[5]) + (u[6] + u[7]))) + p.b[e % C];
+            ys[e] = p.y[e];
+        }
+    }
+}
+
+// PART: the logits arrive as H / 16 partial sums per element (tnn_dense_fwd_head_partials: the previous layer's 16-column
+// tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
+// v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
+// CUT (ablation builds of round 2, kept as a template parameter only): 0 = the kernel; 1 = stop after the logits, 2 = after
+// the statistics, 3 = after dz.
+// DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
+// SH (data parallel): 0 single GPU; 2 the shards' softmax statistics were reduced (and, on the peer-to-peer transport,
+// exchanged and merged) at the tail of the previous launch (dense_fwd_head_kernel) and arrive through HeadMArgs::ext_pairs
+template <int H, int C, bool PART, int CUT, bool DA, int SH = 0>
+__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
+    constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
+    static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
+    constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
+    __shared__ float zs[ROWS * ZS];                // logits (MFMA form only); odd row stride: conflict-free with lane = row
+    __shared__ __attribute__((aligned(16))) float ws[H * WS];      // W, rows padded to 12 (columns >= C hold 0)
+    __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];  // dz [row][12]: the da phase reads whole rows (16-B broadcasts)
+    __shared__ __attribute__((aligned(16))) float dzT[C * TS];     // dz^T [c][row]: the dW / db phases read 4 rows at a time
+    __shared__ __attribute__((aligned(16))) float asT[JPB * TS];   // a[:, 8g : 8g + 8]^T [j][row] for this workgroup's dW rows
+    __shared__ double red[8][4];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int r = t & (ROWS - 1), kq = t >> 7;     // da phase: column r, row group kq
+    const int srow = t >> 2, sub = t & 3;          // statistics: row srow, classes sub, sub + 4, sub + 8
+    const int m = p.m;
+    const bool slive = srow < m;
+
+    // ---- every global read of the kernel is requested here, before the first use, in as few vector-memory
+    // instructions as possible; no exec-mask branches around loads: rows beyond m read a clamped (valid) address and
+    // are neutralised in the arithmetic (their dz is 0, so whatever they loaded never reaches an output).
+    const int sr = min(srow, m - 1);
+    float zc[3] = {0.f, 0.f, 0.f}, yc[3];
+    __shared__ __attribute__((aligned(16))) float zst[PART ? ROWS * C : 4], yst[PART ? ROWS * C : 4];   // staged logits / labels
+    HeadStage<C, NP> stg;
+    f32x4 av[PART ? 1 : KC];
+    if constexpr (PART) {
+        head_stage_request<C, NP>(p, t, stg);
+    } else {
+        const float* arow = p.a + (size_t)min(16 * wid + i16, m - 1) * H + 4 * grp;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) av[c] = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+    }
+    if constexpr (!PART) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) yc[i] = p.y[(size_t)sr * C + min(sub + 4 * i, C - 1)];
+    }
+    constexpr int WV = H * C / 4;                                       // float4 pieces of W (320)
+    f32x4 w4 = {0.f, 0.f, 0.f, 0.f};
+    if (t < WV) w4 = *reinterpret_cast<const f32x4*>(p.w + 4 * t);
+    float am[2] = {0.f, 0.f};
+    const int r0 = g * p.rpb, rend = min(m, r0 + p.rpb);
+    if constexpr (DA) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) am[i] = p.a[(size_t)min(r0 + kq + 4 * i, m - 1) * H + r];
+    }
+    const f32x4 asl = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m - 1) * H + g * JPB + 4 * (t & 1));
+    // Adam's beta powers: read NOW (a dependent global round trip at the very end of workgroup 0 cost 1.3 us of the launch)
+    double pw0 = 0.0, pw1 = 0.0;
+    if (g == 0 && t == 0 && p.tick) { pw0 = p.tick[0]; pw1 = p.tick[1]; }
+
+    // ---- W and the dW slice of a -> LDS (visible after the first barrier below)
+    if (t < H) { ws[t * WS + 10] = 0.f; ws[t * WS + 11] = 0.f; }
+    if (t < WV) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = 4 * t + i; ws[(e / C) * WS + e % C] = w4[i]; }
+    }
+    if (t < 2 * ROWS) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asT[(4 * (t & 1) + i) * TS + (t >> 1)] = (t >> 1) < m ? asl[i] : 0.f;
+    }
+
+    if constexpr (PART) {
+        head_stage_store<C, NP>(p, t, stg, zst, yst);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            zc[i] = zst[sr * C + min(sub + 4 * i, C - 1)];
+            yc[i] = yst[sr * C + min(sub + 4 * i, C - 1)];
+        }
+    } else {
+        // wave w owns the 16-row tile [16 w, 16 w + 16) over the whole K = H: lane (i16, grp) holds a[row i16][16 c + 4 grp + j]
+        // (registers, from global) and W[16 c + 4 grp + j][col i16] (LDS; columns 10, 11 are zeros, lanes i16 >= 12 re-read
+        // column 11); two accumulator chains (40-cycle dependent latency against a 32-cycle issue)
+        __syncthreads();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float* wl = ws + (4 * grp) * WS + min(i16, WS - 1);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][0], wl[(16 * c + 0) * WS], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][1], wl[(16 * c + 1) * WS], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][2], wl[(16 * c + 2) * WS], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][3], wl[(16 * c + 3) * WS], acc1, 0, 0, 0);
+        }
+        if (i16 < C) {
+            const float bias = p.b[i16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zs[(16 * wid + 4 * grp + q) * ZS + i16] = (acc0[q] + acc1[q]) + bias;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 3; ++i) zc[i] = zs[srow * ZS + min(sub + 4 * i, C - 1)];
+    }
+    if constexpr (CUT == 1) {
+        p.da[(size_t)g * 512 + t] = zc[0] + zc[1] + zc[2] + am[0] + am[1] + yc[0];
+        return;
+    }
+
+    HeadStats st;
+    if constexpr (SH == 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, p.ext_pairs, p.ext_n);
+    else head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
+    const bool (&valid)[3] = st.valid;
+    const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
+    const float mx = st.mx, urow = st.urow;
+    const float M = st.M;
+    const double S = st.S;
+    const double L = st.L;
+    double inv_m = 1.0 / (double)m;
+    if constexpr (SH != 0) inv_m = 1.0 / (double)p.m_global;
+    if constexpr (CUT == 2) {
+        p.da[(size_t)g * 512 + t] = (float)(S + L) + M + am[0] + am[1] + ec[0] + ec[1] + ec[2] + eyc[0];
+        return;
+    }
+    float dzc[3];
+    {
+        // v_rcp_f32 (1 ulp) instead of two IEEE divisions on the way to dz (tolerance 1e-5)
+        const float sf = slive ? expf(mx - M) * __builtin_amdgcn_rcpf((float)S) : 0.f, uf = slive ? (float)inv_m * __builtin_amdgcn_rcpf(urow) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dzc[i] = ec[i] * sf - eyc[i] * uf;                  // 0 in the padding rows
+            if (valid[i]) {
+                dzr[srow * WS + sub + 4 * i] = dzc[i];
+                dzT[(sub + 4 * i) * TS + srow] = dzc[i];
+            }
+        }
+        if (sub >= 2) dzr[srow * WS + 8 + sub] = 0.f;          // columns 10, 11 of the 16-B row reads
+    }
+    __syncthreads();
+    if constexpr (CUT == 3) {
+        p.da[(size_t)g * 512 + t] = dzr[r * WS] + asT[r] + am[0] + am[1];
+        return;
+    }
+
+    // ---- da rows of this workgroup: thread (column j = r, row group kq); W[j][:] and the dz row as three 16-B LDS reads
+    // each (the dz row is wave-uniform: a broadcast)
+    if (DA && p.da) {
+        f32x4 wv[WS / 4];
+#pragma unroll
+        for (int i = 0; i < WS / 4; ++i) wv[i] = *reinterpret_cast<const f32x4*>(ws + r * WS + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = r0 + kq + 4 * i;
+            if (row < rend) {
+                float d = 0.f;
+#pragma unroll
+                for (int k = 0; k < WS / 4; ++k) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dzr + row * WS + 4 * k);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d = fmaf(dv[e], wv[k][e], d);      // columns 10, 11: 0 * 0
+                }
+                p.da[(size_t)row * H + r] = (__float_as_uint(am[i]) >> 31) ? 0.f : d;
+            }
+        }
+    }
+    if constexpr (CUT == 4) return;
+    // ---- dW rows [8g, 8g + 8): output o = (jl, c); lane q of a quad takes the 4-row chunks q, q + 4, q + 8 ... of the
+    // transposed images (two 16-B reads per 4 FMAs; neighbouring lanes read neighbouring 16-B pieces: conflict-free).
+    // The first version read a[row][j] and dz[row][c] element by element: 64 LDS reads per thread, 0.7 us.
+    if (t < JPB * C * 4) {                                      // 320 threads = 5 whole waves
+        const int q = t & 3, o = t >> 2, jl = o / C, c = o - jl * C;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ROWS / 16; ++i) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(asT + jl * TS + 16 * i + 4 * q);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(dzT + c * TS + 16 * i + 4 * q);
+            s0 = fmaf(a4[0], d4[0], s0); s1 = fmaf(a4[1], d4[1], s1);
+            s0 = fmaf(a4[2], d4[2], s0); s1 = fmaf(a4[3], d4[3], s1);
+        }
+        float s = s0 + s1;
+        s += tnn::dpp_move<0xB1, 0xf>(0.f, s);
+        s += tnn::dpp_move<0x4E, 0xf>(0.f, s);
+        if (q == 0) p.dw[(size_t)(g * JPB + jl) * C + c] = s;
+    }
+    if constexpr (CUT == 5) return;
+    if (g == 0) {
+        if (wid == 7) {                                         // db[c] = sum_r dz[r][c]: lane (c, row quarter)
+            const int c = min(lane & 15, C - 1), rq = lane >> 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < ROWS / 16; ++i) acc += *reinterpret_cast<const f32x4*>(dzT + c * TS + 32 * rq + 4 * i);
+            float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            if (lane < C) p.db[lane] = s;
+        }
+        if (t == 0) {
+            // data parallel: this rank's SHARE of the global loss (the all-reduce of the gradient arena sums the shares)
+            if (p.loss) p.loss[0] = SH != 0 ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
+                                       : (float)((double)logf((float)S) + (double)M - L * inv_m);
+            if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
+            if (p.tick) { p.tick[0] = pw0 * p.b1; p.tick[1] = pw1 * p.b2; }
+        }
+    }
+    if (g == G - 1 && slive) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (valid[i]) {
+                if (p.logits) p.logits[(size_t)srow * C + sub + 4 * i] = zc[i];
+                if (p.dz) p.dz[(size_t)srow * C + sub + 4 * i] = dzc[i];
+            }
+    }
+}
+
+template <int H, int C, bool PART, int CUT = 0>
+__global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
+    head_block<H, C, PART, CUT, true>(p, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Head + the hidden layer's backward in ONE launch (4-launch step: fwd0 | fwd1 + partial logits | THIS | bwd0 + Adam).
+// The hidden layer's dz (rows x H) is   dz1 = (dz W2^T) * !signbit(a1)   with dz = the loss gradient of the rows x C logits:
+// 10 FMAs per element once dz is known, and dz costs every workgroup the same ~1 us the head's workgroups already spend
+// (sum 8 partial logits, whole-batch statistics).  So the tiles of the hidden layer's backward derive the slice of dz1
+// they contract over THEMSELVES instead of waiting for a launch boundary behind the head:
+//     blocks [0, G)                 the head's workgroups (head_block, no da rows): dW2, db2, loss, stats, beta powers, logits
+//     blocks [G, G + n_dw)          dW1 tile (16 inputs x 16 hidden units) = x^T dz1[:, 16 units]   (K = rows), db1 = column sums
+//     blocks [G + n_dw, ...)        dx tile (16 rows x 16 inputs) = (dz1[16 rows, :] W1^T) * !signbit(x)   (K = H)
+// Tile products as in small_tile_fast (v_mfma_f32_16x16x4_f32, one 16-deep K chunk per wave, 8 waves, partials summed
+// through LDS); the dz1 operand comes from LDS (panel computed in place), the other operand through loads requested first
+// thing.  dz1 is never written to HBM.
+struct HeadBwdArgs {
+    const float* x;                  // [m][n_in]   the hidden layer's input (sign-encoded ReLU output of the layer before)
+    const float* w1;                 // [n_in][H]
+    float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
+    int n_in, tiles_in;              // tiles_in = n_in / 16
+    int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8; TNN_XCD_TILES=0 turns it off)
+};
+
+// CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
+template <int H, int C, int CUT = 0, int SH = 0>
+__global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
+    constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
+    static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
+    if ((int)blockIdx.x < G) {
+        head_block<H, C, true, 0, false, SH>(p, (int)blockIdx.x);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
+    __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];   // dz [row][12] (columns 10, 11 hold 0)
+    __shared__ __attribute__((aligned(16))) float pan[16 * PS];     // dx tiles: dz1 [16 rows][H], stride H + 4
+    __shared__ float redm[8][4][64];
+    __shared__ float bsum[8][64];
+    __shared__ double red[8][4];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    const int srow = t >> 2, sub = t & 3;
+    const int m = p.m;
+    const bool slive = srow < m;
+    const int sr = min(srow, m - 1);
+    const int n_dw = q.tiles_in * TH;
+    const int blk = (int)blockIdx.x - G;
+    const bool is_dw = blk < n_dw;
+    const int n_in = q.n_in;
+    // tile coordinates.  dW: tm over the inputs, tn over the hidden units; dx: tm over the rows, tn over the inputs
+    int tm, tn;
+    if (is_dw) {
+        if (q.xcd && q.tiles_in % 2 == 0) {          // XCD-aware order: XCD x takes inputs' half x % 2, units' quarter x / 2
+            const int xcd = blk & 7, idx = blk >> 3, pm = q.tiles_in / 2;
+            tm = (xcd & 1) * pm + idx % pm;
+            tn = (xcd >> 1) * (TH / 4) + idx / pm;
+        } else { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
+    } else {
+        const int b2 = blk - n_dw, tr = (m + 15) / 16;
+        if (q.xcd && tr % 2 == 0 && q.tiles_in % 4 == 0 && n_dw % 8 == 0) {
+            const int xcd = b2 & 7, idx = b2 >> 3, pm = tr / 2;
+            tm = (xcd & 1) * pm + idx % pm;
+            tn = (xcd >> 1) * (q.tiles_in / 4) + idx / pm;
+        } else { tm = b2 % tr; tn = b2 / tr; }
+    }
+    const int m0 = tm * 16, n0 = tn * 16;
+
+    // ---- every global read, up front.  The dz1 slice of a tile is itself a 16x16x4 MFMA product
+    //   P[row][unit] = sum_c dz[row][c] W2[unit][c]    (K = 12: 10 classes + 2 zero columns, 3 MFMAs per wave)
+    // dW tile: wave w takes rows 16 w .. 16 w + 15 x units n0 .. n0 + 15; dx tile: rows m0 .. m0 + 15 x units 16 w .. 16 w + 15.
+    // Lane (i16, grp) supplies B[k = grp][n = i16] = W2[unit i16][class 4 s + grp] and receives P[row 4 grp + r][unit i16],
+    // r = 0..3 — for the dW tile that IS the B fragment of the tile product (b[j] = dz1[16 w + 4 grp + j][n0 + i16]).
+    HeadStage<C, NP> stg;
+    head_stage_request<C, NP>(p, t, stg);
+    const int urow = (is_dw ? n0 : 16 * wid) + i16;                  // this lane's hidden unit
+    const int prow0 = (is_dw ? 16 * wid : m0) + 4 * grp;             // first of this lane's 4 panel rows
+    float w2f[3], a1m[4];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) w2f[s3] = p.w[(size_t)urow * C + min(4 * s3 + grp, C - 1)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a1m[r] = p.a[(size_t)min(prow0 + r, m - 1) * H + urow];
+    float af[4] = {0.f, 0.f, 0.f, 0.f};          // dW: x fragment
+    f32x4 bf = {0.f, 0.f, 0.f, 0.f};             // dx: W1 fragment
+    float e_pre = 0.f;                           // dx: mask source
+    const int e_r = (t >> 6) & 3, e_ln = t & 63;
+    if (is_dw) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = q.x[(size_t)min(16 * wid + 4 * grp + j, m - 1) * n_in + m0 + i16];
+    } else {
+        bf = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + i16) * H + 16 * wid + 4 * grp);
+        if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, m - 1) * n_in + n0 + (e_ln & 15)];
+    }
+    if (grp >= 2) w2f[2] = 0.f;                  // classes 10, 11 do not exist (the clamped address read class 9)
+    static_assert(C == 10, "the zero columns of the K = 12 product are written for 10 classes");
+
+    head_stage_store<C, NP>(p, t, stg, zs, ys);
+    __syncthreads();
+    float zc[3], yc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        zc[i] = zs[sr * C + min(sub + 4 * i, C - 1)];
+        yc[i] = ys[sr * C + min(sub + 4 * i, C - 1)];
+    }
+    if constexpr (CUT == 1) {
+        q.dx[(size_t)(blk % 64) * 512 + t] = zc[0] + zc[1] + zc[2] + yc[0] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
+        return;
+    }
+    HeadStats st;
+    if constexpr (SH == 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, p.ext_pairs, p.ext_n);
+    else head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
+    if constexpr (CUT == 2) {
+        q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
+        return;
+    }
+    float m_norm = (float)m;
+    if constexpr (SH != 0) m_norm = (float)p.m_global;
+    {
+        const float sf = slive ? expf(st.mx - st.M) * __builtin_amdgcn_rcpf((float)st.S) : 0.f;
+        const float uf = slive ? __builtin_amdgcn_rcpf(m_norm * st.urow) : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (st.valid[i]) dzr[srow * WS + sub + 4 * i] = st.ec[i] * sf - st.eyc[i] * uf;      // 0 in the padding rows
+        if (sub >= 2) dzr[srow * WS + 8 + sub] = 0.f;
+    }
+    // dW tile: wave w reads back only the 16 rows it wrote itself (srow = 16 w + lane / 4) — no workgroup barrier, the
+    // LDS queue of a wave is in order; dx tile: the 16 rows of the tile were written by wave tm
+    if (is_dw) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+    if constexpr (CUT == 3) {
+        q.dx[(size_t)(blk % 64) * 512 + t] = dzr[t] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
+        return;
+    }
+
+    f32x4 pz = {0.f, 0.f, 0.f, 0.f};
+    {
+        const float* drow = dzr + ((is_dw ? 16 * wid : m0) + i16) * WS + grp;          // A[m = i16][k = grp] = dz[row][4 s + grp]
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) pz = __builtin_amdgcn_mfma_f32_16x16x4f32(drow[4 * s3], w2f[s3], pz, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pz[r] = (__float_as_uint(a1m[r]) >> 31) ? 0.f : pz[r];   // rows >= m: dz = 0 there
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bs = 0.f;
+    if (is_dw) {
+        if constexpr (CUT == 4) {
+            q.dx[(size_t)(blk % 64) * 512 + t] = pz[0] + pz[1] + pz[2] + pz[3] + af[0] + af[1] + af[2] + af[3];
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], pz[j], acc, 0, 0, 0);
+        bs = (pz[0] + pz[1]) + (pz[2] + pz[3]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pan[(4 * grp + r) * PS + 16 * wid + i16] = pz[r];
+        __syncthreads();
+        if constexpr (CUT == 4) {
+            q.dx[(size_t)(blk % 64) * 512 + t] = pan[t] + bf[0] + e_pre;
+            return;
+        }
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(pan + i16 * PS + 16 * wid + 4 * grp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) redm[wid][r][lane] = acc[r];
+    bsum[wid][lane] = bs;
+    __syncthreads();
+    if (t < 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += redm[w][e_r][e_ln];
+        const int row = m0 + (e_ln >> 4) * 4 + e_r, col = n0 + (e_ln & 15);           // 16x16x4 C/D layout
+        if (is_dw) q.dw1[(size_t)row * H + col] = s;
+        else if (row < m) q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+    }
+    if (is_dw && tm == 0 && t < 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += (bsum[w][t] + bsum[w][16 + t]) + (bsum[w][32 + t] + bsum[w][48 + t]);
+        q.db1[n0 + t] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // mb / row0: the row block staged (rows [row0, row0 + mb) of the p.m rows the partial array was written for).
 template <int C, int NP>
-__device__ __forceinline__ void head_stage_request(const HeadMArgs& p, const int t, HeadStage<C, NP>& h, const int mb, const int row0) {
+__device__ __forceinline__ void head_stage_request_rb(const HeadMArgs& p, const int t, HeadStage<C, NP>& h, const int mb, const int row0) {
     const int n = mb * C, stride = p.m * C, base = row0 * C;
     if (p.vec && t < (n >> 2)) {
 #pragma unroll
@@ -91,7 +515,7 @@ __device__ __forceinline__ f32x4 head_stage_bias(const HeadMArgs& p, const int t
     return b;
 }
 template <int C, int NP>
-__device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t, const HeadStage<C, NP>& h, float* zs, float* ys,
+__device__ __forceinline__ void head_stage_store_rb(const HeadMArgs& p, const int t, const HeadStage<C, NP>& h, float* zs, float* ys,
                                                  const int mb, const int row0, const f32x4 bias4) {
     static_assert(NP == 8, "the partial-sum tree is written for 8 tiles");
     const int n = mb * C, stride = p.m * C, base = row0 * C;
@@ -114,6 +538,9 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
     }
 }
 
+// ROW-BLOCKED form of head_block (statistics from memory, any number of rows walked in blocks of 128; launched for more than
+// 128 rows only — the <= 128-row kernels above are the code tuned in round 2, untouched: sharing one body with the loop cost
+// them 0.3 us of the 128-row step, measured against the library of the round's start).
 // PART: the logits arrive as H / 16 partial sums per element (tnn_dense_fwd_head_partials: the previous layer's 16-column
 // tiles each contributed their share) and are only ADDED here; otherwise every workgroup computes them itself on
 // v_mfma_f32_16x16x4_f32 (0.9 us of the CU's matrix pipe + the 64 KB activation read, measured).
@@ -124,7 +551,7 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
 // exchanged and merged) at the tail of the previous launch (dense_fwd_head_kernel) and arrive through HeadMArgs::ext_pairs
 // RB (with SH == 2 only): the rows are walked in blocks of 128 (any number of rows); without it one block, as before
 template <int H, int C, bool PART, int CUT, bool DA, int SH = 0, bool RB = false>
-__device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
+__device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
     static_assert(!RB || (SH == 2 && PART && !DA && CUT == 0), "row blocks exist in the form that takes the statistics from memory only");
@@ -165,10 +592,10 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     // chain of loads -> LDS -> statistics -> products is ~1 us of dependent latency plus the loads' own 1.5-2 us, which this hides)
     HeadStage<C, NP> stg_nx;
     f32x4 asl_nx = {0.f, 0.f, 0.f, 0.f};
-    constexpr bool PF = TNN_HEAD_PREFETCH;
+    constexpr bool PF = true;
     if constexpr (RB && PF) {
         const int m0b = min(ROWS, p.m);
-        head_stage_request<C, NP>(p, t, stg_nx, m0b, 0);
+        head_stage_request_rb<C, NP>(p, t, stg_nx, m0b, 0);
         asl_nx = *reinterpret_cast<const f32x4*>(p.a + (size_t)min((t & 255) >> 1, m0b - 1) * H + g * JPB + 4 * (t & 1));
     }
     for (int rb = 0; rb < nb; ++rb) {
@@ -192,7 +619,7 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     f32x4 av[PART ? 1 : KC];
     if constexpr (PART) {
         if constexpr (RB && PF) stg = stg_nx;
-        else head_stage_request<C, NP>(p, tt, stg, m, row0);
+        else head_stage_request_rb<C, NP>(p, tt, stg, m, row0);
     } else {
         const float* arow = a_rb + (size_t)min(16 * wid + i16, m - 1) * H + 4 * grp;
 #pragma unroll
@@ -226,12 +653,12 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
 
     if constexpr (PART) {
-        head_stage_store<C, NP>(p, t, stg, zst, yst, m, row0, bias4);
+        head_stage_store_rb<C, NP>(p, t, stg, zst, yst, m, row0, bias4);
         if constexpr (RB && PF) {
             // the staged values are in LDS, their registers are free: the next block's reads travel from here on
             if (rb + 1 < nb) {
                 const int m1 = min(ROWS, p.m - row0 - ROWS);
-                head_stage_request<C, NP>(p, tt, stg_nx, m1, row0 + ROWS);
+                head_stage_request_rb<C, NP>(p, tt, stg_nx, m1, row0 + ROWS);
                 asl_nx = *reinterpret_cast<const f32x4*>(a_rb + (size_t)(ROWS + min((tt & 255) >> 1, m1 - 1)) * H + g * JPB + 4 * (tt & 1));
             }
         }
@@ -380,38 +807,13 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     }
 }
 
-template <int H, int C, bool PART, int CUT = 0>
-__global__ __launch_bounds__(512) void mlp_head_multi_kernel(HeadMArgs p) {
-    head_block<H, C, PART, CUT, true>(p, (int)blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Head + the hidden layer's backward in ONE launch (4-launch step: fwd0 | fwd1 + partial logits | THIS | bwd0 + Adam).
-// The hidden layer's dz (rows x H) is   dz1 = (dz W2^T) * !signbit(a1)   with dz = the loss gradient of the rows x C logits:
-// 10 FMAs per element once dz is known, and dz costs every workgroup the same ~1 us the head's workgroups already spend
-// (sum 8 partial logits, whole-batch statistics).  So the tiles of the hidden layer's backward derive the slice of dz1
-// they contract over THEMSELVES instead of waiting for a launch boundary behind the head:
-//     blocks [0, G)                 the head's workgroups (head_block, no da rows): dW2, db2, loss, stats, beta powers, logits
-//     blocks [G, G + n_dw)          dW1 tile (16 inputs x 16 hidden units) = x^T dz1[:, 16 units]   (K = rows), db1 = column sums
-//     blocks [G + n_dw, ...)        dx tile (16 rows x 16 inputs) = (dz1[16 rows, :] W1^T) * !signbit(x)   (K = H)
-// Tile products as in small_tile_fast (v_mfma_f32_16x16x4_f32, one 16-deep K chunk per wave, 8 waves, partials summed
-// through LDS); the dz1 operand comes from LDS (panel computed in place), the other operand through loads requested first
-// thing.  dz1 is never written to HBM.
-struct HeadBwdArgs {
-    const float* x;                  // [m][n_in]   the hidden layer's input (sign-encoded ReLU output of the layer before)
-    const float* w1;                 // [n_in][H]
-    float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
-    int n_in, tiles_in;              // tiles_in = n_in / 16
-    int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8; TNN_XCD_TILES=0 turns it off)
-};
-
 // CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
 template <int H, int C, int CUT = 0, int SH = 0, bool RB = false>
-__global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
+__global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMArgs p, HeadBwdArgs q) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
     if ((int)blockIdx.x < G) {
-        head_block<H, C, true, 0, false, SH, RB>(p, (int)blockIdx.x);
+        head_block_rb<H, C, true, 0, false, SH, RB>(p, (int)blockIdx.x);
         return;
     }
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
@@ -483,7 +885,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs
         int row0 = rb * ROWS, tt = t;
         if constexpr (RB) { asm volatile("" : "+s"(row0)); asm volatile("" : "+v"(tt)); }   // see head_block: keeps the addresses out of loop-carried registers
         const int m = RB ? min(ROWS, mt - row0) : mt;
-        head_stage_request<C, NP>(p, tt, stg_nx, m, row0);
+        head_stage_request_rb<C, NP>(p, tt, stg_nx, m, row0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) a1m_nx[r] = p.a[(size_t)(row0 + min(prow0 + r, m - 1)) * H + urow];
         if (is_dw) {
@@ -491,7 +893,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs
             for (int j = 0; j < 4; ++j) af_nx[j] = q.x[(size_t)(row0 + min(16 * wid + 4 * grp + j, m - 1)) * n_in + m0 + i16];
         }
     };
-    constexpr bool PF = RB && TNN_HEAD_PREFETCH;
+    constexpr bool PF = RB && true;
     if (PF) request_block(rb_lo);
     for (int rb = rb_lo; rb < rb_hi; ++rb) {
     if (!PF) request_block(rb);
@@ -503,7 +905,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_kernel(HeadMArgs
     float a1m[4], af[4];                         // af: the dW tile's x fragment
 #pragma unroll
     for (int r = 0; r < 4; ++r) { a1m[r] = a1m_nx[r]; af[r] = af_nx[r]; }
-    head_stage_store<C, NP>(p, t, stg_nx, zs, ys, m, row0, bias4);
+    head_stage_store_rb<C, NP>(p, t, stg_nx, zs, ys, m, row0, bias4);
     // the staged values are in LDS, their registers are free: the next block's reads travel while this one is worked on
     if (PF && rb + 1 < rb_hi) request_block(rb + 1);
     __syncthreads();
@@ -618,6 +1020,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = (int)m_global;
     p.ext_pairs = ext_pairs; p.ext_n = ext_n;
+    TNN_REQUIRE(!whole_logits || rows > 128, "%s: whole logits (n_pairs < 0) come from the row-panel forward, i.e. with more than 128 rows", fn);
     p.nparts = whole_logits ? 1 : 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = nullptr;
@@ -631,7 +1034,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
     if (ext_pairs != nullptr) {          // data parallel: the statistics come from the tail of the previous launch [+ all-gather]
         TNN_REQUIRE(m_global >= rows && ext_n >= 1 && ext_n <= 64, "%s: m_global < rows or bad pair count", fn);
-        if (rows > 128) hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2, true>), grid, 512, 0, tnn::stream(), p, q);
+        if (rows > 128) hipLaunchKernelGGL((mlp_head_bwd_rb_kernel<128, 10, 0, 2, true>), grid, 512, 0, tnn::stream(), p, q);
         else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 2>), grid, 512, 0, tnn::stream(), p, q);
         TNN_LAUNCH_OK();
         return 0;
