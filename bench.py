@@ -16,11 +16,13 @@ less than that.  `value` / `ms_per_step` = MEDIAN over the repeats of (max over 
 
 What `value` is:
   N = 1   configs[1] of BASELINE.json: bs 128 on one GPU (the configuration the metric is quoted on).
-  N > 1   configs[3]: STRONG scaling — global batch 1024, 1024/N rows per rank, same global batches on every N
-          ("scaling": "strong"); every line also carries
-            strong_scaling  the config-D point of THIS N (N = 1: bs 1024 on one GPU = `--workload A --rows 1024`), and at
-                            N > 1 the single-GPU bs-1024 step measured on rank 0 of the same run
+  N > 1   the SAME definition: WEAK scaling — 128 rows per rank, global batch 128 N ("scaling": "weak"; N = 8 is exactly
+          configs[3]'s global batch 1024), so `value` at every N divides by the N = 1 `value`.  `speedup_vs_n1` is that
+          ratio computed inside the run: `value` / (the 128-row single-GPU step measured on rank 0 of the same run,
+          `single_gpu_bs128`).  `--scaling strong` puts `value` on the other curve instead.  Every line also carries
             weak_scaling    128 rows per rank (global batch 128 N)
+            strong_scaling  configs[3] taken literally: global batch 1024 split over the N ranks (N = 1: bs 1024 on one
+                            GPU = `--workload A --rows 1024`), with its own `speedup_vs_n1` against `single_gpu_bs1024`
             batch_sizes     (N = 1) the same net at 256 and 512 rows on the one GPU — the per-rank batches of N = 4 / 2
           so both curves can be drawn from the driver's N = 1/2/4/8 lines.
   Transports at N > 1: RCCL (north_star's named transport) is timed FIRST, the xGMI peer-to-peer path second; both are
@@ -737,7 +739,7 @@ def main():
     ap.add_argument("--workload", default="A", choices=["A", "C", "E"])
     ap.add_argument("--path", default="fused", choices=["fused", "ops", "opsgraph"])
     ap.add_argument("--rows", type=int, default=None, help="rows per GPU for workload A (default 128; N>1: 1024/N)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
                     help="N>1, workload A: which curve `value` is on (the other one is reported beside it)")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--min-ms", type=float, default=50.0)
@@ -968,12 +970,21 @@ def main():
                 replicas_identical=replicas_identical(other))
             del other
         if world > 1:
-            # the single-GPU reference of the strong curve, measured in THIS run on rank 0 while the others wait
+            # the single-GPU references of BOTH curves, measured in THIS run on rank 0 while the others wait; each curve's
+            # speedup is computed on its own definition (weak: 128 rows on one GPU; strong: the whole 1024 rows on one GPU)
             if rank == 0:
-                d1 = FusedRun(widths, GLOBAL_BATCH_D, kind, 32, 0, 1, None, False, use_graph=use_graph)
-                r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, GLOBAL_BATCH_D)
-                curves["single_gpu_bs%d" % GLOBAL_BATCH_D] = brief(r1, note="rank 0 alone, no communicator")
-                del d1
+                for rows_1 in (128, GLOBAL_BATCH_D):
+                    d1 = FusedRun(widths, rows_1, kind, 64 if rows_1 <= 256 else 32, 0, 1, None, False, use_graph=use_graph)
+                    r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, rows_1)
+                    curves["single_gpu_bs%d" % rows_1] = brief(r1, note="rank 0 alone, no communicator")
+                    del d1
+                for name, rows_1 in (("weak_scaling", 128), ("strong_scaling", GLOBAL_BATCH_D)):
+                    if name in curves:
+                        curves[name]["speedup_vs_n1"] = round(
+                            curves[name]["value"] / curves["single_gpu_bs%d" % rows_1]["value"], 4)
+                own = "strong_scaling" if args.scaling == "strong" else "weak_scaling"
+                if line is not None:
+                    line["speedup_vs_n1"] = curves[own]["speedup_vs_n1"]
             comm.barrier()
         if "strong_scaling" in curves:
             curves["strong_scaling"].setdefault("note", strong_note)
@@ -1090,7 +1101,10 @@ def latency_roofline(widths, rows, res, runner):
 
 
 def make_line(args, widths, rows, kind, world, warmup, steps, res, runner, transports, force_dp):
-    cfg_name = {"A": "configs[1]" if world == 1 and rows == 128 else "configs[3]", "C": "configs[2]", "E": "configs[4]"}[args.workload]
+    cfg_a = "configs[1]" if world == 1 and rows == 128 else "configs[3]"
+    if world > 1 and rows == 128:
+        cfg_a = "configs[1] per rank, data-parallel over %d ranks%s" % (world, " = configs[3]" if world * rows == GLOBAL_BATCH_D else "")
+    cfg_name = {"A": cfg_a, "C": "configs[2]", "E": "configs[4]"}[args.workload]
     graph = getattr(runner, "chunk", None) is not None
     scaling = "weak"
     if args.workload == "A" and world > 1 and args.rows is None:

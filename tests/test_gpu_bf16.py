@@ -38,6 +38,48 @@ def test_bf16_gemm_nt_and_epilogues():
 
 
 @pytest.mark.gpu
+def test_bf16_skinny_gemm_split_k_path():
+    """Shapes that take the 256 x 128 split-K kernel (tnn_gemm_bf16_sk.h: bf16 output, about one workgroup per CU): ragged
+    M / N (clamped edge rows, the unstaged epilogue), a leading dimension that is not a multiple of 8, every epilogue, and
+    two different products back to back — a slab or a counter surviving from the previous launch would show at once.
+    Results are bit-identical run to run (fixed summation order of the two K slices)."""
+    rs = np.random.RandomState(43)
+    for (M, N, K) in ((512, 8192, 1024), (300, 8000, 1024), (512, 7990, 640), (257, 16000, 768)):
+        a = bf16.round_to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+        a2 = bf16.round_to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+        b = bf16.round_to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+        A, A2, B = bf16.to_bf16(a), bf16.to_bf16(a2), bf16.to_bf16(b)
+        b64 = b.astype(np.float64)
+        outs = []
+        for rep in range(3):
+            for src, src16 in ((a, A), (a2, A2)):
+                ref = src.astype(np.float64) @ b64.T
+                bound = np.abs(src).astype(np.float64) @ np.abs(b64).T
+                out16 = bf16.gemm_nt(src16, B, out_dtype=np.uint16)
+                raw = np.asarray(out16)
+                c16 = np.asarray(bf16.to_f32(out16), dtype=np.float64)
+                assert (np.abs(c16 - ref) <= 4e-3 * np.abs(ref) + 2e-6 * bound).all(), (M, N, K, rep)
+                outs.append(raw)
+        assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[4])          # bit-identical run to run
+        assert np.array_equal(outs[1], outs[3]) and np.array_equal(outs[1], outs[5])
+        ref = a.astype(np.float64) @ b64.T
+        bound = np.abs(a).astype(np.float64) @ np.abs(b64).T
+        bias = rs.randn(N).astype(np.float32)
+        y16 = bf16.gemm_nt(A, B, out_dtype=np.uint16, bias=tn.asarray(bias), relu=True, relu_sign=True)
+        y = np.asarray(bf16.to_f32(y16))
+        z = ref + bias
+        assert (np.abs(y - np.maximum(z, 0)) <= 4e-3 * np.abs(z) + 1e-5 * bound + 1e-6).all()
+        raw = np.asarray(y16)
+        clearly_neg, clearly_pos = z < -1e-3 * bound - 1e-6, z > 1e-3 * bound + 1e-6
+        assert ((raw[clearly_neg] & 0x8000) != 0).all() and ((raw[clearly_pos] & 0x8000) == 0).all()
+        masked16 = bf16.gemm_nt(A, B, out_dtype=np.uint16, mask=y16)
+        masked = np.asarray(bf16.to_f32(masked16), dtype=np.float64)
+        expect = np.where((raw & 0x8000) != 0, 0.0, ref)
+        assert (np.abs(masked - expect) <= 4e-3 * np.abs(expect) + 2e-6 * bound).all()
+        assert (masked[(raw & 0x8000) != 0] == 0).all()
+
+
+@pytest.mark.gpu
 def test_bf16_transpose_colsum_mse_adam():
     from tinynn_autograd_amd import _lib
     rs = np.random.RandomState(42)

@@ -16,55 +16,15 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
+
 #include "tnn_internal.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef uint16_t bf16_t;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native 16-B vector (HIP's uint4 struct ended up in scratch)
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum { BEPI_PLAIN = 0, BEPI_BIAS_ACT = 1, BEPI_MASK = 2 };
-
-struct BfArgs {
-    const bf16_t* A;
-    const bf16_t* B;
-    void* C;
-    int64_t M, N, K, lda, ldb, ldc;
-    int c_bf16;            // output element type: 1 = bf16, 0 = f32
-    int epi;
-    const float* bias;
-    int act, relu_sign;
-    const bf16_t* Y;
-    int64_t ldy;
-    int tiles_m, tiles_n;
-    // BEPI_ADAM (tnn_gemm_bf16_nt_adam): the product is a weight gradient that Adam consumes in the epilogue
-    float *ap, *am, *av;             // fp32 master weights and moments, [M][ldc] like C
-    bf16_t *aw16, *awT16;            // bf16 working copy [M][ldc] and its transpose [N][ldt]
-    int64_t ldt;
-    float lr, b1, b2, eps;
-    const double* pows;              // {b1^t, b2^t}, already advanced for this step
-    const int* guard;                // data-parallel update guard (tnn_internal.h)
-};
-
-__device__ __forceinline__ bf16_t f2bf(float f) {       // round to nearest even (finite inputs)
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((uint32_t)h << 16); }
-
-__device__ __forceinline__ int xcd_remap16(int b, int nb) {
-    const int nx = 8;
-    if (nb < 2 * nx) return b;
-    int q = nb / nx, r = nb % nx;
-    int xcd = b % nx, local = b / nx;
-    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + local;
-}
+#include "tnn_gemm_bf16_types.h"
 
 constexpr int BM = 128, BN = 128, BK = 64, WM = 2, WN = 2, NT = 256;
 constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
@@ -266,7 +226,49 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
         }
 }
 
-#include "tnn_gemm_bf16_dma.h"     // gemm_bf16_dma_kernel<NW, NS>: the LDS-DMA variant (experimental, see its header)
+#include "tnn_gemm_bf16_dma.h"     // gemm_bf16_dma_kernel<NW, NS>: the LDS-DMA variant (see its header)
+#include "tnn_gemm_bf16_sk.h"      // sk::gemm_bf16_sk_kernel: 256-row tiles + split-K for the skinny (M = 512) products
+
+// Hand-off memory of the split-K kernel: fp32 slabs [tile][slice][256 x 128] + two counter words per tile, one set per stream
+// (two such GEMMs on different streams must not share counters).  Allocated on first use outside a capture and never
+// returned (32 MB for config E's shapes); the counters are zeroed once — every launch leaves them at zero.
+struct SkWorkspace {
+    float* slabs = nullptr;
+    unsigned* counters = nullptr;
+    size_t slab_bytes = 0;
+    int tiles = 0;
+};
+std::mutex g_sk_mu;
+std::unordered_map<hipStream_t, SkWorkspace> g_sk_ws;
+
+bool sk_workspace(hipStream_t s, int tiles, int slices, size_t slab_bytes_per_slice, SkWorkspace* out) {
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    SkWorkspace& w = g_sk_ws[s];
+    const size_t need = (size_t)tiles * slices * slab_bytes_per_slice;
+    if (w.slab_bytes >= need && w.tiles >= tiles) {
+        *out = w;
+        return true;
+    }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;   // not inside a capture
+    if (hipStreamSynchronize(s) != hipSuccess) return false;          // nobody still reads the old buffers
+    if (w.slabs) (void)hipFree(w.slabs);
+    if (w.counters) (void)hipFree(w.counters);
+    w = SkWorkspace();
+    const int n_cnt = tiles > 4096 ? tiles : 4096;
+    if (hipMalloc(&w.slabs, need) != hipSuccess) { (void)hipGetLastError(); w = SkWorkspace(); return false; }
+    if (hipMalloc(&w.counters, (size_t)n_cnt * 2 * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(w.counters, 0, (size_t)n_cnt * 2 * sizeof(unsigned)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(w.slabs);
+        w = SkWorkspace();
+        return false;
+    }
+    w.slab_bytes = need;
+    w.tiles = n_cnt;
+    *out = w;
+    return true;
+}
 
 // bf16 [R, C] -> [C, R], 64x64 tiles.  2-byte accesses made the first version instruction-bound (2.2 TB/s), so:
 // every thread loads a 4x4 block with four 8-B loads, transposes it in registers, writes the four transposed
@@ -633,6 +635,28 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     // deeper ring wins (whole config-E step: 216 k -> 237 k samples/s; bench.py's per-GEMM table rotates operands for this
     // reason).  Variants: reg | dma8s | dma4s | dma8 | dma4 (8 / 4 waves; s = 2 stages).
     const unsigned tiles = (unsigned)(g.tiles_m * g.tiles_n);
+    // Skinny products (at most about one 128 x 128 tile per CU: config E's M = 512 forward / dX shapes, 87 us at 512 x 8192 x
+    // 8192): 256 x 128 tiles with the K range split over two workgroups, 70 us (tnn_gemm_bf16_sk.h; 256 x 256 x 4 slices loses
+    // more to its 48 MB slab exchange than its K loop gains).  One workgroup per CU, so the grid must fit the chip once.
+    {
+        constexpr int S = 2, SK_BN = 128, SK_NSB = 4;
+        const int64_t t256 = ((M + 255) / 256) * ((N + SK_BN - 1) / SK_BN), nk = K / 64;
+        const int cus = tnn::num_cus();
+        if (g.c_bf16 && nk % S == 0 && nk / S > SK_NSB && t256 * S <= cus && t256 * S * 2 >= cus && tiles <= 2u * (unsigned)cus) {
+            SkWorkspace w;
+            if (sk_workspace(tnn::stream(), (int)t256, S, (size_t)256 * SK_BN * 4, &w)) {
+                g.tiles_m = (int)((M + 255) / 256);
+                g.tiles_n = (int)((N + SK_BN - 1) / SK_BN);
+                g.splitk = S;
+                g.sk_ws = w.slabs;
+                g.sk_cnt = w.counters;
+                hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<SK_BN, 4, 2, 3, SK_NSB, S>), dim3((unsigned)(t256 * S)), 512, 0,
+                                   tnn::stream(), g);
+                TNN_LAUNCH_OK();
+                return 0;
+            }
+        }
+    }
     const char* which = tiles >= 2u * (unsigned)tnn::num_cus() ? "dma8s" : "dma8";
     const bool dma = which[0] == 'd' && which[1] == 'm' && which[2] == 'a';
     const bool swap = g.c_bf16 != 0;          // bf16 outputs: 8-B stores per lane; fp32 outputs: whole 128-B row segments
