@@ -1000,10 +1000,13 @@ def main():
         state_e = {"note": "did not finish in %d s" % limit_e}
 
         def stop_e():
+            # a hung sharded-optimizer measurement is NOT a successful run: the line is emitted as it stands, marked, and the
+            # process ends with a code of its own (6) so that self_launch / the driver see the failure
             if line is not None:
                 line["config_E"] = state_e["note"]
+                line["exit_code"] = line.get("exit_code") or 6
             emit(line)
-            os._exit(exit_code)
+            os._exit(exit_code or 6)
         dog_e = threading.Timer(limit_e, stop_e)
         dog_e.daemon = True
         dog_e.start()

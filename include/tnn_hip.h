@@ -455,6 +455,14 @@ TNN_API int tnn_mlp_sync_params(void* handle);
  * tnn_mlp_param_offset).  In the data-parallel sharded-optimizer step it is the complete, rank-identical copy of the
  * weights (each rank's fp32 master arena is authoritative for its own rows only). */
 TNN_API int tnn_mlp_bf16_weights(void* handle, void** w_bf16);
+/* After sharded-optimizer steps at world > 1 (tnn_mlp_step_sharded on a TNN_BF16 trainer) each rank's fp32 master / m / v
+ * arenas are current for its own row slice of every weight matrix only.  tnn_mlp_masters_sharded: *world = the world size
+ * they are sharded over, 0 when whole.  tnn_mlp_gather_masters (COLLECTIVE: every rank calls it) all-gathers the owned
+ * slices so the arenas are whole on every rank — what reads the parameters the way core/model.py:24-33 exposes them, or a
+ * checkpoint, needs first.  No-ops for other trainers.  tnn_mlp_sync_params also marks the arenas whole (the caller has
+ * just written them). */
+TNN_API int tnn_mlp_masters_sharded(void* handle, int* world);
+TNN_API int tnn_mlp_gather_masters(void* handle);
 /* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
 TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
 

@@ -198,10 +198,39 @@ def run_config_e_small(tn, comm, calls, rank, world, dist):
         assert np.median(err) <= 0.1 * lr + 2.0 ** -12, (l, float(np.median(err)))
         # this rank's fp32 master rows are what its bf16 rows were rounded from
         r0, r1 = rank * widths[l] // world, (rank + 1) * widths[l] // world
-        own = np.asarray(trainer.param_view(l, "w"))[r0:r1]
+        own = np.asarray(trainer._view(l, "w"))[r0:r1]
         assert np.array_equal(bf16.round_to_bf16(own), (np.asarray(trainer.weights_bf16(l))[r0:r1].astype(np.uint32) << 16).view(np.float32))
         bias = np.asarray(trainer.param_view(l, "b"), dtype=np.float64)
         assert np.abs(bias - oracle.b[l]).max() <= 2 * steps * lr and np.median(np.abs(bias - oracle.b[l])) <= 0.1 * lr
+    # ---- the fp32 masters are sharded: readers of the whole matrix are refused until the owned slices have been gathered,
+    # and a checkpoint (a collective) holds WHOLE, rank-identical arenas from which a fresh trainer continues bit for bit
+    if world > 1:
+        assert trainer.masters_sharded() == world
+        try:
+            trainer.param_view(0, "w")
+            raise AssertionError("param_view on sharded masters did not raise")
+        except RuntimeError:
+            pass
+    calls["seq"] = []
+    state = trainer.state_dict()
+    if world > 1:
+        shard = [widths[l] // world * widths[l + 1] for l in range(2)]
+        assert calls["seq"] == [("allgather", shard[l], F32) for l in range(2) for _ in range(3)], calls["seq"]
+    assert trainer.masters_sharded() == 0
+    parts = [None] * world
+    dist.all_gather_object(parts, state["params"].tobytes() + state["m"].tobytes() + state["v"].tobytes())
+    assert all(p == parts[0] for p in parts), "gathered fp32 arenas differ across ranks"
+    for l in range(2):
+        whole = np.asarray(trainer.param_view(l, "w"))
+        assert np.array_equal(bf16.round_to_bf16(whole), (np.asarray(trainer.weights_bf16(l)).astype(np.uint32) << 16).view(np.float32))
+    resumed = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=lr, dtype="bfloat16", comm=comm)
+    resumed.load_state_dict(state)
+    la, lb = float(trainer.step(x16, x16)), float(resumed.step(x16, x16))
+    assert la == lb, (la, lb)
+    assert np.array_equal(np.asarray(trainer.weights_bf16()), np.asarray(resumed.weights_bf16()))
+    sa, sb = trainer.state_dict(), resumed.state_dict()
+    for k in ("params", "m", "v", "pows"):
+        assert np.array_equal(sa[k], sb[k]), k
 
 
 if __name__ == "__main__":

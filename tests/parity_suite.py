@@ -1329,7 +1329,7 @@ def deferred_first_layer_backward_semantics():
     backward launch is deferred at backward() time, the loss launch advances Adam's powers.  Every way of using the API in
     between must give the parameters of a model built WITHOUT any fusion (Dense(fused=False), the 12-op loss, Adam(fused=False)):
     plain steps; gradients read between backward and step; two backward calls before one step (accumulation); a backward whose
-    gradients are thrown away by zero_grad (the Model's, or each parameter tensor's own); the loss evaluated twice before the step; a non-default seed; a step with no
+    gradients are thrown away by zero_grad (the Model's, or each parameter tensor's own); the loss evaluated twice before the step (in every order of evaluation and backward); a non-default seed; a step with no
     backward at all in front of it (zero gradients)."""
     from tinynn_autograd_amd.core.layers import Dense, ReLU
     from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
@@ -1383,6 +1383,14 @@ def deferred_first_layer_backward_semantics():
             elif name == "two_losses":
                 fwd_loss(i + 1)                       # evaluated, never differentiated
                 fwd_loss(i).backward()
+            elif name == "loss_a_loss_b_backward_a":
+                la = fwd_loss(i)
+                fwd_loss(i + 1)                       # B's speculative head results land in the same arena views as A's did
+                la.backward()
+            elif name == "loss_a_loss_b_backward_both":
+                la, lb = fwd_loss(i), fwd_loss(i + 1)
+                la.backward()
+                lb.backward()
             elif name == "seed":
                 fwd_loss(i).backward(0.5)
             elif name == "no_backward":
@@ -1391,7 +1399,8 @@ def deferred_first_layer_backward_semantics():
             model.step()
         return np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
 
-    for name in ("plain", "read", "accumulate", "discard", "tensor_zero_grad", "two_losses", "seed", "no_backward"):
+    for name in ("plain", "read", "accumulate", "discard", "tensor_zero_grad", "two_losses", "loss_a_loss_b_backward_a",
+                 "loss_a_loss_b_backward_both", "seed", "no_backward"):
         got = scenario(*build(True), name)
         ref = scenario(*build(False), name)
         np.testing.assert_allclose(got, ref, rtol=0, atol=0.1 * 1e-3, err_msg=name)       # Adam: SURVEY H1
@@ -1429,7 +1438,55 @@ def deferred_first_layer_backward_semantics():
             r = np.asarray(ref_model.net.layers[0].params[k].grad)
             np.testing.assert_allclose(np.asarray(first[k].grad), r, rtol=0, atol=2e-5 * np.abs(r).max(),
                                        err_msg="replayed first-layer gradient %s, replay %d" % (k, i))
-    np.testing.assert_allclose(np.asarray(model.optimizer._pows)[:2], pows_before[:2], rtol=1e-12)
+    # three replays, no step in between: the powers stand advanced ONCE (for the step to come), not three times — and the
+    # eager step that follows consumes that advance instead of adding its own
+    np.testing.assert_allclose(np.asarray(model.optimizer._pows)[:2], pows_before[:2] * np.array([0.9, 0.999]), rtol=1e-12)
+    assert model.optimizer._ticked
+    model.step()
+    ref_model.step()
+    np.testing.assert_allclose(np.asarray(model.optimizer._pows)[:2], pows_before[:2] * np.array([0.9, 0.999]), rtol=1e-12)
+    for lg, lr_ in zip(H.dense_layers(model), H.dense_layers(ref_model)):
+        for k in ("w", "b"):
+            np.testing.assert_allclose(np.asarray(lg.params[k].values), np.asarray(lr_.params[k].values), rtol=0, atol=0.1 * 1e-3)
+
+
+def captured_forward_in_train_phase_replays_fresh_logits():
+    """`tn.capture(lambda: model.forward(x_stage))` with the net in its default TRAIN phase: the classifier's logits are a
+    deferred array (ops.dense_(lazy=True)) whose GEMM is NOT in the graph when nothing inside the captured function reads them.
+    Every replay must still show ITS batch's logits to the host (the first version computed them once, on the first read,
+    and returned those values after every later replay)."""
+    from tinynn_autograd_amd.core.layers import Dense, ReLU
+    from tinynn_autograd_amd.core.nn import Net
+    rs = np.random.RandomState(12)
+    widths, rows = [24, 32, 128, 10], 48
+    Ws = [(rs.randn(widths[i], widths[i + 1]) * 0.2).astype(np.float32) for i in range(3)]
+    Bs = [(rs.randn(1, widths[i + 1]) * 0.1).astype(np.float32) for i in range(3)]
+    layers = []
+    for i in range(3):
+        d = Dense(widths[i + 1], num_in=widths[i])
+        d.params["w"].values = tn.asarray(Ws[i]); d.params["b"].values = tn.asarray(Bs[i])
+        layers.append(d)
+        if i < 2:
+            layers.append(ReLU())
+    net = Net(layers)
+    x_stage = Tensor(np.zeros((rows, widths[0]), np.float32))
+    replay = tn.capture(lambda: net.forward(x_stage), warmup=1)
+
+    def host_forward(x):
+        a = x.astype(np.float64)
+        for i in range(3):
+            a = a @ Ws[i].astype(np.float64) + Bs[i].astype(np.float64)
+            if i < 2:
+                a = np.maximum(a, 0.0)
+        return a
+    for i in range(4):
+        xb = (rs.rand(rows, widths[0]) * (rs.rand(rows, widths[0]) < 0.5)).astype(np.float32)
+        x_stage.values[...] = tn.asarray(xb)
+        out = replay()
+        ref = host_forward(xb)
+        np.testing.assert_allclose(np.asarray(out.values), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg="replay %d" % i)
+        if i == 1:                                    # a second read after the same replay sees the same values
+            np.testing.assert_allclose(np.asarray(out.values), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
 
 
 def graph_released_while_another_capture_is_open():

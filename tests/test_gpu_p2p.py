@@ -165,9 +165,11 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
 @pytest.mark.parametrize("gpus", [2, 4])
 def test_bench_gpus_2_launches_its_own_ranks(gpus):
     """`python3 bench.py --gpus N ...` with NO launcher (the form the driver uses for N = 1): the parent, which never
-    touches the GPU, starts the ranks itself, relays rank 0's one JSON line and passes the children's status on.  N = 2 / 4:
-    512 / 256 rows per rank — the data-parallel 5-launch step whose merged head launch walks the rows in blocks of 128 and
-    whose forward tail reduces the statistics per block before the exchange."""
+    touches the GPU, starts the ranks itself, relays rank 0's one JSON line and passes the children's status on.  `value` is on
+    ONE definition at every N — weak scaling, 128 rows per rank, global batch 128 N — and `speedup_vs_n1` is that value over
+    the 128-row single-GPU step measured on rank 0 of the same run.  The strong curve (configs[3]'s global batch 1024 split
+    over the ranks: 512 / 256 rows per rank at N = 2 / 4 — the data-parallel 5-launch step whose merged head launch walks the
+    rows in blocks of 128) rides beside it with its own speedup."""
     import json
     env = dict(os.environ, TNN_COMM="xgmi", TNN_DEVICE="0", TNN_P2P_TIMEOUT_MS="20000", HSA_ENABLE_IPC_MODE_LEGACY="0",
                PYTHONDONTWRITEBYTECODE="1")
@@ -181,11 +183,18 @@ def test_bench_gpus_2_launches_its_own_ranks(gpus):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == gpus and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong"
-    assert d["config"]["global_batch"] == 1024 and d["config"]["rows_per_rank"] == 1024 // gpus
+    assert d["n_gpus"] == gpus and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 128 * gpus and d["config"]["rows_per_rank"] == 128
     assert d["parity_vs_reference_fixture"]["ok"] and d["exit_code"] == 0
     assert d["config"]["collectives"]["xgmi_p2p"]["replicas_identical"]
-    assert "note" in d["strong_scaling"]
+    # the line's own N = 1 reference and the speedup computed from it, on the line's own definition
+    n1 = d["single_gpu_bs128"]["value"]
+    assert abs(d["value"] / n1 - d["speedup_vs_n1"]) <= 1e-3 * d["speedup_vs_n1"]
+    assert d["weak_scaling"]["rows_per_rank"] == 128 and d["weak_scaling"]["global_batch"] == 128 * gpus
+    assert abs(d["weak_scaling"]["speedup_vs_n1"] - d["speedup_vs_n1"]) < 1e-9
+    st = d["strong_scaling"]
+    assert st["global_batch"] == 1024 and st["rows_per_rank"] == 1024 // gpus and "note" in st
+    assert abs(st["value"] / d["single_gpu_bs1024"]["value"] - st["speedup_vs_n1"]) <= 1e-3 * st["speedup_vs_n1"]
 
 
 @pytest.mark.gpu

@@ -139,6 +139,8 @@ _SIGNATURES = {
     "tnn_mlp_sync_params": [_p],
     "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
     "tnn_mlp_bf16_weights": [_p, POINTER(c_void_p)],
+    "tnn_mlp_masters_sharded": [_p, POINTER(c_int)],
+    "tnn_mlp_gather_masters": [_p],
     "tnn_comm_unique_id": [_p],
     "tnn_comm_init": [c_int, c_int, _p],
     "tnn_comm_destroy": [],

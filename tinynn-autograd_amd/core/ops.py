@@ -453,11 +453,17 @@ def _softmax_head(logits, labels):
     lib = _lib.get()
     stats, loss, dz = da.empty((2,), dt), da.empty((), dt), da.empty((m, c), dt)
 
+    # Speculative results may be written straight into a parameter's arena view, but a LATER loss evaluation (second forward +
+    # loss before this one's backward) would write ITS results into the same view: every view written here is stamped with this
+    # call's token on its tensor, and the hand-over below adopts a view only while the stamp is still this call's.
+    owner = object()
+
     def dest(t, shape):
         """The tensor's arena view when its gradient is lazily zero (what the scheduler would lend), else a fresh buffer."""
         home = getattr(t, "_grad_home", None)
         if (t.requires_grad and home is not None and t._grad is None and t._grad_zero and not t.dependency
                 and home.size == math.prod(shape) and home.dtype == dt and not home._t and home._hv is None):
+            t._spec_owner = owner
             return home, True
         return da.empty(shape, dt), False
     dw, dw_home = dest(w, (hdim, c))
@@ -504,6 +510,7 @@ def _softmax_head(logits, labels):
         dx = da.LazyArray.deferred((m, hdim), dt, hidden_dz)
         dx._tag = xv
         pre1 = {"x": (dx0, False), "w": (dw1, dw1_home), "b": (db1, db1_home)}
+        stamped1 = {"w": w1, "b": b1}
         generic1 = x._fused_vjp
 
         x_ref = weakref.ref(x)                        # not x itself: x._fused_vjp -> this closure -> x would be a cycle that
@@ -517,8 +524,8 @@ def _softmax_head(logits, labels):
                 out = []
                 for name, home in zip(edges1, homes):
                     arr, wrote_home = pre1[name]
-                    if wrote_home and home is not arr:
-                        out = None
+                    if wrote_home and (home is not arr or getattr(stamped1[name], "_spec_owner", None) is not owner):
+                        out = None                    # not this tensor's to adopt, or overwritten by a later loss evaluation
                         break
                     out.append(arr)
                 if out is not None:
@@ -536,6 +543,7 @@ def _softmax_head(logits, labels):
         if dx is not None:
             dx._tag = xv                              # already multiplied by x's ReLU mask
     pre = {"x": (dx, False), "w": (dw, dw_home), "b": (db, db_home)}
+    stamped = {"w": w, "b": b}
 
     logits_ref = weakref.ref(logits)                  # see x_ref above
 
@@ -547,9 +555,9 @@ def _softmax_head(logits, labels):
             out = []
             for name, home in zip(edges, homes):
                 arr, wrote_home = pre[name]
-                if wrote_home and home is not arr:    # the arena view is no longer this tensor's to adopt
-                    out = None
-                    break
+                if wrote_home and (home is not arr or getattr(stamped[name], "_spec_owner", None) is not owner):
+                    out = None                        # the arena view is no longer this tensor's to adopt, or a later loss
+                    break                             # evaluation has overwritten it
                 out.append(arr)
             if out is not None:
                 return out

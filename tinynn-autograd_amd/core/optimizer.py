@@ -71,15 +71,17 @@ class SGD(BaseOptimizer):
 _TICKED = weakref.WeakSet()       # Adam instances whose powers a loss launch has advanced for a step that has not run yet
 
 
-def settle_ticks():
-    """End of a hipGraph capture (graph.py): a captured function that evaluated a loss but did NOT contain the optimizer step
-    would advance the powers on every replay while the step runs outside — take the advance back inside the graph and let
-    the step advance them itself.  (A captured WHOLE step has consumed its tick: nothing to do.)"""
-    for opt in list(_TICKED):
-        if opt._ticked and opt._pows is not None:
-            _lib.get().adam_tick(opt._pows._ptr, 1.0 / opt._b1, 1.0 / opt._b2)
-            opt._ticked = False
+def take_capture_ticks():
+    """End of a hipGraph capture (graph.py): the optimizers whose powers a loss launch INSIDE the captured function advances
+    while the step that consumes the advance is NOT part of it.  Nothing has executed yet, so their `_ticked` flags are
+    cleared here; the captured function sets them after every replay (the replay's loss launch has then really advanced the
+    powers and the eager step that follows must not advance them again — exact, no extra launch in the graph).  A captured
+    WHOLE step has consumed its tick: nothing to hand over."""
+    out = [opt for opt in list(_TICKED) if opt._ticked and opt._pows is not None]
+    for opt in out:
+        opt._ticked = False
     _TICKED.clear()
+    return out
 
 
 def _flat_pair_ok(params, grads):
@@ -135,6 +137,14 @@ class Adam(BaseOptimizer):
         self._ticked = True
         _TICKED.add(self)
         return self._pows._ptr, self._b1, self._b2
+
+    def untick(self):
+        """Take back an advance of the powers that no step has consumed (a loss-only hipGraph replayed twice in a row: its loss
+        launch advances unconditionally).  The multiplication by 1 / b is not the exact inverse in float64 — an ulp at most,
+        on this rare path only."""
+        if self._ticked and self._pows is not None:
+            _lib.get().adam_tick(self._pows._ptr, 1.0 / self._b1, 1.0 / self._b2)
+        self._ticked = False
 
     def apply_with_first_layer(self, params, grads, rows, n_in, n_out, x, dz):
         """The backward of the model's FIRST Dense layer (deferred by Model, core/model.py) and the Adam step over the whole

@@ -64,6 +64,9 @@ struct Mlp {
     char* g16 = nullptr;
     float* bias_g = nullptr;
     std::vector<int64_t> bias_g_off;
+    // world size of the last sharded-optimizer step (0: the fp32 master / m / v arenas are whole).  While it is > 1 every
+    // rank's masters are current for ITS row slice of each weight matrix only (tnn_mlp_gather_masters makes them whole)
+    int masters_world = 0;
     // measurement hook (tnn_mlp_launch_window): primitive calls of a step are numbered 0, 1, ... in issue order and only
     // those inside [win_lo, win_hi) are executed, so each launch of the step can be replayed and timed on its own
     // No window set (the default): every call runs and the counter only reports launches per step; it is reset at the
@@ -295,6 +298,28 @@ int mlp16_step_zero(Mlp* h, const void* x16, const void* y16, int64_t rows, int 
     if (rc) { (void)tnn_comm_join(); return rc; }
     MLP_TRY(tnn_memcpy_d2d(at(h->grads, h->n_params, 4), h->bias_g + nb, 4));
     if (loss_out) MLP_TRY(tnn_memcpy_d2d(loss_out, h->bias_g + nb, 4));
+    h->masters_world = world > 1 ? world : 0;
+    return 0;
+}
+
+// Collective: all-gather every rank's OWNED fp32 rows of W_l (master weights and both Adam moments) so that the three arenas
+// are whole on every rank again — what a checkpoint (MLPTrainer.state_dict) or any reader of the fp32 parameters needs after
+// sharded-optimizer steps.  Biases are replicated already.  3 x 4 B per parameter over the links: checkpoint-time only.
+int mlp16_gather_masters(Mlp* h) {
+    if (h->masters_world <= 1) return 0;
+    int rank = 0, world = 1;
+    MLP_TRY(tnn_comm_world(&rank, &world));
+    if (world != h->masters_world) {
+        tnn::set_error("tnn_mlp_gather_masters: the optimizer was sharded over %d ranks, the communicator now has %d",
+                       h->masters_world, world);
+        return 2;
+    }
+    char* arenas[3] = {h->params, h->m, h->v};
+    for (int l = 0; l < h->L; ++l) {
+        const int64_t n_shard = h->w[l] / world * h->w[l + 1], wo = h->w_off[l], so = wo + (int64_t)rank * n_shard;
+        for (char* a : arenas) MLP_TRY(tnn_allgather(at(a, so, 4), at(a, wo, 4), n_shard, TNN_F32));
+    }
+    h->masters_world = 0;
     return 0;
 }
 
@@ -891,7 +916,21 @@ int tnn_mlp_keep_grads(void* handle, int keep) {
 int tnn_mlp_sync_params(void* handle) {
     Mlp* h = (Mlp*)handle;
     if (!h) { tnn::set_error("tnn_mlp_sync_params: NULL handle"); return 2; }
+    h->masters_world = 0;          // the caller has just written the whole fp32 arena (initial weights, a checkpoint)
     return h->bf16 ? mlp16_sync(h) : 0;
+}
+
+int tnn_mlp_masters_sharded(void* handle, int* world) {
+    Mlp* h = (Mlp*)handle;
+    if (!h || !world) { tnn::set_error("tnn_mlp_masters_sharded: NULL argument"); return 2; }
+    *world = h->masters_world;
+    return 0;
+}
+
+int tnn_mlp_gather_masters(void* handle) {
+    Mlp* h = (Mlp*)handle;
+    if (!h) { tnn::set_error("tnn_mlp_gather_masters: NULL handle"); return 2; }
+    return h->bf16 ? mlp16_gather_masters(h) : 0;
 }
 
 int tnn_mlp_bf16_weights(void* handle, void** w16) {

@@ -21,6 +21,8 @@ import ctypes
 import math
 import numbers
 
+import weakref
+
 import numpy as np
 
 from . import _lib
@@ -668,6 +670,8 @@ class LazyArray(DeviceArray):
     def deferred(cls, shape, dtype, thunk):
         self = cls._new(shape, dtype)          # the buffer exists; only its content is pending
         self._thunk = thunk
+        if _lib.capturing:                     # graph.py re-arms what is still pending when the capture ends
+            _CAPTURE_LAZIES.append(weakref.ref(self))
         return self
 
     @classmethod
@@ -699,6 +703,23 @@ class LazyArray(DeviceArray):
     def __del__(self):
         self._thunk = None
         DeviceArray.__del__(self)
+
+
+_CAPTURE_LAZIES = []       # weak references to the LazyArray.deferred objects created inside the open hipGraph capture
+
+
+def take_capture_lazies():
+    """End of a capture (graph.py): the deferred arrays created inside it that NOTHING has asked for yet, with their producers.
+    Their launch is not in the graph; a replay refreshes the operands they would be computed from, so the captured function
+    re-arms them after every replay — a later read then computes them from the replay's data (eagerly, once) instead of
+    returning what the first read after some earlier replay produced."""
+    out = []
+    for ref in _CAPTURE_LAZIES:
+        arr = ref()
+        if arr is not None and arr._thunk is not None:
+            out.append((ref, arr._thunk))
+    del _CAPTURE_LAZIES[:]
+    return out
 
 
 def from_ptr(ptr, shape, dtype, owner):

@@ -86,7 +86,26 @@ class MLPTrainer(object):
         self._lib.mlp_param_offset(self._h, layer, which, ctypes.byref(off), ctypes.byref(cnt))
         return off.value, cnt.value
 
+    def masters_sharded(self):
+        """World size the fp32 master / moment arenas are currently sharded over (bf16 data-parallel trainer after
+        sharded-optimizer steps), 0 when they are whole."""
+        w = ctypes.c_int(0)
+        self._lib.mlp_masters_sharded(self._h, ctypes.byref(w))
+        return w.value
+
+    def gather_masters(self):
+        """COLLECTIVE (every rank calls it): make the fp32 parameter / Adam arenas whole on every rank after
+        sharded-optimizer steps.  `state_dict`, `save` and `get_parameters` call it themselves."""
+        self._lib.mlp_gather_masters(self._h)
+        return self
+
     def param_view(self, layer, key, arena=None):
+        if arena is None and key == "w" and self.masters_sharded():
+            raise RuntimeError("the fp32 master weights are sharded over %d ranks (sharded-optimizer steps): call "
+                               "gather_masters() on every rank first, or read weights_bf16()" % self.masters_sharded())
+        return self._view(layer, key, arena)
+
+    def _view(self, layer, key, arena=None):
         off, cnt = self._offset(layer, 0 if key == "w" else 1)
         shape = (self.widths[layer], self.widths[layer + 1]) if key == "w" else (1, self.widths[layer + 1])
         base = self.params if arena is None else arena
@@ -101,14 +120,17 @@ class MLPTrainer(object):
             for key in ("w", "b"):
                 src = layer[key]
                 src = src.values if hasattr(src, "values") and not isinstance(src, np.ndarray) else src
-                view = self.param_view(i, key)
+                view = self._view(i, key)             # the whole arena is rewritten: no need for it to be whole before
                 view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
         self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies W, W^T
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):
         """Everything a resumed run needs, as host arrays: parameters, the optimizer's two state arenas and Adam's
-        beta powers (the reference's Model.save only pickles the parameters and its load is broken)."""
+        beta powers (the reference's Model.save only pickles the parameters and its load is broken).  After
+        sharded-optimizer steps (bf16 data-parallel trainer) this is a COLLECTIVE: every rank must call it (the owned
+        fp32 slices are all-gathered first)."""
+        self.gather_masters()                         # collective when the optimizer is sharded: every rank saves
         pows = ctypes.c_void_p()
         self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
         return {"widths": list(self.widths), "dtype": "bfloat16" if self.bf16 else self.dtype.name,
@@ -137,6 +159,7 @@ class MLPTrainer(object):
                                   for k in f.files})
 
     def get_parameters(self):
+        self.gather_masters()                         # collective when the optimizer is sharded
         return [{"w": self.param_view(i, "w"), "b": self.param_view(i, "b")} for i in range(self.n_layers)]
 
     def weights_bf16(self, layer=None):

@@ -28,16 +28,30 @@ class CapturedFunction(object):
             fn()
         _lib.synchronize()
         self._graph = _lib.Graph()
+        from . import device_array as _da
+        from .core import model as _model, optimizer as _optimizer
+        _da.take_capture_lazies()        # (anything left over from an aborted capture)
         with self._graph:
             self.outputs = fn()          # recorded, not executed
-            # work the op-level fusions left for a step that is NOT part of fn (a deferred first-layer backward, an advance
-            # of Adam's powers by the loss launch) is settled inside the graph; a captured whole step leaves nothing
-            from .core import model as _model, optimizer as _optimizer
+            # work the op-level fusions left for a step that is NOT part of fn: a deferred first-layer backward is settled
+            # inside the graph; a captured whole step leaves nothing
             _model.settle_pending()
-            _optimizer.settle_ticks()
+        # ... an advance of Adam's powers by a loss launch whose step runs outside: flagged after every replay;
+        # deferred arrays nobody has read yet (TRAIN-phase logits of a captured forward, the hidden gradient of the fused
+        # head): re-armed after every replay so that a read sees THAT replay's values
+        self._ticked = _optimizer.take_capture_ticks()
+        self._lazies = _da.take_capture_lazies()
 
     def __call__(self):
+        for opt in self._ticked:
+            opt.untick()                 # the previous replay's advance was never consumed by a step
         self._graph.launch()
+        for ref, thunk in self._lazies:
+            arr = ref()
+            if arr is not None:
+                arr._thunk = thunk
+        for opt in self._ticked:
+            opt._ticked = True
         return self.outputs
 
     replay = __call__
