@@ -961,6 +961,15 @@ def main():
                                                  launches_per_step=rb_run.launches_per_step())
                     del rb_run
                 curves["batch_sizes"] = between
+                # the reference's OWN example net (examples/mnist/run.py:59-69), same batch size and optimizer: the trainer's
+                # generic step form (no kernel is instantiated for its 70 -> 30 -> 10 tail); pinned against the reference
+                # by tests/golden/traj_R_example.npz
+                ex_widths = [784, 200, 100, 70, 30, 10]
+                ex_run = FusedRun(ex_widths, 128, kind, 64, 0, 1, None, False, use_graph=use_graph)
+                curves["reference_example_net"] = brief(measure(solo, ex_run, warmup, steps, 3, args.min_ms, 128),
+                                                        widths="-".join(map(str, ex_widths)), rows=128,
+                                                        launches_per_step=ex_run.launches_per_step())
+                del ex_run
         elif other_rows != rows:
             other = FusedRun(widths, other_rows, kind, 64 if other_rows <= 256 else 32, rank, world, comm, False,
                              use_graph=use_graph)

@@ -71,6 +71,10 @@ CONFIGS = {
     "A_ragged": dict(widths=[784, 256, 128, 10], m=80, steps=3, loss="softmax_nll", opt="adam", lr=1e-3, seed=0, data_seed=321),
     "D_adam": dict(widths=[784, 256, 128, 10], m=1024, steps=5, loss="softmax_nll", opt="adam", lr=1e-3, seed=0, data_seed=456),
     "C_small": dict(widths=[256, 256, 256], m=64, steps=5, loss="mse", opt="adam", lr=1e-3, seed=0, data_seed=789),
+    # the reference's OWN example net (examples/mnist/run.py:59-69): five Dense layers, hidden widths that are neither
+    # multiples of 16 nor the 128 -> 10 head the benchmark shape ends in
+    "R_example": dict(widths=[784, 200, 100, 70, 30, 10], m=128, steps=10, loss="softmax_nll", opt="adam", lr=1e-3, seed=0,
+                      data_seed=135),
 }
 
 

@@ -115,6 +115,16 @@ def traj_C_small_mse():
     _check_traj("C_small", fused=True)
 
 
+def traj_R_example_fused():
+    """The reference's OWN example net (examples/mnist/run.py:59-69: 784-200-100-70-30-10, none of the widths the benchmark
+    shape's fast kernels are instantiated for) on the drop-in API with every fusion on."""
+    _check_traj("R_example", fused=True)
+
+
+def traj_R_example_generic_ops():
+    _check_traj("R_example", fused=False)
+
+
 # ------------------------------------------------------------------------------------ whole-step trainer
 def _check_trainer(name, use_graph):
     cfg, gold = H.load_traj(name)
@@ -156,6 +166,15 @@ def trainer_A_adam_graph():
 
 def trainer_A_sgd_graph():
     _check_trainer("A_sgd", use_graph=True)
+
+
+def trainer_R_example_graph():
+    """The whole-step trainer on the reference's own example net (five Dense layers, 70 -> 30 -> 10 at the end), captured."""
+    _check_trainer("R_example", use_graph=True)
+
+
+def trainer_R_example_eager():
+    _check_trainer("R_example", use_graph=False)
 
 
 def trainer_A_adam_multi_step_graph():
