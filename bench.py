@@ -40,6 +40,8 @@ Extra objects on the N = 1 line:
   config_C           whole-step samples/s of configs[2] (4096-4096-4096, bs 512)
   paths              the same config-A step on the drop-in Tensor/ops/Model API: eager and captured (tn.capture)
   cpu_baseline       the numpy port of the reference (oracle/ref_nn.py) on this host, all BLAS threads and 1 thread
+  box                what THIS box's MFMA pipes (fp32; bf16 with random / zero operands), clocks and HBM (float4 copy) do,
+                     probed in ~100 ms after the timed runs; every mfma / hbm roofline object also carries `frac_of_box`
 """
 
 import argparse
@@ -1069,6 +1071,8 @@ def main():
         if not args.no_cpu_baseline and args.workload != "E":
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
 
+    if rank == 0 and world == 1 and line is not None and not args.no_extras:
+        line["box"] = box_object(line)
     emit(line)
     if comm is not None:
         comm.barrier()
@@ -1080,6 +1084,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exit_code = int(t.item())
     return exit_code
+
+
+def box_object(line):
+    """What THIS box can do (tnn_box_probe: MFMA-only loops with random / zero operands and their sustained clocks, a float4
+    copy over 2 GiB), measured after everything else so that it does not disturb the timed runs — and every MFMA- or
+    HBM-bound roofline object on the line gets `frac_of_box` beside its spec-peak `frac`: achieved / the same box's probe
+    (bf16 against the random-operand loop: the chip clocks to its power budget and real data is not zeros)."""
+    box = _lib.box_probe()
+    box["note"] = ("MFMA-only loops: 8 waves per CU, 8 independent accumulators; spec peaks 157.3 (fp32) / 2500 (bf16 dense) "
+                   "TFLOP/s, 8000 GB/s; frac_of_box on the roofline objects = achieved / this box's probe")
+
+    def annotate(obj):
+        if isinstance(obj, dict):
+            if obj.get("bound") in ("mfma", "hbm") and isinstance(obj.get("achieved"), (int, float)):
+                if obj["bound"] == "hbm":
+                    ref = max(box["copy_float4_gbs"], box["stream_4read_3write_gbs"])
+                else:
+                    ref = box["mfma_bf16_tflops_random_operands"] if obj.get("peak") == PEAK_BF16_MFMA_TFLOPS else box["mfma_f32_tflops"]
+                if ref:
+                    obj["box_peak"] = ref
+                    obj["frac_of_box"] = round(obj["achieved"] / ref, 4)
+            for v in obj.values():
+                annotate(v)
+        elif isinstance(obj, list):
+            for v in obj:
+                annotate(v)
+    annotate(line)
+    return box
 
 
 def latency_roofline(widths, rows, res, runner):

@@ -466,6 +466,13 @@ TNN_API int tnn_mlp_gather_masters(void* handle);
 /* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
 TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
 
+/* What THIS box can do, in ~100 ms (measurement infrastructure for bench.py's `box` object; no reference counterpart):
+ * out[0] fp32 MFMA-only TFLOP/s (v_mfma_f32_32x32x2_f32, random operands), out[1] its sustained shader clock in GHz,
+ * out[2] / out[3] bf16 (v_mfma_f32_32x32x16_bf16) with random operands, out[4] / out[5] with zero operands (the chip clocks to
+ * its power budget), out[6] float4 copy bandwidth in GB/s (1 GiB read + 1 GiB written), out[7] GB/s of the optimizer's stream
+ * mix (four 256 MB arrays read, three of them rewritten in place). */
+TNN_API int tnn_box_probe(double* out, int n_out);
+
 /* ------------------------------------------------------------------ RCCL over xGMI (C1, C2) --- */
 /* New relative to the reference (it has no communication).  One process per GPU. */
 TNN_API int tnn_comm_unique_id(void* id128);                /* rank 0: ncclGetUniqueId (128 bytes) */

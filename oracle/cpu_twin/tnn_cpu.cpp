@@ -150,6 +150,12 @@ const char* tnn_last_error(void) { return tnn::g_err; }
 int tnn_backend_kind(void) { return 2; }
 int tnn_init(int) { g_ready = true; return 0; }
 int tnn_shutdown(void) { return 0; }
+int tnn_box_probe(double* out, int n_out) {
+    (void)out; (void)n_out;
+    tnn::set_error("tnn_box_probe: the CPU twin has no device to probe");
+    return 2;
+}
+
 int tnn_device_props(int* cu, int* clk, int64_t* hbm, char* name, int n) {
     if (cu) *cu = 0;
     if (clk) *clk = 0;

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "tnn_mlp_sync_params": [_p],
     "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
     "tnn_mlp_bf16_weights": [_p, POINTER(c_void_p)],
+    "tnn_box_probe": [POINTER(ctypes.c_double), c_int],
     "tnn_mlp_masters_sharded": [_p, POINTER(c_int)],
     "tnn_mlp_gather_masters": [_p],
     "tnn_comm_unique_id": [_p],
@@ -285,6 +286,17 @@ def device_props():
     lib.device_props(ctypes.byref(cu), ctypes.byref(clk), ctypes.byref(hbm), name, 256)
     return {"name": name.value.decode(), "cus": cu.value, "clock_khz": clk.value,
             "hbm_bytes": hbm.value}
+
+
+def box_probe():
+    """tnn_box_probe as a dict: what this box's MFMA pipes, clocks and HBM do right now (~100 ms on the GPU)."""
+    lib = get()
+    out = (c_double * 8)()
+    lib.box_probe(out, 8)
+    return {"mfma_f32_tflops": round(out[0], 1), "mfma_f32_clock_ghz": round(out[1], 3),
+            "mfma_bf16_tflops_random_operands": round(out[2], 1), "mfma_bf16_clock_ghz_random_operands": round(out[3], 3),
+            "mfma_bf16_tflops_zero_operands": round(out[4], 1), "mfma_bf16_clock_ghz_zero_operands": round(out[5], 3),
+            "copy_float4_gbs": round(out[6], 1), "stream_4read_3write_gbs": round(out[7], 1)}
 
 
 def pool_stats():

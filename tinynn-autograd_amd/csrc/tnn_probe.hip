@@ -1,0 +1,183 @@
+// tnn_box_probe: what THIS box can do, measured in ~100 ms — so that a roofline fraction can be normalised by the box it was
+// measured on (box-to-box spread of the MFMA- and HBM-bound numbers is +-4..8 %):
+//   * MFMA-only loops (nothing but v_mfma on register operands, 8 waves per CU, 8 independent accumulators per wave):
+//     fp32 (32x32x2_f32) and bf16 (32x32x16_bf16) with uniform-random operands and, for bf16, with zeros — the chip clocks to
+//     its power budget, so random data is the number a GEMM on real data can approach (1.6-1.8 of the 2.5 PFLOP/s on this
+//     pool) and zeros show the clock-unconstrained pipe;
+//   * the sustained shader clock of each loop: s_memtime (shader cycles) over s_memrealtime (100 MHz) inside the kernel;
+//   * HBM streaming past the 256 MB memory-side cache, bytes read + written per second: a float4 copy (1 GiB + 1 GiB) and
+//     the optimizer's mix (four 256 MB arrays read, three of them rewritten in place).
+// No reference counterpart (measurement infrastructure for bench.py's `box` object).
+#include <vector>
+
+#include "tnn_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// clocks[2 * block] = shader cycles, clocks[2 * block + 1] = 100 MHz ticks spent in the loop (thread 0 of each workgroup)
+template <bool BF16>
+__global__ __launch_bounds__(512) void mfma_only_kernel(int iters, int zero, float* sink, unsigned long long* clocks) {
+    const uint32_t seed = (blockIdx.x * 512u + threadIdx.x) * 2654435761u;
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), t0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (BF16) {
+        u32x4 raw[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // two bf16 values uniform in [-1, 1): sign + exponent of 1.x minus 1 is awkward in bits — take a float, round
+                const uint32_t h = hash32(seed + 16u * i + e);
+                const float f0 = (float)(h & 0xffffu) * (2.0f / 65536.0f) - 1.0f, f1 = (float)(h >> 16) * (2.0f / 65536.0f) - 1.0f;
+                raw[i][e] = zero ? 0u : ((__float_as_uint(f0) >> 16) | (__float_as_uint(f1) & 0xffff0000u));
+            }
+        bf16x8 a[2], b[4];
+        a[0] = __builtin_bit_cast(bf16x8, raw[0]); a[1] = __builtin_bit_cast(bf16x8, raw[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = __builtin_bit_cast(bf16x8, raw[2 + i]);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 1], b[i >> 1], acc[i], 0, 0, 0);
+        }
+    } else {
+        float a[2], b[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = zero ? 0.f : (float)(hash32(seed + i) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = zero ? 0.f : (float)(hash32(seed + 2 + i) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i & 1], b[i >> 1], acc[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(acc[i]));        // the loop's MFMAs have retired
+    const unsigned long long c1 = __builtin_readcyclecounter(), t1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        clocks[2 * blockIdx.x] = c1 - c0;
+        clocks[2 * blockIdx.x + 1] = t1 - t0;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void copy16_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
+// the optimizer's stream mix: four arrays read, three of them rewritten IN PLACE (16 B + 12 B per element; a write that
+// follows the read of the same line finds its DRAM page open — writing to separate arrays measured 5.4 TB/s where this form
+// and the fused Adam reach 6.3-6.4), trivial arithmetic
+__global__ __launch_bounds__(256) void mix43_kernel(f32x4* __restrict__ a, f32x4* __restrict__ b, f32x4* __restrict__ c,
+                                                    const f32x4* __restrict__ d, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        // the fused Adam's cache policies: the gradient and the moments non-temporal, the parameters ordinary
+        const f32x4 vd = __builtin_nontemporal_load(d + i), vb = __builtin_nontemporal_load(b + i),
+                    vc = __builtin_nontemporal_load(c + i), va = a[i];
+        __builtin_nontemporal_store(vb - vd, b + i);
+        __builtin_nontemporal_store(vc + vd, c + i);
+        a[i] = va + vd;
+    }
+}
+
+}  // namespace
+
+extern "C" int tnn_box_probe(double* out, int n_out) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(out != nullptr && n_out >= 8, "tnn_box_probe: out must hold 8 doubles");
+    hipStream_t s = tnn::stream();
+    const int cus = tnn::num_cus();
+    void *sink = nullptr, *clocks = nullptr;
+    if (tnn_malloc(4096, &sink) || tnn_malloc((size_t)cus * 16, &clocks)) return 1;
+    hipEvent_t e0, e1;
+    TNN_CHECK_HIP(hipEventCreate(&e0));
+    TNN_CHECK_HIP(hipEventCreate(&e1));
+    std::vector<unsigned long long> hc((size_t)cus * 2);
+    auto mfma = [&](bool bf, int zero, int iters, double flop_per_mfma, double* tflops, double* ghz) -> int {
+        for (int pass = 0; pass < 2; ++pass) {            // pass 0 warms up (clock ramp), pass 1 is timed
+            TNN_CHECK_HIP(hipEventRecord(e0, s));
+            if (bf) hipLaunchKernelGGL(mfma_only_kernel<true>, dim3(cus), 512, 0, s, iters, zero, (float*)sink, (unsigned long long*)clocks);
+            else hipLaunchKernelGGL(mfma_only_kernel<false>, dim3(cus), 512, 0, s, iters, zero, (float*)sink, (unsigned long long*)clocks);
+            TNN_CHECK_HIP(hipEventRecord(e1, s));
+            TNN_CHECK_HIP(hipEventSynchronize(e1));
+        }
+        float ms = 0.f;
+        TNN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        TNN_CHECK_HIP(hipMemcpy(hc.data(), clocks, hc.size() * 8, hipMemcpyDeviceToHost));
+        double cyc = 0, ticks = 0;
+        for (int b = 0; b < cus; ++b) { cyc += (double)hc[2 * b]; ticks += (double)hc[2 * b + 1]; }
+        *tflops = (double)cus * 8 * iters * 32.0 * flop_per_mfma / (ms * 1e-3) / 1e12;
+        *ghz = ticks > 0 ? cyc / (ticks * 10.0) : 0.0;    // cycles per 10 ns tick -> GHz
+        return 0;
+    };
+    int rc = 0;
+    rc = rc ? rc : mfma(false, 0, 2048, 2.0 * 32 * 32 * 2, &out[0], &out[1]);        // fp32, random operands (~14 ms)
+    rc = rc ? rc : mfma(true, 0, 4096, 2.0 * 32 * 32 * 16, &out[2], &out[3]);        // bf16, random operands (~20 ms)
+    rc = rc ? rc : mfma(true, 1, 4096, 2.0 * 32 * 32 * 16, &out[4], &out[5]);        // bf16, zeros
+    // float4 copy, 1 GiB each way
+    const int64_t bytes = (int64_t)1 << 30;
+    void *a = nullptr, *b = nullptr;
+    if (!rc && (tnn_malloc((size_t)bytes, &a) || tnn_malloc((size_t)bytes, &b))) rc = 1;
+    if (!rc) {
+        TNN_CHECK_HIP(hipMemsetAsync(a, 0x3c, (size_t)bytes, s));
+        for (int pass = 0; pass < 2; ++pass) {
+            TNN_CHECK_HIP(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(copy16_kernel, dim3(tnn::stream_grid(bytes / 16, 256)), 256, 0, s, (const f32x4*)a, (f32x4*)b, bytes / 16);
+            TNN_CHECK_HIP(hipEventRecord(e1, s));
+            TNN_CHECK_HIP(hipEventSynchronize(e1));
+        }
+        float ms = 0.f;
+        TNN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        out[6] = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;      // GB/s, read + written
+    }
+    if (a) tnn_free(a);
+    if (b) tnn_free(b);
+    // the optimizer's mix over 4 x 256 MB
+    const int64_t mb = (int64_t)256 << 20;
+    void* arr[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4 && !rc; ++i)
+        if (tnn_malloc((size_t)mb, &arr[i])) rc = 1;
+    if (!rc) {
+        for (int i = 0; i < 4; ++i) TNN_CHECK_HIP(hipMemsetAsync(arr[i], 0x3c, (size_t)mb, s));
+        for (int pass = 0; pass < 2; ++pass) {
+            TNN_CHECK_HIP(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(mix43_kernel, dim3(tnn::stream_grid(mb / 16, 256)), 256, 0, s, (f32x4*)arr[0], (f32x4*)arr[1],
+                               (f32x4*)arr[2], (const f32x4*)arr[3], mb / 16);
+            TNN_CHECK_HIP(hipEventRecord(e1, s));
+            TNN_CHECK_HIP(hipEventSynchronize(e1));
+        }
+        float ms = 0.f;
+        TNN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        out[7] = 7.0 * (double)mb / (ms * 1e-3) / 1e9;         // GB/s, 4 streams read + 3 written
+    }
+    for (int i = 0; i < 4; ++i)
+        if (arr[i]) tnn_free(arr[i]);
+    tnn_free(sink);
+    tnn_free(clocks);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    TNN_LAUNCH_OK();
+    return rc;
+}

@@ -2,7 +2,10 @@
 """profiles/<round>_traffic.json from rocprofv3 --pmc passes (rocpd SQLite): per kernel and workload tag, the average
 HBM-side bytes per launch, and per workload the bytes of ONE training step.  FETCH_SIZE is reported in KiB and counts a
 wide coalesced stream at HALF its bytes on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section) -> doubled; WRITE_SIZE
-(KiB) is taken as is.
+(KiB) is taken as is.  Round 4 calibrated both counters per access pattern on known-byte kernels
+(profiles/r04_fetch_calibration.txt: tools/probes/fetch_calibration.hip + tools/fetch_calibration.py): the factor is 2.000
+for 16 / 8 / 4-byte streams, 4-byte MFMA-fragment-shaped loads, buffer loads and LDS-DMA alike, WRITE_SIZE 1.000 for every
+store width — one factor for every kernel is what the measurement says, so FETCH_FACTOR stays a single constant.
   python tools/traffic_from_pmc.py --round r02 A:fetch.db:write.db C:fetch.db:write.db > profiles/r02_traffic.json
 The passes must profile a command that runs NOTHING but training steps (`bench.py --no-extras`): bytes per step =
 sum over kernels of (average bytes per launch x launches per step), launches per step = launches / launches of the
@@ -14,6 +17,7 @@ import sys
 
 # kernels that run exactly once per training step: the optimizer-carrying first-layer backward (config A), the loss kernels
 # (configs C / E)
+FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0       # profiles/r04_fetch_calibration.txt
 ONCE_PER_STEP = ("dense_bwd0_adam_kernel", "mse_fwd_bwd_kernel", "mse_bf16_kernel")
 
 
@@ -40,7 +44,7 @@ def main():
         for k in sorted(set(fetch) | set(write)):
             f, n = fetch.get(k, (0.0, 0))
             w, _ = write.get(k, (0.0, 0))
-            table.setdefault(k, {})[tag] = {"fetch_bytes": int(round(f * 1024 * 2)), "write_bytes": int(round(w * 1024)),
+            table.setdefault(k, {})[tag] = {"fetch_bytes": int(round(f * 1024 * FETCH_FACTOR)), "write_bytes": int(round(w * 1024 * WRITE_FACTOR)),
                                             "launches": int(n)}
         once = [k for k in table if tag in table[k] and k.startswith(ONCE_PER_STEP)]
         if once:
