@@ -7,8 +7,9 @@ RCCL runs here through gloo; the launch sequence and the host logic are the same
   mode "D"        strong-scaling config D: global batch 1024, 1024/W rows per rank, softmax loss, against
                   the reference's single-process trajectory tests/golden/traj_D_adam.npz — all-reduce + Adam tail
                   (256 rows per rank at world 4: the row-blocked form of the one-launch head, two blocks of 128 rows)
-  mode "Dbucket"  the same on the generic path (TNN_HEAD_ROW_BLOCKS=0) with the arena split into one bucket per layer
-                  (TNN_BUCKET_BYTES=1)
+  mode "Rbucket"  the reference's OWN example net (784-200-100-70-30-10, tests/golden/traj_R_example.npz) split over the ranks:
+                  no fast head exists for its 70 -> 30 -> 10 tail, so the step takes the generic path — here with the arena
+                  split into one gradient bucket per layer (TNN_BUCKET_BYTES=1)
   mode "Cbucket"  config-C-small (256-256-256 autoencoder, bs 64, sum-of-squares), bucketed, against traj_C_small.npz
   mode "A"        the bs-128 trajectory split over the ranks (32 rows each at world 4): the shard's head fits the one-launch
                   form, so the step takes the RCCL-shaped 6-launch structure — statistics as a launch of their own
@@ -112,7 +113,7 @@ def main():
         print("dp_hook_worker %s rank %d/%d ok" % (mode, rank, world))
         return
 
-    name = "C_small" if mode == "Cbucket" else "A_adam" if mode == "A" else "D_adam"
+    name = {"Cbucket": "C_small", "A": "A_adam", "Rbucket": "R_example"}.get(mode, "D_adam")
     cfg, gold = H.load_traj(name)
     w, m = cfg["widths"], cfg["m"]
     assert m % world == 0

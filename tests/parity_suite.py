@@ -464,6 +464,55 @@ def head_and_hidden_backward_one_launch_vs_numpy():
                                        err_msg="ext %s %s" % (name, tag))
 
 
+def head_bwd_row_block_kernel_equals_the_128_row_kernel():
+    """tnn_head.hip keeps two copies of the merged head + hidden-backward kernel body (mlp_head_bwd_kernel for <= 128 rows,
+    mlp_head_bwd_rb_kernel walking blocks of 128 rows) — a fix in one must be mirrored by hand.  With the softmax statistics
+    given from outside nothing couples the rows, so the SAME 256-row problem goes through both: once as one launch of the
+    row-block kernel, once as two 128-row launches of the other with the same {max, sum-exp} pair and m_global = 256.  Per-row
+    outputs (logits, dz, dx) must be bit-identical, the row sums (dW, db, dW1, db1) equal to fp32 summation order."""
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(77)
+    Hn, C, n_in, m = 128, 10, 64, 256
+    pre0 = rs.randn(m, n_in).astype(np.float32)
+    x = np.where(pre0 < 0, np.float32(-0.0), np.abs(pre0)).astype(np.float32)
+    w1 = (rs.randn(n_in, Hn) * 0.2).astype(np.float32)
+    b1v = rs.randn(Hn).astype(np.float32)
+    w = (rs.randn(Hn, C) * 0.3).astype(np.float32)
+    b = rs.randn(C).astype(np.float32)
+    y = np.eye(C, dtype=np.float32)[rs.randint(0, C, m)]
+    X, W1, B1, W, B, Y = (tn.asarray(v) for v in (x, w1, b1v, w, b, y))
+    A, zpart = tn.empty((m, Hn)), tn.zeros((Hn // 16, m, C))
+    pair, ticket = tn.zeros((2,)), tn.asarray(np.zeros(16, np.int64))
+    lib.dense_fwd_head_partials_stats(m, Hn, n_in, X._ptr, n_in, W1._ptr, Hn, B1._ptr, _lib.ACT_RELU, 1, A._ptr, Hn,
+                                      W._ptr, C, zpart._ptr, B._ptr, Y._ptr, ticket._ptr, pair._ptr, 0, _lib.F32)
+
+    def run(rows, Xr, Ar, Yr, zp):
+        out = {k: tn.zeros(shape) for k, shape in (("logits", (rows, C)), ("dz", (rows, C)), ("dw", (Hn, C)), ("db", (C,)),
+                                                   ("dw1", (n_in, Hn)), ("db1", (Hn,)), ("dx", (rows, n_in)))}
+        loss = tn.empty(())
+        lib.mlp_head_bwd_tick_ext(rows, m, n_in, Hn, C, Xr._ptr, W1._ptr, Ar._ptr, W._ptr, B._ptr, Yr._ptr, zp._ptr,
+                                  pair._ptr, 1, out["logits"]._ptr, out["dz"]._ptr, None, loss._ptr, out["dw"]._ptr,
+                                  out["db"]._ptr, out["dw1"]._ptr, out["db1"]._ptr, out["dx"]._ptr, _lib.F32, None, 0.0, 0.0)
+        res = {k: np.asarray(v).copy() for k, v in out.items()}
+        res["loss"] = float(loss)
+        return res
+    whole = run(m, X, A, Y, zpart)
+    a_h, zp_h = np.asarray(A), np.asarray(zpart)
+    halves = []
+    for r0 in (0, 128):
+        sl = slice(r0, r0 + 128)
+        halves.append(run(128, tn.asarray(x[sl]), tn.asarray(a_h[sl]), tn.asarray(y[sl]),
+                          tn.asarray(np.ascontiguousarray(zp_h[:, sl, :]))))
+    for k in ("logits", "dz", "dx"):
+        both = np.concatenate([halves[0][k], halves[1][k]])
+        assert np.array_equal(whole[k].view(np.uint32), both.view(np.uint32)), k      # bit-identical per row
+    for k in ("dw", "db", "dw1", "db1"):
+        both = halves[0][k].astype(np.float64) + halves[1][k]
+        np.testing.assert_allclose(whole[k], both, rtol=0, atol=2e-6 * np.abs(both).max(), err_msg=k)
+    np.testing.assert_allclose(whole["loss"], halves[0]["loss"] + halves[1]["loss"], rtol=1e-6)
+
+
 def head_row_blocks_vs_numpy():
     """More than 128 rows through the two launches that carry the statistics through memory: the tail of
     tnn_dense_fwd_head_partials_stats reduces {max, sum-exp} block by block (up to 1024 rows) and tnn_mlp_head_bwd_tick_ext
@@ -1699,7 +1748,8 @@ def other_optimizers_match_reference_steps():
 
 
 # host-only cases (the code either side of the path: nothing to learn from a second run on the GPU)
-HOST_ONLY = {"host_side_callers_match_reference"}
+# ... and Model.save / load, trainer checkpoints: SURVEY §5 lists them out of scope — they stay covered on the CPU twin only
+HOST_ONLY = {"host_side_callers_match_reference", "model_save_load_roundtrip", "trainer_checkpoint_resume_is_bit_exact"}
 _ALL = {name: fn for name, fn in list(globals().items())
         if callable(fn) and not name.startswith("_") and getattr(fn, "__module__", None) == __name__}
 SUITE = {name: fn for name, fn in _ALL.items() if name not in HOST_ONLY}

@@ -44,10 +44,10 @@ def test_data_parallel_world2_matches_single_process_reference():
     _run_world(2, "dp_worker.py")
 
 
-@pytest.mark.parametrize("mode", ["D", "Dbucket", "Cbucket", "A", "E"])
+@pytest.mark.parametrize("mode", ["D", "Rbucket", "Cbucket", "A", "E"])
 def test_native_sharded_step_world4_over_gloo(mode):
     """The product's C++ data-parallel step (tnn_mlp_step_sharded) at world 4: strong-scaling config D with 1024/4 rows
     per rank against the reference's bs-1024 trajectory — single-collective and bucketed — and the bucketed path on
     config-C-small (one all-reduce per layer, Adam in bucket order)."""
-    _run_world(4, "dp_hook_worker.py", [mode], {"TNN_BUCKET_BYTES": "1", "TNN_HEAD_ROW_BLOCKS": "0"} if mode.endswith("bucket") else None,
+    _run_world(4, "dp_hook_worker.py", [mode], {"TNN_BUCKET_BYTES": "1"} if mode.endswith("bucket") else None,
                tag="dp_hook_worker " + mode + " rank %d/%d ok")

@@ -1255,14 +1255,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd_small_kernel(GemmArgs gw
 
 // XCD-aware cut of a 16 x 16 tile grid (GemmArgs::xg_m / xg_n): the one with the smallest operand footprint per XCD
 void pick_xcd_cut(GemmArgs& g) {
-    static const int mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
     g.xg_m = g.xg_n = 0;
     int best = 0;
-    if (mode >= 10) {                                 // tuning: force xg_m = mode - 10 where the grid divides
-        const int xm = mode - 10, xn = xm > 0 ? 8 / xm : 0;
-        if (xm > 0 && xm * xn == 8 && g.tiles_m % xm == 0 && g.tiles_n % xn == 0) { g.xg_m = xm; g.xg_n = xn; return; }
-    }
-    for (int xm = 1; xm <= 8 && mode; xm *= 2) {
+    for (int xm = 1; xm <= 8; xm *= 2) {
         const int xn = 8 / xm;
         if (g.tiles_m % xm || g.tiles_n % xn) continue;
         const int cost = g.tiles_m / xm + g.tiles_n / xn;

@@ -328,7 +328,7 @@ struct HeadBwdArgs {
     const float* w1;                 // [n_in][H]
     float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
     int n_in, tiles_in;              // tiles_in = n_in / 16
-    int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8; TNN_XCD_TILES=0 turns it off)
+    int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8)
 };
 
 // CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
@@ -1029,8 +1029,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     q.x = (const float*)x; q.w1 = (const float*)w1;
     q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
     q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
-    static const int xcd_mode = getenv("TNN_XCD_TILES") ? atoi(getenv("TNN_XCD_TILES")) : 1;
-    q.xcd = xcd_mode;
+    q.xcd = 1;
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
     if (ext_pairs != nullptr) {          // data parallel: the statistics come from the tail of the previous launch [+ all-gather]
         TNN_REQUIRE(m_global >= rows && ext_n >= 1 && ext_n <= 64, "%s: m_global < rows or bad pair count", fn);

@@ -330,11 +330,10 @@ int mlp16_gather_masters(Mlp* h) {
 // config D at 2 / 4 ranks): the tiled forward whose tail reduces the statistics per 128-row block behind arrival counters
 // (tnn_dense_fwd_head_partials_stats) — the exchange needs ONE pair per rank.  Measured, same box, us per step at 256 / 512 /
 // 1024 rows: row-panel forward 26.9 / 34.7 / 45.5, counter tail 29.6 / 38.6 / 54.8, the 7-launch form below 35.4 / 41.4 / 52.7
-// (tools/probes/rows_sweep.sh; TNN_HEAD_ROW_BLOCKS_MAX moves the upper limits, TNN_HEAD_ROW_BLOCKS=0 turns the form off).
+// (profiles/r03_rows_sweep.txt; the switches that selected the forms for that sweep are gone).
 bool head_fits_row_blocks(const Mlp* h, int64_t rows, bool sharded) {
     const int L = h->L;
-    static const int64_t env_max = getenv("TNN_HEAD_ROW_BLOCKS_MAX") ? atoll(getenv("TNN_HEAD_ROW_BLOCKS_MAX")) : 0;
-    const int64_t row_blocks_max = env_max > 0 ? env_max : (sharded ? 512 : 1024);
+    const int64_t row_blocks_max = sharded ? 512 : 1024;
     return h->dtype == TNN_F32 && !h->bf16 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 1] == 128 &&
            h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= row_blocks_max && rows <= 1024 && h->zpart != nullptr;
 }
@@ -693,8 +692,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                               h->pows, h->dtype));
         return 0;
     }
-    static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
-    if (row_blocks && head_fits_row_blocks(h, rows, false)) {
+    if (head_fits_row_blocks(h, rows, false)) {
         // 129 .. 1024 rows, 2L - 2 launches (4 for the MNIST net) like the <= 128-row step: the hidden layer's forward leaves the
         // whole-batch {max, sum-exp} as pairs in memory, the merged head launch reads them
         // and walks the rows in blocks of 128 (dW / db / loss accumulated in registers), the first layer's backward carries
@@ -703,9 +701,8 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // one GPU: the hidden layer's forward in its row-panel form — a workgroup owns 16 whole rows, finishes their logits and
         // their softmax statistics itself and leaves one {max, sum-exp} pair per panel (no arrival counter, no re-read of
         // partial logits at the tail of the launch); the merged launch merges the pairs (n_pairs < 0: whole logits)
-        static const bool row_panels = !(getenv("TNN_HEAD_ROW_PANELS") && atoi(getenv("TNN_HEAD_ROW_PANELS")) == 0);
         const int n_panels = (int)((rows + 15) / 16);
-        if (row_panels && h->w[L - 2] % 4 == 0)
+        if (h->w[L - 2] % 4 == 0)
             STEP_CALL(h, tnn_dense_fwd_rows_head_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
                                                        at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
                                                        at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
@@ -721,7 +718,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         STEP_CALL(h, tnn_mlp_head_bwd_tick_ext(rows, rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
                                                at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
                                                at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
-                                               y, h->zpart, h->stats, (row_panels && h->w[L - 2] % 4 == 0) ? -n_panels : 1,
+                                               y, h->zpart, h->stats, (h->w[L - 2] % 4 == 0) ? -n_panels : 1,
                                                h->act[L - 1], h->dact[L - 1], nullptr, loss_dst,
                                                at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
                                                at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
@@ -806,8 +803,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     int head_multi = 0;
     if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
-    static const bool row_blocks = !(getenv("TNN_HEAD_ROW_BLOCKS") && atoi(getenv("TNN_HEAD_ROW_BLOCKS")) == 0);
-    if (!head_multi && row_blocks && head_fits_row_blocks(h, rows, true)) head_multi = 1;     // 129 .. 512 rows per rank: blocks of 128
+    if (!head_multi && head_fits_row_blocks(h, rows, true)) head_multi = 1;     // 129 .. 512 rows per rank: blocks of 128
     if (head_multi) {
         // Classifier head of the one-launch form (<= 128 rows per rank: every weak-scaling point, config D at 8 ranks) —
         // 2L - 1 launches (5 for the MNIST net) + the collectives, ONE form for every transport:

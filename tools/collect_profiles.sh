@@ -21,7 +21,6 @@ cp $S/stepA_timeline.txt $D/${R}_stepA_timeline.txt
 cp $S/p2p_latency.txt $D/${R}_p2p_latency.txt
 cp $S/dw_adam_bf16.txt $D/${R}_dw_adam_bf16.txt
 cp $S/gemm_f32_sweep.txt $D/${R}_gemm_f32_sweep.txt
-cp $S/rows_sweep.txt $D/${R}_rows_sweep.txt
 cp $S/soak.txt $D/${R}_soak.txt
 cp $S/step256_timeline.txt $D/${R}_step256_timeline.txt
 cp $S/eager_phases.txt $D/${R}_eager_phases.txt

@@ -18,7 +18,6 @@ TNN_FORCE_COMM=1 python3 bench.py --no-cpu-baseline > $OUT/benchA_dp_world1.json
 python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
 python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
 SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
-bash tools/probes/rows_sweep.sh > $OUT/rows_sweep.txt 2>> $OUT/log.txt
 python3 tools/probes/soak.py > $OUT/soak.txt 2>> $OUT/log.txt
 python3 tools/probes/eager_phases.py > $OUT/eager_phases.txt 2>> $OUT/log.txt
 TNN_HOST_COMPILED=0 python3 tools/probes/eager_phases.py >> $OUT/eager_phases.txt 2>> $OUT/log.txt
