@@ -925,9 +925,16 @@ def main():
         comm.set_p2p(transports["used"] == "xgmi-p2p")       # everything below runs on the primary transport
     check = None
     if args.path == "fused" and args.workload == "A":
-        check = fixture_check(widths, rows, kind, rank, world, comm, force_dp, use_graph)
+        # the reference's fixtures exist at global batches 128 and 1024: a weak-scaling line at N = 2 / 4 (global batch 256 /
+        # 512) checks the same trainer + transport at config D's split instead (1024 / N rows per rank, the step form its
+        # strong_scaling point times)
+        rows_chk = rows
+        if world > 1 and rows * world not in (128, GLOBAL_BATCH_D) and GLOBAL_BATCH_D % world == 0:
+            rows_chk = GLOBAL_BATCH_D // world
+        check = fixture_check(widths, rows_chk, kind, rank, world, comm, force_dp, use_graph)
         if check is not None:
             check["ok"] = all_ranks(check["ok"])
+            check["rows_per_rank"], check["global_batch"] = rows_chk, rows_chk * world
     if rank == 0:
         line = make_line(args, widths, rows, kind, world, warmup, steps, res, runner, transports, force_dp)
         if check is not None:

@@ -143,22 +143,25 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 128 and d["warmup"] == 64 and d["scaling"] == "strong"
-    # configs[3] as SURVEY §8(e) defines it: global batch 1024, 1024/W rows per rank
-    assert d["config"]["global_batch"] == 1024 and d["config"]["rows_per_rank"] == 512 and d["config"]["parallelism"] == "dp2"
+    assert d["n_gpus"] == 2 and d["steps"] == 128 and d["warmup"] == 64 and d["scaling"] == "weak"
+    # `value` is on the N = 1 line's definition: 128 rows per rank (N = 8 is then configs[3]'s global batch 1024)
+    assert d["config"]["global_batch"] == 256 and d["config"]["rows_per_rank"] == 128 and d["config"]["parallelism"] == "dp2"
     assert d["exit_code"] == 0 and d["timing"]["segments_per_repeat"] >= 1
     coll = d["config"]["collectives"]
     assert coll["used"] == "xgmi-p2p" and "rccl" not in coll            # TNN_COMM=xgmi: no RCCL communicator exists
     p2p = coll["xgmi_p2p"]
     assert p2p["replicas_identical"] and p2p["verified_after_run"] and not p2p["barrier_timed_out"] and p2p["graph_captured"]
     assert d["value"] == p2p["value"] > 0
-    # the sharded step on this transport reproduces the REFERENCE's bs-1024 losses (traj_D_adam, all 5 steps)
+    # the sharded step on this transport reproduces the REFERENCE's bs-1024 losses (traj_D_adam, all 5 steps; no reference
+    # fixture exists at global batch 256, so the check runs at config D's split: 512 rows per rank)
     chk = d["parity_vs_reference_fixture"]
     assert chk["ok"] and chk["steps"] == 5 and "traj_D_adam" in chk["fixture"] and chk["max_rel_err"] <= 1e-5
-    # both curves on the one line: this N's strong point, the weak point (128 rows per rank), the single-GPU reference
-    assert d["strong_scaling"]["global_batch"] == 1024 and d["strong_scaling"]["value"] == d["value"]
-    assert d["weak_scaling"]["global_batch"] == 256 and d["weak_scaling"]["rows_per_rank"] == 128
-    assert d["weak_scaling"]["replicas_identical"] and d["single_gpu_bs1024"]["value"] > 0
+    assert chk["global_batch"] == 1024 and chk["rows_per_rank"] == 512
+    # both curves on the one line: this N's weak point (= value), the strong point, the single-GPU references of both
+    assert d["weak_scaling"]["global_batch"] == 256 and d["weak_scaling"]["value"] == d["value"]
+    assert d["strong_scaling"]["global_batch"] == 1024 and d["strong_scaling"]["rows_per_rank"] == 512
+    assert d["strong_scaling"]["replicas_identical"] and d["single_gpu_bs1024"]["value"] > 0 and d["single_gpu_bs128"]["value"] > 0
+    assert abs(d["value"] / d["single_gpu_bs128"]["value"] - d["speedup_vs_n1"]) <= 1e-3 * d["speedup_vs_n1"]
 
 
 @pytest.mark.gpu
