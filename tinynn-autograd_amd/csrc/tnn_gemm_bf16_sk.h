@@ -15,8 +15,8 @@
 //     FIXED slice order ((p0 + p1) + p2) + p3 with its own partial in its slot — the result does not depend on who arrives
 //     last; then it runs the ordinary epilogue (bias + ReLU / mask, bf16) and re-zeroes the two words for the next launch.
 // K loop: the LDS-DMA ring + XOR swizzle of tnn_gemm_bf16_dma.h (16-B chunk c of row r lives in slot c ^ ((r >> 1) & 7)),
-// separate rings for the two operands — NSA stages of A (activations, L2-resident) and NSB >= NSA stages of B (weights,
-// streamed from HBM: the deeper ring) — 8 waves, wave tile (256 / WM) x (BN / WN), fragments double-buffered per 16-deep
+// separate rings for the two operands — NSA stages of A (activations, L2-resident) and NSB stages of B (weights,
+// streamed from HBM) — 8 waves, wave tile (256 / WM) x (BN / WN), fragments double-buffered per 16-deep
 // k-step (the 128 accumulator registers of a 128 x 64 wave tile leave room for two fragment sets only), ONE raw s_barrier
 // per K-tile: it publishes tile kt + 1 and frees the stages of tile kt, whose refill DMAs are issued BETWEEN the MFMAs of
 // the tile's last k-step.
@@ -52,7 +52,7 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // ABL (probe builds only, timing without meaning), bit mask: 1 = no MFMAs, 2 = no refill DMAs, 4 = no slab exchange,
 // 8 = no fragment reads in the loop, 16 = no barrier in the loop, 32 = timestamps (s_memtime: shader cycles; s_memrealtime:
 // 100 MHz) at kernel entry / loop entry / loop exit / kernel exit / end of the slab exchange into g.sk_trace[10 * block]
-// 64 = B addressed as if stored tile-major ([n-tile][k-tile][BN][64] contiguous 16/32 KB blocks; wrong data, right byte count)
+// 128 = one K-tile per loop trip; 64 = B addressed as if stored tile-major ([n-tile][k-tile][BN][64] contiguous 16/32 KB blocks; wrong data, right byte count)
 template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     constexpr int BM = 256, ROWB = 128, KK = 4;
@@ -60,12 +60,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
     constexpr int DJA = BM / 64, DJB = BN / 64;          // DMA instructions per wave, operand and K-tile (1 KB each)
     static_assert(WM * WN == 8, "eight waves");
-    static_assert(NSA >= 2 && NSB >= NSA, "the weight ring is at least as deep as the activation ring");
+    static_assert(NSA >= 2 && NSB >= 2, "double buffering at least");
+    constexpr int NSMIN = NSA < NSB ? NSA : NSB, NSMAX = NSA < NSB ? NSB : NSA;
     constexpr int LDS_B = NSA * A_TILE_B + NSB * B_TILE_B;
     static_assert(LDS_B <= 163840, "LDS");
     // DMAs issued after the last one tile kt + 1 needs, seen from the barrier of iteration kt (issue order per iteration:
     // A(j + NSA) then B(j + NSB)): the B share of that iteration when the rings differ, then NSA - 2 whole iterations
-    constexpr int C_STEADY = (NSA - 2) * (DJA + DJB) + (NSA < NSB ? DJB : 0);
+    constexpr int C_STEADY = (NSMIN - 2) * (DJA + DJB) + (NSA < NSB ? DJB : 0);
     constexpr int C_PROLOGUE = C_STEADY + DJA + DJB;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_B];      // ONE shared object (tnn_gemm_bf16_dma.h)
 
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
         }
     }
     const int64_t m0 = (int64_t)(tile % g.tiles_m) * BM, n0 = (int64_t)(tile / g.tiles_m) * BN;
-    const int nk = (int)(g.K / 64) / S;                 // K-tiles of this slice (>= NSB + 1, host-checked)
+    const int nk = (int)(g.K / 64) / S;                 // K-tiles of this slice (> max(NSA, NSB), host-checked)
     const uint32_t k_byte0 = (uint32_t)slice * (uint32_t)nk * ROWB;
 
     // ---- DMA geometry: instruction gi = wid + 8 j fills rows 8 gi .. 8 gi + 7 of an operand tile; lane L writes slot L % 8
@@ -181,13 +182,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
 
     // ---- prologue: "iterations" -NSB .. -1 of the steady-state issue order
 #pragma unroll
-    for (int j = -NSB; j < 0; ++j) {
+    for (int j = -NSMAX; j < 0; ++j) {
         if (j + NSA >= 0) {
 #pragma unroll
             for (int q = 0; q < DJA; ++q) issue_a1(j + NSA, j + NSA, q);
         }
+        if (j + NSB >= 0) {
 #pragma unroll
-        for (int q = 0; q < DJB; ++q) issue_b1(j + NSB, j + NSB, q);
+            for (int q = 0; q < DJB; ++q) issue_b1(j + NSB, j + NSB, q);
+        }
     }
     wait_vm_lgkm0<C_PROLOGUE>();
     __builtin_amdgcn_s_barrier();
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
 #pragma unroll
                 for (int q = 0; q < DJA; ++q) issue_a1(kt + NSA, a_cur, q);
             }
-            if ((ABL & 2) == 0 && STEADY) {
+            if ((ABL & 2) == 0 && (STEADY || kt + NSB < nk)) {
 #pragma unroll
                 for (int q = 0; q < DJB; ++q) issue_b1(kt + NSB, b_cur, q);
             }
@@ -246,7 +249,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     };
     if constexpr ((ABL & 32) != 0) { ts[2] = __builtin_readcyclecounter(); ts[3] = __builtin_amdgcn_s_memrealtime(); }
     int kt = 0;
-    for (; kt + NSB < nk; ++kt) k_tile(kt, std::true_type{});
+    // two K-tiles per trip: hipcc waits lgkmcnt(0) at a loop head (the fragments just requested included), inside a trip it
+    // counts exactly
+    if constexpr ((ABL & 128) == 0) {
+        for (; kt + NSMAX + 1 < nk; kt += 2) {
+            k_tile(kt, std::true_type{});
+            k_tile(kt + 1, std::true_type{});
+        }
+    }
+    for (; kt + NSMAX < nk; ++kt) k_tile(kt, std::true_type{});
     for (; kt < nk; ++kt) k_tile(kt, std::false_type{});
     if constexpr ((ABL & 32) != 0) {
 #pragma unroll
