@@ -971,7 +971,7 @@ def main():
                     del rb_run
                 curves["batch_sizes"] = between
                 # the reference's OWN example net (examples/mnist/run.py:59-69), same batch size and optimizer: the trainer's
-                # generic step form (no kernel is instantiated for its 70 -> 30 -> 10 tail); pinned against the reference
+                # 2 L - 2 = 8 launch step (hidden widths padded to multiples of 16, generic merged head kernel); pinned against the reference
                 # by tests/golden/traj_R_example.npz
                 ex_widths = [784, 200, 100, 70, 30, 10]
                 ex_run = FusedRun(ex_widths, 128, kind, 64, 0, 1, None, False, use_graph=use_graph)

@@ -263,7 +263,11 @@ TNN_API int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes,
  *   x [rows, n_in]: the hidden layer's input (sign-encoded ReLU output, it is also dx's mask source), w1 [n_in, n_hidden],
  *   a / w / b / y / logit_partials / logits / dz / stats / loss / dw / db as in tnn_mlp_head_tick (logit_partials required),
  *   dw1 [n_in, n_hidden], db1 [n_hidden], dx [rows, n_in] = (dz1 w1^T) * [x >= 0].
- * Shapes: tnn_mlp_head_fits() and n_in % 16 == 0. */
+ * Shapes: tnn_mlp_head_bwd_fits(). */
+/* tnn_mlp_head_bwd_fits: can tnn_mlp_head_bwd_tick take this head?  The tuned kernels take 128 hidden units x 10 classes; a
+ * generic kernel takes any head with n_hidden %% 16 == 0, 16 <= n_hidden <= 256, n_classes <= 16 — both need f32,
+ * rows <= 128 and n_in %% 16 == 0 (the reference's own 70 -> 30 -> 10 tail once the trainer has padded the hidden widths). */
+TNN_API int tnn_mlp_head_bwd_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, int dtype, int* fits);
 TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x,
                                   const void* w1, const void* a, const void* w, const void* b, const void* y,
                                   const void* logit_partials, void* logits, void* dz, void* stats, void* loss, void* dw,
@@ -470,7 +474,8 @@ TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
  * out[0] fp32 MFMA-only TFLOP/s (v_mfma_f32_32x32x2_f32, random operands), out[1] its sustained shader clock in GHz,
  * out[2] / out[3] bf16 (v_mfma_f32_32x32x16_bf16) with random operands, out[4] / out[5] with zero operands (the chip clocks to
  * its power budget), out[6] float4 copy bandwidth in GB/s (1 GiB read + 1 GiB written), out[7] GB/s of the optimizer's stream
- * mix (four 256 MB arrays read, three of them rewritten in place). */
+ * mix (four 256 MB arrays read, three of them rewritten in place), out[8] / out[9] the fp32 loop with the training step's operand
+ * distribution (a uniform in [0, 1), b uniform in +-0.027).  n_out >= 10. */
 TNN_API int tnn_box_probe(double* out, int n_out);
 
 /* ------------------------------------------------------------------ RCCL over xGMI (C1, C2) --- */

@@ -177,6 +177,28 @@ def trainer_R_example_eager():
     _check_trainer("R_example", use_graph=False)
 
 
+def trainer_R_example_takes_the_2L_minus_2_launch_step():
+    """The reference's own example net (five Dense layers) in 2 L - 2 = 8 launches: hidden widths padded to multiples of 16
+    inside the arenas, the generic merged head + hidden-backward kernel for its 80 -> 32 -> 10 tail.  (The reference-pinned
+    numbers of this step form are trainer_R_example_graph / _eager.)"""
+    import ctypes
+    cfg, _ = H.load_traj("R_example")
+    model, _ = H.build_model(cfg)
+    w = cfg["widths"]
+    trainer = trainer_from_net(model.net, max_rows=cfg["m"], loss=cfg["loss"], optimizer=cfg["opt"], lr=cfg["lr"], use_graph=False)
+    assert trainer.padded and trainer._pwidths == [784, 208, 112, 80, 32, 10]
+    x, y = H.batches(cfg["data_seed"], 1, cfg["m"], w[0], w[-1], cfg["loss"])[0]
+    trainer.step(tn.asarray(x), tn.asarray(y))
+    n = ctypes.c_int(0)
+    trainer._lib.mlp_launch_window(trainer._h, 0, -1, ctypes.byref(n))
+    assert n.value == 2 * trainer.n_layers - 2 == 8, n.value
+    # the padding stays exactly zero through a step
+    for l in range(trainer.n_layers):
+        full = np.asarray(trainer._view(l, "w"))
+        rows, cols = w[l], w[l + 1]
+        assert not full[rows:, :].any() and not full[:, cols:].any(), l
+
+
 def trainer_A_adam_multi_step_graph():
     """All 20 steps captured into ONE hipGraph (each step bound to its own resident batch), replayed once;
     then a second replay must continue the optimizer (device-side Adam state), not restart it."""
@@ -1317,7 +1339,7 @@ def trainer_with_other_optimizers_matches_op_level_model():
             tl = float(trainer.step(tn.asarray(x), tn.asarray(y)))
             np.testing.assert_allclose(tl, float(out.values), rtol=2e-5, err_msg=name)
         flat = np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
-        np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=5e-5 * np.abs(flat).max(), err_msg=name)
+        np.testing.assert_allclose(np.asarray(trainer.flat_parameters()), flat, rtol=0, atol=5e-5 * np.abs(flat).max(), err_msg=name)
 
 
 def trainer_step_forms_agree_with_the_op_level_model():
@@ -1327,14 +1349,16 @@ def trainer_step_forms_agree_with_the_op_level_model():
       [40, 128, 10]          2 layers: forward + partial logits | head | first-layer backward + Adam   (no hidden backward to merge)
       [30, 48, 128, 10]      the 4-launch step of the MNIST net with a 48-wide first layer
       [30, 64, 32, 128, 10]  4 layers: two more launches around the merged one
-      [30, 20, 128, 10]      hidden input width not a multiple of 16: head and hidden backward stay separate launches
-      [30, 48, 64, 10]       a head the one-launch form does not take (64 hidden units): the 7-launch step
+      [30, 20, 128, 10]      a hidden width that is not a multiple of 16: padded to 32 inside the arenas (exact), the 4-launch step
+      [30, 48, 64, 10]       a head only the GENERIC merged kernel takes (64 hidden units): 4 launches too
+      [30, 40, 70, 30, 10]   the reference example net's tail (70 -> 30 -> 10) behind a padded stack: generic kernel, padding
     and batches of 129 .. 1024 rows on the row-blocked form of the same launches."""
     from tinynn_autograd_amd.core.model import Model
     from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss
     from tinynn_autograd_amd.core.optimizer import Adam
     rs = np.random.RandomState(12)
-    cases = [(w, r) for w in ([40, 128, 10], [30, 48, 128, 10], [30, 64, 32, 128, 10], [30, 20, 128, 10], [30, 48, 64, 10])
+    cases = [(w, r) for w in ([40, 128, 10], [30, 48, 128, 10], [30, 64, 32, 128, 10], [30, 20, 128, 10], [30, 48, 64, 10],
+                              [30, 40, 70, 30, 10], [24, 32, 256, 16], [24, 48, 16, 3])
              for r in (128, 37)]
     # 129 .. 1024 rows: the same 2L - 2 launches, the merged launch walking the rows in blocks of 128 (full blocks, a ragged
     # last block, a one-row last block, four and eight blocks); beyond that, and for [40, 128, 10] / [30, 20, 128, 10], the 7-launch form
@@ -1344,7 +1368,7 @@ def trainer_step_forms_agree_with_the_op_level_model():
         if True:
             cfg = dict(widths=widths, seed=5, opt="adam", lr=1e-3, loss="softmax_nll")
             data = [(rs.rand(rows, widths[0]).astype(np.float32),
-                     np.eye(10, dtype=np.float32)[rs.randint(0, 10, rows)]) for _ in range(3)]
+                     np.eye(widths[-1], dtype=np.float32)[rs.randint(0, widths[-1], rows)]) for _ in range(3)]
             ref_model, _ = H.build_model(cfg)
             loss_layer = SoftmaxCrossEntropyLoss()
             model = Model(net=ref_model.net, loss=loss_layer, optimizer=Adam(lr=1e-3))
@@ -1365,7 +1389,7 @@ def trainer_step_forms_agree_with_the_op_level_model():
                             np.testing.assert_allclose(np.asarray(trainer.grad_view(l, k)).reshape(g.shape), g, rtol=0,
                                                        atol=2e-5 * max(np.abs(g).max(), 1e-6), err_msg="%s grad %d%s" % (tag, l, k))
             flat = np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
-            np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
+            np.testing.assert_allclose(np.asarray(trainer.flat_parameters()), flat, rtol=0, atol=0.1 * 1e-3, err_msg=tag)      # Adam: SURVEY H1
 
 
 def trainer_captured_steps_of_mixed_batch_sizes():

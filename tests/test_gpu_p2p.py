@@ -241,7 +241,7 @@ def test_bench_single_gpu_line_has_the_contract_objects():
     assert d["paths"]["ops_eager"]["value"] > 0 and d["paths"]["ops_graph"]["value"] > d["paths"]["ops_eager"]["value"]
     assert d["config_C"]["value"] > 0 and d["strong_scaling"]["global_batch"] == 1024
     ex = d["reference_example_net"]                       # examples/mnist/run.py:59-69, the trainer's generic step form
-    assert ex["widths"] == "784-200-100-70-30-10" and ex["value"] > 0 and ex["launches_per_step"] >= 8
+    assert ex["widths"] == "784-200-100-70-30-10" and ex["value"] > 0 and ex["launches_per_step"] == 8     # 2 L - 2
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["single_thread"]["cores"] == 1 and cpu["cpu_model"]
     # `--workload A --rows 1024` is the same measurement as the strong-scaling N = 1 point

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "tnn_softmax_nll_fused_tick": [_p, _p, c_int64, c_int64, c_int64, c_int, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mlp_head_fits": [c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
+    "tnn_mlp_head_bwd_fits": [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
     "tnn_mlp_head_tick": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head_bwd_tick": [c_int64, c_int64, c_int64, c_int64] + [_p] * 16 + [c_int, _p, c_double, c_double],
     "tnn_mlp_head_bwd_tick_ext": [c_int64, c_int64, c_int64, c_int64, c_int64] + [_p] * 8 + [c_int] + [_p] * 9 + [c_int, _p, c_double, c_double],
@@ -291,9 +292,10 @@ def device_props():
 def box_probe():
     """tnn_box_probe as a dict: what this box's MFMA pipes, clocks and HBM do right now (~100 ms on the GPU)."""
     lib = get()
-    out = (c_double * 8)()
-    lib.box_probe(out, 8)
+    out = (c_double * 10)()
+    lib.box_probe(out, 10)
     return {"mfma_f32_tflops": round(out[0], 1), "mfma_f32_clock_ghz": round(out[1], 3),
+            "mfma_f32_tflops_step_like_operands": round(out[8], 1), "mfma_f32_clock_ghz_step_like_operands": round(out[9], 3),
             "mfma_bf16_tflops_random_operands": round(out[2], 1), "mfma_bf16_clock_ghz_random_operands": round(out[3], 3),
             "mfma_bf16_tflops_zero_operands": round(out[4], 1), "mfma_bf16_clock_ghz_zero_operands": round(out[5], 3),
             "copy_float4_gbs": round(out[6], 1), "stream_4read_3write_gbs": round(out[7], 1)}

@@ -646,10 +646,14 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
     // (e.g. one slot of a per-step loss history) or, by default, to the slot behind the gradient arena
     const int L = h->L;
     void* loss_dst = loss_out ? loss_out : at(h->grads, h->n_params, h->esz);
-    int head_multi = 0;
+    int head_multi = 0, head_bwd = 0;
     if (!h->bf16 && h->opt_kind == 1 && L >= 2)
         MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
-    if (head_multi) {
+    // any other head the merged head + hidden-backward launch takes (generic kernel: hidden widths multiples of 16 up to 256,
+    // <= 16 classes): the same 2L - 2 launch step
+    if (!head_multi && !h->bf16 && h->opt_kind == 1 && L >= 3 && h->zpart != nullptr)
+        MLP_TRY(tnn_mlp_head_bwd_fits(rows, h->w[L - 2], h->w[L - 1], h->w[L], h->dtype, &head_bwd));
+    if (head_multi || head_bwd) {
         // 2L - 1 launches (5 for the MNIST net; 2L - 2 = 4 with the merge below): forward of the hidden layers | the classifier head as ONE multi-workgroup
         // launch (last Dense forward + loss + last Dense backward + Adam's beta powers) | backward of the hidden layers,
         // the first layer's carrying the whole optimizer
@@ -661,7 +665,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
                                                  at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
                                                  h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
                                                  h->dtype));
-        if (L >= 3 && h->w[L - 2] % 16 == 0) {
+        if (head_bwd || (L >= 3 && h->w[L - 2] % 16 == 0)) {
             // 2L - 2 launches (4 for the MNIST net): the head's launch also carries the backward of the hidden layer in
             // front of it — its tiles derive their slice of that layer's dz from the partial logits themselves
             STEP_CALL(h, tnn_mlp_head_bwd_tick(rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],

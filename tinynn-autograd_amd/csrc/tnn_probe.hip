@@ -25,6 +25,8 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {
 }
 
 // clocks[2 * block] = shader cycles, clocks[2 * block + 1] = 100 MHz ticks spent in the loop (thread 0 of each workgroup)
+// zero: 0 = operands uniform in [-1, 1), 1 = zeros, 2 (fp32) = the training step's distribution: a uniform in [0, 1)
+// (activations), b uniform in +-0.027 (Xavier weights of a 4096-wide layer)
 template <bool BF16>
 __global__ __launch_bounds__(512) void mfma_only_kernel(int iters, int zero, float* sink, unsigned long long* clocks) {
     const uint32_t seed = (blockIdx.x * 512u + threadIdx.x) * 2654435761u;
@@ -58,9 +60,15 @@ __global__ __launch_bounds__(512) void mfma_only_kernel(int iters, int zero, flo
     } else {
         float a[2], b[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = zero ? 0.f : (float)(hash32(seed + i) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        for (int i = 0; i < 2; ++i) {
+            const float u = (float)(hash32(seed + i) >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+            a[i] = zero == 1 ? 0.f : zero == 2 ? u : 2.f * u - 1.f;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = zero ? 0.f : (float)(hash32(seed + 2 + i) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+        for (int i = 0; i < 4; ++i) {
+            const float u = (float)(hash32(seed + 2 + i) >> 8) * (1.0f / 16777216.0f);
+            b[i] = zero == 1 ? 0.f : (zero == 2 ? 0.027f : 1.f) * (2.f * u - 1.f);
+        }
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256) void mix43_kernel(f32x4* __restrict__ a, f32x4
 
 extern "C" int tnn_box_probe(double* out, int n_out) {
     TNN_NEED_INIT();
-    TNN_REQUIRE(out != nullptr && n_out >= 8, "tnn_box_probe: out must hold 8 doubles");
+    TNN_REQUIRE(out != nullptr && n_out >= 10, "tnn_box_probe: out must hold 10 doubles");
     hipStream_t s = tnn::stream();
     const int cus = tnn::num_cus();
     void *sink = nullptr, *clocks = nullptr;
@@ -136,6 +144,7 @@ extern "C" int tnn_box_probe(double* out, int n_out) {
     rc = rc ? rc : mfma(false, 0, 2048, 2.0 * 32 * 32 * 2, &out[0], &out[1]);        // fp32, random operands (~14 ms)
     rc = rc ? rc : mfma(true, 0, 4096, 2.0 * 32 * 32 * 16, &out[2], &out[3]);        // bf16, random operands (~20 ms)
     rc = rc ? rc : mfma(true, 1, 4096, 2.0 * 32 * 32 * 16, &out[4], &out[5]);        // bf16, zeros
+    rc = rc ? rc : mfma(false, 2, 2048, 2.0 * 32 * 32 * 2, &out[8], &out[9]);        // fp32, the step's operand distribution
     // float4 copy, 1 GiB each way
     const int64_t bytes = (int64_t)1 << 30;
     void *a = nullptr, *b = nullptr;

@@ -33,6 +33,18 @@ class MLPTrainer(object):
         self.widths = [int(w) for w in widths]
         self.n_layers = len(self.widths) - 1
         self.max_rows = int(max_rows)
+        # Hidden widths that are not multiples of 16 (the reference's own example net: 200-100-70-30) are PADDED to the next
+        # multiple inside the arenas so that the 2L - 2 launch step's tiled kernels apply.  Exact, not approximate: a padded
+        # unit has zero incoming weights and zero bias (pre-activation 0, activation 0), zero outgoing weights (its dz is a
+        # sum of zeros), hence zero gradients everywhere and a zero Adam step — it stays zero for ever.  `param_view` /
+        # `grad_view` / `get_parameters` present the logical shapes; `params` / `state_dict` are the padded arenas.
+        self._pwidths = list(self.widths)
+        if (loss == "softmax_nll" and optimizer == "adam" and comm is None and self.n_layers >= 3
+                and not (isinstance(dtype, str) and dtype in ("bfloat16", "bf16")) and np.dtype(dtype) == np.float32
+                and any(w % 16 for w in self.widths[1:-1]) and self.widths[-1] <= 16
+                and (self.widths[-2] + 15) // 16 * 16 <= 256):
+            self._pwidths = [self.widths[0]] + [(w + 15) // 16 * 16 for w in self.widths[1:-1]] + [self.widths[-1]]
+        self.padded = self._pwidths != self.widths
         # dtype "bfloat16": bf16 inputs / activations / working weights, fp32 master weights + gradients + Adam
         # state (BASELINE.json configs[4]).  The arenas exposed below are then the fp32 ones.
         self.bf16 = isinstance(dtype, str) and dtype in ("bfloat16", "bf16")
@@ -44,7 +56,7 @@ class MLPTrainer(object):
         self._lib = _lib.get()
         self._h = ctypes.c_void_p()
         code = _lib.BF16 if self.bf16 else da._CODE[self.dtype]
-        self._lib.mlp_create(self.n_layers, da._i64arr(self.widths), self.max_rows, _LOSS[loss],
+        self._lib.mlp_create(self.n_layers, da._i64arr(self._pwidths), self.max_rows, _LOSS[loss],
                              _OPT[optimizer], float(lr), float(beta1), float(beta2), float(epsilon),
                              code, ctypes.byref(self._h))
         p, g, m, v = (ctypes.c_void_p() for _ in range(4))
@@ -103,13 +115,29 @@ class MLPTrainer(object):
         if arena is None and key == "w" and self.masters_sharded():
             raise RuntimeError("the fp32 master weights are sharded over %d ranks (sharded-optimizer steps): call "
                                "gather_masters() on every rank first, or read weights_bf16()" % self.masters_sharded())
-        return self._view(layer, key, arena)
+        view = self._view(layer, key, arena)
+        if self.padded and view.shape != self._shape(layer, key, self.widths):
+            rows, cols = self._shape(layer, key, self.widths)
+            view = view[:rows, :cols]                  # a COPY of the logical block (the padding is zeros)
+        return view
+
+    @staticmethod
+    def _shape(layer, key, widths):
+        return (widths[layer], widths[layer + 1]) if key == "w" else (1, widths[layer + 1])
 
     def _view(self, layer, key, arena=None):
+        """The parameter's block of the arena as stored (padded widths)."""
         off, cnt = self._offset(layer, 0 if key == "w" else 1)
-        shape = (self.widths[layer], self.widths[layer + 1]) if key == "w" else (1, self.widths[layer + 1])
         base = self.params if arena is None else arena
-        return base[off:off + cnt].reshape(shape)
+        return base[off:off + cnt].reshape(self._shape(layer, key, self._pwidths))
+
+    def flat_parameters(self, arena=None):
+        """The parameters (or another arena) as ONE flat vector in the reference optimizer's order (layer by layer, "w" then
+        "b": core/optimizer.py:14-15) with the logical shapes — the arena itself unless hidden widths are padded."""
+        if not self.padded:
+            return self.params if arena is None else arena
+        return da.asarray(np.concatenate([np.asarray(self.param_view(l, k, arena)).ravel()
+                                          for l in range(self.n_layers) for k in ("w", "b")]))
 
     def grad_view(self, layer, key):
         return self.param_view(layer, key, arena=self.grads)
@@ -121,7 +149,13 @@ class MLPTrainer(object):
                 src = layer[key]
                 src = src.values if hasattr(src, "values") and not isinstance(src, np.ndarray) else src
                 view = self._view(i, key)             # the whole arena is rewritten: no need for it to be whole before
-                view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
+                rows, cols = self._shape(i, key, self.widths)
+                if view.shape != (rows, cols):         # padded block: zeros around the logical values
+                    host = np.zeros(view.shape, self.dtype)
+                    host[:rows, :cols] = np.asarray(src, dtype=self.dtype).reshape(rows, cols)
+                    view[...] = da.asarray(host)
+                else:
+                    view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
         self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies W, W^T
 
     # ------------------------------------------------------------------ checkpoint / resume
@@ -133,7 +167,8 @@ class MLPTrainer(object):
         self.gather_masters()                         # collective when the optimizer is sharded: every rank saves
         pows = ctypes.c_void_p()
         self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
-        return {"widths": list(self.widths), "dtype": "bfloat16" if self.bf16 else self.dtype.name,
+        return {"widths": list(self.widths), "padded_widths": list(self._pwidths),
+                "dtype": "bfloat16" if self.bf16 else self.dtype.name,
                 "params": np.asarray(self.params).copy(), "m": np.asarray(self.adam_m).copy(),
                 "v": np.asarray(self.adam_v).copy(),
                 "pows": np.asarray(da.from_ptr(pows.value, (4,), np.float64, self)).copy()}
@@ -141,6 +176,9 @@ class MLPTrainer(object):
     def load_state_dict(self, state):
         if list(state["widths"]) != list(self.widths):
             raise ValueError("checkpoint is for widths %s, this trainer has %s" % (state["widths"], self.widths))
+        if list(state.get("padded_widths", state["widths"])) != list(self._pwidths):
+            raise ValueError("checkpoint arenas are laid out for widths %s, this trainer's for %s"
+                             % (list(state.get("padded_widths", state["widths"])), self._pwidths))
         pows = ctypes.c_void_p()
         self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
         self.params[...] = da.asarray(np.asarray(state["params"]), dtype=self.dtype)
@@ -155,7 +193,7 @@ class MLPTrainer(object):
 
     def load(self, path):
         with np.load(path, allow_pickle=False) as f:
-            self.load_state_dict({k: (f[k].tolist() if k == "widths" else (str(f[k]) if k == "dtype" else f[k]))
+            self.load_state_dict({k: (f[k].tolist() if k in ("widths", "padded_widths") else (str(f[k]) if k == "dtype" else f[k]))
                                   for k in f.files})
 
     def get_parameters(self):
@@ -178,7 +216,8 @@ class MLPTrainer(object):
     def activation(self, layer, rows):
         p = ctypes.c_void_p()
         self._lib.mlp_activation(self._h, layer, ctypes.byref(p))
-        return da.from_ptr(p.value, (rows, self.widths[layer + 1]), np.uint16 if self.bf16 else self.dtype, self)
+        act = da.from_ptr(p.value, (rows, self._pwidths[layer + 1]), np.uint16 if self.bf16 else self.dtype, self)
+        return act[:, :self.widths[layer + 1]] if self._pwidths[layer + 1] != self.widths[layer + 1] else act
 
     # ------------------------------------------------------------------ compute
     def _prep16(self, x, y=None):
