@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of one profiling pass (gpurun_out/<round>prof/, produced by tools/profile_round.sh) into profiles/ under
 # the round's prefix:  bash tools/collect_profiles.sh r03
-R=${1:-r03}
+R=${1:-r04}
 S=gpurun_out/${R}prof
 D=profiles
 cp $S/benchA.json $D/${R}_benchA.json
@@ -13,7 +13,11 @@ cp $S/ktAstep_kernel_stats.txt $D/${R}_benchA_step_kernel_stats.txt
 cp $S/ktC_kernel_stats.txt $D/${R}_benchC_kernel_stats.txt
 cp $S/ktE_kernel_stats.txt $D/${R}_benchE_kernel_stats.txt
 for w in A C E; do cat $S/pmc${w}_fetch.txt $S/pmc${w}_write.txt > $D/${R}_bench${w}_pmc.txt; done
-cp $S/pmcbf_sq.txt $D/${R}_gemm_bf16_pmc.txt
+cat $S/pmcbf_sq.txt $S/pmcsk_sq.txt > $D/${R}_gemm_bf16_pmc.txt
+cp $S/gemm_bf16_sk_probe.txt $D/${R}_gemm_bf16_sk_probe.txt
+cp $S/box_probe.txt $D/${R}_box_probe.txt
+cp $S/gemm_f32_data_ab.txt $D/${R}_gemm_f32_data_ab.txt
+cp $S/fetch_calibration.txt $D/${R}_fetch_calibration_rerun.txt
 cp $S/pmcg32_sq.txt $D/${R}_gemm_f32_pmc.txt
 cp $S/traffic.json $D/${R}_traffic.json
 cp $S/dp_world1_timeline.txt $D/${R}_dp_world1_timeline.txt

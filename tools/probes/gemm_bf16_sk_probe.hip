@@ -306,11 +306,19 @@ int main(int argc, char** argv) {
     }
     //            BN  WM WN NSA NSB S ABL          ABL bits: 1 no MFMA, 2 no refill DMA, 4 no exchange, 8 no frag reads, 16 no barrier, 32 trace,
     //                                              64 B addressed tile-major (timing only), 128 one K-tile per loop trip
-    sk_variant<128, 4, 2, 3, 4, 2, 0>("sk 256x128 S2 A3 B4 (waves 4x2)", c, true);
-    sk_variant<128, 4, 2, 4, 2, 2, 0>("sk 256x128 S2 A4 B2", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 0>("sk 256x128 S2 A3 B4 (shipped)", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 32>("sk 256x128 S2 A3 B4 [traced]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 128>("sk 256x128 S2 A3 B4 [one K-tile per trip]", c, true);
     sk_variant<128, 4, 2, 3, 3, 2, 0>("sk 256x128 S2 A3 B3", c, true);
     sk_variant<128, 4, 2, 2, 4, 2, 0>("sk 256x128 S2 A2 B4", c, true);
-    sk_variant<128, 4, 2, 3, 2, 2, 0>("sk 256x128 S2 A3 B2", c, true);
+    sk_variant<128, 4, 2, 4, 2, 2, 0>("sk 256x128 S2 A4 B2", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 4>("sk 256x128 S2 A3 B4 [no exchange]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 4 + 2>("sk 256x128 S2 A3 B4 [no exchange, no DMA]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 64>("sk 256x128 S2 A3 B4 [B tile-major]", c, false);
+    sk_variant<256, 2, 4, 2, 3, 4, 0>("sk 256x256 S4 A2 B3", c, true);
+    sk_variant<256, 2, 4, 2, 3, 4, 32>("sk 256x256 S4 A2 B3 [traced]", c, false);
+    sk_variant<256, 2, 4, 2, 3, 4, 4>("sk 256x256 S4 A2 B3 [no exchange]", c, false);
+    sk_variant<256, 2, 4, 2, 3, 4, 4 + 2 + 8 + 16>("sk 256x256 S4 [MFMA only]", c, false);
     run_interleaved(c, 9);
     return 0;
 }

@@ -4,7 +4,7 @@
 # Bench lines, rocprofv3 kernel traces of the same commands, separate --pmc passes (FETCH_SIZE / WRITE_SIZE for the HBM-side
 # traffic, SQ counters for the bf16 GEMM).  Everything lands under gpurun_out/<round>prof/; tools/rocpd_summary.py,
 # tools/rocpd_pmc.py and tools/traffic_from_pmc.py turn the databases into the text files committed under profiles/.
-R=${1:-r03}
+R=${1:-r04}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${R}prof
@@ -20,6 +20,18 @@ python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
 SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
 python3 tools/probes/soak.py > $OUT/soak.txt 2>> $OUT/log.txt
 python3 tools/probes/eager_phases.py > $OUT/eager_phases.txt 2>> $OUT/log.txt
+# round 4: the skinny bf16 GEMM's variants / ablations / timelines, the box probe, the counter calibration
+tools/probes/bin/gemm_bf16_sk_probe > $OUT/gemm_bf16_sk_probe.txt 2>> $OUT/log.txt
+python3 -c "
+import json
+from tinynn_autograd_amd import _lib
+for i in range(3): print(json.dumps(_lib.box_probe()))" > $OUT/box_probe.txt 2>> $OUT/log.txt
+python3 tools/probes/gemm_f32_data_ab.py > $OUT/gemm_f32_data_ab.txt 2>> $OUT/log.txt
+mkdir -p $OUT/cal
+tools/probes/bin/fetch_calibration > $OUT/cal/known.txt 2>> $OUT/log.txt
+run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal -- tools/probes/bin/fetch_calibration
+run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal/write -o cal -- tools/probes/bin/fetch_calibration
+python3 tools/fetch_calibration.py $OUT/cal/known.txt $(find $OUT/cal/fetch -name "*.db" | head -1) $(find $OUT/cal/write -name "*.db" | head -1) > $OUT/fetch_calibration.txt 2>> $OUT/log.txt
 TNN_HOST_COMPILED=0 python3 tools/probes/eager_phases.py >> $OUT/eager_phases.txt 2>> $OUT/log.txt
 
 run rocprofv3 --kernel-trace --stats -d $OUT/ktA -o A -- python3 bench.py --steps 20 --warmup 5
@@ -39,6 +51,7 @@ run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcE_fetch -o E -- python3
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcE_write -o E -- python3 bench.py --workload E --no-extras
 run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcbf_sq -o bf -- python3 tools/gemm_bf16_sweep.py
 run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcg32_sq -o g32 -- python3 tools/gemm_pmc_driver.py
+run rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmcsk_sq -o sk -- tools/probes/bin/gemm_bf16_sk_probe
 
 for d in ktA ktAstep ktC ktE; do
     db=$(find $OUT/$d -name "*.db" | head -1)
@@ -52,7 +65,7 @@ db=$(find $OUT/ktC -name "*.db" | head -1)
 [ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.3 > $OUT/stepC_timeline.txt 2>> $OUT/log.txt
 db=$(find $OUT/kt256 -name "*.db" | head -1)
 [ -n "$db" ] && python3 tools/step_timeline.py $db --frac 0.5 > $OUT/step256_timeline.txt 2>> $OUT/log.txt
-for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcE_fetch pmcE_write pmcbf_sq pmcg32_sq; do
+for d in pmcA_fetch pmcA_write pmcC_fetch pmcC_write pmcE_fetch pmcE_write pmcbf_sq pmcg32_sq pmcsk_sq; do
     db=$(find $OUT/$d -name "*.db" | head -1)
     [ -n "$db" ] && python3 tools/rocpd_pmc.py $db > $OUT/${d}.txt 2>> $OUT/log.txt
 done
