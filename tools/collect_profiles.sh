@@ -26,6 +26,7 @@ cp $S/p2p_latency.txt $D/${R}_p2p_latency.txt
 cp $S/dw_adam_bf16.txt $D/${R}_dw_adam_bf16.txt
 cp $S/gemm_f32_sweep.txt $D/${R}_gemm_f32_sweep.txt
 cp $S/soak.txt $D/${R}_soak.txt
+cp $S/soak_e.txt $D/${R}_soak_e.txt
 cp $S/step256_timeline.txt $D/${R}_step256_timeline.txt
 cp $S/eager_phases.txt $D/${R}_eager_phases.txt
 ls -la $D/${R}_*

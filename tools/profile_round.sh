@@ -19,6 +19,7 @@ python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
 python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
 SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
 python3 tools/probes/soak.py > $OUT/soak.txt 2>> $OUT/log.txt
+python3 tools/probes/soak_e.py > $OUT/soak_e.txt 2>> $OUT/log.txt
 python3 tools/probes/eager_phases.py > $OUT/eager_phases.txt 2>> $OUT/log.txt
 # round 4: the skinny bf16 GEMM's variants / ablations / timelines, the box probe, the counter calibration
 tools/probes/bin/gemm_bf16_sk_probe > $OUT/gemm_bf16_sk_probe.txt 2>> $OUT/log.txt
