@@ -369,6 +369,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
         return;
     }
     if constexpr (!SWAP) {
+        if constexpr (NS * STAGE_B >= BM * BN * 4) {
+            // Plain fp32 output (the weight gradient of the data-parallel / keep-gradients step: 268 MB per 8192 x 8192
+            // product), interior tiles: through the idle ring like the Adam form — the tile comes back row-major and leaves
+            // as 16-B stores, a wave instruction covering two whole 512-B tile rows (lane = column wrote 128-B segments of
+            // two rows per instruction, 4 B per lane: 143-147 us for the 8192 x 8192 x 512 product).
+            const bool staged = !g.c_bf16 && g.epi == BEPI_PLAIN && m0 + BM <= g.M && n0 + BN <= g.N && g.ldc % 4 == 0 &&
+                                (reinterpret_cast<uintptr_t>(g.C) & 15) == 0;
+            if (staged) {                         // block-uniform
+                float* tile = reinterpret_cast<float*>(lds);
+                __syncthreads();                  // every wave is done with the last stage's fragments
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            tile[(wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * BN + wn * TN + ni * 32 + l31] = acc[mi][ni][r];
+                __syncthreads();
+                float* cout = reinterpret_cast<float*>(g.C);
+                constexpr int PIECES = BM * (BN / 4) / (NW * 64);          // 16-B pieces per thread
+#pragma unroll
+                for (int it = 0; it < PIECES; ++it) {
+                    const int p = tid + it * (NW * 64), row = p / (BN / 4), c4 = p % (BN / 4);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * BN + 4 * c4);
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(cout + (m0 + row) * g.ldc + n0 + 4 * c4));
+                }
+                return;
+            }
+        }
         // epilogue, lane = column: col = l31, row = (r & 3) + 8 (r >> 2) + 4 lhi of each 32 x 32 block
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -394,7 +423,59 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
             }
         return;
     }
-    // ---- epilogue: block (mi, ni) is rows m0 + wm 64 + mi 32 + l31, register r the column (r & 3) + 8 (r >> 2) + 4 lhi
+    // ---- epilogue, bf16 output, interior tiles: through an LDS image of the output tile (tnn_gemm_bf16_sk.h has the account:
+    // in the accumulator layout a store instruction writes 8-B pieces of 32 different rows).  Image [128][128] bf16 in the idle
+    // ring, 8-B slot s of row r at s ^ (r & 15); read back as 16-B pieces, 16 lanes per 256-B row segment.
+    {
+        const bool staged = g.c_bf16 && m0 + BM <= g.M && n0 + BN <= g.N && g.ldc % 8 == 0 &&
+                            (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                            (g.epi != BEPI_MASK || (g.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0));
+        if (staged) {                                       // block-uniform
+            constexpr int IMG_ROWB = BN * 2;
+            __syncthreads();                                // every wave is done with the ring
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int row = wm * TM + mi * 32 + l31;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int col = wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float x = acc[mi][ni][4 * q + j];
+                            if (g.epi == BEPI_BIAS_ACT) {
+                                x += g.bias ? g.bias[n0 + col + j] : 0.f;
+                                if (g.act == TNN_ACT_RELU) x = x < 0.f ? (g.relu_sign ? -0.0f : 0.f) : fabsf(x);
+                            }
+                            v[j] = x;
+                        }
+                        const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                        *reinterpret_cast<u32x2*>(lds + row * IMG_ROWB + (((col >> 2) ^ (row & 15)) << 3)) = pk;
+                    }
+            }
+            __syncthreads();
+            constexpr int PPR = BN / 8, PIECES = BM * PPR / (NW * 64);
+            bf16_t* cout = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+            for (int it = 0; it < PIECES; ++it) {
+                const int p = tid + it * (NW * 64), row = p / PPR, j = p % PPR;
+                u32x4 v = *reinterpret_cast<const u32x4*>(lds + row * IMG_ROWB + ((j ^ ((row & 15) >> 1)) << 4));
+                if (row & 1) v = u32x4{v[2], v[3], v[0], v[1]};      // odd rows: the two 8-B slots of the pair are swapped
+                if (g.epi == BEPI_MASK) {
+                    const u32x4 y = *reinterpret_cast<const u32x4*>(g.Y + (m0 + row) * g.ldy + n0 + 8 * j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] &= ((y[e] & 0x8000u) ? 0u : 0xffffu) | ((y[e] & 0x80000000u) ? 0u : 0xffff0000u);
+                }
+                *reinterpret_cast<u32x4*>(cout + (m0 + row) * g.ldc + n0 + 8 * j) = v;
+            }
+            return;
+        }
+    }
+    // ---- epilogue, edge tiles / fp32 outputs: block (mi, ni) is rows m0 + wm 64 + mi 32 + l31, register r the column
+    // (r & 3) + 8 (r >> 2) + 4 lhi
     const bool vec_out = g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
                          (g.epi != BEPI_MASK || (g.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 7) == 0));
 #pragma unroll
