@@ -140,6 +140,16 @@ TNN_API int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, 
                                      void* db, void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b,
                                      void* flat_p, const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n,
                                      double lr, double b1, double b2, double eps, const void* pows_f64, int dtype);
+/* Backward of the FIRST Dense layer + all-reduce of the whole gradient arena + Adam, for the data-parallel step
+ * (examples/mnist/run.py:82-83: the gradients are summed over the ranks before the optimizer sees them;
+ * core/optimizer.py:67-79): dw / db as in tnn_dense_bwd land at grads[w_off ..] / grads[b_off ..], then
+ * tnn_allreduce_adam(grads, n_reduce, ...) (pows NOT advanced; grads[scalar_index] -> *scalar_dst).  On the xGMI
+ * peer-to-peer transport and MNIST-size layers (<= 256 rows per rank) ONE launch: the product's tiles are pushed straight into
+ * the owning ranks' receive slots instead of being stored and read back.  Anything else: the two calls it replaces. */
+TNN_API int tnn_dense_bwd_first_allreduce_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz,
+                                               void* grads, int64_t n_reduce, int64_t w_off, int64_t b_off, void* p, void* m,
+                                               void* v, int64_t n_params, double lr, double b1, double b2, double eps,
+                                               const void* pows_f64, int64_t scalar_index, void* scalar_dst, int dtype);
 
 /* ------------------------------------------------------------------ elementwise (K2,K3) ------- */
 /* out[shape] = a (op) b with numpy broadcasting expressed as element strides (0 = broadcast dim).

@@ -809,6 +809,18 @@ int tnn_sgd(void* p, const void* g, int64_t n, double lr, int dtype) {
     });
     return 0;
 }
+int tnn_dense_bwd_first_allreduce_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* grads,
+                                       int64_t n_reduce, int64_t w_off, int64_t b_off, void* p, void* m, void* v,
+                                       int64_t n_params, double lr, double b1, double b2, double eps, const void* pows,
+                                       int64_t scalar_index, void* scalar_dst, int dtype) {
+    const size_t esz = dtype == TNN_F64 ? 8 : 4;       // no peer-to-peer transport here: the two calls the launch replaces
+    if (int rc = tnn_gemm_tn_colsum(n_in, n_out, rows, x, n_in, dz, n_out, (char*)grads + (size_t)w_off * esz, n_out,
+                                    (char*)grads + (size_t)b_off * esz, dtype))
+        return rc;
+    return tnn_allreduce_adam(grads, n_reduce, p, m, v, n_params, lr, b1, b2, eps, const_cast<void*>(pows), 0, dtype,
+                              scalar_index, scalar_dst);
+}
+
 int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* dw, void* db,
                              void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b, void* flat_p,
                              const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n, double lr, double b1,

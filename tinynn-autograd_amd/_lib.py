@@ -106,6 +106,8 @@ _SIGNATURES = {
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
     "tnn_dense_bwd_first_adam": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64,
                                  c_double, c_double, c_double, c_double, _p, c_int],
+    "tnn_dense_bwd_first_allreduce_adam": [c_int64, c_int64, c_int64, _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int64,
+                                           c_double, c_double, c_double, c_double, _p, c_int64, _p, c_int],
     "tnn_optim_step": [c_int, _p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, c_int],
     "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],
     "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, c_int, _p, _p],

@@ -724,9 +724,12 @@ __device__ __forceinline__ float adam_apply(const AdamEpi& ad, float ic1, float 
     return p + (-ad.lr * (m * ic1) / (sqrtf(v * ic2) + ad.eps));
 }
 
-template <bool AKC, bool BKC, int WAVES, bool ADAM = false>
+// TO_LDS: the finished tile goes to out_lds [16][16] (row-major; entries outside the matrix are not written) and the column
+// sums of the first tile row to out_lds[256 .. 272) instead of memory — for a caller that sends them elsewhere itself
+template <bool AKC, bool BKC, int WAVES, bool ADAM = false, bool TO_LDS = false>
 __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict__ colsum, int block,
-                                           float (*red)[4][64], float (*bsum)[64], const AdamEpi* ad = nullptr) {
+                                           float (*red)[4][64], float (*bsum)[64], const AdamEpi* ad = nullptr,
+                                           float* out_lds = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
     int tm, tn;
@@ -812,7 +815,8 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
         const int64_t row = m0 + (ln >> 4) * 4 + r, col = n0 + (ln & 15);   // 16x16x4 C/D layout
         if (row < g.M && col < g.N) {
             const float gval = apply_epilogue(g, s, row, col);
-            if (!ADAM || g.C != nullptr) g.C[row * g.ldc + col] = gval;      // ADAM: the gradient itself only on request
+            if constexpr (TO_LDS) out_lds[((ln >> 4) * 4 + r) * 16 + (ln & 15)] = gval;
+            else if (!ADAM || g.C != nullptr) g.C[row * g.ldc + col] = gval;      // ADAM: the gradient itself only on request
             if constexpr (ADAM) {
                 const int64_t i = row * g.ldc + col;
                 ad->pw[i] = adam_apply(*ad, ic1, ic2, gval, a_m, a_v, a_p);
@@ -821,11 +825,12 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
             }
         }
     }
-    if (colsum != nullptr && tm == 0 && tid < 16 && n0 + tid < g.N) {
+    if ((TO_LDS || colsum != nullptr) && tm == 0 && tid < 16 && n0 + tid < g.N) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) s += (bsum[w][tid] + bsum[w][16 + tid]) + (bsum[w][32 + tid] + bsum[w][48 + tid]);
-        colsum[n0 + tid] = s;
+        if constexpr (TO_LDS) out_lds[256 + tid] = s;
+        else colsum[n0 + tid] = s;
         if constexpr (ADAM) {
             ad->pb[n0 + tid] = adam_apply(*ad, ic1, ic2, s, ab_m, ab_v, ab_p);
             ad->mb[n0 + tid] = ab_m;
@@ -1299,6 +1304,98 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_adam_kernel(GemmArgs gw
         ad.fp[i] = adam_apply(ad, ic1, ic2, ad.fg[i], m, v, ad.fp[i]);
         ad.fm[i] = m;
         ad.fv[i] = v;
+    }
+}
+
+// Backward of the FIRST Dense layer + gradient all-reduce + Adam in ONE launch (data-parallel step on the xGMI peer-to-peer
+// transport; examples/mnist/run.py:82-83 is where the exchange sits, core/optimizer.py:67-79 the update):
+//   blocks [0, n_dw): dW0 = X^T dZ0 tiles + db0 — the finished tile never goes to the gradient arena: its 64 float4 are
+//     pushed straight into the recv slots of the ranks that own them (stage A of the all-reduce, tnn_p2p.hip);
+//   blocks >= n_dw (always the LAST of the grid, so every tile block of this rank has been placed before one of them can
+//     start to wait): stage A for the rest of the arena (the other layers' gradients and the loss, finished by earlier
+//     launches), then stages B and C with Adam — tnn::p2p::allreduce_body, the body of p2p_allreduce_kernel.
+// One launch and one L2 round trip less than tnn_dense_bwd + tnn_allreduce_adam, and the pollers' start-up and the
+// rest-of-arena sends hide behind the product.  Slot tags: polling workgroup b advances ar_epoch[b] as in
+// p2p_allreduce_kernel (the entries are equal between launches); tile block j reads ITS tag from entry j % P and then
+// arrives at gate j % P, and polling workgroup b advances its entry only after all of them have — no launch-wide ticket
+// (912 agent-scope atomics on one word cost 25 us, measured; here 6 or 7 per word).
+struct ArTileArgs {
+    float* buf;                      // gradient arena (+ slots behind it): [0, n) is reduced
+    int64_t n, slice;
+    int64_t w_off, b_off;            // where dW0 [M][N] and db0 [N] live in it (multiples of 4)
+    int n_dw;
+};
+
+#ifdef TNN_AR_TRACE
+__device__ unsigned long long g_ar_trace[1024 * 4];
+#endif
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_bwd0_allreduce_adam_kernel(GemmArgs gw, ArTileArgs f,
+                                                                               tnn::p2p::LaunchCtx ctx,
+                                                                               tnn::p2p::AdamTail t) {
+    using namespace tnn::p2p;
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    __shared__ __attribute__((aligned(16))) float tile[16 * 16 + 16];
+    const Peers& p = ctx.peers;
+    const int tid = threadIdx.x, P = ctx.ar_grid;
+#ifdef TNN_AR_TRACE
+    if (tid == 0 && blockIdx.x < 1024) g_ar_trace[blockIdx.x * 4] = wall_clock64();
+#endif
+    if ((int)blockIdx.x < f.n_dw) {
+        const int b = (int)blockIdx.x % P;
+        const uint32_t tag = ctx.ar_epoch[b] + 1;
+        small_tile<false, false, WAVES, false, true>(gw, nullptr, (int)blockIdx.x, red, bsum, nullptr, tile);
+        __syncthreads();
+#ifdef TNN_AR_TRACE
+        if (tid == 0 && blockIdx.x < 1024) g_ar_trace[blockIdx.x * 4 + 1] = wall_clock64();
+#endif
+        if (tid < 68 && __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            int tm, tn;
+            small_tile_coords(gw, (int)blockIdx.x, tm, tn);
+            const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
+            int64_t e;
+            bool live;
+            f32x4 v;
+            if (tid < 64) {
+                const int row = tid >> 2, c4 = tid & 3;
+                live = m0 + row < gw.M && n0 + 4 * c4 < gw.N;
+                e = f.w_off + (m0 + row) * gw.ldc + n0 + 4 * c4;
+                v = *reinterpret_cast<const f32x4*>(tile + row * 16 + 4 * c4);
+            } else {
+                const int c4 = tid - 64;
+                live = tm == 0 && n0 + 4 * c4 < gw.N;
+                e = f.b_off + n0 + 4 * c4;
+                v = *reinterpret_cast<const f32x4*>(tile + 256 + 4 * c4);
+            }
+            if (live) {
+                const int q = (int)(e / f.slice);
+                ll_send(p.base[q] + ll_recv_off(p, p.rank, (e - (int64_t)q * f.slice) / 4), v, tag);
+            }
+        }
+        __syncthreads();                                  // every thread has its tag, the stores are issued
+        if (tid == 0) __hip_atomic_fetch_add(ctx.ar_gate + b * GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef TNN_AR_TRACE
+        if (tid == 0 && blockIdx.x < 1024) g_ar_trace[blockIdx.x * 4 + 2] = wall_clock64();
+#endif
+        return;
+    }
+    const int b = (int)blockIdx.x - f.n_dw;               // polling workgroup b of P
+    const uint32_t tag = ctx.ar_epoch[b] + 1;
+    unsigned* const gate = ctx.ar_gate + b * GATE_STRIDE;
+    SkipRanges skip;
+    skip.lo0 = f.w_off; skip.hi0 = f.w_off + gw.M * gw.N;
+    skip.lo1 = f.b_off; skip.hi1 = f.b_off + gw.N;
+#ifdef TNN_AR_TRACE
+    if (blockIdx.x < 1024) skip.trace = g_ar_trace + blockIdx.x * 4;
+#endif
+    allreduce_body<true, 2>(p, f.buf, f.n, f.slice, tag, ctx.dead, ctx.timeout_ticks, t, (int64_t)b * (WAVES * 64) + tid,
+                         (int64_t)P * (WAVES * 64), skip, gate, b < f.n_dw ? (unsigned)((f.n_dw - b + P - 1) / P) : 0u);
+    __syncthreads();                                      // every thread has read epoch[b]
+    if (tid == 0) {
+        __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // its producers have all arrived
+        ctx.ar_epoch[b] = tag;
     }
 }
 
@@ -1946,6 +2043,9 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
             // measured at bs 128 (8 chunks): 4 waves with two chunks each 21.5 us/step, 8 waves with one chunk each 22.2, 16
             // waves 23.7 — the launch's 784 workgroups cost more per wave than the second load round trip saves
             const int waves = nchunks <= 16 ? 4 : nchunks <= 48 ? 8 : 16;
+            // (one WAVE per tile over the whole K, four tiles per workgroup — a quarter of the waves for the dispatcher to place —
+            // was built and measured in round 4: bit-identical, 22.5 instead of 21.4 us/step; the per-wave chain of 64 loads
+            // and 32 MFMAs costs more than the placement saves)
             if (waves == 4) TNN_BWD0(4);
             else if (waves == 8) TNN_BWD0(8);
             else TNN_BWD0(16);
@@ -1962,6 +2062,69 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
     if (flat_n > 0)
         return tnn_adam_ex(flat_p, flat_g, flat_m, flat_v, flat_n, lr, b1, b2, eps, pows, nullptr, dtype, 0, nullptr, nullptr);
     return 0;
+}
+
+#ifdef TNN_AR_TRACE
+__attribute__((visibility("default"))) int tnn_debug_ar_trace(unsigned long long* out, int n) {
+    TNN_CHECK_HIP(hipDeviceSynchronize());
+    TNN_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ar_trace), (size_t)std::min(n, 4096) * 8));
+    return 0;
+}
+#endif
+
+int tnn_dense_bwd_first_allreduce_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* grads,
+                                       int64_t n_reduce, int64_t w_off, int64_t b_off, void* p, void* m, void* v,
+                                       int64_t n_params, double lr, double b1, double b2, double eps, const void* pows_f64,
+                                       int64_t scalar_index, void* scalar_dst, int dtype) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(rows > 0 && n_in > 0 && n_out > 0, "tnn_dense_bwd_first_allreduce_adam: empty layer");
+    TNN_REQUIRE(grads && p && m && v && pows_f64, "tnn_dense_bwd_first_allreduce_adam: NULL argument");
+    TNN_REQUIRE(n_params > 0 && n_reduce >= n_params && w_off >= 0 && b_off >= 0 && w_off + n_in * n_out <= n_params &&
+                    b_off + n_out <= n_params,
+                "tnn_dense_bwd_first_allreduce_adam: the layer's blocks do not lie inside the arena");
+    TNN_REQUIRE(!scalar_dst || (scalar_index >= 0 && scalar_index < n_reduce), "tnn_dense_bwd_first_allreduce_adam: scalar_index");
+    const size_t esz = dtype == TNN_F64 ? 8 : 4;
+    if (dtype == TNN_F32) {
+        GemmArgs gw = {};
+        gw.A = (const float*)x; gw.B = (const float*)dz; gw.C = nullptr;
+        gw.M = n_in; gw.N = n_out; gw.K = rows; gw.lda = n_in; gw.ldb = n_out; gw.ldc = n_out;
+        gw.alpha = 1.f; gw.beta = 0.f; gw.epi = EPI_AXPBY;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(p) |
+                               reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+        tnn::p2p::LaunchCtx ctx;
+        // one launch: the latency kernel's 4-wave form (<= 256 rows per rank), every float4 of the layer's blocks whole and
+        // inside one slice, the transport up and large enough
+        if (aligned && use_small_path(gw) && !use_mid_path(gw, 1, 0) && rows <= 256 && n_out % 4 == 0 && w_off % 4 == 0 &&
+            b_off % 4 == 0 && (!scalar_dst || scalar_index >= n_params) &&
+            tnn::p2p_can_allreduce(n_reduce, dtype, TNN_RSUM) && tnn::p2p_launch_ctx(&ctx)) {
+            if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_bwd_first_allreduce_adam")) return rc;
+            gw.tiles_m = (int)((gw.M + 15) / 16); gw.tiles_n = (int)((gw.N + 15) / 16); gw.splits = 1;
+            pick_xcd_cut(gw);
+            const int W = ctx.peers.world;
+            ArTileArgs f;
+            f.buf = (float*)grads; f.n = n_reduce;
+            f.slice = ((n_reduce + W - 1) / W + 3) / 4 * 4;
+            f.w_off = w_off; f.b_off = b_off;
+            f.n_dw = gw.tiles_m * gw.tiles_n;
+            tnn::p2p::AdamTail t;
+            t.p = (float*)p; t.m = (float*)m; t.v = (float*)v; t.n_params = n_params;
+            t.lr = (float)lr; t.b1 = (float)b1; t.b2 = (float)b2; t.eps = (float)eps;
+            t.pows = (const double*)pows_f64;
+            t.scalar_index = scalar_dst ? scalar_index : -1;
+            t.scalar_dst = (float*)scalar_dst;
+            // the transport's polling workgroups (128 by default) behind the tiles, 256 threads each: with up to eight ranks'
+            // launches on ONE GPU (the tests) they still leave half the wave slots to the producers
+            hipLaunchKernelGGL((dense_bwd0_allreduce_adam_kernel<4>), f.n_dw + ctx.ar_grid, 256, 0, tnn::stream(), gw, f, ctx, t);
+            TNN_LAUNCH_OK();
+            return 0;
+        }
+    }
+    // anything else: the two launches this replaces
+    if (int rc = tnn_dense_bwd(rows, n_in, n_out, x, dz, nullptr, (char*)grads + (size_t)w_off * esz,
+                               (char*)grads + (size_t)b_off * esz, nullptr, nullptr, dtype))
+        return rc;
+    return tnn_allreduce_adam(grads, n_reduce, p, m, v, n_params, lr, b1, b2, eps, const_cast<void*>(pows_f64), 0, dtype,
+                              scalar_index, scalar_dst);
 }
 
 int tnn_gemm_bias_act(int transA, int transB, int64_t M, int64_t N, int64_t K, const void* A,

@@ -837,9 +837,12 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
                                           at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
                                           at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
                                           h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
-        MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 0));
-        return tnn_allreduce_adam(h->grads, h->n_params + 1, h->params, h->m, h->v, h->n_params, h->lr, h->b1, h->b2,
-                                  h->eps, h->pows, 0, h->dtype, h->n_params, loss_out);
+        // remaining backward; the first layer's in one launch with the gradient all-reduce and Adam (peer-to-peer transport:
+        // its tiles go straight into the owners' receive slots; RCCL: the launches that replaces)
+        MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 1));
+        return tnn_dense_bwd_first_allreduce_adam(rows, h->w[0], h->w[1], x, h->dact[0], h->grads, h->n_params + 1,
+                                                  h->w_off[0], h->b_off[0], h->params, h->m, h->v, h->n_params, h->lr,
+                                                  h->b1, h->b2, h->eps, h->pows, h->n_params, loss_out, h->dtype);
     }
     if (p2p_on && h->dtype == TNN_F32 && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
         // xGMI peer-to-peer transport and a head that fits one workgroup — 8 launches, like the single-GPU step:

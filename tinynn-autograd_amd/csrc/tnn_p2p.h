@@ -14,6 +14,7 @@ constexpr int MAXW = 16;          // ranks
 constexpr int MAXB = 128;         // workgroups of the all-reduce kernel
 constexpr int AG_BYTES = 256;     // per-rank payload limit of the small all-gather
 constexpr int THREADS = 512;
+constexpr int GATE_STRIDE = 64;  // uint32 words between two gate counters (a 256-B line of their own each)
 
 // Flag words are polled straight from DRAM (uncached).  With every workgroup's words packed into one 4 KB page all
 // pollers hit one HBM channel and the flag stores queue behind them (measured: 64 workgroups cost +7 us per
@@ -55,6 +56,11 @@ struct LaunchCtx {                                // what a kernel embedding an 
                                                   // single-workgroup exchanges use it, so the exchanging kernel advances it itself
     int* dead;
     int64_t timeout_ticks;
+    uint32_t* ar_epoch;                           // [ar_grid] launch counts of the all-reduce workgroups = the tags of its slots (all
+                                                  // equal between launches); a kernel that embeds the all-reduce keeps to the same
+                                                  // ar_grid polling workgroups, so the entries stay equal whichever kind runs
+    unsigned* ar_gate;                            // [MAXB][GATE_STRIDE] arrival counters of such a kernel's producer workgroups
+    int ar_grid;
 };
 
 // Signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine.
@@ -168,6 +174,297 @@ __device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, fl
         }
     }
     return __uint_as_float((uint32_t)v[0]);
+}
+
+
+constexpr int UNROLL = 4;          // independent 16-B accesses in flight per thread and loop trip
+
+__device__ __forceinline__ f32x4 load_guarded(const float* buf, int64_t i, int64_t n) {
+    if (i + 4 <= n) return *reinterpret_cast<const f32x4*>(buf + i);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) v[k] = buf[i + k];
+    return v;
+}
+__device__ __forceinline__ void store_guarded(float* buf, int64_t i, int64_t n, f32x4 v) {
+    if (i + 4 <= n) {
+        *reinterpret_cast<f32x4*>(buf + i) = v;
+        return;
+    }
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) buf[i + k] = v[k];
+}
+
+// Optional optimizer tail: stage (C) holds the reduced gradient in registers anyway, so Adam
+// (core/optimizer.py:67-79, the maths of adam_kernel in tnn_fused.hip) is applied right there — no second launch and
+// no second pass over the gradient.  pows must already hold b1^t, b2^t of THIS step.
+struct AdamTail {
+    float* p;
+    float* m;
+    float* v;
+    int64_t n_params;              // elements [0, n_params) of buf are gradients of p; the rest is only reduced
+    float lr, b1, b2, eps;
+    const double* pows;
+    int64_t scalar_index;          // buf[scalar_index] is also written to *scalar_dst (e.g. the loss); -1 = none
+    float* scalar_dst;
+};
+
+// ---- tagged ("low-latency") slots for the bulk data: every 4-byte payload word travels next to a 4-byte tag in ONE
+// naturally aligned 8-byte half of a 16-byte store, so the receiver polls the DATA itself until every tag is the one it
+// expects.  No store-acknowledgement wait, no flag exchange, no second read per stage: a stage costs one fabric latency
+// end to end where the flag-barrier version of rounds 1-2 paid three dependent ones (ack wait, flag store -> poll, data
+// load).  Wire efficiency is 50 % — irrelevant at 0.94 MB.  A float4 element i of a slice occupies 32 bytes:
+//     {p0, tag, p1, tag | p2, tag, p3, tag}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_load16(u32x4& v, const char* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(v) : "v"(ptr) : "memory");
+}
+// s_nop: a VMEM store of more than 64 bits reads its data VGPRs for a few cycles after issue; the compiler keeps VALU
+// writes away from its OWN stores (a gfx9 hazard it knows) but cannot see through inline asm — without the wait states
+// the v_movs that assemble the NEXT slot overwrote word 0 of this one in some lanes (measured: lanes 12-15 of each row)
+__device__ __forceinline__ void ll_store16(char* ptr, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(ptr), "v"(v) : "memory");
+}
+// slot of (source rank src, float4 element i) inside a region: recv half (stage A -> B) or out half (stage B -> C)
+__device__ __forceinline__ size_t ll_recv_off(const Peers& p, int src, int64_t i) {
+    return HEADER_BYTES + (size_t)((int64_t)src * (p.slice_cap / 4) + i) * 32;
+}
+__device__ __forceinline__ size_t ll_out_off(const Peers& p, int src, int64_t i) {
+    return HEADER_BYTES + (size_t)((int64_t)(p.world + src) * (p.slice_cap / 4) + i) * 32;
+}
+__device__ __forceinline__ void ll_send(char* dst, f32x4 v, uint32_t tag) {
+    ll_store16(dst, u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag});
+    ll_store16(dst + 16, u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag});
+}
+// Poll N slots until every live one carries `tag` in all four tag words; false = the transport is (now) dead.
+template <int N>
+__device__ __forceinline__ bool ll_poll(const char* const (&src)[N], const bool (&live)[N], f32x4 (&out)[N], uint32_t tag,
+                                        const Peers& p, int* dead, int64_t timeout_ticks) {
+    uint64_t t0 = 0;
+    uint32_t polls = 0;
+    for (;;) {
+        u32x4 lo[N], hi[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (live[k]) { ll_load16(lo[k], src[k]); ll_load16(hi[k], src[k] + 16); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bool ok = true;
+        uint32_t seen = tag;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (!live[k]) continue;
+            asm volatile("" : "+v"(lo[k]), "+v"(hi[k]));          // uses stay behind the wait
+            const bool ready = lo[k][1] == tag && lo[k][3] == tag && hi[k][1] == tag && hi[k][3] == tag;
+            if (!ready) { ok = false; seen = lo[k][1]; }
+            out[k] = f32x4{__uint_as_float(lo[k][0]), __uint_as_float(lo[k][2]), __uint_as_float(hi[k][0]), __uint_as_float(hi[k][2])};
+        }
+        if (ok) return true;
+        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++polls & 63u) == 0) {
+            const uint64_t now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if ((int64_t)(now - t0) > timeout_ticks) {
+                mark_dead(p, dead, 1, tag, seen, blockIdx.x, threadIdx.x);
+                return false;
+            }
+        }
+    }
+}
+
+
+// What a thread of an all-reduce does with ITS elements of every slice, i_k = first + k stride (k = 0 .. while i_k < slice / 4):
+// stages (A), (B), (C) of p2p_allreduce_kernel (tnn_p2p.hip has the protocol).  Also the tail of kernels that PRODUCE part of
+// the buffer themselves and push it straight into the owners' recv slots (tnn_gemm.hip: dense_bwd0_allreduce_adam_kernel) —
+// `skip` names the element ranges of buf that stage (A) must leave to them.
+struct SkipRanges {
+    int64_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;      // [lo, hi) element ranges of buf, multiples of 4
+#ifdef TNN_AR_TRACE
+    unsigned long long* trace = nullptr;             // debug build: [4] wall-clock stamps of this workgroup (start, A, B, C)
+#endif
+    __device__ __forceinline__ bool has(int64_t e) const { return (e >= lo0 && e < hi0) || (e >= lo1 && e < hi1); }
+};
+// UN: independent 16-B accesses in flight per thread and loop trip in stages (A) and (C)
+template <bool ADAM, int UN = UNROLL>
+__device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict__ buf, const int64_t n, const int64_t slice,
+                                               const uint32_t tag, int* dead, const int64_t timeout_ticks, const AdamTail& t,
+                                               const int64_t first, const int64_t stride, const SkipRanges skip,
+                                               const unsigned* gate = nullptr, const unsigned gate_count = 0) {
+    const int W = p.world, r = p.rank;
+    const int64_t s4 = slice / 4;
+    const int cnt = first < s4 ? (int)((s4 - first + stride - 1) / stride) : 0;
+    const int items = cnt * W;                            // (element k, slice) pairs of this thread
+    bool ok = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+
+    // (A) slice order starts at my right-hand neighbour so the links fill evenly.  Loads first (L2 hits: the gradients
+    // were just written), then the posted stores.
+    for (int j0 = 0; ok && j0 < items; j0 += UN) {
+        f32x4 v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u;
+            if (j < items) {
+                const int q = (r + 1 + j % W) % W;
+                v[u] = load_guarded(buf, (int64_t)q * slice + 4 * (first + (j / W) * stride), n);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u;
+            if (j < items) {
+                const int q = (r + 1 + j % W) % W;
+                const int64_t i = first + (j / W) * stride;
+                if (!skip.has((int64_t)q * slice + 4 * i)) ll_send(p.base[q] + ll_recv_off(p, r, i), v[u], tag);
+            }
+        }
+    }
+
+#ifdef TNN_AR_TRACE
+    if (skip.trace && threadIdx.x == 0) skip.trace[1] = wall_clock64();
+#endif
+    // (B) reduce my slice in rank order and broadcast the result.  The (element, source) pairs of this thread are walked in
+    // order, four slots requested together (eight at once spilled registers): a thread with several elements and few
+    // sources polls them side by side instead of paying one memory round trip per element; the sum of an element still
+    // runs over the sources in rank order.
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; ok && j0 < items; j0 += 4) {
+            const char* src[4];
+            bool live[4];
+            f32x4 part[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                live[u] = j < items;
+                src[u] = p.base[r] + ll_recv_off(p, live[u] ? j % W : 0, first + (live[u] ? j / W : 0) * stride);
+            }
+            ok = ll_poll<4>(src, live, part, tag, p, dead, timeout_ticks);
+            if (!ok) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!live[u]) continue;
+                const int x = (j0 + u) % W;
+                acc = x == 0 ? part[u] : acc + part[u];
+                if (x == W - 1) {
+                    const int64_t i = first + ((j0 + u) / W) * stride;
+                    for (int y = 0; y < W; ++y) {
+                        const int q = (r + 1 + y) % W;
+                        ll_send(p.base[q] + ll_out_off(p, r, i), acc, tag);
+                    }
+                }
+            }
+        }
+    }
+
+#ifdef TNN_AR_TRACE
+    if (skip.trace && threadIdx.x == 0) skip.trace[2] = wall_clock64();
+#endif
+    // (C) gathered result -> caller's buffer (+ the optimizer update when ADAM).  A thread that lost a poll (timeout, dead
+    // transport) updates nothing; with a peer missing that is every thread of every rank (see above).
+    float ic1 = 0.f, ic2 = 0.f, omb1 = 0.f, omb2 = 0.f;
+    if constexpr (ADAM) {
+        ic1 = (float)(1.0 / (1.0 - t.pows[0]));
+        ic2 = (float)(1.0 / (1.0 - t.pows[1]));
+        omb1 = 1.f - t.b1;
+        omb2 = 1.f - t.b2;
+    }
+    auto adam1 = [&](float g, float& mi, float& vi, float& pi) {
+        mi = mi + omb1 * (g - mi);
+        vi = vi + omb2 * (g * g - vi);
+        const float mh = mi * ic1, vh = vi * ic2;
+        pi = pi + (-t.lr * mh / (sqrtf(vh) + t.eps));
+    };
+    for (int j0 = 0; ok && j0 < items; j0 += UN) {
+        f32x4 g[UN] = {};
+        const char* gsrc[UN];
+        bool glive[UN];
+        int64_t at[UN];                               // element offset in buf (n = nothing to do)
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u;
+            glive[u] = j < items;
+            const int q = glive[u] ? j % W : 0;
+            const int64_t i = first + (glive[u] ? j / W : 0) * stride;
+            gsrc[u] = p.base[r] + ll_out_off(p, q, i);
+            at[u] = glive[u] ? (int64_t)q * slice + 4 * i : n;
+        }
+        if constexpr (ADAM) {
+            // the parameter / moment loads do not depend on the peers: issue them under the same wait
+            f32x4 pm[UN] = {}, mm[UN] = {}, vm[UN] = {};
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (at[u] + 4 <= t.n_params) {
+                    pm[u] = *reinterpret_cast<const f32x4*>(t.p + at[u]);
+                    mm[u] = *reinterpret_cast<const f32x4*>(t.m + at[u]);
+                    vm[u] = *reinterpret_cast<const f32x4*>(t.v + at[u]);
+                }
+            }
+            ok = ll_poll<UN>(gsrc, glive, g, tag, p, dead, timeout_ticks);
+            if (!ok) break;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int64_t i0 = at[u];
+                if (i0 >= n) continue;
+                if (i0 + 4 <= t.n_params) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float mi = mm[u][k], vi = vm[u][k], pi = pm[u][k];
+                        adam1(g[u][k], mi, vi, pi);
+                        mm[u][k] = mi; vm[u][k] = vi; pm[u][k] = pi;
+                    }
+                    *reinterpret_cast<f32x4*>(t.m + i0) = mm[u];
+                    *reinterpret_cast<f32x4*>(t.v + i0) = vm[u];
+                    *reinterpret_cast<f32x4*>(t.p + i0) = pm[u];
+                    *reinterpret_cast<f32x4*>(buf + i0) = g[u];
+                } else {                                         // the arena's ragged end and the slots behind it
+                    for (int k = 0; k < 4; ++k) {
+                        const int64_t i = i0 + k;
+                        if (i >= n) break;
+                        if (i < t.n_params) {
+                            float mi = t.m[i], vi = t.v[i], pi = t.p[i];
+                            adam1(g[u][k], mi, vi, pi);
+                            t.m[i] = mi; t.v[i] = vi; t.p[i] = pi;
+                        }
+                        buf[i] = g[u][k];
+                        if (i == t.scalar_index) *t.scalar_dst = g[u][k];
+                    }
+                }
+            }
+        } else {
+            ok = ll_poll<UN>(gsrc, glive, g, tag, p, dead, timeout_ticks);
+            if (!ok) break;
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (at[u] < n) store_guarded(buf, at[u], n, g[u]);
+        }
+    }
+#ifdef TNN_AR_TRACE
+    if (skip.trace && threadIdx.x == 0) skip.trace[3] = wall_clock64();
+#endif
+    // A kernel whose OTHER workgroups produce the skipped ranges: gate_count of them draw their tag from THIS workgroup's
+    // launch count and arrive at `gate` (an agent-scope counter in ordinary memory) once they have — the caller may advance
+    // the count only after that.  Checked here, at the end, where it has long happened (one load off the critical path;
+    // waiting for it BEFORE the first poll cost 1-2 us of atomic round trips).  Bounded like every other wait.  Block-uniform.
+    if (gate != nullptr) {
+        if (threadIdx.x == 0 && ok) {
+            uint64_t t0 = 0;
+            uint32_t polls = 0;
+            while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate_count) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++polls & 255u) == 0) {
+                    const uint64_t now = wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if ((int64_t)(now - t0) > timeout_ticks) {
+                        mark_dead(p, dead, 3, gate_count, __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), blockIdx.x, 0);
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
 }
 
 }  // namespace p2p

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Where the time goes inside dense_bwd0_allreduce_adam_kernel (data-parallel step, peer-to-peer transport, world 1).
+
+Needs the debug library (`make -C tinynn-autograd_amd/csrc trace`, stamps compiled in with -DTNN_AR_TRACE):
+    TNN_LIB_PATH=tinynn-autograd_amd/lib/libtnn_hip_trace.so TNN_FORCE_COMM=1 python tools/probes/ar_fused_trace.py
+Prints, relative to the first workgroup's start (100 MHz wall clock, 10 ns steps): when the tile blocks started, finished
+their product and had issued their sends; when the polling blocks started, finished stage A (rest of the arena), B, C."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: F401,E402  (first: one HIP runtime in the process)
+import tinynn_autograd_amd as tn  # noqa: E402
+from tinynn_autograd_amd import _lib  # noqa: E402
+from tinynn_autograd_amd.fused import MLPTrainer  # noqa: E402
+
+os.environ["TNN_FORCE_COMM"] = "1"
+comm = tn.dist.init_from_env()
+widths, rows = [784, 256, 128, 10], 128
+rng = np.random.default_rng(0)
+x = tn.asarray(rng.standard_normal((rows, 784)).astype(np.float32))
+y = tn.asarray(np.eye(10, dtype=np.float32)[rng.integers(0, 10, rows)])
+t = MLPTrainer(widths, rows, loss="softmax_nll", optimizer="adam", lr=1e-3, comm=comm, force_dp=True)
+lib = _lib.get()
+fn = lib.cdll.tnn_debug_ar_trace
+fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros(4096, dtype=np.uint64)
+acc = []
+for it in range(40):
+    t.step(x, y)
+    if it >= 20:
+        assert fn(buf.ctypes.data, 4096) == 0
+        acc.append(buf.reshape(1024, 4).astype(np.int64).copy())
+n_dw, P = 784, 128
+tr = np.stack(acc)                                     # [launch][block][stamp]
+t0 = tr[:, :n_dw + P, 0].min(axis=1)[:, None, None]
+rel = (tr - t0) / 100.0                                # us
+tiles, poll = rel[:, :n_dw], rel[:, n_dw:n_dw + P]
+
+
+def q(a):
+    return "min %6.2f  med %6.2f  max %6.2f" % (np.min(a), np.median(a), np.median(np.max(a, axis=1)))
+
+
+print("tile blocks   start        ", q(tiles[:, :, 0]))
+print("tile blocks   product done ", q(tiles[:, :, 1]))
+print("tile blocks   sends issued ", q(tiles[:, :, 2]))
+print("polling blocks start       ", q(poll[:, :, 0]))
+print("polling blocks stage A done", q(poll[:, :, 1]))
+print("polling blocks stage B done", q(poll[:, :, 2]))
+print("polling blocks stage C done", q(poll[:, :, 3]))
