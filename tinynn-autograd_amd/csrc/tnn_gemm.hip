@@ -1032,6 +1032,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, 
 // transport — exchanges and merges them with the other ranks' (head_tail_stats, tnn_head_stats.h).  The head launch
 // behind this one only READS the pair(s): no statistics launch, no workgroup of the head waiting for a peer, no
 // requirement that the ranks' launches be resident together (core/losses.py:26-27 is why the exchange exists).
+#ifdef TNN_AR_TRACE
+__device__ unsigned long long g_fh_trace[128 * 8];   // debug build: stamps of dense_fwd_head_kernel (tools/probes/ar_fused_trace.py)
+#endif
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, HeadTail ta, tnn::p2p::LaunchCtx ctx) {
     static_assert(WAVES == 8, "head_tail_stats is written for 512 threads");
@@ -1041,7 +1044,13 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
     __shared__ __attribute__((aligned(16))) float zs[128 * 10], ys[128 * 10];
     __shared__ double dred[8][4];
     __shared__ int is_last;
+#ifdef TNN_AR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 128) g_fh_trace[blockIdx.x * 8] = wall_clock64();
+#endif
     small_tile_fast<true, false, WAVES, true>(g, nullptr, (int)blockIdx.x, red, bsum, head_lds);
+#ifdef TNN_AR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 128) g_fh_trace[blockIdx.x * 8 + 1] = wall_clock64();
+#endif
     // Shards of more than 128 rows: every 128-row block has its own arrival counter (ticket[1 + rb], the block's 8 tile rows x
     // all tile columns), so the blocks' statistics are reduced in parallel, each by the workgroup that finishes the block; the
     // pairs meet through memory (system scope) behind a second counter (ticket[0]) whose last arrival merges them in block
@@ -1055,6 +1064,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
     float* const pairs = reinterpret_cast<float*>(ta.ticket + 16);          // [8][2] behind the 16 counters
     if (threadIdx.x < 64) {                                    // wave 0 wrote this tile's partial logits
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TNN_AR_TRACE
+        if (threadIdx.x == 0 && blockIdx.x < 128) g_fh_trace[blockIdx.x * 8 + 2] = wall_clock64();
+#endif
         if (threadIdx.x == 0) {
             const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = prev == cnt - 1 ? 1 : 0;
@@ -1063,9 +1075,15 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
         }
     }
     __syncthreads();
+#ifdef TNN_AR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 128) { g_fh_trace[blockIdx.x * 8 + 3] = wall_clock64(); g_fh_trace[blockIdx.x * 8 + 6] = is_last; }
+#endif
     if (!is_last) return;
     float M, S;
     head_tail_stats<10, 8>(ta, 128 * rb, min(ta.m, 128 * rb + 128), zs, ys, dred, M, S);
+#ifdef TNN_AR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 128) g_fh_trace[blockIdx.x * 8 + 4] = wall_clock64();
+#endif
     if (nb > 1) {
         __syncthreads();                                       // is_last is about to be reused
         if (threadIdx.x == 0) {
@@ -1089,6 +1107,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
         }
     }
     head_tail_finish(ta, ctx, M, S);
+#ifdef TNN_AR_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 128) g_fh_trace[blockIdx.x * 8 + 5] = wall_clock64();
+#endif
 }
 
 // Forward of the hidden layer in front of a classifier head for batches of MORE than 128 rows on one GPU, ROW-PANEL form:
@@ -2065,6 +2086,11 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
 }
 
 #ifdef TNN_AR_TRACE
+__attribute__((visibility("default"))) int tnn_debug_fh_trace(unsigned long long* out, int n) {
+    TNN_CHECK_HIP(hipDeviceSynchronize());
+    TNN_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fh_trace), (size_t)std::min(n, 1024) * 8));
+    return 0;
+}
 __attribute__((visibility("default"))) int tnn_debug_ar_trace(unsigned long long* out, int n) {
     TNN_CHECK_HIP(hipDeviceSynchronize());
     TNN_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ar_trace), (size_t)std::min(n, 4096) * 8));

@@ -28,12 +28,17 @@ lib = _lib.get()
 fn = lib.cdll.tnn_debug_ar_trace
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros(4096, dtype=np.uint64)
-acc = []
+fh = lib.cdll.tnn_debug_fh_trace
+fh.argtypes = [ctypes.c_void_p, ctypes.c_int]
+fbuf = np.zeros(1024, dtype=np.uint64)
+acc, facc = [], []
 for it in range(40):
     t.step(x, y)
     if it >= 20:
         assert fn(buf.ctypes.data, 4096) == 0
         acc.append(buf.reshape(1024, 4).astype(np.int64).copy())
+        assert fh(fbuf.ctypes.data, 1024) == 0
+        facc.append(fbuf.reshape(128, 8).astype(np.int64).copy())
 n_dw, P = 784, 128
 tr = np.stack(acc)                                     # [launch][block][stamp]
 t0 = tr[:, :n_dw + P, 0].min(axis=1)[:, None, None]
@@ -52,3 +57,17 @@ print("polling blocks start       ", q(poll[:, :, 0]))
 print("polling blocks stage A done", q(poll[:, :, 1]))
 print("polling blocks stage B done", q(poll[:, :, 2]))
 print("polling blocks stage C done", q(poll[:, :, 3]))
+
+# the hidden layer's forward + statistics launch (dense_fwd_head_kernel): 64 tile blocks, the last arrival does the tail
+ft = np.stack(facc)[:, :64]
+f0 = ft[:, :, 0].min(axis=1)[:, None]
+rel = lambda k: (ft[:, :, k] - f0) / 100.0
+print("fwd1 tile blocks start        ", q(rel(0)))
+print("fwd1 tile + partial logits    ", q(rel(1)))
+print("fwd1 partial logits acked     ", q(rel(2)))
+print("fwd1 ticket drawn             ", q(rel(3)))
+last = ft[:, :, 6] == 1
+lastrel = lambda k: np.array([(ft[i, last[i], k] - f0[i]) / 100.0 for i in range(ft.shape[0])]).ravel()
+print("fwd1 last block: ticket        med %6.2f" % np.median(lastrel(3)))
+print("fwd1 last block: statistics    med %6.2f" % np.median(lastrel(4)))
+print("fwd1 last block: exchange done med %6.2f" % np.median(lastrel(5)))

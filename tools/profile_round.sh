@@ -16,6 +16,10 @@ python3 bench.py --workload C > $OUT/benchC.json 2>> $OUT/log.txt
 python3 bench.py --workload E > $OUT/benchE.json 2>> $OUT/log.txt
 TNN_FORCE_COMM=1 python3 bench.py --no-cpu-baseline > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
 python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
+# in-kernel wall-clock stamps of the data-parallel step's two communicating launches (debug library: make -C tinynn-autograd_amd/csrc trace)
+if [ -f tinynn-autograd_amd/lib/libtnn_hip_trace.so ]; then
+  TNN_LIB_PATH=$PWD/tinynn-autograd_amd/lib/libtnn_hip_trace.so TNN_FORCE_COMM=1 timeout 200 python3 tools/probes/ar_fused_trace.py < /dev/null 2>> $OUT/log.txt | grep "blocks\|fwd1" > $OUT/dp_step_stamps.txt
+fi
 python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
 SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
 python3 tools/probes/soak.py > $OUT/soak.txt 2>> $OUT/log.txt
