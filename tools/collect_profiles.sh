@@ -23,6 +23,7 @@ cp $S/traffic.json $D/${R}_traffic.json
 cp $S/dp_world1_timeline.txt $D/${R}_dp_world1_timeline.txt
 cp $S/stepA_timeline.txt $D/${R}_stepA_timeline.txt
 cp $S/p2p_latency.txt $D/${R}_p2p_latency.txt
+[ -f $S/p2p_stress.txt ] && cp $S/p2p_stress.txt $D/${R}_p2p_stress.txt
 [ -f $S/dp_step_stamps.txt ] && cp $S/dp_step_stamps.txt $D/${R}_dp_step_stamps.txt
 cp $S/dw_adam_bf16.txt $D/${R}_dw_adam_bf16.txt
 cp $S/gemm_f32_sweep.txt $D/${R}_gemm_f32_sweep.txt

@@ -1,7 +1,10 @@
 """Stress the xGMI peer-to-peer collectives (csrc/tnn_p2p.hip) with W ranks sharing GPU 0: thousands of all-reduces
 of random sizes whose inputs every rank can reproduce, checked BIT-EXACTLY every iteration, interleaved with small
 all-gathers and, every few iterations, un-synchronised bursts (no host sync between calls) so buffer reuse and the
-epoch logic are exercised back to back.
+epoch logic are exercised back to back.  Every third iteration a data-parallel TRAINING step runs in between (the launch
+that carries the first layer's backward, the gradient all-reduce and Adam: it shares the slots and the per-workgroup tags with
+the plain all-reduce), on different rows per rank; afterwards the replicas' parameters must be bit-identical (a checksum of
+their bit patterns, all-gathered).
   python tools/p2p_stress.py --spawn 4 --iters 3000"""
 import argparse
 import os
@@ -31,7 +34,27 @@ def worker(args):
     comm = XgmiCommunicator(rank, world, p2p_bytes=4 << 20)
     rs = np.random.RandomState(99)                       # same stream on every rank
     bad = 0
+    from tinynn_autograd_amd.fused import MLPTrainer
+    widths, rows = [784, 256, 128, 10], 64
+    init = [{"w": rs.uniform(-0.1, 0.1, (a, b)).astype(np.float32), "b": rs.uniform(-0.1, 0.1, (1, b)).astype(np.float32)}
+            for a, b in zip(widths[:-1], widths[1:])]
+    trainer = MLPTrainer(widths, rows, loss="softmax_nll", optimizer="adam", lr=1e-3, comm=comm, force_dp=True)
+    trainer.set_parameters(init)
+    rows_rng = np.random.RandomState(1000 + rank)        # this rank's rows
+    steps = 0
     for it in range(args.iters):
+        if it % 3 == 0:
+            x = tn.asarray(rows_rng.uniform(-1, 1, (rows, widths[0])).astype(np.float32))
+            y = tn.asarray(np.eye(10, dtype=np.float32)[rows_rng.randint(0, 10, rows)])
+            trainer.step(x, y)
+            steps += 1
+            if it % 30 == 0:
+                p = np.asarray(trainer.flat_parameters())
+                h = int(np.ascontiguousarray(p).view(np.uint32).astype(np.uint64).sum())       # checksum of the bit patterns
+                words = tn.asarray(np.array([(h >> (16 * k)) & 0xffff for k in range(4)], np.float32))
+                got = np.asarray(comm.allgather(words))
+                if not (got == got[0]).all() or not np.isfinite(p).all():
+                    bad += 1
         n = int(rs.choice([1, 3, 17, 257, 1000, 4099, 29400, 65536, 235147, 500001, 1 << 20]))
         burst = 1 + int(rs.randint(0, 4)) if it % 5 == 0 else 1
         bufs, wants = [], []
@@ -56,7 +79,8 @@ def worker(args):
     st = comm.p2p_status()
     comm.barrier()
     comm.close()
-    print("rank %d/%d: %d iterations, %d mismatches, dead=%s" % (rank, world, args.iters, bad, st["dead"]), flush=True)
+    print("rank %d/%d: %d iterations (%d training steps in between), %d mismatches, dead=%s" % (rank, world, args.iters, steps, bad,
+                                                                                             st["dead"]), flush=True)
     sys.exit(1 if bad or st["dead"] else 0)
 
 

@@ -16,6 +16,7 @@ python3 bench.py --workload C > $OUT/benchC.json 2>> $OUT/log.txt
 python3 bench.py --workload E > $OUT/benchE.json 2>> $OUT/log.txt
 TNN_FORCE_COMM=1 python3 bench.py --no-cpu-baseline > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
 python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
+for w in 2 4 8; do timeout 400 python3 tools/p2p_stress.py --spawn $w --iters 1500 < /dev/null 2>> $OUT/log.txt | grep "^rank" >> $OUT/p2p_stress.txt; done
 # in-kernel wall-clock stamps of the data-parallel step's two communicating launches (debug library: make -C tinynn-autograd_amd/csrc trace)
 if [ -f tinynn-autograd_amd/lib/libtnn_hip_trace.so ]; then
   TNN_LIB_PATH=$PWD/tinynn-autograd_amd/lib/libtnn_hip_trace.so TNN_FORCE_COMM=1 timeout 200 python3 tools/probes/ar_fused_trace.py < /dev/null 2>> $OUT/log.txt | grep "blocks\|fwd1" > $OUT/dp_step_stamps.txt
