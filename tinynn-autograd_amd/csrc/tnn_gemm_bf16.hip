@@ -650,7 +650,7 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
                 g.splitk = S;
                 g.sk_ws = w.slabs;
                 g.sk_cnt = w.counters;
-                hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<SK_BN, 4, 2, 3, SK_NSB, S>), dim3((unsigned)(t256 * S)), 512, 0,
+                hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<SK_BN, 4, 2, 3, SK_NSB, S, 0, 1>), dim3((unsigned)(t256 * S)), 512, 0,
                                    tnn::stream(), g);
                 TNN_LAUNCH_OK();
                 return 0;

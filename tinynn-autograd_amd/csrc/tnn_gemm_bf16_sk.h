@@ -6,6 +6,8 @@
 // ring depth and occupancy all landed within 1 % of each other — the operand stream INTO the CU bounds the
 // shape.  A 256 x 256 tile halves the bytes per flop; to still fill 256 CUs the K range is split over S workgroups per tile
 // (64 tiles x 4 slices) and the fp32 partial tiles are combined inside the launch:
+// (S = 2, the shipped form, hands over SYMMETRICALLY — each partner finishes half the rows; see SYM at the kernel.  The ticket
+// protocol below is the general one: any S, no assumption that a partner is running.)
 //   * every workgroup draws an arrival ticket for its tile when its K loop is done;
 //   * tickets 0 .. S-2 store their accumulators as a slab (register order: float4 i of thread t at [i][t] — every store
 //     instruction writes 1 KB contiguous; write-through `sc1` so no L2 write-back fence is needed), drain, and bump the
@@ -53,7 +55,15 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // 8 = no fragment reads in the loop, 16 = no barrier in the loop, 32 = timestamps (s_memtime: shader cycles; s_memrealtime:
 // 100 MHz) at kernel entry / loop entry / loop exit / kernel exit / end of the slab exchange into g.sk_trace[10 * block]
 // 128 = one K-tile per loop trip; 64 = B addressed as if stored tile-major ([n-tile][k-tile][BN][64] contiguous 16/32 KB blocks; wrong data, right byte count)
-template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0>
+// SYM (S == 2): the SYMMETRIC hand-off — instead of one partner publishing its whole partial tile and the other adding it and
+// running the whole epilogue, each of the two workgroups keeps the accumulator blocks of HALF the rows (slice s: the blocks
+// mi with mi / (MI / 2) == s), publishes the other half, waits for the partner's flag, adds what it received (p0 + p1:
+// the same bits whichever side adds) and finishes its half of the output tile: half the slab bytes per workgroup, both
+// directions in flight at once, half an epilogue each.  The two flags of a tile count launches in lockstep (own flag + 1 is the
+// value to wait for in the partner's): nothing is ever reset.  Unlike the ticket protocol each side waits for a workgroup
+// that may not have FINISHED its K loop yet; it has been dispatched, though — the partners are adjacent block indices — so the
+// wait ends unless the device stops running dispatched workgroups (bounded spin, as everywhere).
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0, int SYM = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     constexpr int BM = 256, ROWB = 128, KK = 4;
     constexpr int A_TILE_B = BM * ROWB, B_TILE_B = BN * ROWB;
@@ -269,7 +279,62 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     }
 
     // ---- split-K exchange
-    if constexpr (S > 1 && (ABL & 4) == 0) {
+    static_assert(!SYM || (S == 2 && MI % 2 == 0), "the symmetric hand-off pairs two slices and splits the row blocks in two");
+    constexpr int MH = SYM ? MI / 2 : MI;                  // accumulator row blocks this workgroup finishes ...
+    const int mi0 = SYM ? slice * MH : 0;                  // ... starting at this one
+    if constexpr (SYM && (ABL & 4) == 0) {
+        gu32* flag = (gu32*)(g.sk_cnt + 2 * tile);
+        const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.sk_ws + (int64_t)tile * S * (BM * BN), 0, 0xffffffffu, 0x00020000);
+        constexpr uint32_t SLAB_B = BM * BN * 4;
+        const int give0 = (1 - slice) * MH;               // first row block of the half the partner finishes
+        const uint32_t base = (uint32_t)slice * SLAB_B + (uint32_t)tid * 16;
+#pragma unroll
+        for (int i = 0; i < MH; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = (i * NI + j) * 4 + q;
+                    // both halves are read with compile-time indices (a run-time block index spills the accumulators)
+                    const f32x4 lo = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    const f32x4 hi = {acc[MH + i][j][4 * q], acc[MH + i][j][4 * q + 1], acc[MH + i][j][4 * q + 2], acc[MH + i][j][4 * q + 3]};
+                    const u32x4 v = __builtin_bit_cast(u32x4, give0 == 0 ? lo : hi);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ws_rsrc, base + (uint32_t)ch * 8192, 0, 16 /* sc1: write-through */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned mine = __hip_atomic_load(flag + slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            __hip_atomic_store(flag + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(flag + (1 - slice), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mine) < 0 && ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        constexpr int NCHH = MH * NI * 4, CB = 4;
+#pragma unroll
+        for (int c0 = 0; c0 < NCHH; c0 += CB) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 in[CB];
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                in[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            ws_rsrc, (uint32_t)tid * 16 + (uint32_t)(c0 + c) * 8192, (uint32_t)(1 - slice) * SLAB_B, 16 /* sc1 */));
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int ch = c0 + c, i = ch / (NI * 4), j = (ch / 4) % NI, q = ch % 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // p0 + p1 on both sides (IEEE addition commutes: the same bits)
+                    if (slice == 0) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] + in[c][e];
+                    else acc[MH + i][j][4 * q + e] = in[c][e] + acc[MH + i][j][4 * q + e];
+                }
+            }
+        }
+    }
+    if constexpr (S > 1 && !SYM && (ABL & 4) == 0) {
         gu32* cnt = (gu32*)(g.sk_cnt + 2 * tile);
         unsigned* bcast = reinterpret_cast<unsigned*>(lds);
         __syncthreads();                                  // every wave is done with the ring
@@ -370,9 +435,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
         constexpr int IMG_ROWB = BN * 2;
         static_assert(BM * IMG_ROWB <= LDS_B, "the output image lives in the ring");
         __syncthreads();                                    // every wave is done with the ring
+        // (SYM: the image holds this workgroup's half of the rows only, compactly: wave row wm's MH * 32 rows at wm * MH * 32)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int row = wm * TM + mi * 32 + l31;
+            if (SYM && (mi / MH) * MH != mi0) continue;     // block-uniform
+            const int row = wm * (MH * 32) + (mi % MH) * 32 + l31;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -394,13 +461,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
         }
         __syncthreads();
         constexpr int PPR = BN / 8;                          // 16-B pieces per row
-        constexpr int PIECES = BM * PPR / 512;               // per thread
+        constexpr int PIECES = (BM / (SYM ? 2 : 1)) * PPR / 512;     // per thread
         bf16_t* cout = reinterpret_cast<bf16_t*>(g.C);
 #pragma unroll
         for (int it = 0; it < PIECES; ++it) {
-            const int p = tid + it * 512, row = p / PPR, j = p % PPR;
-            u32x4 v = *reinterpret_cast<const u32x4*>(lds + row * IMG_ROWB + ((j ^ ((row & 15) >> 1)) << 4));
-            if (row & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // odd rows: the two 8-B slots of the pair are swapped
+            const int p = tid + it * 512, irow = p / PPR, j = p % PPR;        // irow: row of the image
+            const int row = (irow / (MH * 32)) * TM + mi0 * 32 + irow % (MH * 32);      // row of the tile
+            u32x4 v = *reinterpret_cast<const u32x4*>(lds + irow * IMG_ROWB + ((j ^ ((irow & 15) >> 1)) << 4));
+            if (irow & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // odd rows: the two 8-B slots of the pair are swapped
             if (g.epi == BEPI_MASK) {
                 const u32x4 y = *reinterpret_cast<const u32x4*>(g.Y + (m0 + row) * g.ldy + n0 + 8 * j);
 #pragma unroll
@@ -421,6 +489,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
                          (g.epi != BEPI_MASK || (g.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 7) == 0));
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        if (SYM && (mi / MH) * MH != mi0) continue;         // the partner finishes the other half
         const int64_t row = m0 + wm * TM + mi * 32 + l31;
         if (row >= g.M) continue;
 #pragma unroll

@@ -201,17 +201,20 @@ void run_variant(const char* name, Ctx& c, F launch, bool check) {
     fflush(stdout);
 }
 
-template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL>
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL, int SYM = 0>
 void sk_variant(const char* name, Ctx& c, bool check) {
     auto launch = [&](int b) {
         BfArgs g = base_args(c, b);
         g.tiles_m = (c.M + 255) / 256;
         g.tiles_n = (c.N + BN - 1) / BN;
         g.splitk = S;
-        hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<BN, WM, WN, NSA, NSB, S, ABL>), dim3(g.tiles_m * g.tiles_n * S), 512, 0, 0, g);
+        if (SYM) g.sk_cnt = c.cnt + 2048;      // the symmetric hand-off's flags count launches; the ticket protocol's words return to zero
+        hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<BN, WM, WN, NSA, NSB, S, ABL, SYM>), dim3(g.tiles_m * g.tiles_n * S), 512, 0, 0, g);
     };
     run_variant(name, c, launch, check && ABL == 0);
     if constexpr ((ABL & 32) != 0) {
+        for (int i = 0; i < 4; ++i) launch(i % (int)c.B.size());
+        CK(hipDeviceSynchronize());
         // the last launch's timestamps: medians over the workgroups of {prologue, K loop, tail} in shader cycles and in us
         const int nb = ((c.M + 255) / 256) * ((c.N + BN - 1) / BN) * S;
         std::vector<unsigned long long> t((size_t)nb * 10);
@@ -306,8 +309,10 @@ int main(int argc, char** argv) {
     }
     //            BN  WM WN NSA NSB S ABL          ABL bits: 1 no MFMA, 2 no refill DMA, 4 no exchange, 8 no frag reads, 16 no barrier, 32 trace,
     //                                              64 B addressed tile-major (timing only), 128 one K-tile per loop trip
-    sk_variant<128, 4, 2, 3, 4, 2, 0>("sk 256x128 S2 A3 B4 (shipped)", c, true);
-    sk_variant<128, 4, 2, 3, 4, 2, 32>("sk 256x128 S2 A3 B4 [traced]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1>("sk 256x128 S2 A3 B4 symmetric hand-off", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 32, 1>("sk 256x128 S2 A3 B4 symmetric [traced]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 0>("sk 256x128 S2 A3 B4 ticket hand-off", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 32>("sk 256x128 S2 A3 B4 ticket [traced]", c, false);
     sk_variant<128, 4, 2, 3, 4, 2, 128>("sk 256x128 S2 A3 B4 [one K-tile per trip]", c, true);
     sk_variant<128, 4, 2, 3, 3, 2, 0>("sk 256x128 S2 A3 B3", c, true);
     sk_variant<128, 4, 2, 2, 4, 2, 0>("sk 256x128 S2 A2 B4", c, true);
