@@ -9,43 +9,43 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${R}prof
 mkdir -p $OUT
-run() { echo "== $*" >> $OUT/log.txt; "$@" >> $OUT/log.txt 2>&1; echo "rc=$?" >> $OUT/log.txt; }
+run() { echo "== $*" >> $OUT/log.txt; timeout 900 "$@" >> $OUT/log.txt 2>&1 < /dev/null; echo "rc=$?" >> $OUT/log.txt; }
 
-python3 bench.py --steps 20 --warmup 5 > $OUT/benchA.json 2>> $OUT/log.txt
-python3 bench.py --workload C > $OUT/benchC.json 2>> $OUT/log.txt
-python3 bench.py --workload E > $OUT/benchE.json 2>> $OUT/log.txt
-TNN_FORCE_COMM=1 python3 bench.py --no-cpu-baseline > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
-python3 tools/p2p_bench.py > $OUT/p2p_latency.txt 2>> $OUT/log.txt
+timeout 900 python3 bench.py --steps 20 --warmup 5 < /dev/null > $OUT/benchA.json 2>> $OUT/log.txt
+timeout 900 python3 bench.py --workload C < /dev/null > $OUT/benchC.json 2>> $OUT/log.txt
+timeout 900 python3 bench.py --workload E < /dev/null > $OUT/benchE.json 2>> $OUT/log.txt
+TNN_FORCE_COMM=1 timeout 900 python3 bench.py --no-cpu-baseline < /dev/null > $OUT/benchA_dp_world1.json 2>> $OUT/log.txt
+timeout 900 python3 tools/p2p_bench.py < /dev/null > $OUT/p2p_latency.txt 2>> $OUT/log.txt
 for w in 2 4 8; do timeout 400 python3 tools/p2p_stress.py --spawn $w --iters 1500 < /dev/null 2>> $OUT/log.txt | grep "^rank" >> $OUT/p2p_stress.txt; done
 # in-kernel wall-clock stamps of the data-parallel step's two communicating launches (debug library: make -C tinynn-autograd_amd/csrc trace)
 if [ -f tinynn-autograd_amd/lib/libtnn_hip_trace.so ]; then
   TNN_LIB_PATH=$PWD/tinynn-autograd_amd/lib/libtnn_hip_trace.so TNN_FORCE_COMM=1 timeout 200 python3 tools/probes/ar_fused_trace.py < /dev/null 2>> $OUT/log.txt | grep "blocks\|fwd1" > $OUT/dp_step_stamps.txt
 fi
-python3 tools/probes/dw_adam.py > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
-SWEEP_SPLITK=1 python3 tools/gemm_sweep.py > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
-python3 tools/probes/soak.py > $OUT/soak.txt 2>> $OUT/log.txt
-python3 tools/probes/soak_e.py > $OUT/soak_e.txt 2>> $OUT/log.txt
-python3 tools/probes/eager_phases.py > $OUT/eager_phases.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/dw_adam.py < /dev/null > $OUT/dw_adam_bf16.txt 2>> $OUT/log.txt
+SWEEP_SPLITK=1 timeout 900 python3 tools/gemm_sweep.py < /dev/null > $OUT/gemm_f32_sweep.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/soak.py < /dev/null > $OUT/soak.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/soak_e.py < /dev/null > $OUT/soak_e.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/eager_phases.py < /dev/null > $OUT/eager_phases.txt 2>> $OUT/log.txt
 # round 4: the skinny bf16 GEMM's variants / ablations / timelines, the box probe, the counter calibration
-tools/probes/bin/gemm_bf16_sk_probe > $OUT/gemm_bf16_sk_probe.txt 2>> $OUT/log.txt
-python3 -c "
+timeout 900 tools/probes/bin/gemm_bf16_sk_probe < /dev/null > $OUT/gemm_bf16_sk_probe.txt 2>> $OUT/log.txt
+timeout 900 python3 -c "
 import json
 from tinynn_autograd_amd import _lib
-for i in range(3): print(json.dumps(_lib.box_probe()))" > $OUT/box_probe.txt 2>> $OUT/log.txt
-python3 tools/probes/gemm_f32_data_ab.py > $OUT/gemm_f32_data_ab.txt 2>> $OUT/log.txt
+for i in range(3): print(json.dumps(_lib.box_probe()))" < /dev/null > $OUT/box_probe.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/gemm_f32_data_ab.py < /dev/null > $OUT/gemm_f32_data_ab.txt 2>> $OUT/log.txt
 mkdir -p $OUT/cal
-tools/probes/bin/fetch_calibration > $OUT/cal/known.txt 2>> $OUT/log.txt
+timeout 900 tools/probes/bin/fetch_calibration < /dev/null > $OUT/cal/known.txt 2>> $OUT/log.txt
 run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal -- tools/probes/bin/fetch_calibration
 run rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/cal/write -o cal -- tools/probes/bin/fetch_calibration
-python3 tools/fetch_calibration.py $OUT/cal/known.txt $(find $OUT/cal/fetch -name "*.db" | head -1) $(find $OUT/cal/write -name "*.db" | head -1) > $OUT/fetch_calibration.txt 2>> $OUT/log.txt
-TNN_HOST_COMPILED=0 python3 tools/probes/eager_phases.py >> $OUT/eager_phases.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/fetch_calibration.py $OUT/cal/known.txt $(find $OUT/cal/fetch -name "*.db" | head -1) $(find $OUT/cal/write -name "*.db" | head -1) < /dev/null > $OUT/fetch_calibration.txt 2>> $OUT/log.txt
+TNN_HOST_COMPILED=0 timeout 900 python3 tools/probes/eager_phases.py < /dev/null >> $OUT/eager_phases.txt 2>> $OUT/log.txt
 
 run rocprofv3 --kernel-trace --stats -d $OUT/ktA -o A -- python3 bench.py --steps 20 --warmup 5
 run rocprofv3 --kernel-trace --stats -d $OUT/ktAstep -o Astep -- python3 bench.py --no-extras --steps 2000 --warmup 64
 run rocprofv3 --kernel-trace --stats -d $OUT/ktC -o C -- python3 bench.py --workload C --no-cpu-baseline
 run rocprofv3 --kernel-trace --stats -d $OUT/ktE -o E -- python3 bench.py --workload E
 # the data-parallel step at world 1 (RCCL leg first, then the peer-to-peer leg) and the single-GPU step: duration + gap per launch
-TNN_FORCE_COMM=1 rocprofv3 --kernel-trace -d $OUT/ktDP -o dp -- python3 bench.py --no-extras --no-cpu-baseline --steps 2000 --warmup 64 >> $OUT/log.txt 2>&1
+TNN_FORCE_COMM=1 timeout 900 rocprofv3 --kernel-trace -d $OUT/ktDP -o dp -- python3 bench.py --no-extras --no-cpu-baseline --steps 2000 --warmup 64 >> $OUT/log.txt 2>&1 < /dev/null
 
 run rocprofv3 --kernel-trace -d $OUT/kt256 -o r256 -- python3 bench.py --rows 256 --no-extras --no-cpu-baseline --steps 2000 --warmup 64
 
@@ -78,7 +78,7 @@ done
 fa=$(find $OUT/pmcA_fetch -name "*.db" | head -1); wa=$(find $OUT/pmcA_write -name "*.db" | head -1)
 fc=$(find $OUT/pmcC_fetch -name "*.db" | head -1); wc=$(find $OUT/pmcC_write -name "*.db" | head -1)
 fe=$(find $OUT/pmcE_fetch -name "*.db" | head -1); we=$(find $OUT/pmcE_write -name "*.db" | head -1)
-python3 tools/traffic_from_pmc.py --round $R A:$fa:$wa C:$fc:$wc E:$fe:$we > $OUT/traffic.json 2>> $OUT/log.txt
+timeout 900 python3 tools/traffic_from_pmc.py --round $R A:$fa:$wa C:$fc:$wc E:$fe:$we < /dev/null > $OUT/traffic.json 2>> $OUT/log.txt
 # the databases themselves are large: keep only the summaries in what gpurun merges back
 find $OUT -name "*.db" -size +20M -delete
 tail -5 $OUT/log.txt
