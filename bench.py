@@ -224,7 +224,7 @@ def time_gemms_bf16(widths, rows, reps=10):
     achieved = tot_flops / tot_us / 1e6
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "gemm_bf16_dma_kernel (v_mfma_f32_32x32x16_bf16, fp32 accumulate, LDS-DMA operand ring)",
+            "kernel": "sk::gemm_bf16_sk_kernel (256 x 128 tiles, K split over two workgroups, hand-off inside the launch) for the 512-row products, gemm_bf16_dma_kernel (128 x 128) for the dW shape; v_mfma_f32_32x32x16_bf16, fp32 accumulate, LDS-DMA operand rings",
             "operands": "%d sets per shape used in turn (weights come from HBM as in the step); *_same_operands: one set re-used" % rot,
             "algorithmic_gflop_per_step": round(tot_flops / 1e9, 2), "gemm_us_per_step": round(tot_us, 1),
             "per_gemm": results}
