@@ -38,7 +38,8 @@ struct Peers {
 
 // A barrier timed out: the sticky device word stops every later wait, the host mirror lets the next host-side call fail
 // loudly (tnn_p2p.hip: p2p_failed) instead of running on partial sums.
-// `why` (non-zero) says which wait gave up — 1: a flag barrier of a collective, 2: the tagged {max, sum-exp} exchange;
+// `why` (non-zero) says which wait gave up — 1: a flag barrier / tagged poll of a collective, 2: the tagged {max, sum-exp} exchange,
+// 3: a polling workgroup's gate (producer workgroups of its OWN launch that never arrived: allreduce_body);
 // tnn_p2p_status reports the word as it is.
 // The host mirror is 16 ints: [0] the word, [1..4] what the FIRST wait that gave up was looking at (expected value, last
 // value seen, peer / workgroup, a wait-specific detail) — tnn_p2p_debug reads them without a stream sync.
