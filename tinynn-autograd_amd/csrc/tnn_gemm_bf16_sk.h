@@ -63,9 +63,23 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // value to wait for in the partner's): nothing is ever reset.  Unlike the ticket protocol each side waits for a workgroup
 // that may not have FINISHED its K loop yet; it has been dispatched, though — the partners are adjacent block indices — so the
 // wait ends unless the device stops running dispatched workgroups (bounded spin, as everywhere).
-template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0, int SYM = 0>
+// BNC: the B operand is given N-CONTIGUOUS — B [K][ldb], element (k, n) — instead of K-contiguous ([N][ldb]): C = A B, the
+// forward product z = a W with W stored [in][out] as the dX product wants it, so that ONE bf16 weight copy serves both
+// (core/ops.py:151 and :157).  LDS-DMA cannot transpose (the image is lane-linear), so the K-tile lands as it is stored —
+// 64 k-rows of BN x 2 = 256 B, four rows per DMA instruction, whole rows per 16 lanes — and the MFMA fragment (8 consecutive
+// k of one column per lane) is gathered by `ds_read_b64_tr_b16`: each 16-lane group hands in 16 addresses of 4 consecutive n
+// (4 k-rows x 16 columns) and gets back, per lane, one column's 4 k — two reads per fragment instead of one ds_read_b128,
+// the same bytes.  Bank conflicts: the 4 k-rows of a group are 256 B = one whole bank cycle apart, so 16-B chunk c of row k
+// lives at chunk c ^ ((k & 3) << 2): the 2 x 4 chunk pairs that the two groups of a 32-lane half touch are then all
+// different.
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0, int SYM = 0, int BNC = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     constexpr int BM = 256, ROWB = 128, KK = 4;
+    static_assert(!BNC || BN == 128, "the n-contiguous B image is laid out for 16 chunks per k-row");
+    // (probe builds, timing without meaning: BNC = 2 takes the n-contiguous DMA with the k-contiguous fragment reads, 3 the reverse)
+    // (4: k-contiguous DMA + tr reads addressed as [k/32][n/16][32][16] subtiles; 5: the DMA that would build those subtiles — each
+    // instruction gathers 32 k-rows x 32 B — + k-contiguous reads)
+    constexpr bool BNC_DMA = BNC == 1 || BNC == 2, BNC_READ = BNC == 1 || BNC == 3 || BNC == 4 || BNC == 6, BNC_SUBT = BNC == 4, BNC_SUBD = BNC == 5;   // 6: as 3 with plain ds_read_b64
     constexpr int A_TILE_B = BM * ROWB, B_TILE_B = BN * ROWB;
     constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
     constexpr int DJA = BM / 64, DJB = BN / 64;          // DMA instructions per wave, operand and K-tile (1 KB each)
@@ -125,11 +139,26 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     }
 #pragma unroll
     for (int j = 0; j < DJB; ++j) {
-        const int row = 8 * (wid + 8 * j) + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t gn = n0 + row;
-        b_voff[j] = (uint32_t)(((gn < g.N ? gn : 0) * g.ldb + chunk * 8) * 2);
-        if constexpr ((ABL & 64) != 0) b_voff[j] = (uint32_t)((row * 64 + chunk * 8) * 2);
+        if constexpr (BNC_SUBD) {
+            // instruction gi = subtile (k-half gi / 8, n-block gi % 8): lane L loads 16 B of k-row 32 (gi / 8) + L / 2, columns
+            // 16 (gi % 8) + 8 (L % 2)
+            const int gi = wid + 8 * j, krow = 32 * (gi / 8) + (lane >> 1);
+            const int64_t gn = n0 + 16 * (gi % 8) + 8 * (lane & 1);
+            b_voff[j] = (uint32_t)(((int64_t)krow * g.ldb + (gn < g.N ? gn : 0)) * 2);
+        } else if constexpr (BNC_DMA) {
+            // instruction gi fills k-rows 4 gi .. 4 gi + 3 of the tile (256 B each); lane L writes physical chunk L % 16 of row
+            // 4 gi + L / 16 and therefore LOADS logical chunk (L % 16) ^ ((row & 3) << 2) of that row
+            const int krow = 4 * (wid + 8 * j) + (lane >> 4), chunk = (lane & 15) ^ ((krow & 3) << 2);
+            const int64_t gn = n0 + chunk * 8;
+            b_voff[j] = (uint32_t)(((int64_t)krow * g.ldb + (gn < g.N ? gn : 0)) * 2);
+        } else {
+            const int row = 8 * (wid + 8 * j) + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int64_t gn = n0 + row;
+            b_voff[j] = (uint32_t)(((gn < g.N ? gn : 0) * g.ldb + chunk * 8) * 2);
+            if constexpr ((ABL & 64) != 0) b_voff[j] = (uint32_t)((row * 64 + chunk * 8) * 2);
+        }
     }
+    const uint32_t b_ktile_bytes = (BNC_DMA || BNC_SUBD) ? (uint32_t)(64 * g.ldb * 2) : (uint32_t)ROWB;      // B's byte step per K-tile
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, 0xffffffffu, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.B), 0, 0xffffffffu, 0x00020000);
     char* const a_ring = lds;
@@ -141,6 +170,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
         if constexpr ((ABL & 64) != 0) {
             const uint32_t blk = (uint32_t)(tile / g.tiles_m) * (uint32_t)(g.K / 64) + (uint32_t)slice * nk + (uint32_t)kt;
             dma16(b_rsrc, b_ring + slot * B_TILE_B + (wid + 8 * j) * 1024, b_voff[j], blk * (uint32_t)B_TILE_B);
+            return;
+        }
+        if constexpr (BNC_DMA || BNC_SUBD) {
+            dma16(b_rsrc, b_ring + slot * B_TILE_B + (wid + 8 * j) * 1024, b_voff[j], ((uint32_t)slice * (uint32_t)nk + (uint32_t)kt) * b_ktile_bytes);
             return;
         }
         dma16(b_rsrc, b_ring + slot * B_TILE_B + (wid + 8 * j) * 1024, b_voff[j], k_byte0 + (uint32_t)kt * ROWB);
@@ -162,13 +195,45 @@ __global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
     for (int kk = 0; kk < KK; ++kk) foff[kk] = ((2 * kk + lhi) ^ swz) * 16;
     const int a_base = (wm * TM + l31) * ROWB;
     const int b_base = (wn * TN + l31) * ROWB;
+    // BNC: group g16 = lane >> 4 covers columns 16 (g16 & 1) .. + 15 and k 8 (g16 >> 1) .. + 7 of a 32-column, 16-deep block; lane
+    // p = lane & 15 of the group hands in the address of 4 consecutive n at k-row p >> 2 (second read: + 4 rows)
+    constexpr int RB = BN * 2;                            // bytes per k-row of the n-contiguous image
+    const int g16 = lane >> 4, p16 = lane & 15;
+    const int btr_row = (8 * (g16 >> 1) + (p16 >> 2)) * RB, btr_sz = ((p16 >> 2) & 3) << 2;
+    int btr_col[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = wn * TN + j * 32 + 16 * (g16 & 1) + 4 * (p16 & 3);
+        btr_col[j] = (((n >> 3) ^ btr_sz) << 4) + (n & 7) * 2;
+    }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
     bf16x8 fa[2][MI], fb[2][NI];
     auto read_frag = [&](int set, const char* a_st, const char* b_st, int kk, bool in_loop = true) {
         if ((ABL & 8) != 0 && in_loop) return;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-            fb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_st + b_base + j * 32 * ROWB + foff[kk]));
+        for (int j = 0; j < NI; ++j) {
+            if constexpr (BNC_READ) {
+                // (BNC_SUBT: subtile (k / 32, n / 16) at 1 KB each, rows 32 B apart, odd n-blocks with their rows rotated by 4)
+                const int nb = (wn * TN + j * 32) / 16 + (g16 & 1);
+                const int k0 = kk * 16 + 8 * (g16 >> 1) + (p16 >> 2);
+                const char* q = BNC_SUBT ? b_st + ((k0 / 32) * 8 + nb) * 1024 + (((k0 % 32) ^ (4 * (nb & 1))) * 32) + (p16 & 3) * 8
+                                         : b_st + btr_row + kk * 16 * RB + btr_col[j];
+                s16x4 lo, hi;
+                if constexpr (BNC == 6) {
+                    lo = *reinterpret_cast<const s16x4*>(q);
+                    hi = *reinterpret_cast<const s16x4*>(q + 4 * RB);
+                } else {
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(BNC_SUBT ? q + 4 * 32 : q + 4 * RB));
+                }
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                fb[set][j] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            } else {
+                fb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_st + b_base + j * 32 * ROWB + foff[kk]));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
             fa[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_st + a_base + i * 32 * ROWB + foff[kk]));

@@ -77,6 +77,7 @@ struct Ctx {
     int M = 512, N = 8192, K = 8192;
     bf16_t* A = nullptr;
     std::vector<bf16_t*> B;
+    std::vector<bf16_t*> Bt;             // the same matrices stored [K][N] (n-contiguous) for the BNC variants
     bf16_t* C = nullptr;
     float* ref = nullptr;
     float* ws = nullptr;
@@ -201,15 +202,22 @@ void run_variant(const char* name, Ctx& c, F launch, bool check) {
     fflush(stdout);
 }
 
-template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL, int SYM = 0>
+__global__ void transpose_probe_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols) {
+    // dst[c][r] = src[r][c] (set-up only)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)rows * cols) { const int r = (int)(i / cols), cc = (int)(i % cols); dst[(int64_t)cc * rows + r] = src[i]; }
+}
+
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL, int SYM = 0, int BNC = 0>
 void sk_variant(const char* name, Ctx& c, bool check) {
     auto launch = [&](int b) {
         BfArgs g = base_args(c, b);
+        if (BNC == 1 || BNC == 2 || BNC == 5) { g.B = c.Bt[b]; g.ldb = c.N; }
         g.tiles_m = (c.M + 255) / 256;
         g.tiles_n = (c.N + BN - 1) / BN;
         g.splitk = S;
         if (SYM) g.sk_cnt = c.cnt + 2048;      // the symmetric hand-off's flags count launches; the ticket protocol's words return to zero
-        hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<BN, WM, WN, NSA, NSB, S, ABL, SYM>), dim3(g.tiles_m * g.tiles_n * S), 512, 0, 0, g);
+        hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<BN, WM, WN, NSA, NSB, S, ABL, SYM, BNC>), dim3(g.tiles_m * g.tiles_n * S), 512, 0, 0, g);
     };
     run_variant(name, c, launch, check && ABL == 0);
     if constexpr ((ABL & 32) != 0) {
@@ -261,6 +269,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&c.trace, 4096 * 10 * 8));
     fill_kernel<<<2048, 256>>>(c.A, (int64_t)c.M * c.K, 0x1234u);
     for (int i = 0; i < NB; ++i) fill_kernel<<<2048, 256>>>(c.B[i], (int64_t)c.N * c.K, 0x9e37u + 77u * i);
+    c.Bt.resize(NB);
+    for (int i = 0; i < NB; ++i) {
+        CK(hipMalloc(&c.Bt[i], (size_t)c.N * c.K * 2));
+        transpose_probe_kernel<<<(unsigned)(((int64_t)c.N * c.K + 255) / 256), 256>>>(c.B[i], c.Bt[i], c.N, c.K);
+    }
     ref_kernel<<<dim3((c.N + 255) / 256, c.M), 256>>>(c.A, c.B[0], c.ref, c.M, c.N, c.K);
     CK(hipDeviceSynchronize());
     c.h_ref.resize((size_t)c.M * c.N);
@@ -310,6 +323,12 @@ int main(int argc, char** argv) {
     //            BN  WM WN NSA NSB S ABL          ABL bits: 1 no MFMA, 2 no refill DMA, 4 no exchange, 8 no frag reads, 16 no barrier, 32 trace,
     //                                              64 B addressed tile-major (timing only), 128 one K-tile per loop trip
     sk_variant<128, 4, 2, 3, 4, 2, 0, 1>("sk 256x128 S2 A3 B4 symmetric hand-off", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1, 1>("sk 256x128 S2 A3 B4 symmetric, B n-contiguous (tr reads)", c, true);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1, 2>("  ... n-contiguous DMA, k-contiguous reads [timing only]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1, 3>("  ... k-contiguous DMA, tr reads [timing only]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1, 6>("  ... k-contiguous DMA, the same addresses read with plain ds_read_b64 [timing only]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1, 4>("  ... k-contiguous DMA, tr reads of [32][16] subtiles [timing only]", c, false);
+    sk_variant<128, 4, 2, 3, 4, 2, 0, 1, 5>("  ... subtile-gather DMA (32 rows x 32 B), k-contiguous reads [timing only]", c, false);
     sk_variant<128, 4, 2, 3, 4, 2, 32, 1>("sk 256x128 S2 A3 B4 symmetric [traced]", c, false);
     sk_variant<128, 4, 2, 3, 4, 2, 0>("sk 256x128 S2 A3 B4 ticket hand-off", c, true);
     sk_variant<128, 4, 2, 3, 4, 2, 32>("sk 256x128 S2 A3 B4 ticket [traced]", c, false);
