@@ -71,3 +71,17 @@ lastrel = lambda k: np.array([(ft[i, last[i], k] - f0[i]) / 100.0 for i in range
 print("fwd1 last block: ticket        med %6.2f" % np.median(lastrel(3)))
 print("fwd1 last block: statistics    med %6.2f" % np.median(lastrel(4)))
 print("fwd1 last block: exchange done med %6.2f" % np.median(lastrel(5)))
+
+# which tile blocks are the slow ones?  (mean product-done time per block index over the traced launches)
+import collections
+mean_done = tiles[:, :, 1].mean(axis=0)
+order = np.argsort(mean_done)
+print("slowest tile blocks (index: us):", ", ".join("%d: %.2f" % (i, mean_done[i]) for i in order[-12:]))
+print("fastest tile blocks (index: us):", ", ".join("%d: %.2f" % (i, mean_done[i]) for i in order[:6]))
+byx = collections.defaultdict(list)
+for i in range(n_dw):
+    byx[i % 8].append(mean_done[i])
+print("mean product-done time by block index mod 8 (XCD):", ", ".join("%d: %.2f" % (x, np.mean(byx[x])) for x in range(8)))
+dur = (tiles[:, :, 1] - tiles[:, :, 0]).mean(axis=0)
+print("product duration (start -> done) by position in the grid: first 98 blocks %.2f, middle %.2f, last 98 %.2f" % (
+    dur[:98].mean(), dur[98:-98].mean(), dur[-98:].mean()))
