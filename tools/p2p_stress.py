@@ -5,7 +5,9 @@ epoch logic are exercised back to back.  Every third iteration a data-parallel T
 that carries the first layer's backward, the gradient all-reduce and Adam: it shares the slots and the per-workgroup tags with
 the plain all-reduce), on different rows per rank; afterwards the replicas' parameters must be bit-identical (a checksum of
 their bit patterns, all-gathered).
-  python tools/p2p_stress.py --spawn 4 --iters 3000"""
+  python tools/p2p_stress.py --spawn 4 --iters 3000
+Debugging switches: STRESS_SIZE=<floats> (one message size only), STRESS_NO_BURST=1 (a host sync after every all-reduce),
+STRESS_NO_STEPS=1 (no training steps in between); on failure every rank prints the transport's debug words."""
 import argparse
 import os
 import socket
@@ -43,7 +45,7 @@ def worker(args):
     rows_rng = np.random.RandomState(1000 + rank)        # this rank's rows
     steps = 0
     for it in range(args.iters):
-        if it % 3 == 0:
+        if it % 3 == 0 and not os.environ.get("STRESS_NO_STEPS"):
             x = tn.asarray(rows_rng.uniform(-1, 1, (rows, widths[0])).astype(np.float32))
             y = tn.asarray(np.eye(10, dtype=np.float32)[rows_rng.randint(0, 10, rows)])
             trainer.step(x, y)
@@ -56,7 +58,11 @@ def worker(args):
                 if not (got == got[0]).all() or not np.isfinite(p).all():
                     bad += 1
         n = int(rs.choice([1, 3, 17, 257, 1000, 4099, 29400, 65536, 235147, 500001, 1 << 20]))
+        if os.environ.get("STRESS_SIZE"):                # one size only (debugging)
+            n = int(os.environ["STRESS_SIZE"])
         burst = 1 + int(rs.randint(0, 4)) if it % 5 == 0 else 1
+        if os.environ.get("STRESS_NO_BURST"):
+            burst = 1
         bufs, wants = [], []
         for b in range(burst):
             parts = [contribution(np, r, n, it * 8 + b) for r in range(world)]
@@ -99,7 +105,16 @@ def main():
                        MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--iters", str(args.iters)], env=env))
         sys.exit(max(p.wait() for p in procs))
-    worker(args)
+    try:
+        worker(args)
+    except Exception:
+        import ctypes
+        from tinynn_autograd_amd import _lib
+        w = (ctypes.c_int * 16)()
+        _lib.get().p2p_debug(w)
+        print("rank %s: failed; the transport's debug words (which wait gave up, expected, seen, peer / workgroup, detail): %s"
+              % (os.environ.get("RANK", "0"), [int(x) & 0xffffffff for x in list(w)[:5]]), flush=True)
+        raise
 
 
 if __name__ == "__main__":
