@@ -409,6 +409,48 @@ def cpu_baseline(widths, rows, kind, budget_s=8.0):
     return out
 
 
+def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=128, num_ep=3):
+    """The reference's LOOP end to end (examples/mnist/run.py:76-93 + utils/data_iterator.py:22-34), wall clock, through
+    this build's counterpart `examples/mnist_run.train`: per epoch np.random.shuffle of the row order, its upload, the
+    device gather of inputs and one-hot targets, [graph capture + instantiation], 390 steps of 128 rows + the ragged 80-row
+    step, the read-back of the 391 losses — and, timed separately, the evaluation (forward on 10,000 test rows, argmax,
+    AccEvaluator).  Three paths: `trainer` (whole-step trainer, the epoch as ONE hipGraph captured in epoch 0 and replayed),
+    `ops_captured` (the drop-in Tensor / ops / Model loop body recorded with tn.capture in epoch 1 and replayed), `ops_eager`
+    (the same loop body issued op by op from Python: what a user of the reference's loop gets with no opt-in).
+    `value` of a path = rows / wall time of its LAST epoch's training part (a replayed epoch on the graph paths);
+    `all_epochs` is everything from the first shuffle to the last loss, captures included."""
+    from tinynn_autograd_amd.examples import mnist_run
+    (train_x, train_y), (test_x, test_y), source = mnist_run.prepare_dataset("/nonexistent", n_train=n_train, n_test=n_test)
+    out = {"workload": "%d epochs x %d rows, bs %d (%d full batches + a ragged %d-row batch), eval on %d rows; %s"
+                       % (num_ep, n_train, batch_size, n_train // batch_size, n_train % batch_size, n_test, source),
+           "unit": "samples/s", "phases_unit": "ms"}
+    ms = lambda v: round(v * 1e3, 3)                                               # noqa: E731
+    for name, kw in (("trainer", {"trainer": True}), ("ops_captured", {"capture": True}), ("ops_eager", {})):
+        np.random.seed(0)
+        stats = []
+        t0 = time.perf_counter()
+        losses, preds, results = mnist_run.train(train_x, train_y, test_x, test_y, [256, 128], num_ep, batch_size, 1e-3,
+                                                 stats=stats, **kw)
+        wall = time.perf_counter() - t0
+        last = stats[-1]
+        train_all = sum(st["train"] for st in stats)
+        out[name] = {
+            "value": round(n_train / last["train"], 1),
+            "epoch_ms": [ms(st["train"]) for st in stats],
+            "phases_last_epoch": {k: ms(last[k]) for k in ("data", "capture", "steps")},
+            "phases_per_epoch": {k: [ms(st[k]) for st in stats] for k in ("data", "capture", "steps", "eval")},
+            "all_epochs": {"value": round(num_ep * n_train / train_all, 1), "train_ms": ms(train_all)},
+            "eval": {"ms": ms(last["eval"]), "value": round(n_test / last["eval"], 1), "accuracy": results[-1]["accuracy"]},
+            "wall_s_incl_setup": round(wall, 3),
+            "steps_per_epoch": last["n_steps"], "first_loss": round(losses[0], 6), "last_loss": round(losses[-1], 6),
+            "frac_of_headline": round(n_train / last["train"] / headline_value, 4),
+        }
+    out["note"] = ("headline = the timed replay of pre-captured step graphs over resident batches (`value` of this line); this object "
+                   "is the loop a user of examples/mnist/run.py runs.  trainer: epoch 0 pays lazy init + trainer creation + the "
+                   "capture of the epoch graph (phases_per_epoch.capture[0]); epochs >= 1 replay it (capture 0.0).")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ measured runs
 class Runner(object):
     """Something that can run `count` consecutive training steps from global step index `first` and report the last
@@ -748,6 +790,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (config_C, paths, ...)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--epoch-loop-only", action="store_true", help="N = 1: print just the epoch_loop object")
     args = ap.parse_args()
 
     # `python3 bench.py --gpus N` with no launcher: become the launcher BEFORE anything touches the GPU
@@ -792,6 +835,9 @@ def main():
     line = None
     exit_code = 0
 
+    if args.epoch_loop_only:
+        emit({"epoch_loop": epoch_loop_object(float(os.environ.get("TNN_HEADLINE", "5.98e6")))})
+        return 0
     if args.workload == "A":
         widths, kind = WIDTHS_A, "softmax_nll"
         if args.rows is not None:
@@ -1075,6 +1121,7 @@ def main():
                                          mfma_frac_of_whole_step=round(85.8993e9 / (rc["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
                 del c
                 line["config_E"] = config_e_object(solo)
+                line["epoch_loop"] = epoch_loop_object(res["value"])
         if not args.no_cpu_baseline and args.workload != "E":
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
 

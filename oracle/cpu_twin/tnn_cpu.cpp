@@ -694,7 +694,8 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
                                       int64_t head_c, void* head_z, const void* head_b, const void* y, void* ticket, void* out_pair,
                                       int exchange, int dtype) {
     NEED_INIT();
-    REQ(head_b && y && ticket && out_pair && dtype == TNN_F32 && M <= 1024 && N == 128 && head_c == 10,
+    REQ(head_b && y && ticket && out_pair && dtype == TNN_F32 && M <= 1024 && N >= 16 && N <= 256 && N % 16 == 0 && head_c >= 1 &&
+            head_c <= 16,
         "cpu twin: tnn_dense_fwd_head_partials_stats needs every buffer, f32, the head's shapes");
     RECORD(tnn_dense_fwd_head_partials_stats(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z, head_b, y,
                                              ticket, out_pair, exchange, dtype));

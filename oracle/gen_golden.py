@@ -75,6 +75,10 @@ CONFIGS = {
     # multiples of 16 nor the 128 -> 10 head the benchmark shape ends in
     "R_example": dict(widths=[784, 200, 100, 70, 30, 10], m=128, steps=10, loss="softmax_nll", opt="adam", lr=1e-3, seed=0,
                       data_seed=135),
+    # ... the same net at config D's global batch: the single-process answer of its data-parallel runs and of the row-block
+    # step forms (256 / 512 / 1024 rows per GPU)
+    "R_example_D": dict(widths=[784, 200, 100, 70, 30, 10], m=1024, steps=5, loss="softmax_nll", opt="adam", lr=1e-3, seed=0,
+                        data_seed=246),
 }
 
 

@@ -128,7 +128,8 @@ def main():
         losses.append(float(trainer.step(tn.asarray(x[sl]), tn.asarray(y[sl]))))
         if mode.endswith("bucket"):
             # one all-reduce per layer, last layer first, the last layer's bucket carrying the loss slot
-            sizes = [w[l] * w[l + 1] + w[l + 1] for l in range(n_layers)]
+            pw = trainer._pwidths                         # (hidden widths padded to multiples of 16 inside the arenas)
+            sizes = [pw[l] * pw[l + 1] + pw[l + 1] for l in range(n_layers)]
             want = [sizes[-1] + 1] + sizes[-2::-1]
             assert calls["allreduce"] == want, (calls["allreduce"], want)
         else:

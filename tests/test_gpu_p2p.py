@@ -165,6 +165,16 @@ def test_p2p_two_processes_five_launch_step():
 
 
 @pytest.mark.gpu
+def test_p2p_reference_example_net_two_and_eight_ranks():
+    """The reference's OWN example net (examples/mnist/run.py:59-69, tests/golden/traj_R_example_D.npz: bs 1024) split over
+    2 ranks (512 rows each: the generic merged head walks four blocks of 128) and 8 ranks (128 rows each) sharing the box's
+    one GPU — the merged 2L - 2 launch data-parallel step for a head that is NOT the benchmark's 128 -> 10, eager and captured,
+    replicas identical, timeout drill."""
+    _run_p2p_workers(2, "R_example_D")
+    _run_p2p_workers(8, "R_example_D")
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_under_torchrun_share_the_gpu():
     """bench.py's N > 1 flow exactly as the driver launches it (python -m torch.distributed.run ... bench.py --gpus 2),
     with both ranks on the box's one GPU and the peer-to-peer-only communicator (RCCL refuses ranks that share a

@@ -69,6 +69,32 @@ def test_sharded_steps_captured_with_rccl_in_graph(comm):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1024, 512, 128])
+def test_reference_example_net_sharded_step_world1(comm, rows):
+    """The reference's OWN example net (examples/mnist/run.py:59-69) through the data-parallel step at world 1 on RCCL: the
+    merged 2L - 2 launch form (forward tail reducing the statistics behind an arrival counter, all-gather of the pair, the
+    generic merged head taking the pair from memory in blocks of 128 rows, first-layer backward + all-reduce + Adam) — losses
+    against the reference's bs-1024 trajectory (tests/golden/traj_R_example_D.npz) at 1024 rows, against the unsharded
+    trainer at 512 / 128 rows per rank (the per-rank batches of 2 / 8 ranks), eager and replayed from a hipGraph."""
+    cfg, gold = H.load_traj("R_example_D")
+    w = cfg["widths"]
+    model, _ = H.build_model(cfg)
+    dp = tn.trainer_from_net(model.net, max_rows=rows, lr=cfg["lr"], comm=comm, force_dp=True)
+    assert dp.comm is comm and dp.padded and dp._pwidths == [784, 208, 112, 80, 32, 10]
+    model2, _ = H.build_model(cfg)
+    solo = tn.trainer_from_net(model2.net, max_rows=rows, lr=cfg["lr"])
+    data = [(tn.asarray(x[:rows]), tn.asarray(y[:rows])) for x, y in H.batches(cfg["data_seed"], 5, cfg["m"], w[0], w[-1], cfg["loss"])]
+    got = [float(dp.step(x, y)) for x, y in data[:3]]
+    graph = dp.capture_steps(data[3:])
+    got += [float(v) for v in np.asarray(graph.launch())]
+    want = [float(solo.step(x, y)) for x, y in data]
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    if rows == cfg["m"]:
+        np.testing.assert_allclose(got, gold["loss"], rtol=1e-5)
+    np.testing.assert_allclose(np.asarray(dp.flat_parameters()), np.asarray(solo.flat_parameters()), rtol=1e-5, atol=5e-5)
+
+
+@pytest.mark.gpu
 def test_bf16_trainer_sharded_step_world1(comm):
     """bf16 trainer through tnn_mlp_step_sharded at world 1 = the sharded-optimizer step (mlp16_step_zero): reduce-scatter of
     the bf16 weight gradient / Adam on the owned rows (all of them here) / all-gather of the bf16 rows, each layer's chain on

@@ -36,7 +36,7 @@ def _run_ref_nn(cfg):
     return losses, logits, layers
 
 
-@pytest.mark.parametrize("name", ["A_adam", "A_sgd", "A_ragged", "C_small", "R_example"])
+@pytest.mark.parametrize("name", ["A_adam", "A_sgd", "A_ragged", "C_small", "R_example", "R_example_D"])
 def test_trajectory_bit_exact(name):
     cfg, gold = H.load_traj(name)
     if name in ("A_adam", "A_sgd"):

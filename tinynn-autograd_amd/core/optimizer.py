@@ -77,11 +77,21 @@ def take_capture_ticks():
     cleared here; the captured function sets them after every replay (the replay's loss launch has then really advanced the
     powers and the eager step that follows must not advance them again — exact, no extra launch in the graph).  A captured
     WHOLE step has consumed its tick: nothing to hand over."""
-    out = [opt for opt in list(_TICKED) if opt._ticked and opt._pows is not None]
+    out = [opt for opt in list(_TICKED) if opt._ticked and opt._tick_captured and opt._pows is not None]
     for opt in out:
-        opt._ticked = False
-    _TICKED.clear()
+        opt._ticked = opt._tick_captured = False
+        _TICKED.discard(opt)
     return out
+
+
+def settle_eager_ticks():
+    """Start of a hipGraph capture (graph.py): an advance that an EAGER loss launch has made and no step has consumed yet
+    (a warm-up call of a loss-only function, another model's pending loss) is taken back, so that the captured function's own
+    loss launch records its advance in the graph and `take_capture_ticks` hands over exactly the optimizers that ticked while
+    the capture was open."""
+    for opt in list(_TICKED):
+        opt.untick()
+    _TICKED.clear()
 
 
 def _flat_pair_ok(params, grads):
@@ -102,6 +112,7 @@ class Adam(BaseOptimizer):
         self._v = 0
         self._pows = None      # device double[4]: {b1^(t-1), b2^(t-1), ticket, pad}
         self._ticked = False   # the powers have ALREADY been advanced for the coming step (by the loss launch, see take_tick)
+        self._tick_captured = False   # ... by a launch recorded into an open hipGraph capture (not executed yet)
 
     def _compute_step(self, grad):
         self._t += 1
@@ -135,6 +146,7 @@ class Adam(BaseOptimizer):
         if not self.fused or self._pows is None or self._ticked:
             return None
         self._ticked = True
+        self._tick_captured = bool(_lib.capturing)
         _TICKED.add(self)
         return self._pows._ptr, self._b1, self._b2
 

@@ -16,11 +16,31 @@ Differences that are deliberate (DESIGN.md "dtype policy" and "backward schedule
     buffer instead of doing memset + add.
 """
 
+import weakref
+
 import numpy as np
 
+from .. import _lib
 from .. import device_array as da
 from ..device_array import DeviceArray
 from . import ops
+
+_CAPTURE_LEAVES = {}      # id -> weakref of the leaf tensors that received a gradient while a hipGraph capture was open
+
+
+def take_capture_grads():
+    """End of a hipGraph capture (graph.py): the host-side gradient state of every leaf tensor (parameter) the captured
+    function accumulated into, as (weakref, grad array, shared flag).  A replay refreshes those BUFFERS but not the Python
+    attributes — and an eager `model.step()` between two replays drops them (`param.values = ...`, core/tensor.py:35-38) — so
+    the captured function re-installs this state after every replay: `loss-only graph; model.step()` in a loop then sees
+    the gradients of THAT replay, like the eager loop body of examples/mnist/run.py:79-83."""
+    out = []
+    for ref in _CAPTURE_LEAVES.values():
+        t = ref()
+        if t is not None and t._grad is not None:
+            out.append((ref, t._grad, t._grad_shared))
+    _CAPTURE_LEAVES.clear()
+    return out
 
 
 def as_tensor(obj):
@@ -280,6 +300,8 @@ class Tensor(object):
             self._grad, self._grad_shared = self._grad + g, False
         else:
             self._grad += g
+        if _lib.capturing and not self.dependency:
+            _CAPTURE_LEAVES[id(self)] = weakref.ref(self)
 
     def backward(self, grad=None):
         assert self.requires_grad, "Call backward() on a non-requires-grad tensor."

@@ -1112,6 +1112,73 @@ __global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_kernel(GemmArgs g, 
 #endif
 }
 
+// The same launch for ANY classifier head the merged head + hidden-backward launch takes (tnn_mlp_head_bwd_fits: hidden width a
+// multiple of 16 up to 256, <= 16 classes; e.g. the 32 -> 10 tail of the reference's own example net, examples/mnist/run.py:59-69)
+// and up to 1024 rows: ONE arrival counter for the launch; the last workgroup to arrive reduces the shard's {max, sum-exp} with a
+// thread per row (rows t, t + 512: logits = bias + the tiles' partials in tile order, row max, row sum-exp; then the rows' pairs
+// are merged by DPP wave reductions and an 8-entry LDS exchange — a fixed order, so the pair does not depend on which workgroup
+// came last).  The tuned 128 -> 10 form above keeps its per-128-row-block counters and four-threads-per-row statistics.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void dense_fwd_head_generic_kernel(GemmArgs g, HeadTail ta, tnn::p2p::LaunchCtx ctx) {
+    static_assert(WAVES == 8, "512 threads");
+    __shared__ float red[WAVES][4][64];
+    __shared__ float bsum[WAVES][64];
+    __shared__ __attribute__((aligned(16))) float head_lds[16 * 20];
+    __shared__ float wred[WAVES][2];
+    __shared__ int is_last;
+    small_tile_fast<true, false, WAVES, true>(g, nullptr, (int)blockIdx.x, red, bsum, head_lds);
+    using namespace tnn::p2p;
+    if (threadIdx.x < 64) {                                    // wave 0 wrote this tile's partial logits
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned prev = __hip_atomic_fetch_add(ta.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == gridDim.x - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(ta.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // graph replays start from 0
+            is_last = last;
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int C = g.head_c, NP = g.tiles_n, m = ta.m;
+    float mx = -INFINITY, sx = 0.f;                            // this thread's rows: {max, sum-exp relative to it}
+    for (int r = t; r < m; r += WAVES * 64) {
+        uint32_t u[16][1];
+        float z[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) z[k] = k < C ? ta.bias[k] : -INFINITY;
+        for (int tn = 0; tn < NP; ++tn) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ta.zpart) + ((size_t)tn * m + r) * C;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (k < C) load_sys(u[k][0], src + k);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                asm volatile("" : "+v"(u[k][0]));
+                if (k < C) z[k] += __uint_as_float(u[k][0]);
+            }
+        }
+        float rm = -INFINITY, rs = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < C) rm = fmaxf(rm, z[k]);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (k < C) rs += expf(z[k] - rm);
+        const float nm = fmaxf(mx, rm);
+        sx = sx * expf(mx - nm) + rs * expf(rm - nm);          // (mx = -inf, sx = 0 on the first row: 0 * exp(-inf) = 0)
+        mx = nm;
+    }
+    const float wm = tnn::wave_max_dpp(mx);
+    const float ws = tnn::wave_sum_dpp(mx > -INFINITY ? sx * expf(mx - wm) : 0.f);
+    if (lane == 0) { wred[wid][0] = wm; wred[wid][1] = ws; }
+    __syncthreads();
+    float M = -INFINITY, S = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) M = fmaxf(M, wred[w][0]);
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) S += wred[w][0] > -INFINITY ? wred[w][1] * expf(wred[w][0] - M) : 0.f;
+    head_tail_finish(ta, ctx, M, S);
+}
+
 // Forward of the hidden layer in front of a classifier head for batches of MORE than 128 rows on one GPU, ROW-PANEL form:
 // a workgroup owns 16 whole rows — its 8 waves take the 8 column tiles of the 128 hidden units, each over the whole K — so
 // the classifier's logits of those rows (8 partial products summed through LDS) and the rows' softmax statistics are
@@ -2207,8 +2274,8 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
                                       void* out_pair_f32, int exchange, int dtype) {
     TNN_NEED_INIT();
     if (int rc = check_shapes("tnn_dense_fwd_head_partials_stats", 0, 0, M, N, K, lda, ldb, ldc)) return rc;
-    TNN_REQUIRE(dtype == TNN_F32 && M >= 1 && M <= 1024 && N == 128 && head_c == 10,
-                "tnn_dense_fwd_head_partials_stats: f32, rows <= 1024, 128 hidden units, 10 classes");
+    TNN_REQUIRE(dtype == TNN_F32 && M >= 1 && M <= 1024 && N >= 16 && N <= 256 && N % 16 == 0 && head_c >= 1 && head_c <= 16,
+                "tnn_dense_fwd_head_partials_stats: f32, rows <= 1024, hidden width a multiple of 16 up to 256, <= 16 classes");
     TNN_REQUIRE(head_w && head_z && head_b && y && ticket_u32 && out_pair_f32,
                 "tnn_dense_fwd_head_partials_stats: head_w, head_z, head_b, y, ticket and out_pair are required");
     TNN_REQUIRE(act == TNN_ACT_NONE || act == TNN_ACT_RELU, "tnn_dense_fwd_head_partials_stats: activation %d", act);
@@ -2235,7 +2302,10 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
         if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_fwd_head_partials_stats")) return rc;
         TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_head_partials_stats: the peer-to-peer transport is not enabled");
     }
-    hipLaunchKernelGGL(dense_fwd_head_kernel<8>, dim3((unsigned)(g.tiles_m * g.tiles_n)), 512, 0, tnn::stream(), g, ta, ctx);
+    if (N == 128 && head_c == 10)
+        hipLaunchKernelGGL(dense_fwd_head_kernel<8>, dim3((unsigned)(g.tiles_m * g.tiles_n)), 512, 0, tnn::stream(), g, ta, ctx);
+    else
+        hipLaunchKernelGGL(dense_fwd_head_generic_kernel<8>, dim3((unsigned)(g.tiles_m * g.tiles_n)), 512, 0, tnn::stream(), g, ta, ctx);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -996,11 +996,16 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
 
 // ------------------------------------------------------------------------------------------------------------------
 // GENERIC merged head + hidden-layer backward: the same launch as mlp_head_bwd_kernel for any classifier head with
-// H % 16 == 0, 16 <= H <= 256 hidden units, C <= 16 classes, n_in % 16 == 0 inputs of the hidden layer, <= 128 rows — e.g. the
+// H % 16 == 0, 16 <= H <= 256 hidden units, C <= 16 classes, n_in % 16 == 0 inputs of the hidden layer — e.g. the
 // 80 -> 32 -> 10 tail of the reference's own example net (examples/mnist/run.py:59-69, hidden widths padded to multiples of
 // 16 by the trainer).  Plain VALU loops over LDS panels, 256 threads, no shape baked in: it exists so that the 2L - 2 launch
 // step is not tied to the benchmark's 128 -> 10 head; the tuned kernels above keep that shape.
-//     every workgroup : logits = bias + sum of the H / 16 partial tiles, whole-batch {M, S}, dz [m][C] (LDS)
+//   statistics INSIDE (ext_pairs == NULL, <= 128 rows): every workgroup reduces the whole batch's {M, S} itself;
+//   statistics from MEMORY (ext_pairs: ext_n {M_q, S_q} pairs left by the forward launch's tail, tnn_dense_fwd_head_partials_stats
+//   [+ an all-gather over the ranks]; <= 1024 rows): nothing couples the rows inside the launch, so the head and dW1 roles walk
+//   them in blocks of 128 with their sums in registers, a dx tile only looks at its own 16 rows, and 1 / m is the GLOBAL batch's
+//   (core/losses.py:26-32 — the data-parallel step and every batch of more than 128 rows).
+//     every workgroup : logits = bias + sum of the H / 16 partial tiles, dz [rows][C] (LDS)
 //     blocks [0, H/16)            : dW2 rows [16 g, 16 g + 16) = a^T dz; block 0 also db2, loss, stats, beta powers; the last one
 //                                   writes logits / dz out
 //     blocks [H/16, + n_dw)       : dW1 tile (16 inputs x 16 units) = x^T dz1[:, 16 units], db1 (tiles of the first tile row);
@@ -1008,6 +1013,8 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
 //     the rest                    : dx tile (16 rows x 16 inputs) = (dz1[16 rows, :] W1^T) * !signbit(x)
 struct HeadGenArgs {
     int m, H, C, n_in;
+    int m_global, ext_n;             // ext_pairs != NULL: rows of the GLOBAL batch, number of pairs (<= 64)
+    const float* ext_pairs;
     const float *a, *w, *b, *y, *zpart, *x, *w1;
     float *logits, *dz, *stats, *loss, *dw, *db, *dw1, *db1, *dx;
     double* tick;
@@ -1016,7 +1023,7 @@ struct HeadGenArgs {
 
 __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p) {
     constexpr int ROWS = 128, CS = 17, HMAX = 256, CMAX = 16;
-    __shared__ float dzs[ROWS * CS];                 // dz [row][class], stride 17
+    __shared__ float dzs[ROWS * CS];                 // dz [row of the block][class], stride 17
     __shared__ float pan[ROWS * CS];                 // head: a[:, 16 g ..] / dW1: dz1 [row][16 units] / dx: unused
     __shared__ float xs[ROWS * CS];                  // dW1: x[:, 16 inputs]
     __shared__ float w2s[HMAX * CMAX];               // W2 [H][C]
@@ -1028,92 +1035,127 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
     const int m = p.m, H = p.H, C = p.C, n_in = p.n_in;
     const int G = H / 16, tiles_in = n_in / 16, n_dw = tiles_in * G, np = H / 16;
     const int blk = (int)blockIdx.x;
+    const bool ext = p.ext_pairs != nullptr;         // block-uniform
     double pw0 = 0.0, pw1 = 0.0;
     if (blk == 0 && t == 0 && p.tick) { pw0 = p.tick[0]; pw1 = p.tick[1]; }
-
-    // ---- logits and per-row statistics: thread r = row r
-    float e[CMAX], yv[CMAX];
-    float mx = -INFINITY, srow = 0.f, qy = 0.f;
-    if (t < m) {
-#pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            float z = 0.f;
-            yv[k] = 0.f;
-            if (k < C) {
-                z = p.b[k];
-                for (int tn = 0; tn < np; ++tn) z += p.zpart[((size_t)tn * m + t) * C + k];
-                yv[k] = p.y[(size_t)t * C + k];
-                mx = fmaxf(mx, z);
-            }
-            e[k] = z;                                 // the logit for now
-        }
-        if (blk == G - 1 && p.logits) {
-#pragma unroll
-            for (int k = 0; k < CMAX; ++k) if (k < C) p.logits[(size_t)t * C + k] = e[k];
-        }
-#pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            e[k] = k < C ? expf(e[k] - mx) : 0.f;
-            srow += e[k];
-            qy += e[k] * yv[k];
-        }
+    float M = 0.f;
+    double S = 1.0, L = 0.0;                         // L (statistics inside): sum over rows of log(e . y) + row max
+    if (ext) {
+        float Mx, Sx;
+        head_merge_pairs(p.ext_pairs, p.ext_n, lane, Mx, Sx);      // every wave computes the same pair
+        M = Mx;
+        S = (double)Sx;
     }
-    if (t < ROWS) {
-        r_mx[t] = t < m ? mx : -INFINITY;
-        r_s[t] = t < m ? srow : 0.f;
-        r_lq[t] = t < m ? mx + logf(qy) : 0.f;
-    }
+    const double inv_m = 1.0 / (double)(ext ? p.m_global : m);
     // W2 -> LDS (every role needs it except the head's, which needs only dz): coalesced
     for (int i = t; i < H * C; i += 256) w2s[i] = p.w[i];
-    __syncthreads();
-    if (wid == 0) {
-        float M0 = fmaxf(r_mx[lane], r_mx[lane + 64]);
-        M0 = tnn::wave_max(M0);
-        double S0 = (double)r_s[lane] * (double)expf(r_mx[lane] - M0) + (double)r_s[lane + 64] * (double)expf(r_mx[lane + 64] - M0);
-        double L0 = (double)r_lq[lane] + (double)r_lq[lane + 64];
-        S0 = tnn::wave_sum(S0);
-        L0 = tnn::wave_sum(L0);
-        if (lane == 0) { red[0] = (double)M0; red[1] = S0; red[2] = L0; }
-    }
-    __syncthreads();
-    const float M = (float)red[0];
-    const double S = red[1], L = red[2];
-    const double inv_m = 1.0 / (double)m;
-    if (t < ROWS) {
-        const float sf = t < m ? expf(mx - M) / (float)S : 0.f, uf = t < m ? (float)inv_m / qy : 0.f;
+
+    // dz of rows [row0, row0 + n) into dzs[0 .. n) (rows >= m: zeros); returns this thread's row's log(e . y) + row max
+    // (threads >= n, rows >= m: 0).  Statistics inside: n = 128 = the whole batch, M / S / L are reduced here.
+    // Barriers inside; dzs is complete for every thread when it returns.
+    auto block_dz = [&](const int row0, const int n, const bool write_out) -> float {
+        float e[CMAX], yv[CMAX];
+        float mx = -INFINITY, srow = 0.f, qy = 1.f;
+        const int r = row0 + t;
+        const bool live = t < n && r < m;
+        if (live) {
 #pragma unroll
-        for (int k = 0; k < CMAX; ++k) {
-            const float d = t < m ? e[k] * sf - e[k] * yv[k] * uf : 0.f;
-            dzs[t * CS + k] = d;                      // classes >= C: 0
-            if (blk == G - 1 && p.dz && t < m && k < C) p.dz[(size_t)t * C + k] = d;
+            for (int k = 0; k < CMAX; ++k) {
+                float z = 0.f;
+                yv[k] = 0.f;
+                if (k < C) {
+                    z = p.b[k];
+                    for (int tn = 0; tn < np; ++tn) z += p.zpart[((size_t)tn * m + r) * C + k];
+                    yv[k] = p.y[(size_t)r * C + k];
+                    mx = fmaxf(mx, z);
+                }
+                e[k] = z;                                 // the logit for now
+            }
+            if (write_out && p.logits) {
+#pragma unroll
+                for (int k = 0; k < CMAX; ++k) if (k < C) p.logits[(size_t)r * C + k] = e[k];
+            }
+            qy = 0.f;
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) {
+                e[k] = k < C ? expf(e[k] - mx) : 0.f;
+                srow += e[k];
+                qy += e[k] * yv[k];
+            }
         }
-    }
-    __syncthreads();
+        if (!ext) {
+            if (t < ROWS) {
+                r_mx[t] = live ? mx : -INFINITY;
+                r_s[t] = live ? srow : 0.f;
+                r_lq[t] = live ? mx + logf(qy) : 0.f;
+            }
+            __syncthreads();
+            if (wid == 0) {
+                float M0 = fmaxf(r_mx[lane], r_mx[lane + 64]);
+                M0 = tnn::wave_max(M0);
+                double S0 = (double)r_s[lane] * (double)expf(r_mx[lane] - M0) + (double)r_s[lane + 64] * (double)expf(r_mx[lane + 64] - M0);
+                double L0 = (double)r_lq[lane] + (double)r_lq[lane + 64];
+                S0 = tnn::wave_sum(S0);
+                L0 = tnn::wave_sum(L0);
+                if (lane == 0) { red[0] = (double)M0; red[1] = S0; red[2] = L0; }
+            }
+            __syncthreads();
+            M = (float)red[0];
+            S = red[1];
+            L = red[2];
+        }
+        if (t < n) {
+            const float sf = live ? expf(mx - M) / (float)S : 0.f, uf = live ? (float)inv_m / qy : 0.f;
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k) {
+                const float d = live ? e[k] * sf - e[k] * yv[k] * uf : 0.f;
+                dzs[t * CS + k] = d;                      // classes >= C: 0
+                if (write_out && p.dz && live && k < C) p.dz[(size_t)r * C + k] = d;
+            }
+        }
+        __syncthreads();
+        return live ? mx + logf(qy) : 0.f;
+    };
+    const int nblk = ext ? (m + ROWS - 1) / ROWS : 1;
 
     if (blk < G) {
         // ---- head role: dW2 rows [16 blk, 16 blk + 16)
-        for (int i = t; i < ROWS * 16; i += 256) {
-            const int r = i >> 4, j = i & 15;
-            pan[r * CS + j] = r < m ? p.a[(size_t)r * H + 16 * blk + j] : 0.f;
-        }
-        __syncthreads();
-        if (t < 16 * C) {
-            const int j = t / C, c = t - j * C;
-            float s0 = 0.f, s1 = 0.f;
-            for (int r = 0; r < ROWS; r += 2) {
-                s0 = fmaf(pan[r * CS + j], dzs[r * CS + c], s0);          // |a|: the sign bit is the ReLU mask, a >= 0 in value
-                s1 = fmaf(pan[(r + 1) * CS + j], dzs[(r + 1) * CS + c], s1);
+        const int j = t / C, c = t - j * C;               // t < 16 C: this thread's element
+        float s0 = 0.f, s1 = 0.f, dbs = 0.f;
+        double lsum = 0.0;
+        for (int rb = 0; rb < nblk; ++rb) {
+            const int row0 = rb * ROWS;
+            const float lq = block_dz(row0, ROWS, blk == G - 1);
+            if (ext && blk == 0) lsum += (double)lq;
+            for (int i = t; i < ROWS * 16; i += 256) {
+                const int r = i >> 4, jj = i & 15;
+                pan[r * CS + jj] = row0 + r < m ? p.a[(size_t)(row0 + r) * H + 16 * blk + jj] : 0.f;
             }
-            p.dw[(size_t)(16 * blk + j) * C + c] = s0 + s1;
+            __syncthreads();
+            if (t < 16 * C) {
+                for (int r = 0; r < ROWS; r += 2) {
+                    s0 = fmaf(pan[r * CS + j], dzs[r * CS + c], s0);          // |a|: the sign bit is the ReLU mask, a >= 0 in value
+                    s1 = fmaf(pan[(r + 1) * CS + j], dzs[(r + 1) * CS + c], s1);
+                }
+            }
+            if (blk == 0 && t < C)
+                for (int r = 0; r < ROWS; ++r) dbs += dzs[r * CS + t];
+            if (rb + 1 < nblk) __syncthreads();           // dzs / pan are rewritten by the next block
         }
+        if (t < 16 * C) p.dw[(size_t)(16 * blk + j) * C + c] = s0 + s1;
         if (blk == 0) {
-            if (t < C) {
-                float s = 0.f;
-                for (int r = 0; r < ROWS; ++r) s += dzs[r * CS + t];
-                p.db[t] = s;
+            if (t < C) p.db[t] = dbs;
+            if (ext) {                                    // sum of the rows' log terms: DPP-free, four waves through LDS
+                lsum = tnn::wave_sum(lsum);
+                __syncthreads();
+                if (lane == 0) red[wid] = lsum;
+                __syncthreads();
+                L = (red[0] + red[1]) + (red[2] + red[3]);
             }
             if (t == 0) {
-                if (p.loss) p.loss[0] = (float)((double)logf((float)S) + (double)M - L * inv_m);
+                // data parallel: this rank's SHARE of the global loss (the all-reduce of the gradient arena sums the shares)
+                if (p.loss) p.loss[0] = ext ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
+                                            : (float)((double)logf((float)S) + (double)M - L * inv_m);
                 if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
                 if (p.tick) { p.tick[0] = pw0 * p.b1; p.tick[1] = pw1 * p.b2; }
             }
@@ -1123,47 +1165,51 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
     if (blk < G + n_dw) {
         // ---- dW1 tile: inputs [m0, m0 + 16) x units [n0, n0 + 16)
         const int b2 = blk - G, tm = b2 % tiles_in, tn = b2 / tiles_in, m0 = tm * 16, n0 = tn * 16;
-        for (int i = t; i < ROWS * 16; i += 256) {
-            const int r = i >> 4, j = i & 15;
-            float d1 = 0.f, xv = 0.f;
-            if (r < m) {
-                const float av = p.a[(size_t)r * H + n0 + j];
-                float acc = 0.f;
-                for (int c = 0; c < C; ++c) acc = fmaf(dzs[r * CS + c], w2s[(n0 + j) * C + c], acc);
-                d1 = (__float_as_uint(av) >> 31) ? 0.f : acc;
-                xv = p.x[(size_t)r * n_in + m0 + j];
+        const int ti = t >> 4, tj = t & 15;
+        float s0 = 0.f, s1 = 0.f, dbs = 0.f;
+        for (int rb = 0; rb < nblk; ++rb) {
+            const int row0 = rb * ROWS;
+            block_dz(row0, ROWS, false);
+            for (int i = t; i < ROWS * 16; i += 256) {
+                const int r = i >> 4, j = i & 15;
+                float d1 = 0.f, xv = 0.f;
+                if (row0 + r < m) {
+                    const float av = p.a[(size_t)(row0 + r) * H + n0 + j];
+                    float acc = 0.f;
+                    for (int c = 0; c < C; ++c) acc = fmaf(dzs[r * CS + c], w2s[(n0 + j) * C + c], acc);
+                    d1 = (__float_as_uint(av) >> 31) ? 0.f : acc;
+                    xv = p.x[(size_t)(row0 + r) * n_in + m0 + j];
+                }
+                pan[r * CS + j] = d1;
+                xs[r * CS + j] = xv;
             }
-            pan[r * CS + j] = d1;
-            xs[r * CS + j] = xv;
-        }
-        __syncthreads();
-        {
-            const int i = t >> 4, j = t & 15;
-            float s0 = 0.f, s1 = 0.f;
+            __syncthreads();
             for (int r = 0; r < ROWS; r += 2) {
-                s0 = fmaf(xs[r * CS + i], pan[r * CS + j], s0);
-                s1 = fmaf(xs[(r + 1) * CS + i], pan[(r + 1) * CS + j], s1);
+                s0 = fmaf(xs[r * CS + ti], pan[r * CS + tj], s0);
+                s1 = fmaf(xs[(r + 1) * CS + ti], pan[(r + 1) * CS + tj], s1);
             }
-            p.dw1[(size_t)(m0 + i) * H + n0 + j] = s0 + s1;
+            if (tm == 0 && t < 16)
+                for (int r = 0; r < ROWS; ++r) dbs += pan[r * CS + t];
+            if (rb + 1 < nblk) __syncthreads();
         }
-        if (tm == 0 && t < 16) {
-            float s = 0.f;
-            for (int r = 0; r < ROWS; ++r) s += pan[r * CS + t];
-            p.db1[n0 + t] = s;
-        }
+        p.dw1[(size_t)(m0 + ti) * H + n0 + tj] = s0 + s1;
+        if (tm == 0 && t < 16) p.db1[n0 + t] = dbs;
         return;
     }
     // ---- dx tile: rows [m0, m0 + 16) x inputs [n0, n0 + 16)
     {
         const int b3 = blk - G - n_dw, tr = (m + 15) / 16, tm = b3 % tr, tn = b3 / tr, m0 = tm * 16, n0 = tn * 16;
         const int HS = H + 1;
+        // statistics from memory: dz of this tile's 16 rows only; inside: the whole (<= 128-row) batch is needed for M and S
+        const int dz0 = ext ? m0 : 0;
+        block_dz(dz0, ext ? 16 : ROWS, false);
         for (int i = t; i < 16 * H; i += 256) {
             const int rr = i / H, j = i - rr * H, r = m0 + rr;
             float d1 = 0.f;
             if (r < m) {
                 const float av = p.a[(size_t)r * H + j];
                 float acc = 0.f;
-                for (int c = 0; c < C; ++c) acc = fmaf(dzs[r * CS + c], w2s[j * C + c], acc);
+                for (int c = 0; c < C; ++c) acc = fmaf(dzs[(r - dz0) * CS + c], w2s[j * C + c], acc);
                 d1 = (__float_as_uint(av) >> 31) ? 0.f : acc;
             }
             pz[rr * HS + j] = d1;
@@ -1183,9 +1229,10 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
     }
 }
 
-bool head_bwd_generic_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, int dtype) {
-    return dtype == TNN_F32 && rows >= 1 && rows <= 128 && n_hidden % 16 == 0 && n_hidden >= 16 && n_hidden <= 256 &&
-           n_classes >= 1 && n_classes <= 16 && n_in >= 16 && n_in % 16 == 0;
+// ext: the statistics come from memory (row blocks: up to 1024 rows); else the workgroups reduce them (<= 128 rows)
+bool head_bwd_generic_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, int dtype, bool ext = false) {
+    return dtype == TNN_F32 && rows >= 1 && rows <= (ext ? 1024 : 128) && n_hidden % 16 == 0 && n_hidden >= 16 &&
+           n_hidden <= 256 && n_classes >= 1 && n_classes <= 16 && n_in >= 16 && n_in % 16 == 0;
 }
 
 bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtype) {
@@ -1201,11 +1248,13 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     TNN_REQUIRE(x && w1 && a && w && b && y && logit_partials && dw && db && dw1 && db1 && dx,
                 "%s: x, w1, a, w, b, y, logit_partials, dw, db, dw1, db1 and dx are required", fn);
     auto al = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
-    if (ext_pairs == nullptr && !head_multi_fits(rows, n_hidden, n_classes, dtype) &&
-        head_bwd_generic_fits(rows, n_in, n_hidden, n_classes, dtype)) {
+    if (!head_multi_fits(1, n_hidden, n_classes, dtype) && !whole_logits &&
+        head_bwd_generic_fits(rows, n_in, n_hidden, n_classes, dtype, ext_pairs != nullptr)) {
         // any other head the merged launch can take: the generic kernel (shapes as run-time arguments)
+        TNN_REQUIRE(ext_pairs == nullptr || (m_global >= rows && ext_n >= 1 && ext_n <= 64), "%s: m_global < rows or bad pair count", fn);
         HeadGenArgs ga;
         ga.m = (int)rows; ga.H = (int)n_hidden; ga.C = (int)n_classes; ga.n_in = (int)n_in;
+        ga.m_global = (int)m_global; ga.ext_n = ext_n; ga.ext_pairs = ext_pairs;
         ga.a = (const float*)a; ga.w = (const float*)w; ga.b = (const float*)b; ga.y = (const float*)y;
         ga.zpart = (const float*)logit_partials; ga.x = (const float*)x; ga.w1 = (const float*)w1;
         ga.logits = (float*)logits; ga.dz = (float*)dz; ga.stats = (float*)stats; ga.loss = (float*)loss;

@@ -333,9 +333,18 @@ int mlp16_gather_masters(Mlp* h) {
 // (profiles/r03_rows_sweep.txt; the switches that selected the forms for that sweep are gone).
 bool head_fits_row_blocks(const Mlp* h, int64_t rows, bool sharded) {
     const int L = h->L;
-    const int64_t row_blocks_max = sharded ? 512 : 1024;
-    return h->dtype == TNN_F32 && !h->bf16 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 1] == 128 &&
-           h->w[L] == 10 && h->w[L - 2] % 16 == 0 && rows > 128 && rows <= row_blocks_max && rows <= 1024 && h->zpart != nullptr;
+    const int64_t row_blocks_max = 1024;             // 8 blocks of 128: the forward tail's counters and pair slots (h->ticket)
+    (void)sharded;
+    // the tuned 128 -> 10 head, or any head the generic merged kernel takes (tnn_mlp_head_bwd_fits: hidden width a multiple of 16
+    // up to 256, <= 16 classes — the reference's own 30 -> 10, padded to 32)
+    const bool head_ok = h->w[L - 1] % 16 == 0 && h->w[L - 1] >= 16 && h->w[L - 1] <= 256 && h->w[L] >= 1 && h->w[L] <= 16;
+    return h->dtype == TNN_F32 && !h->bf16 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && head_ok &&
+           h->w[L - 2] % 16 == 0 && rows > 128 && rows <= row_blocks_max && rows <= 1024 && h->zpart != nullptr;
+}
+
+// the data-parallel step's merged form (statistics from memory at every row count): the same heads, 1 .. 1024 rows per rank
+bool head_fits_sharded(const Mlp* h, int64_t rows) {
+    return rows <= 128 ? head_fits_row_blocks(h, rows + 128, true) : head_fits_row_blocks(h, rows, true);
 }
 
 // limits of the single-workgroup loss kernel (tnn_softmax_nll_fused_tick)
@@ -706,7 +715,8 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // their softmax statistics itself and leaves one {max, sum-exp} pair per panel (no arrival counter, no re-read of
         // partial logits at the tail of the launch); the merged launch merges the pairs (n_pairs < 0: whole logits)
         const int n_panels = (int)((rows + 15) / 16);
-        if (h->w[L - 2] % 4 == 0)
+        const bool tuned_head = h->w[L - 1] == 128 && h->w[L] == 10;       // (any other head: the counter tail, one merged pair)
+        if (tuned_head && h->w[L - 2] % 4 == 0)
             STEP_CALL(h, tnn_dense_fwd_rows_head_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
                                                        at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
                                                        at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
@@ -722,7 +732,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         STEP_CALL(h, tnn_mlp_head_bwd_tick_ext(rows, rows, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
                                                at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
                                                at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
-                                               y, h->zpart, h->stats, (h->w[L - 2] % 4 == 0) ? -n_panels : 1,
+                                               y, h->zpart, h->stats, (tuned_head && h->w[L - 2] % 4 == 0) ? -n_panels : 1,
                                                h->act[L - 1], h->dact[L - 1], nullptr, loss_dst,
                                                at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
                                                at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
@@ -804,11 +814,14 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
     MLP_TRY(tnn_p2p_status(nullptr, &p2p_on, nullptr));
     const int L = h->L;
     void* loss_slot = at(h->grads, h->n_params, h->esz);
-    int head_multi = 0;
-    if (h->dtype == TNN_F32 && h->opt_kind == 1 && h->loss_kind == 0 && L >= 3 && h->w[L - 2] % 16 == 0)
-        MLP_TRY(tnn_mlp_head_fits(rows, h->w[L - 1], h->w[L], h->dtype, &head_multi));
-    if (!head_multi && head_fits_row_blocks(h, rows, true)) head_multi = 1;     // 129 .. 512 rows per rank: blocks of 128
-    if (head_multi) {
+    // (the tuned 128 -> 10 head or any head of the generic merged kernel; <= 128 rows per rank in one block, 129 .. 1024 in
+    // blocks of 128)
+    // large arenas (config C: 134 MB, config E: 1 GB of fp32 gradients) take the per-layer buckets further down whatever
+    // their head: one all-reduce per layer on the communication stream, overlapping the remaining backward
+    // (TNN_BUCKET_BYTES moves the switch-over point; default 4 MiB — below it the arena is one latency-bound message)
+    static const size_t bucket_bytes = getenv("TNN_BUCKET_BYTES") ? (size_t)atoll(getenv("TNN_BUCKET_BYTES")) : ((size_t)4 << 20);
+    const bool bucketed = (size_t)(h->n_params + 1) * h->esz > bucket_bytes;
+    if (!bucketed && head_fits_sharded(h, rows)) {
         // Classifier head of the one-launch form (<= 128 rows per rank: every weak-scaling point, config D at 8 ranks) —
         // 2L - 1 launches (5 for the MNIST net) + the collectives, ONE form for every transport:
         //   forward of the hidden layers; the LAST workgroup of the last one to finish also reduces the shard's {max, sum-exp}
@@ -844,7 +857,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
                                                   h->w_off[0], h->b_off[0], h->params, h->m, h->v, h->n_params, h->lr,
                                                   h->b1, h->b2, h->eps, h->pows, h->n_params, loss_out, h->dtype);
     }
-    if (p2p_on && h->dtype == TNN_F32 && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
+    if (!bucketed && p2p_on && h->dtype == TNN_F32 && h->opt_kind == 1 && head_fits_one_workgroup(h, rows)) {
         // xGMI peer-to-peer transport and a head that fits one workgroup — 8 launches, like the single-GPU step:
         //   forward | loss kernel that exchanges the shards' {max, sum-exp} itself (stats + C2 + merge + loss + dz)
         //   and advances Adam's beta powers | backward | all-reduce whose last stage applies Adam and files the loss
@@ -860,11 +873,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
         MLP_TRY(tnn_allgather(h->stats, h->stats_all, 2, h->dtype));
         MLP_TRY(tnn_lse_merge(h->stats_all, world, h->stats, h->dtype));
     }
-    // large arenas (config C: 134 MB, config E: 1 GB of fp32 gradients): one all-reduce per layer, issued to the
-    // communication stream right behind that layer's backward launch, overlapping the remaining backward
-    // (TNN_BUCKET_BYTES moves the switch-over point; default 4 MiB — below it the arena is one latency-bound message)
-    static const size_t bucket_bytes = getenv("TNN_BUCKET_BYTES") ? (size_t)atoll(getenv("TNN_BUCKET_BYTES")) : ((size_t)4 << 20);
-    if ((size_t)(h->n_params + 1) * h->esz > bucket_bytes) {
+    if (bucketed) {
         // any failure from here to the optimizer drains the bucket events already issued (tnn_comm_join) before the
         // error is returned, so the next step never waits on this one's leftovers
         int rc = mlp_backward_impl(h, x, y, rows, rows * world, h->stats, nullptr, true);

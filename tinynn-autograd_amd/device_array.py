@@ -449,6 +449,27 @@ class DeviceArray(object):
                                     src._code())
         return out
 
+    def take(self, indices, axis=0, out=None, mode="raise"):
+        """np.take(a, indices, axis=0[, out]): the row gather of `a[indices]` (tnn_gather_rows), optionally INTO an existing
+        array — a per-epoch permutation of a resident dataset (utils/data_iterator.py:27-28) then lands at the same HBM
+        addresses every epoch, which is what lets a hipGraph captured over the epoch's batches be replayed."""
+        if not (axis == 0 or (axis is None and self.ndim == 1)) or mode != "raise":
+            raise TypeError("take: only axis 0 / mode 'raise' are implemented on device")
+        src = self._contig()
+        if src.ndim < 1:
+            raise IndexError("too many indices for array")
+        idx = src._index_array(indices)
+        shape = (idx.size,) + src.shape[1:]
+        if out is None:
+            out = DeviceArray._new(shape, src.dtype)
+        elif (not isinstance(out, DeviceArray) or out.shape != shape or out.dtype != src.dtype or out._t
+              or out._hv is not None):
+            raise ValueError("take: `out` must be a dense device array of shape %s and dtype %s" % (shape, src.dtype))
+        if out.size:
+            _lib.get().gather_rows(src._ptr, idx._ptr, out._ptr, idx.size, _prod(src.shape[1:]), src.shape[0],
+                                   src._code())
+        return out
+
     def __setitem__(self, key, value):
         if self._t or self._hv is not None:
             raise TypeError("cannot assign into a transposed view or host scalar")
@@ -1138,6 +1159,7 @@ _ARRAY_FUNCTIONS = {
     np.pad: _np_pad,
     np.where: _np_where,
     np.copy: lambda a, **_: asarray(a).copy(),
+    np.take: lambda a, indices, axis=None, out=None, mode="raise": asarray(a).take(indices, axis=axis, out=out, mode=mode),
     np.shape: lambda a: asarray(a).shape,
     np.ndim: lambda a: asarray(a).ndim,
     np.size: lambda a, axis=None: asarray(a).size if axis is None else asarray(a).shape[axis],

@@ -7,7 +7,9 @@ in this environment (no network), so `--data_dir` is accepted but the
 
     python -m tinynn_autograd_amd.examples.mnist_run --num_ep 2 --batch_size 128 --seed 0 [--trainer]
 
---trainer    run the epoch through the whole-step trainer (one hipGraph per epoch) instead of the op-level path
+--trainer    run the epoch through the whole-step trainer (ONE hipGraph of the epoch's steps, captured in epoch 0 and
+             replayed every epoch) instead of the op-level path
+--capture    op-level path recorded once with tn.capture (epoch 0 eager, epoch 1 recorded) and replayed afterwards
 --widths     hidden widths (default 256,128 = BASELINE.json's 784-256-128-10; the reference example hard-codes
              200,100,70,30, examples/mnist/run.py:59-69)
 """
@@ -55,12 +57,27 @@ def prepare_dataset(data_dir, n_train=51200, n_test=10000):
     return make(n_train), make(n_test), "synthetic (MNIST-like sparsity, linear-teacher labels)"
 
 
-def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trainer=False, log=None):
+def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trainer=False, capture=False, log=None,
+          stats=None, reuse_buffers=True):
     """The loop of examples/mnist/run.py:50-93 on device Tensors.  `train_y` / `test_y` are integer labels.  Returns
     (loss_list as floats, per-epoch argmax vectors, per-epoch AccEvaluator dicts).
 
+    Three ways through the epoch, same results (tests/parity_suite.py `epoch_loop_*`):
+      default   the reference's loop body issued op by op from Python (core/tensor.py / core/ops.py seam)
+      capture   the same loop body recorded ONCE with tn.capture (epoch 0 runs eagerly: lazy init, arena binding, optimizer
+                state; epoch 1 is recorded) and replayed for every later epoch
+      trainer   the whole-step trainer (fused.MLPTrainer), every step of the epoch in ONE hipGraph captured in epoch 0
+    The replays work because `BatchIterator(reuse_buffers=True)` gathers every epoch's permutation into the same HBM
+    buffers: the captured kernels read this epoch's rows at last epoch's addresses.  Per-step losses stay in HBM (one
+    history vector) and come back with ONE device-to-host copy per epoch.
+
     RNG order is the reference's: the first epoch's shuffle is drawn BEFORE the lazily initialised Dense layers draw
-    their weights at the first forward (core/layers.py:45-46) — also on the trainer path."""
+    their weights at the first forward (core/layers.py:45-46) — also on the trainer path.
+
+    stats: optional list; one dict per epoch is appended — wall-clock seconds of the phases `data` (shuffle + index upload
+    + device gather), `capture` (graph capture + instantiation, 0.0 when a graph is replayed), `steps` (issue + run +
+    the loss read-back), `train` (their sum = the reference's "Epoch .. tim cost"), `eval` (forward on the test rows +
+    argmax + AccEvaluator), and `n_rows`."""
     train_y = get_one_hot(train_y, 10)
     train_x, train_y = Tensor(train_x), Tensor(train_y)    # resident in HBM for the whole run
     test_x = Tensor(test_x)
@@ -71,38 +88,67 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
     net = Net(layers)
     model = Model(net=net, loss=SoftmaxCrossEntropyLoss(), optimizer=Adam(lr=lr))
     loss_layer = SoftmaxCrossEntropyLoss()
-    iterator = BatchIterator(batch_size=batch_size)
+    iterator = BatchIterator(batch_size=batch_size, reuse_buffers=reuse_buffers)
     evaluator = AccEvaluator()
-    step_trainer = None
+    n_batches = iterator.num_batches(len(train_x))
+    loss_hist = tn.empty((n_batches,), tn.get_default_float())   # this epoch's per-step losses, in HBM
+    step_trainer = epoch_graph = epoch_key = None
+    bound = False
     loss_list, preds, results = [], [], []
+
+    def one_step(i, batch):
+        model.zero_grad()
+        pred = model.forward(batch.inputs)
+        loss = loss_layer.loss(pred, batch.targets)
+        loss.backward()
+        model.step()
+        loss_hist[i:i + 1] = loss.values                   # a 4-byte device copy: no host sync inside the loop
+        return loss
+
     for epoch in range(num_ep):
-        t_start = time.time()
-        if trainer:
-            batches = [(b.inputs.values, b.targets.values) for b in iterator(train_x, train_y)]   # shuffle drawn here
-            if step_trainer is None:
-                model.forward(Tensor(batches[0][0][:1]))   # lazy Dense init from the first batch's width
-                step_trainer = tn.trainer_from_net(net, max_rows=batch_size, lr=lr, dtype=tn.get_default_float())
-            full = [b for b in batches if b[0].shape[0] == batch_size]
-            graph = step_trainer.capture_steps(full)       # the epoch's full batches as ONE hipGraph launch
-            loss_list.extend(float(v) for v in np.asarray(graph.launch()))
-            for x, y in batches[len(full):]:               # ragged last batch
-                loss_list.append(float(step_trainer.step(x, y)))
-            for i, layer in enumerate(l for l in net.layers if isinstance(l, Dense)):
-                layer.params["w"].values = step_trainer.param_view(i, "w")
-                layer.params["b"].values = step_trainer.param_view(i, "b")
-        else:
-            device_losses = []
-            for batch in iterator(train_x, train_y):
-                model.zero_grad()
-                pred = model.forward(batch.inputs)
-                loss = loss_layer.loss(pred, batch.targets)
-                loss.backward()
-                model.step()
-                device_losses.append(loss.values)          # a 0-d DeviceArray: no host sync inside the loop
-            loss_list.extend(float(v) for v in device_losses)
         tn.synchronize()
+        t_start = time.time()
+        batches = list(iterator(train_x, train_y))         # shuffle drawn here (or ahead, see below); ONE gather per array
+        key = iterator.buffers_token                       # unchanged = the batches sit where the captured kernels read them
+        more = epoch + 1 < num_ep
+        t_data = time.time()
+        t_capture = t_data
+        if trainer:
+            if step_trainer is None:
+                model.forward(Tensor(batches[0].inputs.values[:1]))   # lazy Dense init from the first batch's width
+                step_trainer = tn.trainer_from_net(net, max_rows=batch_size, lr=lr, dtype=tn.get_default_float())
+            if epoch_graph is None or epoch_key != key:
+                # every step of the epoch (the ragged last batch included) as ONE hipGraph launch
+                epoch_graph = step_trainer.capture_steps([(b.inputs.values, b.targets.values) for b in batches])
+                epoch_key = key
+                t_capture = time.time()
+            device_losses = epoch_graph.launch()           # asynchronous: the GPU works through the epoch ...
+            if more:
+                iterator.prefetch_order(len(train_x))      # ... while the host draws the next epoch's permutation
+            losses = np.asarray(device_losses)             # the one synchronising read-back of the epoch
+            if not bound or step_trainer.padded:           # (views of the trainer's arena: bound once; padded nets: copies)
+                for i, layer in enumerate(l for l in net.layers if isinstance(l, Dense)):
+                    layer.params["w"].values = step_trainer.param_view(i, "w")
+                    layer.params["b"].values = step_trainer.param_view(i, "b")
+                bound = True
+        elif capture and epoch > 0:
+            if epoch_graph is None or epoch_key != key:
+                epoch_graph = tn.capture(lambda: [one_step(i, b) for i, b in enumerate(batches)], warmup=0)
+                epoch_key = key
+                t_capture = time.time()
+            epoch_graph()
+            if more:
+                iterator.prefetch_order(len(train_x))
+            losses = np.asarray(loss_hist)
+        else:
+            for i, batch in enumerate(batches):
+                one_step(i, batch)
+            losses = np.asarray(loss_hist)
+        loss_list.extend(losses.tolist())
+        tn.synchronize()
+        t_train = time.time()
         if log:
-            log("Epoch %d tim cost: %.4f" % (epoch, time.time() - t_start))
+            log("Epoch %d tim cost: %.4f" % (epoch, t_train - t_start))
         model.set_phase("TEST")
         test_pred = model.forward(test_x)
         test_pred_idx = np.argmax(test_pred, axis=1)
@@ -112,6 +158,10 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
         if log:
             log(res)
         model.set_phase("TRAIN")
+        if stats is not None:
+            stats.append({"data": t_data - t_start, "capture": t_capture - t_data, "steps": t_train - t_capture,
+                          "train": t_train - t_start, "eval": time.time() - t_train, "n_rows": len(train_x),
+                          "n_steps": len(batches)})
     return loss_list, preds, results
 
 
@@ -123,7 +173,7 @@ def main(args):
     print("backend:", tn.backend_name())
     widths = [int(w) for w in args.widths.split(",")]
     loss_list, _, _ = train(train_x, train_y, test_x, test_y, widths, args.num_ep, args.batch_size, args.lr,
-                            trainer=args.trainer, log=print)
+                            trainer=args.trainer, capture=args.capture, log=print)
     print("last loss: %.6f" % loss_list[-1])
 
 
@@ -136,4 +186,5 @@ if __name__ == "__main__":
     parser.add_argument("--seed", default=-1, type=int)
     parser.add_argument("--widths", default="256,128", type=str)
     parser.add_argument("--trainer", action="store_true")
+    parser.add_argument("--capture", action="store_true")
     main(parser.parse_args())

@@ -39,7 +39,7 @@ class MLPTrainer(object):
         # sum of zeros), hence zero gradients everywhere and a zero Adam step — it stays zero for ever.  `param_view` /
         # `grad_view` / `get_parameters` present the logical shapes; `params` / `state_dict` are the padded arenas.
         self._pwidths = list(self.widths)
-        if (loss == "softmax_nll" and optimizer == "adam" and comm is None and self.n_layers >= 3
+        if (loss == "softmax_nll" and optimizer == "adam" and self.n_layers >= 3
                 and not (isinstance(dtype, str) and dtype in ("bfloat16", "bf16")) and np.dtype(dtype) == np.float32
                 and any(w % 16 for w in self.widths[1:-1]) and self.widths[-1] <= 16
                 and (self.widths[-2] + 15) // 16 * 16 <= 256):

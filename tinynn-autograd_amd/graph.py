@@ -29,8 +29,12 @@ class CapturedFunction(object):
         _lib.synchronize()
         self._graph = _lib.Graph()
         from . import device_array as _da
-        from .core import model as _model, optimizer as _optimizer
+        from .core import model as _model, optimizer as _optimizer, tensor as _tensor
+        _tensor.take_capture_grads()
         _da.take_capture_lazies()        # (anything left over from an aborted capture)
+        # an advance of Adam's powers made by an EAGER loss launch (a warm-up call above, another model's pending loss) that
+        # no step has consumed is taken back first: the capture's own loss launch must record the advance in the graph
+        _optimizer.settle_eager_ticks()
         with self._graph:
             self.outputs = fn()          # recorded, not executed
             # work the op-level fusions left for a step that is NOT part of fn: a deferred first-layer backward is settled
@@ -40,7 +44,11 @@ class CapturedFunction(object):
         # deferred arrays nobody has read yet (TRAIN-phase logits of a captured forward, the hidden gradient of the fused
         # head): re-armed after every replay so that a read sees THAT replay's values
         self._ticked = _optimizer.take_capture_ticks()
+        self._pending = _optimizer._TICKED
         self._lazies = _da.take_capture_lazies()
+        # ... and the gradient attributes of the parameters the function accumulated into (an eager step between replays drops
+        # them): re-installed after every replay
+        self._grads = _tensor.take_capture_grads()
 
     def __call__(self):
         for opt in self._ticked:
@@ -50,8 +58,13 @@ class CapturedFunction(object):
             arr = ref()
             if arr is not None:
                 arr._thunk = thunk
+        for ref, grad, shared in self._grads:
+            t = ref()
+            if t is not None:
+                t._grad, t._grad_shared, t._grad_zero = grad, shared, False
         for opt in self._ticked:
-            opt._ticked = True
+            opt._ticked, opt._tick_captured = True, False      # this replay's loss launch HAS advanced the powers
+            self._pending.add(opt)
         return self.outputs
 
     replay = __call__
