@@ -1140,12 +1140,30 @@ def main():
     return exit_code
 
 
+def box_probe():
+    """tools/probes/bin/libtnn_probe.so (its own library: `make -C tinynn-autograd_amd/csrc probe`, built by
+    __graft_entry__.build()) -> what this box's MFMA pipes, clocks and HBM do right now (~100 ms on the GPU)."""
+    path = os.path.join(ROOT, "tools", "probes", "bin", "libtnn_probe.so")
+    lib = ctypes.CDLL(path)
+    lib.tnn_probe_box.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    lib.tnn_probe_box.restype = ctypes.c_int
+    out = (ctypes.c_double * 10)()
+    rc = lib.tnn_probe_box(out, 10)
+    if rc:
+        raise RuntimeError("tnn_probe_box failed with code %d" % rc)
+    return {"mfma_f32_tflops": round(out[0], 1), "mfma_f32_clock_ghz": round(out[1], 3),
+            "mfma_f32_tflops_step_like_operands": round(out[8], 1), "mfma_f32_clock_ghz_step_like_operands": round(out[9], 3),
+            "mfma_bf16_tflops_random_operands": round(out[2], 1), "mfma_bf16_clock_ghz_random_operands": round(out[3], 3),
+            "mfma_bf16_tflops_zero_operands": round(out[4], 1), "mfma_bf16_clock_ghz_zero_operands": round(out[5], 3),
+            "copy_float4_gbs": round(out[6], 1), "stream_4read_3write_gbs": round(out[7], 1)}
+
+
 def box_object(line):
-    """What THIS box can do (tnn_box_probe: MFMA-only loops with random / zero operands and their sustained clocks, a float4
+    """What THIS box can do (libtnn_probe.so: MFMA-only loops with random / zero operands and their sustained clocks, a float4
     copy over 2 GiB), measured after everything else so that it does not disturb the timed runs — and every MFMA- or
     HBM-bound roofline object on the line gets `frac_of_box` beside its spec-peak `frac`: achieved / the same box's probe
     (bf16 against the random-operand loop: the chip clocks to its power budget and real data is not zeros)."""
-    box = _lib.box_probe()
+    box = box_probe()
     box["note"] = ("MFMA-only loops: 8 waves per CU, 8 independent accumulators; spec peaks 157.3 (fp32) / 2500 (bf16 dense) "
                    "TFLOP/s, 8000 GB/s; frac_of_box on the roofline objects = achieved / this box's probe")
 

@@ -381,6 +381,17 @@ TNN_API int tnn_adam_ex(void* p, const void* g, void* m, void* v, int64_t n, dou
 TNN_API int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                              int64_t ldb, void* C, int64_t ldc, int c_dtype, const void* bias_f32, int act,
                              int relu_sign, const void* mask_y, int64_t ldy);
+/* ... with a SECOND bf16 output: C_t [N, ldct] = the transpose of C (element (m, n) at C_t[n * ldct + m]) — the K-contiguous
+ * operand the dW product of the backward pass needs for a^T and dz^T (core/ops.py:159-160), written by the epilogue that
+ * already holds the finished tile in LDS instead of by a tnn_transpose_bf16 launch.  Output dtype is bf16.  (Shapes the
+ * split-K kernel does not take fall back to GEMM + transpose: two launches, same bytes.) */
+TNN_API int tnn_gemm_bf16_nt_t(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                               void* C, int64_t ldc, const void* bias_f32, int act, int relu_sign, const void* mask_y,
+                               int64_t ldy, void* C_t, int64_t ldct);
+/* Allocate, outside any hipGraph capture, whatever hand-off memory tnn_gemm_bf16_nt / _nt_t needs for this shape (the
+ * split-K kernel's slabs), so that the first call may be inside a capture and eager and captured steps run the same
+ * kernel.  No reference counterpart (new). */
+TNN_API int tnn_gemm_bf16_reserve(int64_t M, int64_t N, int64_t K);
 TNN_API int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols);     /* [R,C] -> [C,R] */
 TNN_API int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16);              /* f32 <-> bf16 (RNE) */
 TNN_API int tnn_colsum_bf16(const void* in, void* out_f32, int64_t rows, int64_t cols);    /* bias gradient */
@@ -390,6 +401,17 @@ TNN_API int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_g
  * adam_pows_f64 != NULL, one thread advances {b1^t, b2^t} (tnn_adam_tick without its launch). */
 TNN_API int tnn_mse_bf16_tick(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32,
                               void* loss_out2_f32, void* dpred, void* adam_pows_f64, double b1, double b2);
+/* The loss launch of a whole bf16 step, with the backward pass's operand preparation folded in (ONE launch instead of
+ * tnn_mse_bf16_tick's two + two tnn_transpose_bf16): loss = sum((pred - y)^2) / m_global to loss_out_f32 (and loss_out2_f32
+ * when not NULL), dpred = 2 (pred - y) / m_global [rows, cols] AND its transpose dpred_t [cols, rows] (NULL = skip), x_t
+ * [x_cols, rows] = the transpose of the batch x [rows, x_cols] (x / x_t NULL = skip), Adam's {b1^t, b2^t} advanced when
+ * adam_pows_f64 != NULL.  rows, cols, x_cols multiples of 64.  partials_f64: workspace of rows / 64 * cols / 64 doubles;
+ * ticket_u32: one word that is ZERO on entry and is left zero (arrival counter of the loss reduction).
+ * core/losses.py (sum-of-squares form), core/ops.py:159-160 for the transposed operands. */
+TNN_API int tnn_mse_bf16_prep(const void* pred, const void* y, int64_t rows, int64_t cols, int64_t m_global,
+                              void* loss_out_f32, void* loss_out2_f32, void* dpred, void* dpred_t, const void* x,
+                              int64_t x_cols, void* x_t, void* partials_f64, void* ticket_u32, void* adam_pows_f64,
+                              double b1, double b2);
 /* The bias of one bf16 Dense layer in ONE launch: db_f32 [cols] = column sums of dz (bf16 [rows, cols], core/ops.py:52-54)
  * and, when p_master / m / v [cols] are given, Adam on the fp32 master bias (core/optimizer.py:67-79, pows already advanced)
  * + its bf16 copy w_bf16 (may be NULL).  Replaces tnn_colsum_bf16 (two launches at this size) + tnn_adam_master_bf16_2d. */
@@ -413,6 +435,12 @@ TNN_API int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void
 TNN_API int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                   void* g_out_f32, void* p_master, void* m, void* v, void* w_bf16, void* wT_bf16,
                                   double lr, double b1, double b2, double eps, const void* pows_f64);
+/* tnn_bias_bf16_adam for SEVERAL layers in one launch (the last launch of the single-GPU bf16 step): arrays of n_layers
+ * pointers / column counts, dz[l] bf16 [rows, cols[l]]; p_master / m / v / w_bf16 arrays may be NULL as a whole (gradients only)
+ * and w_bf16[l] individually.  Layer by layer the same summation order as tnn_bias_bf16_adam.  n_layers <= 16. */
+TNN_API int tnn_bias_bf16_adam_multi(int n_layers, const void* const* dz, int64_t rows, const int64_t* cols,
+                                     void* const* db_f32, void* const* p_master, void* const* m, void* const* v,
+                                     void* const* w_bf16, double lr, double b1, double b2, double eps, const void* pows_f64);
 /* Adam on a flat slice of the fp32 master parameters whose gradient arrives as bf16 (the reduce-scattered slice of the
  * sharded-optimizer step): p / m / v fp32 updated in place, the slice's bf16 working copy refreshed.  pows_f64 already
  * advanced for this step. */
@@ -479,14 +507,6 @@ TNN_API int tnn_mlp_masters_sharded(void* handle, int* world);
 TNN_API int tnn_mlp_gather_masters(void* handle);
 /* intermediate activations for parity tests: layer l output [rows, widths[l+1]] */
 TNN_API int tnn_mlp_activation(void* handle, int layer, void** ptr);
-
-/* What THIS box can do, in ~100 ms (measurement infrastructure for bench.py's `box` object; no reference counterpart):
- * out[0] fp32 MFMA-only TFLOP/s (v_mfma_f32_32x32x2_f32, random operands), out[1] its sustained shader clock in GHz,
- * out[2] / out[3] bf16 (v_mfma_f32_32x32x16_bf16) with random operands, out[4] / out[5] with zero operands (the chip clocks to
- * its power budget), out[6] float4 copy bandwidth in GB/s (1 GiB read + 1 GiB written), out[7] GB/s of the optimizer's stream
- * mix (four 256 MB arrays read, three of them rewritten in place), out[8] / out[9] the fp32 loop with the training step's operand
- * distribution (a uniform in [0, 1), b uniform in +-0.027).  n_out >= 10. */
-TNN_API int tnn_box_probe(double* out, int n_out);
 
 /* ------------------------------------------------------------------ RCCL over xGMI (C1, C2) --- */
 /* New relative to the reference (it has no communication).  One process per GPU. */

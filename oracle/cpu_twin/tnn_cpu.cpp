@@ -150,11 +150,6 @@ const char* tnn_last_error(void) { return tnn::g_err; }
 int tnn_backend_kind(void) { return 2; }
 int tnn_init(int) { g_ready = true; return 0; }
 int tnn_shutdown(void) { return 0; }
-int tnn_box_probe(double* out, int n_out) {
-    (void)out; (void)n_out;
-    tnn::set_error("tnn_box_probe: the CPU twin has no device to probe");
-    return 2;
-}
 
 int tnn_device_props(int* cu, int* clk, int64_t* hbm, char* name, int n) {
     if (cu) *cu = 0;
@@ -1062,6 +1057,63 @@ int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_
     if (g_out) memcpy(g_out, g.data(), g.size() * 4);
     adam_master_rows(false, (float*)p, g.data(), (float*)m, (float*)v, (bf16_t*)w16, (bf16_t*)wT16, M, N, M, lr, b1, b2, eps,
                             (const double*)pows);
+    return 0;
+}
+int tnn_bias_bf16_adam_multi(int n_layers, const void* const* dz, int64_t rows, const int64_t* cols, void* const* db, void* const* p,
+                             void* const* m, void* const* v, void* const* w16, double lr, double b1, double b2, double eps,
+                             const void* pows) {
+    NEED_INIT();
+    REQ(n_layers >= 1 && n_layers <= 16 && dz && cols && db && rows > 0, "tnn_bias_bf16_adam_multi: bad arguments");
+    // (the pointer arrays belong to the caller: copied before a capture stores the call)
+    std::vector<const void*> dzv(dz, dz + n_layers);
+    std::vector<int64_t> cv(cols, cols + n_layers);
+    std::vector<void*> dbv(db, db + n_layers), pv, mv, vv, wv;
+    if (p) pv.assign(p, p + n_layers);
+    if (m) mv.assign(m, m + n_layers);
+    if (v) vv.assign(v, v + n_layers);
+    if (w16) wv.assign(w16, w16 + n_layers);
+    auto run = [=]() -> int {
+        for (int l = 0; l < n_layers; ++l)
+            if (int rc = tnn_bias_bf16_adam(dzv[l], rows, cv[l], dbv[l], pv.empty() ? nullptr : pv[l], mv.empty() ? nullptr : mv[l],
+                                            vv.empty() ? nullptr : vv[l], wv.empty() ? nullptr : wv[l], lr, b1, b2, eps, pows))
+                return rc;
+        return 0;
+    };
+    if (g_capturing) { g_capturing->calls.push_back(run); return 0; }
+    return run();
+}
+int tnn_gemm_bf16_nt_t(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       const void* bias, int act, int relu_sign, const void* mask_y, int64_t ldy, void* Ct, int64_t ldct) {
+    NEED_INIT();
+    REQ(Ct != nullptr && ldct >= M, "tnn_gemm_bf16_nt_t: C_t is required with ldct >= M");
+    RECORD(tnn_gemm_bf16_nt_t(M, N, K, A, lda, B, ldb, C, ldc, bias, act, relu_sign, mask_y, ldy, Ct, ldct));
+    if (int rc = tnn_gemm_bf16_nt(M, N, K, A, lda, B, ldb, C, ldc, TNN_BF16, bias, act, relu_sign, mask_y, ldy)) return rc;
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) ((bf16_t*)Ct)[j * ldct + i] = ((const bf16_t*)C)[i * ldc + j];
+    return 0;
+}
+int tnn_gemm_bf16_reserve(int64_t, int64_t, int64_t) {
+    NEED_INIT();
+    return 0;
+}
+int tnn_mse_bf16_prep(const void* pred, const void* y, int64_t rows, int64_t cols, int64_t m_global, void* loss_out, void* loss_out2,
+                      void* dpred, void* dpred_t, const void* x, int64_t x_cols, void* x_t, void* partials, void* ticket, void* pows,
+                      double b1, double b2) {
+    NEED_INIT();
+    REQ(pred && y && rows > 0 && cols > 0 && rows % 64 == 0 && cols % 64 == 0 && partials && ticket && (x == nullptr) == (x_t == nullptr) &&
+            (x == nullptr || x_cols % 64 == 0),
+        "tnn_mse_bf16_prep: bad arguments");
+    REQ(loss_out != nullptr || loss_out2 == nullptr, "tnn_mse_bf16_prep: loss_out2 needs loss_out");
+    RECORD(tnn_mse_bf16_prep(pred, y, rows, cols, m_global, loss_out, loss_out2, dpred, dpred_t, x, x_cols, x_t, partials, ticket, pows, b1, b2));
+    std::vector<bf16_t> dz((size_t)(rows * cols));
+    if (int rc = tnn_mse_bf16_tick(pred, y, rows * cols, m_global, loss_out, loss_out2, dpred ? dpred : dz.data(), pows, b1, b2)) return rc;
+    const bf16_t* d = dpred ? (const bf16_t*)dpred : dz.data();
+    if (dpred_t)
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t c = 0; c < cols; ++c) ((bf16_t*)dpred_t)[c * rows + r] = d[r * cols + c];
+    if (x_t)
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t c = 0; c < x_cols; ++c) ((bf16_t*)x_t)[c * rows + r] = ((const bf16_t*)x)[r * x_cols + c];
     return 0;
 }
 int tnn_adam_tick(void* pows, double b1, double b2) {

@@ -80,6 +80,82 @@ def test_bf16_skinny_gemm_split_k_path():
 
 
 @pytest.mark.gpu
+def test_bf16_gemm_transposed_second_output():
+    """tnn_gemm_bf16_nt_t: C and C^T from ONE launch (the split-K kernel's LDS image read a second time column-wise) — C bit-equal
+    to tnn_gemm_bf16_nt's, C^T its exact transpose, for the plain / bias + ReLU / mask epilogues (the mask must be applied to
+    the transposed copy too), interior and ragged tiles, and on a shape the split-K kernel does not take (GEMM + transpose)."""
+    rs = np.random.RandomState(44)
+    for (M, N, K) in ((512, 8192, 1024), (512, 8064, 640), (300, 8000, 1024), (256, 384, 128)):
+        a = bf16.round_to_bf16(rs.uniform(-1, 1, (M, K)).astype(np.float32))
+        b = bf16.round_to_bf16(rs.uniform(-1, 1, (N, K)).astype(np.float32))
+        A, B = bf16.to_bf16(a), bf16.to_bf16(b)
+        bias = tn.asarray(rs.randn(N).astype(np.float32))
+        plain = np.asarray(bf16.gemm_nt(A, B, out_dtype=np.uint16))
+        c, ct = bf16.gemm_nt_t(A, B)
+        assert np.array_equal(np.asarray(c), plain) and np.array_equal(np.asarray(ct), plain.T), (M, N, K, "plain")
+        act16 = bf16.gemm_nt(A, B, out_dtype=np.uint16, bias=bias, relu=True, relu_sign=True)
+        c, ct = bf16.gemm_nt_t(A, B, bias=bias, relu=True, relu_sign=True)
+        assert np.array_equal(np.asarray(c), np.asarray(act16)) and np.array_equal(np.asarray(ct), np.asarray(act16).T), (M, N, K, "relu")
+        masked = np.asarray(bf16.gemm_nt(A, B, out_dtype=np.uint16, mask=act16))
+        c, ct = bf16.gemm_nt_t(A, B, mask=act16)
+        assert np.array_equal(np.asarray(c), masked) and np.array_equal(np.asarray(ct), masked.T), (M, N, K, "mask")
+        assert (masked[(np.asarray(act16) & 0x8000) != 0] & 0x7fff == 0).all()
+
+
+@pytest.mark.gpu
+def test_bf16_prep_launch_and_multi_layer_bias_launch():
+    """tnn_mse_bf16_prep (loss + dz + dz^T + x^T + beta powers in one launch) against tnn_mse_bf16_tick + two transposes, and
+    tnn_bias_bf16_adam_multi (every layer's bias gradient + Adam in one launch) against one tnn_bias_bf16_adam per layer:
+    every output bit-identical (the loss to float32 rounding of an f64 sum)."""
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(45)
+    rows, cols, xc = 256, 640, 384
+    pred = bf16.to_bf16(rs.randn(rows, cols).astype(np.float32))
+    y = bf16.to_bf16(rs.randn(rows, cols).astype(np.float32))
+    x = bf16.to_bf16(rs.rand(rows, xc).astype(np.float32))
+    dz_ref, loss_ref = tn.empty((rows, cols), np.uint16), tn.empty((2,), np.float32)
+    pows_ref = tn.asarray(np.array([0.9, 0.999, 0.0, 0.0]), dtype=np.float64)
+    lib.mse_bf16_tick(pred._ptr, y._ptr, rows * cols, rows, loss_ref._ptr, loss_ref._ptr + 4, dz_ref._ptr, pows_ref._ptr, 0.9, 0.999)
+    dz, dzt, xt = tn.empty((rows, cols), np.uint16), tn.empty((cols, rows), np.uint16), tn.empty((xc, rows), np.uint16)
+    loss = tn.empty((2,), np.float32)
+    pows = tn.asarray(np.array([0.9, 0.999, 0.0, 0.0]), dtype=np.float64)
+    ws, ticket = tn.empty((rows // 64 * (cols // 64),), np.float64), tn.asarray(np.zeros(2, np.int64))
+    for rep in range(2):                                     # the ticket returns to zero: a second launch works the same
+        lib.mse_bf16_prep(pred._ptr, y._ptr, rows, cols, rows, loss._ptr, loss._ptr + 4, dz._ptr, dzt._ptr, x._ptr, xc, xt._ptr,
+                          ws._ptr, ticket._ptr, pows._ptr if rep == 0 else None, 0.9, 0.999)
+        assert np.array_equal(np.asarray(dz), np.asarray(dz_ref)) and np.array_equal(np.asarray(dzt), np.asarray(dz_ref).T)
+        assert np.array_equal(np.asarray(xt), np.asarray(x).T)
+        np.testing.assert_allclose(np.asarray(loss), np.asarray(loss_ref), rtol=2e-7)
+        assert np.asarray(loss)[0] == np.asarray(loss)[1] and np.asarray(ticket)[0] == 0
+    assert np.array_equal(np.asarray(pows), np.asarray(pows_ref))
+
+    # the biases of several layers in ONE launch against one tnn_bias_bf16_adam launch per layer
+    import ctypes
+    widths = [640, 200, 64]
+    dzs = [bf16.to_bf16((rs.randn(rows, c) * 0.01).astype(np.float32)) for c in widths]
+    results = []
+    for multi in (False, True):
+        st = [[tn.asarray(np.random.RandomState(8 + i).randn(c).astype(np.float32)), tn.zeros((c,), np.float32), tn.zeros((c,), np.float32),
+               tn.empty((c,), np.uint16), tn.empty((c,), np.float32)] for i, c in enumerate(widths)]          # p, m, v, w16, db
+        pw = tn.asarray(np.array([0.9, 0.999, 0.0, 0.0]), dtype=np.float64)
+        for _ in range(2):
+            if multi:
+                arr = lambda k: (ctypes.c_void_p * 3)(*[s_[k]._ptr for s_ in st])          # noqa: E731
+                lib.bias_bf16_adam_multi(3, (ctypes.c_void_p * 3)(*[d._ptr for d in dzs]), rows, (ctypes.c_int64 * 3)(*widths),
+                                         arr(4), arr(0), arr(1), arr(2), arr(3), 1e-3, 0.9, 0.999, 1e-8, pw._ptr)
+            else:
+                for d, c, s_ in zip(dzs, widths, st):
+                    lib.bias_bf16_adam(d._ptr, rows, c, s_[4]._ptr, s_[0]._ptr, s_[1]._ptr, s_[2]._ptr, s_[3]._ptr, 1e-3, 0.9, 0.999,
+                                       1e-8, pw._ptr)
+        results.append([np.asarray(a).copy() for s_ in st for a in s_])
+    for i, (a, b) in enumerate(zip(*results)):
+        assert np.array_equal(a, b), i
+    np.testing.assert_allclose(results[1][4], np.asarray(bf16.to_f32(dzs[0])).astype(np.float64).sum(0), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_bf16_transpose_colsum_mse_adam():
     from tinynn_autograd_amd import _lib
     rs = np.random.RandomState(42)

@@ -197,3 +197,10 @@ def test_config_E_trainer_step_at_full_size():
     t2.set_parameters([{"w": W[i], "b": B[i]} for i in range(L)])
     assert float(t2.step(x16, x16)) == loss and float(t2.step(x16, x16)) == loss2
     assert np.array_equal(np.asarray(t2.params), p_ref) and np.array_equal(np.asarray(t2.adam_m), m_ref)
+    # ... in 3 L + 1 = 13 launches: 4 forward GEMMs (the hidden ones writing a^T from their epilogues), the prep launch (loss, dz,
+    # dz^T, x^T, beta powers), 3 dX GEMMs (writing dz^T), 4 dW GEMMs with Adam in the epilogue, one launch for the four biases
+    # (25 launches before)
+    import ctypes
+    n = ctypes.c_int(0)
+    t2._lib.mlp_launch_window(t2._h, 0, -1, ctypes.byref(n))
+    assert n.value == 3 * L + 1 == 13, n.value

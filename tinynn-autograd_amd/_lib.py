@@ -113,6 +113,11 @@ _SIGNATURES = {
     "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, c_int, _p, _p],
     "tnn_gemm_bf16_nt": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, c_int, _p, c_int, c_int,
                          _p, c_int64],
+    "tnn_gemm_bf16_nt_t": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
+                           _p, c_int64],
+    "tnn_gemm_bf16_reserve": [c_int64, c_int64, c_int64],
+    "tnn_mse_bf16_prep": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, c_int64, _p, _p, _p, _p, c_double, c_double],
+    "tnn_bias_bf16_adam_multi": [c_int, _p, c_int64, _i64p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
     "tnn_transpose_bf16": [_p, _p, c_int64, c_int64],
     "tnn_cast_bf16": [_p, _p, c_int64, c_int],
     "tnn_colsum_bf16": [_p, _p, c_int64, c_int64],
@@ -142,7 +147,6 @@ _SIGNATURES = {
     "tnn_mlp_sync_params": [_p],
     "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
     "tnn_mlp_bf16_weights": [_p, POINTER(c_void_p)],
-    "tnn_box_probe": [POINTER(ctypes.c_double), c_int],
     "tnn_mlp_masters_sharded": [_p, POINTER(c_int)],
     "tnn_mlp_gather_masters": [_p],
     "tnn_comm_unique_id": [_p],
@@ -289,18 +293,6 @@ def device_props():
     lib.device_props(ctypes.byref(cu), ctypes.byref(clk), ctypes.byref(hbm), name, 256)
     return {"name": name.value.decode(), "cus": cu.value, "clock_khz": clk.value,
             "hbm_bytes": hbm.value}
-
-
-def box_probe():
-    """tnn_box_probe as a dict: what this box's MFMA pipes, clocks and HBM do right now (~100 ms on the GPU)."""
-    lib = get()
-    out = (c_double * 10)()
-    lib.box_probe(out, 10)
-    return {"mfma_f32_tflops": round(out[0], 1), "mfma_f32_clock_ghz": round(out[1], 3),
-            "mfma_f32_tflops_step_like_operands": round(out[8], 1), "mfma_f32_clock_ghz_step_like_operands": round(out[9], 3),
-            "mfma_bf16_tflops_random_operands": round(out[2], 1), "mfma_bf16_clock_ghz_random_operands": round(out[3], 3),
-            "mfma_bf16_tflops_zero_operands": round(out[4], 1), "mfma_bf16_clock_ghz_zero_operands": round(out[5], 3),
-            "copy_float4_gbs": round(out[6], 1), "stream_4read_3write_gbs": round(out[7], 1)}
 
 
 def pool_stats():

@@ -43,6 +43,20 @@ def gemm_nt(a16, b16, out_dtype=np.float32, bias=None, relu=False, relu_sign=Fal
     return out
 
 
+def gemm_nt_t(a16, b16, bias=None, relu=False, relu_sign=False, mask=None):
+    """gemm_nt with bf16 output that also returns C^T [N, M], written by the producing epilogue (tnn_gemm_bf16_nt_t):
+    (C, C_t)."""
+    M, K = a16.shape
+    N, K2 = b16.shape
+    if K != K2:
+        raise ValueError("gemm_nt_t: K mismatch %d vs %d" % (K, K2))
+    out, out_t = da.empty((M, N), np.uint16), da.empty((N, M), np.uint16)
+    _lib.get().gemm_bf16_nt_t(M, N, K, a16._ptr, K, b16._ptr, K, out._ptr, N, None if bias is None else bias._ptr,
+                              _lib.ACT_RELU if relu else _lib.ACT_NONE, int(relu_sign), None if mask is None else mask._ptr, N,
+                              out_t._ptr, M)
+    return out, out_t
+
+
 def round_to_bf16(x):
     """Host emulation of the device's f32 -> bf16 -> f32 round trip (for oracles in tests)."""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)

@@ -367,6 +367,106 @@ __global__ __launch_bounds__(256) void mse_bf16_kernel(const bf16_t* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = ((lds[0] + lds[1]) + (lds[2] + lds[3])) * inv_m;
 }
+// The "prep" launch of a whole bf16 training step (tnn_mse_bf16_prep), 64 x 64 tiles, two roles in ONE grid:
+//   blocks [0, n_loss)     a tile of pred / y [R][C]: e = pred - y, the tile's share of sum(e^2) / m (f64 block partial),
+//                          dz = 2 e / m row-major (8-B stores, the load geometry) AND dz^T [C][R] through an LDS image of the
+//                          transposed tile (transpose_bf16_kernel's scheme) — the K-contiguous operand of the last layer's dW
+//                          product (core/ops.py:159-160);
+//                          the LAST of these blocks to finish (agent-scope arrival ticket, back at 0 afterwards) adds the block
+//                          partials in index order — sum_partials_f32_kernel's order, so the loss does not depend on who is last;
+//   blocks [n_loss, ...)   a tile of the batch x [R][XC] -> x^T [XC][R], the first layer's dW operand.
+// Replaces mse_bf16_kernel + sum_partials_f32_kernel + two transpose_bf16_kernel launches.  R, C, XC multiples of 64.
+__global__ __launch_bounds__(256) void mse_prep_bf16_kernel(const bf16_t* __restrict__ pred, const bf16_t* __restrict__ y,
+                                                            int64_t R, int64_t C, double inv_m, double* __restrict__ partial,
+                                                            unsigned* __restrict__ ticket, float* __restrict__ loss_out,
+                                                            float* __restrict__ loss_out2, bf16_t* __restrict__ dz,
+                                                            bf16_t* __restrict__ dzT, const bf16_t* __restrict__ x, int64_t XC,
+                                                            bf16_t* __restrict__ xT, double* __restrict__ tick, double tb1,
+                                                            double tb2, const int* guard) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];     // [c][r], 144-B rows
+    __shared__ double lds4[4];
+    __shared__ int is_last;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;             // 16 x 16 threads, 4x4 elements each
+    const int n_tc = (int)(C / 64), n_loss = (int)(R / 64) * n_tc;
+    const int b = (int)blockIdx.x;
+    const bool loss_role = b < n_loss;                                  // block-uniform
+    if (tick != nullptr && b == 0 && threadIdx.x == 0 &&
+        (guard == nullptr || __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)) {
+        tick[0] *= tb1;                                                 // Adam's {b1^t, b2^t}: nothing in this launch reads them
+        tick[1] *= tb2;
+    }
+    const int bb = loss_role ? b : b - n_loss, ntc = loss_role ? n_tc : (int)(XC / 64);
+    const int64_t r0 = (int64_t)(bb / ntc) * 64, c0 = (int64_t)(bb % ntc) * 64;
+    const int64_t ld = loss_role ? C : XC;
+    const bf16_t* src = loss_role ? pred : x;
+    bf16_t* dstT = loss_role ? dzT : xT;
+    u32x2 row[4];
+    double local = 0.0;
+    const float two_inv_m = (float)(2.0 * inv_m);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t o = (r0 + 4 * ty + i) * ld + c0 + 4 * tx;
+        row[i] = *reinterpret_cast<const u32x2*>(src + o);
+        if (loss_role) {
+            const u32x2 yv = *reinterpret_cast<const u32x2*>(y + o);
+            float e[4] = {__uint_as_float(row[i].x << 16) - __uint_as_float(yv.x << 16),
+                          __uint_as_float(row[i].x & 0xffff0000u) - __uint_as_float(yv.x & 0xffff0000u),
+                          __uint_as_float(row[i].y << 16) - __uint_as_float(yv.y << 16),
+                          __uint_as_float(row[i].y & 0xffff0000u) - __uint_as_float(yv.y & 0xffff0000u)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) local += (double)e[k] * (double)e[k];
+            row[i].x = (uint32_t)f2bf(two_inv_m * e[0]) | ((uint32_t)f2bf(two_inv_m * e[1]) << 16);
+            row[i].y = (uint32_t)f2bf(two_inv_m * e[2]) | ((uint32_t)f2bf(two_inv_m * e[3]) << 16);
+            if (dz) *reinterpret_cast<u32x2*>(dz + o) = row[i];
+        }
+    }
+    if (dstT != nullptr) {
+        // column j of the 4x4 block = elements {row0[j], row1[j], row2[j], row3[j]}
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int w = j >> 1;
+            u32x2 col;
+            if (j & 1) {
+                col.x = (row[0][w] >> 16) | (row[1][w] & 0xffff0000u);
+                col.y = (row[2][w] >> 16) | (row[3][w] & 0xffff0000u);
+            } else {
+                col.x = (row[0][w] & 0xffffu) | (row[1][w] << 16);
+                col.y = (row[2][w] & 0xffffu) | (row[3][w] << 16);
+            }
+            *reinterpret_cast<u32x2*>(&tile[4 * tx + j][4 * ty]) = col;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (threadIdx.x >> 3) + 32 * i, seg = threadIdx.x & 7;      // output row c, 16-B segment
+            *reinterpret_cast<u32x4*>(dstT + (c0 + c) * R + r0 + seg * 8) = *reinterpret_cast<const u32x4*>(&tile[c][seg * 8]);
+        }
+    }
+    if (!loss_role) return;
+    local = tnn::wave_sum(local);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) lds4[w] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // system-scope (write-through) store + drain instead of a release fence: a fence at agent scope writes back every dirty
+        // line of this XCD's L2 — the dz / dz^T tiles just stored — once per workgroup (34 us for the launch, measured)
+        __hip_atomic_store(partial + b, ((lds4[0] + lds4[1]) + (lds4[2] + lds4[3])) * inv_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (unsigned)n_loss - 1 ? 1 : 0;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // graph replays start from 0
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last || loss_out == nullptr || threadIdx.x >= 64) return;
+    double sl = 0.0;      // (system-scope loads: this XCD's L2 may hold last launch's partials)
+    for (int i = threadIdx.x; i < n_loss; i += 64) sl += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    sl = tnn::wave_sum(sl);
+    if (threadIdx.x == 0) {
+        loss_out[0] = (float)sl;
+        if (loss_out2) loss_out2[0] = (float)sl;
+    }
+}
 __global__ __launch_bounds__(64) void sum_partials_f32_kernel(const double* __restrict__ partial, int n,
                                                               float* __restrict__ out, float* __restrict__ out2 = nullptr) {
     double s = 0.0;
@@ -540,14 +640,14 @@ __global__ __launch_bounds__(256) void adam_master_bf16_2d_kernel(float* __restr
 // colsum_bf16_kernel) and, when p != NULL, Adam on the fp32 master bias + refresh of its bf16 copy (core/optimizer.py:67-79).
 // Block = 64 columns x all rows: thread (4 columns, one of 16 row lanes), 8-B loads, the lanes meet in LDS.  Replaces the
 // two column-reduction launches + the bias optimizer launch of the bf16 step (3 x ~5-10 us per layer for 32 KB of output).
-__global__ __launch_bounds__(256) void bias_bf16_kernel(const bf16_t* __restrict__ dz, int64_t R, int64_t C,
-                                                        float* __restrict__ db, float* __restrict__ p, float* __restrict__ m,
-                                                        float* __restrict__ v, bf16_t* __restrict__ w16, float lr, float b1,
-                                                        float b2, float eps, const double* __restrict__ state,
-                                                        const int* guard) {
+__device__ __forceinline__ void bias_bf16_block(const int block, const bf16_t* __restrict__ dz, int64_t R, int64_t C,
+                                                float* __restrict__ db, float* __restrict__ p, float* __restrict__ m,
+                                                float* __restrict__ v, bf16_t* __restrict__ w16, float lr, float b1,
+                                                float b2, float eps, const double* __restrict__ state,
+                                                const int* guard) {
     __shared__ float part[16][64 + 4];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int64_t c0 = (int64_t)blockIdx.x * 64 + 4 * cq;
+    const int64_t c0 = (int64_t)block * 64 + 4 * cq;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (c0 + 3 < C && C % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 7) == 0) {
         constexpr int UN = 8;
@@ -573,7 +673,7 @@ __global__ __launch_bounds__(256) void bias_bf16_kernel(const bf16_t* __restrict
     for (int e = 0; e < 4; ++e) part[rl][4 * cq + e] = a[e];
     __syncthreads();
     if (threadIdx.x < 64) {
-        const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        const int64_t c = (int64_t)block * 64 + threadIdx.x;
         if (c < C) {
             float s = 0.f;
 #pragma unroll
@@ -594,6 +694,32 @@ __global__ __launch_bounds__(256) void bias_bf16_kernel(const bf16_t* __restrict
     }
 }
 
+__global__ __launch_bounds__(256) void bias_bf16_kernel(const bf16_t* __restrict__ dz, int64_t R, int64_t C,
+                                                        float* __restrict__ db, float* __restrict__ p, float* __restrict__ m,
+                                                        float* __restrict__ v, bf16_t* __restrict__ w16, float lr, float b1,
+                                                        float b2, float eps, const double* __restrict__ state,
+                                                        const int* guard) {
+    bias_bf16_block((int)blockIdx.x, dz, R, C, db, p, m, v, w16, lr, b1, b2, eps, state, guard);
+}
+// the biases of SEVERAL layers in one launch (tnn_bias_bf16_adam_multi: the last launch of the single-GPU bf16 step): block b
+// belongs to the layer whose block range holds it and does exactly what bias_bf16_kernel's block does — the same bits
+struct BiasMulti {
+    static constexpr int MAXL = 16;
+    int n;
+    int first_block[MAXL + 1];
+    const bf16_t* dz[MAXL];
+    int64_t C[MAXL];
+    float *db[MAXL], *p[MAXL], *m[MAXL], *v[MAXL];
+    bf16_t* w16[MAXL];
+};
+__global__ __launch_bounds__(256) void bias_bf16_multi_kernel(BiasMulti a, int64_t R, float lr, float b1, float b2, float eps,
+                                                              const double* __restrict__ state, const int* guard) {
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.first_block[l + 1]) ++l;      // block-uniform
+    bias_bf16_block((int)blockIdx.x - a.first_block[l], a.dz[l], R, a.C[l], a.db[l], a.p[l], a.m[l], a.v[l], a.w16[l], lr, b1, b2,
+                    eps, state, guard);
+}
+
 __global__ void adam_advance16_kernel(double* __restrict__ state, double b1, double b2, const int* guard) {
     TNN_GUARD_RETURN(guard);
     state[0] *= b1;
@@ -604,9 +730,49 @@ __global__ void adam_advance16_kernel(double* __restrict__ state, double b1, dou
 
 extern "C" {
 
+// the skinny-product test of tnn_gemm_bf16_nt: does (M, N, K) -> bf16 take the split-K kernel on this chip?
+static bool sk_shape(int64_t M, int64_t N, int64_t K, int64_t* t256_out) {
+    constexpr int S = 2, SK_BN = 128, SK_NSB = 4;
+    const int64_t t256 = ((M + 255) / 256) * ((N + SK_BN - 1) / SK_BN), nk = K / 64;
+    const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int cus = tnn::num_cus();
+    if (t256_out) *t256_out = t256;
+    return nk % S == 0 && nk / S > SK_NSB && t256 * S <= cus && t256 * S * 2 >= cus && tiles <= 2 * (int64_t)cus;
+}
+
+static int gemm_bf16_nt_impl(const char* fn, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                             void* C, int64_t ldc, int c_dtype, const void* bias_f32, int act, int relu_sign,
+                             const void* mask_y, int64_t ldy, void* CT, int64_t ldct);
+
 int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                      void* C, int64_t ldc, int c_dtype, const void* bias_f32, int act, int relu_sign,
                      const void* mask_y, int64_t ldy) {
+    return gemm_bf16_nt_impl("tnn_gemm_bf16_nt", M, N, K, A, lda, B, ldb, C, ldc, c_dtype, bias_f32, act, relu_sign, mask_y, ldy,
+                             nullptr, 0);
+}
+
+int tnn_gemm_bf16_nt_t(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                       void* C, int64_t ldc, const void* bias_f32, int act, int relu_sign, const void* mask_y, int64_t ldy,
+                       void* C_t, int64_t ldct) {
+    TNN_REQUIRE(C_t != nullptr && ldct >= M, "tnn_gemm_bf16_nt_t: C_t is required, with ldct >= M");
+    return gemm_bf16_nt_impl("tnn_gemm_bf16_nt_t", M, N, K, A, lda, B, ldb, C, ldc, TNN_BF16, bias_f32, act, relu_sign, mask_y, ldy,
+                             C_t, ldct);
+}
+
+int tnn_gemm_bf16_reserve(int64_t M, int64_t N, int64_t K) {
+    TNN_NEED_INIT();
+    int64_t t256 = 0;
+    if (!sk_shape(M, N, K, &t256)) return 0;
+    SkWorkspace w;
+    TNN_REQUIRE(sk_workspace(tnn::stream(), (int)t256, 2, (size_t)256 * 128 * 4, &w),
+                "tnn_gemm_bf16_reserve: could not allocate the split-K hand-off memory (inside a capture, or out of memory)");
+    return 0;
+}
+
+static int gemm_bf16_nt_impl(const char* fn, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                             void* C, int64_t ldc, int c_dtype, const void* bias_f32, int act, int relu_sign,
+                             const void* mask_y, int64_t ldy, void* CT, int64_t ldct) {
+    (void)fn;
     TNN_NEED_INIT();
     TNN_REQUIRE(M > 0 && N > 0 && K > 0, "tnn_gemm_bf16_nt: empty problem");
     TNN_REQUIRE(K % BK == 0, "tnn_gemm_bf16_nt: K (%lld) must be a multiple of %d", (long long)K, BK);
@@ -640,17 +806,20 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     // more to its 48 MB slab exchange than its K loop gains).  One workgroup per CU, so the grid must fit the chip once.
     {
         constexpr int S = 2, SK_BN = 128, SK_NSB = 4;
-        const int64_t t256 = ((M + 255) / 256) * ((N + SK_BN - 1) / SK_BN), nk = K / 64;
-        const int cus = tnn::num_cus();
-        if (g.c_bf16 && nk % S == 0 && nk / S > SK_NSB && t256 * S <= cus && t256 * S * 2 >= cus && tiles <= 2u * (unsigned)cus) {
+        int64_t t256 = 0;
+        if (g.c_bf16 && sk_shape(M, N, K, &t256)) {
             SkWorkspace w;
+            // (the hand-off memory is allocated on first use OUTSIDE a capture; tnn_gemm_bf16_reserve — called by the trainer
+            // when it is created — does that up front, so an eager step and a captured one run the same kernel)
             if (sk_workspace(tnn::stream(), (int)t256, S, (size_t)256 * SK_BN * 4, &w)) {
                 g.tiles_m = (int)((M + 255) / 256);
                 g.tiles_n = (int)((N + SK_BN - 1) / SK_BN);
                 g.splitk = S;
                 g.sk_ws = w.slabs;
                 g.sk_cnt = w.counters;
-                hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<SK_BN, 4, 2, 3, SK_NSB, S, 0, 1>), dim3((unsigned)(t256 * S)), 512, 0,
+                g.CT = (bf16_t*)CT; g.ldct = ldct;
+                g.fault = tnn::fault_word();
+                hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<SK_BN, 4, 2, 3, SK_NSB>), dim3((unsigned)(t256 * S)), 512, 0,
                                    tnn::stream(), g);
                 TNN_LAUNCH_OK();
                 return 0;
@@ -673,6 +842,11 @@ int tnn_gemm_bf16_nt(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda
     else
         hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3(tiles), NT, 0, tnn::stream(), g);
     TNN_LAUNCH_OK();
+    // the transposed second output on a shape the split-K kernel does not take: a launch of its own (needs C dense)
+    if (CT != nullptr) {
+        TNN_REQUIRE(ldc == N && ldct == M, "%s: the transposed output of this shape needs dense C and C_t", fn);
+        return tnn_transpose_bf16(C, CT, M, N);
+    }
     return 0;
 }
 
@@ -704,6 +878,57 @@ int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_
     g.guard = tnn::update_guard();
     const unsigned tiles = (unsigned)(g.tiles_m * g.tiles_n);
     hipLaunchKernelGGL((gemm_bf16_dma_kernel<8, 2, false, true>), dim3(tiles), 8 * 64, 0, tnn::stream(), g);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_bias_bf16_adam_multi(int n_layers, const void* const* dz, int64_t rows, const int64_t* cols, void* const* db_f32,
+                             void* const* p_master, void* const* m, void* const* v, void* const* w_bf16, double lr, double b1,
+                             double b2, double eps, const void* pows_f64) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(n_layers >= 1 && n_layers <= BiasMulti::MAXL && dz && cols && db_f32 && rows > 0,
+                "tnn_bias_bf16_adam_multi: 1 .. %d layers, dz / cols / db required", BiasMulti::MAXL);
+    TNN_REQUIRE((p_master != nullptr) == (m != nullptr) && (p_master != nullptr) == (v != nullptr) &&
+                    (p_master == nullptr || pows_f64 != nullptr),
+                "tnn_bias_bf16_adam_multi: p / m / v / pows go together");
+    BiasMulti a = {};
+    a.n = n_layers;
+    int blocks = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        TNN_REQUIRE(dz[l] && db_f32[l] && cols[l] > 0, "tnn_bias_bf16_adam_multi: layer %d: dz, db and cols are required", l);
+        a.dz[l] = (const bf16_t*)dz[l]; a.C[l] = cols[l]; a.db[l] = (float*)db_f32[l];
+        a.p[l] = p_master ? (float*)p_master[l] : nullptr;
+        a.m[l] = m ? (float*)m[l] : nullptr;
+        a.v[l] = v ? (float*)v[l] : nullptr;
+        a.w16[l] = w_bf16 ? (bf16_t*)w_bf16[l] : nullptr;
+        a.first_block[l] = blocks;
+        blocks += (int)((cols[l] + 63) / 64);
+    }
+    a.first_block[n_layers] = blocks;
+    hipLaunchKernelGGL(bias_bf16_multi_kernel, dim3((unsigned)blocks), 256, 0, tnn::stream(), a, rows, (float)lr, (float)b1, (float)b2,
+                       (float)eps, (const double*)pows_f64, tnn::update_guard());
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_mse_bf16_prep(const void* pred, const void* y, int64_t rows, int64_t cols, int64_t m_global, void* loss_out_f32,
+                      void* loss_out2_f32, void* dpred, void* dpred_t, const void* x, int64_t x_cols, void* x_t,
+                      void* partials_f64, void* ticket_u32, void* adam_pows_f64, double b1, double b2) {
+    TNN_NEED_INIT();
+    TNN_REQUIRE(pred && y && rows > 0 && cols > 0 && m_global > 0, "tnn_mse_bf16_prep: empty batch");
+    TNN_REQUIRE(rows % 64 == 0 && cols % 64 == 0 && (x == nullptr || x_cols % 64 == 0),
+                "tnn_mse_bf16_prep: rows, cols and x_cols must be multiples of 64");
+    TNN_REQUIRE((x == nullptr) == (x_t == nullptr), "tnn_mse_bf16_prep: x and x_t go together");
+    TNN_REQUIRE(partials_f64 && ticket_u32, "tnn_mse_bf16_prep: the partial-sum workspace (rows / 64 * cols / 64 doubles) and the zeroed ticket word are required");
+    TNN_REQUIRE(loss_out_f32 != nullptr || loss_out2_f32 == nullptr, "tnn_mse_bf16_prep: loss_out2 needs loss_out");
+    auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    TNN_REQUIRE(al(pred, 8) && al(y, 8) && al(dpred, 8) && al(dpred_t, 16) && al(x, 8) && al(x_t, 16), "tnn_mse_bf16_prep: misaligned operand");
+    const int64_t n_loss = (rows / 64) * (cols / 64), n_x = x ? (rows / 64) * (x_cols / 64) : 0;
+    TNN_REQUIRE(n_loss + n_x < (int64_t(1) << 31), "tnn_mse_bf16_prep: too many tiles");
+    hipLaunchKernelGGL(mse_prep_bf16_kernel, dim3((unsigned)(n_loss + n_x)), 256, 0, tnn::stream(), (const bf16_t*)pred,
+                       (const bf16_t*)y, rows, cols, 1.0 / (double)m_global, (double*)partials_f64, (unsigned*)ticket_u32,
+                       (float*)loss_out_f32, (float*)loss_out2_f32, (bf16_t*)dpred, (bf16_t*)dpred_t, (const bf16_t*)x, x_cols,
+                       (bf16_t*)x_t, (double*)adam_pows_f64, b1, b2, tnn::update_guard());
     TNN_LAUNCH_OK();
     return 0;
 }

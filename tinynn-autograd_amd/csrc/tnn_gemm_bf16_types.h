@@ -32,11 +32,16 @@ struct BfArgs {
     const double* pows;              // {b1^t, b2^t}, already advanced for this step
     const int* guard;                // data-parallel update guard (tnn_internal.h)
     // split-K kernel (tnn_gemm_bf16_sk.h): K slices per output tile, fp32 partial slabs [tile][slice][32][512] float4 and
-    // two words per tile {arrival tickets, published slabs}, zero between launches
+    // two flag words per tile (they count launches, never reset)
     int splitk;
     float* sk_ws;
     unsigned* sk_cnt;
     unsigned long long* sk_trace;   // probe builds only: per-workgroup timestamps
+    // optional second output of the bf16 epilogues: the TRANSPOSE of C, CT [N][ldct] (element (m, n) at CT[n * ldct + m]) —
+    // the K-contiguous operand the dW product of the backward pass wants (core/ops.py:159-160), NULL = not wanted
+    bf16_t* CT;
+    int64_t ldct;
+    int* fault;                     // the process's sticky fault word (tnn::fault_word), NULL in probe builds
 };
 
 __device__ __forceinline__ bf16_t f2bf(float f) {       // round to nearest even (finite inputs)

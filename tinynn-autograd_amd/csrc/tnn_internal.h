@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include "tnn_hip.h"
 
+enum { TNN_FAULT_SPLITK_HANDOFF = 1 };
+
 namespace tnn {
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 hipStream_t stream();          // the one library stream (valid after tnn_init) — or the override below while one is set
@@ -15,6 +17,11 @@ int num_cus();                 // 256 on MI355X
 // (parameters, optimizer state and beta powers keep their contents).  nullptr = no guard.  Set around a data-parallel
 // step to the peer-to-peer transport's sticky `dead` word (tnn_p2p_guard_updates), so an update that would consume a
 // discarded collective is discarded too, whichever kernel applies it.
+// Process-wide sticky fault word in host-pinned, device-visible memory: a kernel whose bounded in-launch wait runs out
+// stores a TNN_FAULT_* code there (system scope) instead of consuming data that never arrived; tnn_stream_sync and
+// tnn_memcpy_d2h report it (rc 1 + tnn_last_error) from then on.
+int* fault_word();
+int check_fault(const char* where);
 const int* update_guard();
 void set_update_guard(const int* device_word);
 }  // namespace tnn

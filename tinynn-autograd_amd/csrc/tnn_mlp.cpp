@@ -58,6 +58,7 @@ struct Mlp {
     std::vector<void*> actT16;       // act[l]^T [w[l+1], max_rows]   (dW operand of layer l+1)
     std::vector<void*> dactT16;      // dact[l]^T [w[l+1], max_rows]  (dW operand of layer l)
     void* xT16 = nullptr;            // x^T [w[0], max_rows]
+    void* prep_ws = nullptr;         // block partials of the prep launch's loss reduction (tnn_mse_bf16_prep)
     // sharded-optimizer step (data-parallel bf16 trainer, mlp16_step_zero): the weight gradients as bf16 in arena order
     // (wire format of the reduce-scatter) and a contiguous fp32 staging vector [b_0 | ... | b_{L-1} | loss] for the one
     // small all-reduce of the bias gradients and the loss
@@ -140,16 +141,75 @@ int mlp16_sync(Mlp* h) {      // refresh the bf16 working copies from the fp32 m
     return 0;
 }
 
-int mlp16_forward(Mlp* h, const void* x16, int64_t rows) {
+// emit_t: the hidden layers' activations also leave TRANSPOSED (actT16[l] [w[l+1], rows], the K-contiguous operand of layer
+// l + 1's dW product) from the epilogue that produces them — no transpose launches in the backward pass
+int mlp16_forward(Mlp* h, const void* x16, int64_t rows, bool emit_t = false) {
     const void* in = x16;
     for (int l = 0; l < h->L; ++l) {
         const bool hidden = l < h->L - 1;
         // z_l = a_{l-1} W_l + b_l : A = a [rows, in] (K = in), B = W_l^T [out, in]
-        MLP_TRY(tnn_gemm_bf16_nt(rows, h->w[l + 1], h->w[l], in, h->w[l], h->wT16[l], h->w[l], h->act[l],
-                                 h->w[l + 1], TNN_BF16, at(h->params, h->b_off[l], 4),
-                                 hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, nullptr, 0));
+        if (emit_t && hidden)
+            STEP_CALL(h, tnn_gemm_bf16_nt_t(rows, h->w[l + 1], h->w[l], in, h->w[l], h->wT16[l], h->w[l], h->act[l], h->w[l + 1],
+                                       at(h->params, h->b_off[l], 4), TNN_ACT_RELU, 1, nullptr, 0, h->actT16[l], rows));
+        else
+            STEP_CALL(h, tnn_gemm_bf16_nt(rows, h->w[l + 1], h->w[l], in, h->w[l], h->wT16[l], h->w[l], h->act[l],
+                                     h->w[l + 1], TNN_BF16, at(h->params, h->b_off[l], 4),
+                                     hidden ? TNN_ACT_RELU : TNN_ACT_NONE, hidden ? 1 : 0, nullptr, 0));
         in = h->act[l];
     }
+    return 0;
+}
+
+// can the single-GPU bf16 step take its 3L + 1 launch form (mlp16_step_fused)?  The prep launch works on 64 x 64 tiles.
+bool mlp16_fused_fits(const Mlp* h, int64_t rows) {
+    // TNN_E_STEP=long: the 25-launch sequence of separate transposes / bias / loss launches (same-box A/B runs under profiles/)
+    // (read at every step: tools/probes/e_step_ab.py alternates the two forms inside ONE process, the only A/B this pool's
+    // +-3 % run-to-run clock drift leaves meaningful)
+    const char* form = getenv("TNN_E_STEP");
+    const bool long_form = form != nullptr && form[0] == 'l';
+    return !long_form && h->bf16 && h->opt_kind == 1 && h->loss_kind == 1 && rows % 64 == 0 && h->w[0] % 64 == 0 && h->w[h->L] % 64 == 0 &&
+           h->prep_ws != nullptr;
+}
+
+// Single-GPU bf16 step, weight gradients consumed where they are produced (tnn_mlp_keep_grads(h, 0)), 3L + 1 launches (13 for the
+// four 8192-wide layers of configs[4]; 25 before):
+//   L   forward GEMMs, the hidden ones also writing a_l^T from their epilogues
+//   1   prep: loss, dz_L, dz_L^T, x^T, Adam's beta powers (tnn_mse_bf16_prep)
+//   L-1 dz_{l-1} = (dz_l W_l^T) * mask, also writing dz_{l-1}^T — ALL of them before the first dW: each reads the bf16 W_l that
+//       dW_l's epilogue rewrites, and a skinny GEMM launched right behind a dW + Adam launch runs ~10 us slower (it starts behind
+//       that launch's 1.9 GB of writes still draining to HBM; measured in-step, profiles/r05_e_step_ab.txt)
+//   L   dW_l = a_{l-1}^T dz_l with Adam on W_l in the epilogue (tnn_gemm_bf16_nt_adam), back to back
+//   1   every layer's bias: db_l + Adam on b_l (tnn_bias_bf16_adam_multi) — last, so that the next step's first forward GEMM
+//       does not start right behind a dW + Adam launch either.  (The bias as a role of the dW launch's tile-row-0 workgroups
+//       was built and measured: + 7.6 us on the launch's critical path against 6.8 us for a launch of its own — dropped.)
+// Same arithmetic, element for element, as the 25-launch sequence (transposes are exact, the bias sums keep their order).
+int mlp16_step_fused(Mlp* h, const void* x16, const void* y16, int64_t rows, void* loss_out) {
+    const int L = h->L;
+    auto f32 = [](void* base, int64_t off) { return (void*)((float*)base + off); };
+    MLP_TRY(mlp16_forward(h, x16, rows, true));
+    STEP_CALL(h, tnn_mse_bf16_prep(h->act[L - 1], y16, rows, h->w[L], rows, at(h->grads, h->n_params, 4), loss_out, h->dact[L - 1],
+                                   h->dactT16[L - 1], x16, h->w[0], h->xT16, h->prep_ws, h->ticket, h->pows, h->b1, h->b2));
+    for (int l = L - 1; l > 0; --l)
+        STEP_CALL(h, tnn_gemm_bf16_nt_t(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, h->w_off[l]), h->w[l + 1],
+                                        h->dact[l - 1], h->w[l], nullptr, TNN_ACT_NONE, 0, h->act[l - 1], h->w[l],
+                                        h->dactT16[l - 1], rows));
+    for (int l = L - 1; l >= 0; --l) {
+        void* inT = l == 0 ? h->xT16 : h->actT16[l - 1];
+        const int64_t wo = h->w_off[l];
+        STEP_CALL(h, tnn_gemm_bf16_nt_adam(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows, nullptr, f32(h->params, wo),
+                                           f32(h->m, wo), f32(h->v, wo), at16(h->w16, wo), h->wT16[l], h->lr, h->b1, h->b2, h->eps,
+                                           h->pows));
+    }
+    if (L > 16) { tnn::set_error("bf16 trainer: more than 16 layers"); return 2; }
+    const void* dz[16];
+    int64_t cols[16];
+    void *db[16], *bp[16], *bm[16], *bv[16], *bw[16];
+    for (int l = 0; l < L; ++l) {
+        const int64_t bo = h->b_off[l];
+        dz[l] = h->dact[l]; cols[l] = h->w[l + 1];
+        db[l] = f32(h->grads, bo); bp[l] = f32(h->params, bo); bm[l] = f32(h->m, bo); bv[l] = f32(h->v, bo); bw[l] = at16(h->w16, bo);
+    }
+    STEP_CALL(h, tnn_bias_bf16_adam_multi(L, dz, rows, cols, db, bp, bm, bv, bw, h->lr, h->b1, h->b2, h->eps, h->pows));
     return 0;
 }
 
@@ -461,6 +521,12 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     if (h->bf16 && !rc) {
         rc |= tnn_malloc((size_t)h->arena * 2, (void**)&h->w16);
         rc |= tnn_malloc((size_t)(max_rows * widths[0]) * 2, &h->xT16);
+        rc |= tnn_malloc((size_t)((max_rows + 63) / 64 * ((widths[n_layers] + 63) / 64)) * sizeof(double), &h->prep_ws);
+        // hand-off memory of the skinny GEMMs, allocated now: the first step may already be inside a hipGraph capture
+        for (int l = 0; l < n_layers && !rc; ++l) {
+            rc |= tnn_gemm_bf16_reserve(max_rows, widths[l + 1], widths[l]);
+            rc |= tnn_gemm_bf16_reserve(max_rows, widths[l], widths[l + 1]);
+        }
     }
     if (!rc) {
         rc |= tnn_memset(h->params, 0, bytes);
@@ -488,7 +554,7 @@ int tnn_mlp_destroy(void* handle) {
     for (void* p : h->wT16) tnn_free(p);
     for (void* p : h->actT16) tnn_free(p);
     for (void* p : h->dactT16) tnn_free(p);
-    tnn_free(h->w16); tnn_free(h->xT16); tnn_free(h->g16); tnn_free(h->bias_g);
+    tnn_free(h->w16); tnn_free(h->xT16); tnn_free(h->g16); tnn_free(h->bias_g); tnn_free(h->prep_ws);
     delete h;
     return 0;
 }
@@ -610,6 +676,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // round trip through HBM (8 of the 36 bytes per parameter and step; measured 8192 x 8192 x 512: 385-405 us against
         // 450-495 for GEMM + optimizer).  With the gradient ALSO stored the fused launch is slower than the two (517 us):
         // keep_grads stays on the separate launches.
+        if (mlp16_fused_fits(h, rows)) return mlp16_step_fused(h, x, y, rows, loss_out);
         MLP_TRY(mlp16_forward(h, x, rows));
         return mlp16_backward(h, x, y, rows, rows, loss_out, false, true, true);
     }

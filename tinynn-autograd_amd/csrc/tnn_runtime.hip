@@ -43,6 +43,7 @@ struct State {
     GraphRec* capturing = nullptr;
     std::unordered_map<uint64_t, GraphRec*> graphs;
     std::vector<GraphRec*> destroy_later;             // graphs released while another capture was open (tnn_graph_destroy)
+    int* fault = nullptr;                             // host-pinned, device-visible sticky fault word (tnn::fault_word)
 };
 State g;
 
@@ -71,6 +72,17 @@ void set_stream_override(hipStream_t s) { g_stream_override = s; }
 bool initialised() { return g.ready; }
 int num_cus() { return g.cus; }
 
+int* fault_word() { return g.fault; }
+// Sticky device fault (a kernel's bounded in-launch wait ran out, tnn_internal.h TNN_FAULT_*): reported by every
+// synchronising entry point from then on — results produced after the fault are not to be trusted.
+int check_fault(const char* where) {
+    const int code = g.fault ? __atomic_load_n(g.fault, __ATOMIC_RELAXED) : 0;
+    if (code == 0) return 0;
+    set_error("%s: a kernel reported device fault %d (%s); outputs since then are invalid", where, code,
+              code == TNN_FAULT_SPLITK_HANDOFF ? "the split-K bf16 GEMM's partner workgroup did not publish its slab in time" : "unknown");
+    return 1;
+}
+
 static const int* g_update_guard = nullptr;
 const int* update_guard() { return g_update_guard; }
 void set_update_guard(const int* device_word) { g_update_guard = device_word; }
@@ -96,6 +108,8 @@ int tnn_init(int device) {
     TNN_CHECK_HIP(hipGetDeviceProperties(&p, device));
     g.cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     TNN_CHECK_HIP(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    TNN_CHECK_HIP(hipHostMalloc((void**)&g.fault, 64, hipHostMallocMapped));
+    *g.fault = 0;
     g.device = device;
     g.ready = true;
     return 0;
@@ -117,6 +131,8 @@ int tnn_shutdown(void) {
     g.live_bytes = g.cached_bytes = 0;
     hipStreamDestroy(g.stream);
     g.stream = nullptr;
+    if (g.fault) hipHostFree(g.fault);
+    g.fault = nullptr;
     g.ready = false;
     return 0;
 }
@@ -237,7 +253,7 @@ int tnn_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return 0;
     TNN_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.stream));
     TNN_CHECK_HIP(hipStreamSynchronize(g.stream));
-    return 0;
+    return tnn::check_fault("tnn_memcpy_d2h");
 }
 
 int tnn_memcpy_d2d(void* dst, const void* src, size_t bytes) {
@@ -257,7 +273,7 @@ int tnn_memset(void* dst, int byte, size_t bytes) {
 int tnn_stream_sync(void) {
     TNN_NEED_INIT();
     TNN_CHECK_HIP(hipStreamSynchronize(g.stream));
-    return 0;
+    return tnn::check_fault("tnn_stream_sync");
 }
 
 int tnn_event_create(void** ev) {

@@ -1,4 +1,4 @@
-// tnn_box_probe: what THIS box can do, measured in ~100 ms — so that a roofline fraction can be normalised by the box it was
+// libtnn_probe.so — tnn_probe_box: what THIS box can do, measured in ~100 ms — so that a roofline fraction can be normalised by the box it was
 // measured on (box-to-box spread of the MFMA- and HBM-bound numbers is +-4..8 %):
 //   * MFMA-only loops (nothing but v_mfma on register operands, 8 waves per CU, 8 independent accumulators per wave):
 //     fp32 (32x32x2_f32) and bf16 (32x32x16_bf16) with uniform-random operands and, for bf16, with zeros — the chip clocks to
@@ -7,10 +7,14 @@
 //   * the sustained shader clock of each loop: s_memtime (shader cycles) over s_memrealtime (100 MHz) inside the kernel;
 //   * HBM streaming past the 256 MB memory-side cache, bytes read + written per second: a float4 copy (1 GiB + 1 GiB) and
 //     the optimizer's mix (four 256 MB arrays read, three of them rewritten in place).
-// No reference counterpart (measurement infrastructure for bench.py's `box` object).
-#include <vector>
+// No reference counterpart: measurement infrastructure for bench.py's `box` object, a library of its OWN (not part of the
+// product's libtnn_hip.so, no symbol of include/tnn_hip.h): own stream, own buffers, plain int return codes.
+//   make -C tinynn-autograd_amd/csrc probe      ->  tools/probes/bin/libtnn_probe.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
 
-#include "tnn_internal.h"
+#include <vector>
 
 namespace {
 
@@ -112,28 +116,53 @@ __global__ __launch_bounds__(256) void mix43_kernel(f32x4* __restrict__ a, f32x4
 
 }  // namespace
 
-extern "C" int tnn_box_probe(double* out, int n_out) {
-    TNN_NEED_INIT();
-    TNN_REQUIRE(out != nullptr && n_out >= 10, "tnn_box_probe: out must hold 10 doubles");
-    hipStream_t s = tnn::stream();
-    const int cus = tnn::num_cus();
+
+#define PB_CHECK(expr)                                                                                       \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess) {                                                                             \
+            fprintf(stderr, "tnn_probe_box: %s -> %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return 1;                                                                                        \
+        }                                                                                                    \
+    } while (0)
+
+static unsigned stream_grid(int64_t items, int cus) {
+    int64_t b = (items + 255) / 256, cap = (int64_t)cus * 8;
+    return (unsigned)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+/* out[0] fp32 MFMA-only TFLOP/s (v_mfma_f32_32x32x2_f32, random operands), out[1] its sustained shader clock in GHz,
+ * out[2] / out[3] bf16 (v_mfma_f32_32x32x16_bf16) with random operands, out[4] / out[5] with zero operands (the chip clocks to
+ * its power budget), out[6] float4 copy bandwidth in GB/s (1 GiB read + 1 GiB written), out[7] GB/s of the optimizer's stream
+ * mix (four 256 MB arrays read, three of them rewritten in place), out[8] / out[9] the fp32 loop with the training step's operand
+ * distribution (a uniform in [0, 1), b uniform in +-0.027).  n_out >= 10.  Uses the CURRENT HIP device. */
+extern "C" __attribute__((visibility("default"))) int tnn_probe_box(double* out, int n_out) {
+    if (out == nullptr || n_out < 10) return 2;
+    int dev = 0;
+    PB_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PB_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipStream_t s;
+    PB_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     void *sink = nullptr, *clocks = nullptr;
-    if (tnn_malloc(4096, &sink) || tnn_malloc((size_t)cus * 16, &clocks)) return 1;
+    PB_CHECK(hipMalloc(&sink, 4096));
+    PB_CHECK(hipMalloc(&clocks, (size_t)cus * 16));
     hipEvent_t e0, e1;
-    TNN_CHECK_HIP(hipEventCreate(&e0));
-    TNN_CHECK_HIP(hipEventCreate(&e1));
+    PB_CHECK(hipEventCreate(&e0));
+    PB_CHECK(hipEventCreate(&e1));
     std::vector<unsigned long long> hc((size_t)cus * 2);
     auto mfma = [&](bool bf, int zero, int iters, double flop_per_mfma, double* tflops, double* ghz) -> int {
         for (int pass = 0; pass < 2; ++pass) {            // pass 0 warms up (clock ramp), pass 1 is timed
-            TNN_CHECK_HIP(hipEventRecord(e0, s));
+            PB_CHECK(hipEventRecord(e0, s));
             if (bf) hipLaunchKernelGGL(mfma_only_kernel<true>, dim3(cus), 512, 0, s, iters, zero, (float*)sink, (unsigned long long*)clocks);
             else hipLaunchKernelGGL(mfma_only_kernel<false>, dim3(cus), 512, 0, s, iters, zero, (float*)sink, (unsigned long long*)clocks);
-            TNN_CHECK_HIP(hipEventRecord(e1, s));
-            TNN_CHECK_HIP(hipEventSynchronize(e1));
+            PB_CHECK(hipEventRecord(e1, s));
+            PB_CHECK(hipEventSynchronize(e1));
         }
         float ms = 0.f;
-        TNN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
-        TNN_CHECK_HIP(hipMemcpy(hc.data(), clocks, hc.size() * 8, hipMemcpyDeviceToHost));
+        PB_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        PB_CHECK(hipMemcpy(hc.data(), clocks, hc.size() * 8, hipMemcpyDeviceToHost));
         double cyc = 0, ticks = 0;
         for (int b = 0; b < cus; ++b) { cyc += (double)hc[2 * b]; ticks += (double)hc[2 * b + 1]; }
         *tflops = (double)cus * 8 * iters * 32.0 * flop_per_mfma / (ms * 1e-3) / 1e12;
@@ -148,45 +177,46 @@ extern "C" int tnn_box_probe(double* out, int n_out) {
     // float4 copy, 1 GiB each way
     const int64_t bytes = (int64_t)1 << 30;
     void *a = nullptr, *b = nullptr;
-    if (!rc && (tnn_malloc((size_t)bytes, &a) || tnn_malloc((size_t)bytes, &b))) rc = 1;
+    if (!rc && (hipMalloc(&a, (size_t)bytes) != hipSuccess || hipMalloc(&b, (size_t)bytes) != hipSuccess)) rc = 1;
     if (!rc) {
-        TNN_CHECK_HIP(hipMemsetAsync(a, 0x3c, (size_t)bytes, s));
+        PB_CHECK(hipMemsetAsync(a, 0x3c, (size_t)bytes, s));
         for (int pass = 0; pass < 2; ++pass) {
-            TNN_CHECK_HIP(hipEventRecord(e0, s));
-            hipLaunchKernelGGL(copy16_kernel, dim3(tnn::stream_grid(bytes / 16, 256)), 256, 0, s, (const f32x4*)a, (f32x4*)b, bytes / 16);
-            TNN_CHECK_HIP(hipEventRecord(e1, s));
-            TNN_CHECK_HIP(hipEventSynchronize(e1));
+            PB_CHECK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(copy16_kernel, dim3(stream_grid(bytes / 16, cus)), 256, 0, s, (const f32x4*)a, (f32x4*)b, bytes / 16);
+            PB_CHECK(hipEventRecord(e1, s));
+            PB_CHECK(hipEventSynchronize(e1));
         }
         float ms = 0.f;
-        TNN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        PB_CHECK(hipEventElapsedTime(&ms, e0, e1));
         out[6] = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;      // GB/s, read + written
     }
-    if (a) tnn_free(a);
-    if (b) tnn_free(b);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
     // the optimizer's mix over 4 x 256 MB
     const int64_t mb = (int64_t)256 << 20;
     void* arr[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < 4 && !rc; ++i)
-        if (tnn_malloc((size_t)mb, &arr[i])) rc = 1;
+        if (hipMalloc(&arr[i], (size_t)mb) != hipSuccess) rc = 1;
     if (!rc) {
-        for (int i = 0; i < 4; ++i) TNN_CHECK_HIP(hipMemsetAsync(arr[i], 0x3c, (size_t)mb, s));
+        for (int i = 0; i < 4; ++i) PB_CHECK(hipMemsetAsync(arr[i], 0x3c, (size_t)mb, s));
         for (int pass = 0; pass < 2; ++pass) {
-            TNN_CHECK_HIP(hipEventRecord(e0, s));
-            hipLaunchKernelGGL(mix43_kernel, dim3(tnn::stream_grid(mb / 16, 256)), 256, 0, s, (f32x4*)arr[0], (f32x4*)arr[1],
+            PB_CHECK(hipEventRecord(e0, s));
+            hipLaunchKernelGGL(mix43_kernel, dim3(stream_grid(mb / 16, cus)), 256, 0, s, (f32x4*)arr[0], (f32x4*)arr[1],
                                (f32x4*)arr[2], (const f32x4*)arr[3], mb / 16);
-            TNN_CHECK_HIP(hipEventRecord(e1, s));
-            TNN_CHECK_HIP(hipEventSynchronize(e1));
+            PB_CHECK(hipEventRecord(e1, s));
+            PB_CHECK(hipEventSynchronize(e1));
         }
         float ms = 0.f;
-        TNN_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+        PB_CHECK(hipEventElapsedTime(&ms, e0, e1));
         out[7] = 7.0 * (double)mb / (ms * 1e-3) / 1e9;         // GB/s, 4 streams read + 3 written
     }
     for (int i = 0; i < 4; ++i)
-        if (arr[i]) tnn_free(arr[i]);
-    tnn_free(sink);
-    tnn_free(clocks);
+        if (arr[i]) (void)hipFree(arr[i]);
+    (void)hipFree(sink);
+    (void)hipFree(clocks);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    TNN_LAUNCH_OK();
+    (void)hipStreamDestroy(s);
+    PB_CHECK(hipGetLastError());
     return rc;
 }

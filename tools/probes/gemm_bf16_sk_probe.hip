@@ -1,7 +1,8 @@
 // Stand-alone probe of the skinny bf16 GEMM (512 x 8192 x 8192 -> bf16, config E's forward / dX shape): the split-K
-// 256-row-tile kernel of tnn_gemm_bf16_sk.h in several geometries + timing-only ablation builds, against the library's
+// 256-row-tile kernel in several geometries + timing-only ablation builds (gemm_bf16_sk_probe_kernel.h; the library ships only
+// the chosen form, csrc/tnn_gemm_bf16_sk.h), against the library's
 // 128 x 128 LDS-DMA kernel and a naive reference product.  Build + run (GPU box):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tinynn-autograd_amd/csrc tools/probes/gemm_bf16_sk_probe.hip \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I tinynn-autograd_amd/csrc -I tools/probes tools/probes/gemm_bf16_sk_probe.hip \
 //         -o tools/probes/bin/gemm_bf16_sk_probe && tools/probes/bin/gemm_bf16_sk_probe
 // Weights rotate over three matrices (402 MB > the 256 MB memory-side cache) so every call streams them from HBM, like
 // the training step does.
@@ -23,7 +24,7 @@
 namespace {
 #include "tnn_gemm_bf16_types.h"
 #include "tnn_gemm_bf16_dma.h"
-#include "tnn_gemm_bf16_sk.h"
+#include "gemm_bf16_sk_probe_kernel.h"   // the probe's OWN copy: every geometry / hand-off protocol / ablation switch tried
 
 __global__ void ref_kernel(const bf16_t* A, const bf16_t* B, float* C, int M, int N, int K) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;

@@ -1,0 +1,618 @@
+// PROBE COPY (tools/probes/gemm_bf16_sk_probe.hip only): the split-K bf16 kernel with every geometry, hand-off protocol and
+// ablation switch that was tried (ABL / BNC modes, ticket and symmetric hand-off).  The product ships the chosen form only:
+// tinynn-autograd_amd/csrc/tnn_gemm_bf16_sk.h.
+// 256-row tiles + split-K for the SKINNY bf16 products of config E (M = 512: forward z = a W and dX = dz W^T,
+// core/ops.py:151,157 at bf16).  Included by tnn_gemm_bf16.hip inside its anonymous namespace, after tnn_gemm_bf16_types.h.
+//
+// Why: with 128 x 128 tiles a 512 x 8192 x 8192 product has exactly one tile per CU and every CU pulls 2 x 2 MB of operands
+// through the L2 -> LDS path (1 GB per product, 12 TB/s at the measured 87 us); three kernels with different LDS traffic,
+// ring depth and occupancy all landed within 1 % of each other — the operand stream INTO the CU bounds the
+// shape.  A 256 x 256 tile halves the bytes per flop; to still fill 256 CUs the K range is split over S workgroups per tile
+// (64 tiles x 4 slices) and the fp32 partial tiles are combined inside the launch:
+// (S = 2, the shipped form, hands over SYMMETRICALLY — each partner finishes half the rows; see SYM at the kernel.  The ticket
+// protocol below is the general one: any S, no assumption that a partner is running.)
+//   * every workgroup draws an arrival ticket for its tile when its K loop is done;
+//   * tickets 0 .. S-2 store their accumulators as a slab (register order: float4 i of thread t at [i][t] — every store
+//     instruction writes 1 KB contiguous; write-through `sc1` so no L2 write-back fence is needed), drain, and bump the
+//     tile's `published` word;
+//   * the LAST ticket keeps its accumulators in registers, waits until S-1 slabs are published (only workgroups that have
+//     already finished their K loops are waited for: no dependence on dispatch order or residency), and adds the slabs in
+//     FIXED slice order ((p0 + p1) + p2) + p3 with its own partial in its slot — the result does not depend on who arrives
+//     last; then it runs the ordinary epilogue (bias + ReLU / mask, bf16) and re-zeroes the two words for the next launch.
+// K loop: the LDS-DMA ring + XOR swizzle of tnn_gemm_bf16_dma.h (16-B chunk c of row r lives in slot c ^ ((r >> 1) & 7)),
+// separate rings for the two operands — NSA stages of A (activations, L2-resident) and NSB stages of B (weights,
+// streamed from HBM) — 8 waves, wave tile (256 / WM) x (BN / WN), fragments double-buffered per 16-deep
+// k-step (the 128 accumulator registers of a 128 x 64 wave tile leave room for two fragment sets only), ONE raw s_barrier
+// per K-tile: it publishes tile kt + 1 and frees the stages of tile kt, whose refill DMAs are issued BETWEEN the MFMAs of
+// the tile's last k-step.
+// Block -> (tile, slice) map (speed only): XCD x = block % 8 works on slice x % S, so an XCD's L2 holds ONE K-slice of the
+// activation panel (2 MB of the 8 MB), and the M-tiles that share a weight tile sit next to each other on the same XCD.
+namespace sk {
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0() {
+    static_assert(N >= 0 && N <= 24 && N % 2 == 0, "unexpected DMA count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+}
+
+// one LDS-DMA instruction (64 lanes x 16 B -> lds_dst + lane * 16); a NON-template function, see tnn_gemm_bf16_dma.h
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+// ABL (probe builds only, timing without meaning), bit mask: 1 = no MFMAs, 2 = no refill DMAs, 4 = no slab exchange,
+// 8 = no fragment reads in the loop, 16 = no barrier in the loop, 32 = timestamps (s_memtime: shader cycles; s_memrealtime:
+// 100 MHz) at kernel entry / loop entry / loop exit / kernel exit / end of the slab exchange into g.sk_trace[10 * block]
+// 128 = one K-tile per loop trip; 64 = B addressed as if stored tile-major ([n-tile][k-tile][BN][64] contiguous 16/32 KB blocks; wrong data, right byte count)
+// SYM (S == 2): the SYMMETRIC hand-off — instead of one partner publishing its whole partial tile and the other adding it and
+// running the whole epilogue, each of the two workgroups keeps the accumulator blocks of HALF the rows (slice s: the blocks
+// mi with mi / (MI / 2) == s), publishes the other half, waits for the partner's flag, adds what it received (p0 + p1:
+// the same bits whichever side adds) and finishes its half of the output tile: half the slab bytes per workgroup, both
+// directions in flight at once, half an epilogue each.  The two flags of a tile count launches in lockstep (own flag + 1 is the
+// value to wait for in the partner's): nothing is ever reset.  Unlike the ticket protocol each side waits for a workgroup
+// that may not have FINISHED its K loop yet; it has been dispatched, though — the partners are adjacent block indices — so the
+// wait ends unless the device stops running dispatched workgroups (bounded spin, as everywhere).
+// BNC: the B operand is given N-CONTIGUOUS — B [K][ldb], element (k, n) — instead of K-contiguous ([N][ldb]): C = A B, the
+// forward product z = a W with W stored [in][out] as the dX product wants it, so that ONE bf16 weight copy serves both
+// (core/ops.py:151 and :157).  LDS-DMA cannot transpose (the image is lane-linear), so the K-tile lands as it is stored —
+// 64 k-rows of BN x 2 = 256 B, four rows per DMA instruction, whole rows per 16 lanes — and the MFMA fragment (8 consecutive
+// k of one column per lane) is gathered by `ds_read_b64_tr_b16`: each 16-lane group hands in 16 addresses of 4 consecutive n
+// (4 k-rows x 16 columns) and gets back, per lane, one column's 4 k — two reads per fragment instead of one ds_read_b128,
+// the same bytes.  Bank conflicts: the 4 k-rows of a group are 256 B = one whole bank cycle apart, so 16-B chunk c of row k
+// lives at chunk c ^ ((k & 3) << 2): the 2 x 4 chunk pairs that the two groups of a 32-lane half touch are then all
+// different.
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0, int SYM = 0, int BNC = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
+    constexpr int BM = 256, ROWB = 128, KK = 4;
+    static_assert(!BNC || BN == 128, "the n-contiguous B image is laid out for 16 chunks per k-row");
+    // (probe builds, timing without meaning: BNC = 2 takes the n-contiguous DMA with the k-contiguous fragment reads, 3 the reverse)
+    // (4: k-contiguous DMA + tr reads addressed as [k/32][n/16][32][16] subtiles; 5: the DMA that would build those subtiles — each
+    // instruction gathers 32 k-rows x 32 B — + k-contiguous reads)
+    constexpr bool BNC_DMA = BNC == 1 || BNC == 2, BNC_READ = BNC == 1 || BNC == 3 || BNC == 4 || BNC == 6, BNC_SUBT = BNC == 4, BNC_SUBD = BNC == 5;   // 6: as 3 with plain ds_read_b64
+    constexpr int A_TILE_B = BM * ROWB, B_TILE_B = BN * ROWB;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+    constexpr int DJA = BM / 64, DJB = BN / 64;          // DMA instructions per wave, operand and K-tile (1 KB each)
+    static_assert(WM * WN == 8, "eight waves");
+    static_assert(NSA >= 2 && NSB >= 2, "double buffering at least");
+    constexpr int NSMIN = NSA < NSB ? NSA : NSB, NSMAX = NSA < NSB ? NSB : NSA;
+    constexpr int LDS_B = NSA * A_TILE_B + NSB * B_TILE_B;
+    static_assert(LDS_B <= 163840, "LDS");
+    // DMAs issued after the last one tile kt + 1 needs, seen from the barrier of iteration kt (issue order per iteration:
+    // A(j + NSA) then B(j + NSB)): the B share of that iteration when the rings differ, then NSA - 2 whole iterations
+    constexpr int C_STEADY = (NSMIN - 2) * (DJA + DJB) + (NSA < NSB ? DJB : 0);
+    constexpr int C_PROLOGUE = C_STEADY + DJA + DJB;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_B];      // ONE shared object (tnn_gemm_bf16_dma.h)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long ts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr ((ABL & 32) != 0) { ts[0] = __builtin_readcyclecounter(); ts[1] = __builtin_amdgcn_s_memrealtime(); }
+    auto emit_trace = [&]() {
+        if constexpr ((ABL & 32) != 0) {
+            ts[6] = __builtin_readcyclecounter();
+            ts[7] = __builtin_amdgcn_s_memrealtime();
+            if (tid == 0)
+                for (int i = 0; i < 10; ++i) g.sk_trace[10 * blockIdx.x + i] = ts[i];
+        }
+    };
+    const int wm = wid / WN, wn = wid % WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    // ---- block -> (tile, slice)
+    static_assert(S == 1 || S == 2 || S == 4, "slices per tile");
+    const int tiles = g.tiles_m * g.tiles_n, nb = tiles * S;
+    int tile, slice;
+    {
+        const int b = (int)blockIdx.x;
+        constexpr int G = 8 / S;
+        if (nb % 8 == 0 && tiles % G == 0) {
+            const int x = b & 7, j = b >> 3;
+            slice = x % S;
+            tile = (x / S) * (tiles / G) + j;
+        } else {
+            slice = b % S;
+            tile = b / S;
+        }
+    }
+    const int64_t m0 = (int64_t)(tile % g.tiles_m) * BM, n0 = (int64_t)(tile / g.tiles_m) * BN;
+    const int nk = (int)(g.K / 64) / S;                 // K-tiles of this slice (> max(NSA, NSB), host-checked)
+    const uint32_t k_byte0 = (uint32_t)slice * (uint32_t)nk * ROWB;
+
+    // ---- DMA geometry: instruction gi = wid + 8 j fills rows 8 gi .. 8 gi + 7 of an operand tile; lane L writes slot L % 8
+    // of row 8 gi + L / 8 and therefore LOADS chunk slot ^ swz(row)
+    uint32_t a_voff[DJA], b_voff[DJB];
+#pragma unroll
+    for (int j = 0; j < DJA; ++j) {
+        const int row = 8 * (wid + 8 * j) + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t gm = m0 + row;
+        a_voff[j] = (uint32_t)(((gm < g.M ? gm : 0) * g.lda + chunk * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < DJB; ++j) {
+        if constexpr (BNC_SUBD) {
+            // instruction gi = subtile (k-half gi / 8, n-block gi % 8): lane L loads 16 B of k-row 32 (gi / 8) + L / 2, columns
+            // 16 (gi % 8) + 8 (L % 2)
+            const int gi = wid + 8 * j, krow = 32 * (gi / 8) + (lane >> 1);
+            const int64_t gn = n0 + 16 * (gi % 8) + 8 * (lane & 1);
+            b_voff[j] = (uint32_t)(((int64_t)krow * g.ldb + (gn < g.N ? gn : 0)) * 2);
+        } else if constexpr (BNC_DMA) {
+            // instruction gi fills k-rows 4 gi .. 4 gi + 3 of the tile (256 B each); lane L writes physical chunk L % 16 of row
+            // 4 gi + L / 16 and therefore LOADS logical chunk (L % 16) ^ ((row & 3) << 2) of that row
+            const int krow = 4 * (wid + 8 * j) + (lane >> 4), chunk = (lane & 15) ^ ((krow & 3) << 2);
+            const int64_t gn = n0 + chunk * 8;
+            b_voff[j] = (uint32_t)(((int64_t)krow * g.ldb + (gn < g.N ? gn : 0)) * 2);
+        } else {
+            const int row = 8 * (wid + 8 * j) + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int64_t gn = n0 + row;
+            b_voff[j] = (uint32_t)(((gn < g.N ? gn : 0) * g.ldb + chunk * 8) * 2);
+            if constexpr ((ABL & 64) != 0) b_voff[j] = (uint32_t)((row * 64 + chunk * 8) * 2);
+        }
+    }
+    const uint32_t b_ktile_bytes = (BNC_DMA || BNC_SUBD) ? (uint32_t)(64 * g.ldb * 2) : (uint32_t)ROWB;      // B's byte step per K-tile
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.A), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(g.B), 0, 0xffffffffu, 0x00020000);
+    char* const a_ring = lds;
+    char* const b_ring = lds + NSA * A_TILE_B;
+    auto issue_a1 = [&](int kt, int slot, int j) {
+        dma16(a_rsrc, a_ring + slot * A_TILE_B + (wid + 8 * j) * 1024, a_voff[j], k_byte0 + (uint32_t)kt * ROWB);
+    };
+    auto issue_b1 = [&](int kt, int slot, int j) {
+        if constexpr ((ABL & 64) != 0) {
+            const uint32_t blk = (uint32_t)(tile / g.tiles_m) * (uint32_t)(g.K / 64) + (uint32_t)slice * nk + (uint32_t)kt;
+            dma16(b_rsrc, b_ring + slot * B_TILE_B + (wid + 8 * j) * 1024, b_voff[j], blk * (uint32_t)B_TILE_B);
+            return;
+        }
+        if constexpr (BNC_DMA || BNC_SUBD) {
+            dma16(b_rsrc, b_ring + slot * B_TILE_B + (wid + 8 * j) * 1024, b_voff[j], ((uint32_t)slice * (uint32_t)nk + (uint32_t)kt) * b_ktile_bytes);
+            return;
+        }
+        dma16(b_rsrc, b_ring + slot * B_TILE_B + (wid + 8 * j) * 1024, b_voff[j], k_byte0 + (uint32_t)kt * ROWB);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: lane (row l31, k-group lhi) reads chunk 2 kk + lhi of its row; (row >> 1) & 7 == (l31 >> 1) & 7
+    // for every block row offset used (multiples of 32)
+    const int swz = (l31 >> 1) & 7;
+    int foff[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) foff[kk] = ((2 * kk + lhi) ^ swz) * 16;
+    const int a_base = (wm * TM + l31) * ROWB;
+    const int b_base = (wn * TN + l31) * ROWB;
+    // BNC: group g16 = lane >> 4 covers columns 16 (g16 & 1) .. + 15 and k 8 (g16 >> 1) .. + 7 of a 32-column, 16-deep block; lane
+    // p = lane & 15 of the group hands in the address of 4 consecutive n at k-row p >> 2 (second read: + 4 rows)
+    constexpr int RB = BN * 2;                            // bytes per k-row of the n-contiguous image
+    const int g16 = lane >> 4, p16 = lane & 15;
+    const int btr_row = (8 * (g16 >> 1) + (p16 >> 2)) * RB, btr_sz = ((p16 >> 2) & 3) << 2;
+    int btr_col[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = wn * TN + j * 32 + 16 * (g16 & 1) + 4 * (p16 & 3);
+        btr_col[j] = (((n >> 3) ^ btr_sz) << 4) + (n & 7) * 2;
+    }
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+    bf16x8 fa[2][MI], fb[2][NI];
+    auto read_frag = [&](int set, const char* a_st, const char* b_st, int kk, bool in_loop = true) {
+        if ((ABL & 8) != 0 && in_loop) return;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            if constexpr (BNC_READ) {
+                // (BNC_SUBT: subtile (k / 32, n / 16) at 1 KB each, rows 32 B apart, odd n-blocks with their rows rotated by 4)
+                const int nb = (wn * TN + j * 32) / 16 + (g16 & 1);
+                const int k0 = kk * 16 + 8 * (g16 >> 1) + (p16 >> 2);
+                const char* q = BNC_SUBT ? b_st + ((k0 / 32) * 8 + nb) * 1024 + (((k0 % 32) ^ (4 * (nb & 1))) * 32) + (p16 & 3) * 8
+                                         : b_st + btr_row + kk * 16 * RB + btr_col[j];
+                s16x4 lo, hi;
+                if constexpr (BNC == 6) {
+                    lo = *reinterpret_cast<const s16x4*>(q);
+                    hi = *reinterpret_cast<const s16x4*>(q + 4 * RB);
+                } else {
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(BNC_SUBT ? q + 4 * 32 : q + 4 * RB));
+                }
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                fb[set][j] = __builtin_bit_cast(bf16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            } else {
+                fb[set][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(b_st + b_base + j * 32 * ROWB + foff[kk]));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            fa[set][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(a_st + a_base + i * 32 * ROWB + foff[kk]));
+    };
+    auto mfma_set = [&](int set) {
+        if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[set][i]));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(fb[set][j]));
+            return;
+        }
+        // operands swapped: the accumulator block is (A B^T)^T — lane l31 owns an output ROW, a register quad 4 consecutive
+        // columns (8-B bf16 stores in the epilogue)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: "iterations" -NSB .. -1 of the steady-state issue order
+#pragma unroll
+    for (int j = -NSMAX; j < 0; ++j) {
+        if (j + NSA >= 0) {
+#pragma unroll
+            for (int q = 0; q < DJA; ++q) issue_a1(j + NSA, j + NSA, q);
+        }
+        if (j + NSB >= 0) {
+#pragma unroll
+            for (int q = 0; q < DJB; ++q) issue_b1(j + NSB, j + NSB, q);
+        }
+    }
+    wait_vm_lgkm0<C_PROLOGUE>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int a_cur = 0, b_cur = 0;                            // ring slots of tile kt
+    read_frag(0, a_ring, b_ring, 0, false);
+    if constexpr ((ABL & 8) != 0) read_frag(1, a_ring, b_ring, 1, false);
+    // One K-tile.  STEADY: tiles kt + 1 .. kt + NSB all exist — no conditionals, the refill DMAs of the two freed stages are
+    // spread between the MFMAs of k-step 3.  The accumulators are written at ONE place per k-step in both forms (MFMAs in
+    // different branches of a conditional made hipcc copy the 128 accumulator registers through scratch every iteration).
+    auto k_tile = [&](int kt, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const char* a_st = a_ring + a_cur * A_TILE_B;
+        const char* b_st = b_ring + b_cur * B_TILE_B;
+        read_frag(1, a_st, b_st, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(0, a_st, b_st, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(1, a_st, b_st, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_set(0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int a_nxt = a_cur + 1 == NSA ? 0 : a_cur + 1, b_nxt = b_cur + 1 == NSB ? 0 : b_cur + 1;
+        if (STEADY || kt + 1 < nk) {
+            // every DMA counted in C_STEADY exists as long as iteration kt - 1 issued its B share
+            if constexpr (STEADY) wait_vm_lgkm0<C_STEADY>();
+            else wait_vm_lgkm0<0>();
+            if constexpr ((ABL & 16) == 0) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            read_frag(0, a_ring + a_nxt * A_TILE_B, b_ring + b_nxt * B_TILE_B, 0);
+            if ((ABL & 2) == 0 && (STEADY || kt + NSA < nk)) {
+#pragma unroll
+                for (int q = 0; q < DJA; ++q) issue_a1(kt + NSA, a_cur, q);
+            }
+            if ((ABL & 2) == 0 && (STEADY || kt + NSB < nk)) {
+#pragma unroll
+                for (int q = 0; q < DJB; ++q) issue_b1(kt + NSB, b_cur, q);
+            }
+        }
+        mfma_set(1);
+        if constexpr (STEADY && (ABL & 3) == 0) {
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);        // the next tile's first fragments
+#pragma unroll
+            for (int q = 0; q < DJA + DJB; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one VMEM read (the DMA)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+        b_cur = b_nxt;
+    };
+    if constexpr ((ABL & 32) != 0) { ts[2] = __builtin_readcyclecounter(); ts[3] = __builtin_amdgcn_s_memrealtime(); }
+    int kt = 0;
+    // two K-tiles per trip: hipcc waits lgkmcnt(0) at a loop head (the fragments just requested included), inside a trip it
+    // counts exactly
+    if constexpr ((ABL & 128) == 0) {
+        for (; kt + NSMAX + 1 < nk; kt += 2) {
+            k_tile(kt, std::true_type{});
+            k_tile(kt + 1, std::true_type{});
+        }
+    }
+    for (; kt + NSMAX < nk; ++kt) k_tile(kt, std::true_type{});
+    for (; kt < nk; ++kt) k_tile(kt, std::false_type{});
+    if constexpr ((ABL & 32) != 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" : "+v"(acc[i][j]));       // the loop's MFMAs have retired
+        ts[4] = __builtin_readcyclecounter();
+        ts[5] = __builtin_amdgcn_s_memrealtime();
+    }
+
+    // ---- split-K exchange
+    static_assert(!SYM || (S == 2 && MI % 2 == 0), "the symmetric hand-off pairs two slices and splits the row blocks in two");
+    constexpr int MH = SYM ? MI / 2 : MI;                  // accumulator row blocks this workgroup finishes ...
+    const int mi0 = SYM ? slice * MH : 0;                  // ... starting at this one
+    if constexpr (SYM && (ABL & 4) == 0) {
+        gu32* flag = (gu32*)(g.sk_cnt + 2 * tile);
+        const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.sk_ws + (int64_t)tile * S * (BM * BN), 0, 0xffffffffu, 0x00020000);
+        constexpr uint32_t SLAB_B = BM * BN * 4;
+        const int give0 = (1 - slice) * MH;               // first row block of the half the partner finishes
+        const uint32_t base = (uint32_t)slice * SLAB_B + (uint32_t)tid * 16;
+#pragma unroll
+        for (int i = 0; i < MH; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = (i * NI + j) * 4 + q;
+                    // both halves are read with compile-time indices (a run-time block index spills the accumulators)
+                    const f32x4 lo = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    const f32x4 hi = {acc[MH + i][j][4 * q], acc[MH + i][j][4 * q + 1], acc[MH + i][j][4 * q + 2], acc[MH + i][j][4 * q + 3]};
+                    const u32x4 v = __builtin_bit_cast(u32x4, give0 == 0 ? lo : hi);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, ws_rsrc, base + (uint32_t)ch * 8192, 0, 16 /* sc1: write-through */);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // EVERY storing wave drains its write-through stores
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned mine = __hip_atomic_load(flag + slice, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            __hip_atomic_store(flag + slice, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(flag + (1 - slice), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mine) < 0 && ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        constexpr int NCHH = MH * NI * 4, CB = 4;
+#pragma unroll
+        for (int c0 = 0; c0 < NCHH; c0 += CB) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 in[CB];
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                in[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            ws_rsrc, (uint32_t)tid * 16 + (uint32_t)(c0 + c) * 8192, (uint32_t)(1 - slice) * SLAB_B, 16 /* sc1 */));
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int ch = c0 + c, i = ch / (NI * 4), j = (ch / 4) % NI, q = ch % 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // p0 + p1 on both sides (IEEE addition commutes: the same bits)
+                    if (slice == 0) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] + in[c][e];
+                    else acc[MH + i][j][4 * q + e] = in[c][e] + acc[MH + i][j][4 * q + e];
+                }
+            }
+        }
+    }
+    if constexpr (S > 1 && !SYM && (ABL & 4) == 0) {
+        gu32* cnt = (gu32*)(g.sk_cnt + 2 * tile);
+        unsigned* bcast = reinterpret_cast<unsigned*>(lds);
+        __syncthreads();                                  // every wave is done with the ring
+        if (tid == 0) bcast[0] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = bcast[0];
+        const __amdgpu_buffer_rsrc_t ws_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.sk_ws + (int64_t)tile * S * (BM * BN), 0, 0xffffffffu, 0x00020000);
+        constexpr uint32_t SLAB_B = BM * BN * 4;
+        constexpr int NCH = MI * NI * 4;                   // float4 chunks per thread
+        if (ticket + 1 < (unsigned)S) {
+            const uint32_t base = (uint32_t)slice * SLAB_B + (uint32_t)tid * 16;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ch = (i * NI + j) * 4 + q;
+                        const u32x4 v = __builtin_bit_cast(u32x4, f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1],
+                                                                      acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]});
+                        __builtin_amdgcn_raw_buffer_store_b128(v, ws_rsrc, base + (uint32_t)ch * 8192, 0, 16 /* sc1: write-through */);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // EVERY storing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            emit_trace();
+            return;
+        }
+        // last ticket: wait for the S - 1 slabs (their writers have all left their K loops), then add in slice order
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 < (unsigned)S && ++spins < (1u << 24))
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // the next launch starts from zero
+            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // Four chunks x (S - 1) slabs in flight per thread.  Fixed order ((p0 + p1) + p2) + p3 with my own partial (in the
+        // accumulators) at position `slice`: the NB = slice slabs in front of me are summed first, then the accumulator joins
+        // (t + own == own + t exactly), then the slabs behind me one by one.  One instantiation per position — a run-time
+        // select per element made hipcc spill the accumulators.
+        auto reduce = [&](auto nb_tag) {
+            constexpr int NB = decltype(nb_tag)::value;    // slabs in front of mine
+            if constexpr (NB < S) {
+                constexpr int CB = 4;
+#pragma unroll
+                for (int c0 = 0; c0 < NCH; c0 += CB) {
+                    __builtin_amdgcn_sched_barrier(0);    // keep the batches apart (hoisted loads spill the accumulators)
+                    f32x4 in[S > 1 ? S - 1 : 1][CB];
+#pragma unroll
+                    for (int s = 0; s < S - 1; ++s) {
+                        const int os = s < NB ? s : s + 1;           // s-th slab that is not mine
+#pragma unroll
+                        for (int c = 0; c < CB; ++c)
+                            in[s][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                           ws_rsrc, (uint32_t)tid * 16 + (uint32_t)(c0 + c) * 8192, (uint32_t)os * SLAB_B, 16 /* sc1 */));
+                    }
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        const int ch = c0 + c, i = ch / (NI * 4), j = (ch / 4) % NI, q = ch % 4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float sum = acc[i][j][4 * q + e];
+                            if constexpr (NB > 0) {
+                                float t = in[0][c][e];
+#pragma unroll
+                                for (int k = 1; k < NB; ++k) t += in[k][c][e];
+                                sum = t + sum;
+                            }
+#pragma unroll
+                            for (int k = NB; k < S - 1; ++k) sum += in[k][c][e];
+                            acc[i][j][4 * q + e] = sum;
+                        }
+                    }
+                }
+            }
+        };
+        switch (slice) {                                    // block-uniform
+            case 0: reduce(std::integral_constant<int, 0>{}); break;
+            case 1: reduce(std::integral_constant<int, 1>{}); break;
+            case 2: reduce(std::integral_constant<int, 2>{}); break;
+            default: reduce(std::integral_constant<int, 3>{}); break;
+        }
+    }
+
+    if constexpr ((ABL & 32) != 0) { ts[8] = __builtin_readcyclecounter(); ts[9] = __builtin_amdgcn_s_memrealtime(); }
+    // ---- epilogue, interior bf16 tiles: through an LDS image of the output tile.  In the accumulator layout a lane owns a ROW
+    // (8-B pieces of 32 different rows per store instruction: 64 partial lines — measured 12 us for the 8 MB of a
+    // 512 x 8192 output); the image [256][BN] bf16 (the idle ring: 128 KB) is written as 8-B items, slot s of row r at
+    // s ^ (r & 15) (16 lanes that write 16 rows at one s hit 16 different bank pairs), and read back as 16-B pieces, 32 lanes
+    // per 512-B row segment: whole lines, and the ReLU mask of dX (BEPI_MASK) is read with the same coalesced geometry.
+    const bool staged = g.c_bf16 && m0 + BM <= g.M && n0 + BN <= g.N && g.ldc % 8 == 0 &&
+                        (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                        (g.epi != BEPI_MASK || (g.ldy % 8 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 15) == 0));
+    if (staged) {                                           // block-uniform
+        constexpr int IMG_ROWB = BN * 2;
+        static_assert(BM * IMG_ROWB <= LDS_B, "the output image lives in the ring");
+        __syncthreads();                                    // every wave is done with the ring
+        // (SYM: the image holds this workgroup's half of the rows only, compactly: wave row wm's MH * 32 rows at wm * MH * 32)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (SYM && (mi / MH) * MH != mi0) continue;     // block-uniform
+            const int row = wm * (MH * 32) + (mi % MH) * 32 + l31;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int col = wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = acc[mi][ni][4 * q + j];
+                        if (g.epi == BEPI_BIAS_ACT) {
+                            x += g.bias ? g.bias[n0 + col + j] : 0.f;
+                            if (g.act == TNN_ACT_RELU) x = x < 0.f ? (g.relu_sign ? -0.0f : 0.f) : fabsf(x);
+                        }
+                        v[j] = x;
+                    }
+                    const u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(lds + row * IMG_ROWB + (((col >> 2) ^ (row & 15)) << 3)) = pk;
+                }
+        }
+        __syncthreads();
+        constexpr int PPR = BN / 8;                          // 16-B pieces per row
+        constexpr int PIECES = (BM / (SYM ? 2 : 1)) * PPR / 512;     // per thread
+        bf16_t* cout = reinterpret_cast<bf16_t*>(g.C);
+#pragma unroll
+        for (int it = 0; it < PIECES; ++it) {
+            const int p = tid + it * 512, irow = p / PPR, j = p % PPR;        // irow: row of the image
+            const int row = (irow / (MH * 32)) * TM + mi0 * 32 + irow % (MH * 32);      // row of the tile
+            u32x4 v = *reinterpret_cast<const u32x4*>(lds + irow * IMG_ROWB + ((j ^ ((irow & 15) >> 1)) << 4));
+            if (irow & 1) v = u32x4{v[2], v[3], v[0], v[1]};  // odd rows: the two 8-B slots of the pair are swapped
+            if (g.epi == BEPI_MASK) {
+                const u32x4 y = *reinterpret_cast<const u32x4*>(g.Y + (m0 + row) * g.ldy + n0 + 8 * j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // bf16 pair e: element 2e in the low half; a set sign bit in Y (the -0.0 of a negative pre-activation) zeroes it
+                    const uint32_t keep = ((y[e] & 0x8000u) ? 0u : 0xffffu) | ((y[e] & 0x80000000u) ? 0u : 0xffff0000u);
+                    v[e] &= keep;
+                }
+            }
+            *reinterpret_cast<u32x4*>(cout + (m0 + row) * g.ldc + n0 + 8 * j) = v;
+        }
+        emit_trace();
+        return;
+    }
+    // ---- epilogue, edge tiles / fp32 outputs: block (mi, ni) is rows m0 + wm TM + mi 32 + l31, register r the column
+    // (r & 3) + 8 (r >> 2) + 4 lhi
+    const bool vec_out = g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 &&
+                         (g.epi != BEPI_MASK || (g.ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(g.Y) & 7) == 0));
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (SYM && (mi / MH) * MH != mi0) continue;         // the partner finishes the other half
+        const int64_t row = m0 + wm * TM + mi * 32 + l31;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t col = n0 + wn * TN + ni * 32 + 8 * q + 4 * lhi;
+                if (col >= g.N) continue;
+                const bool full = vec_out && col + 3 < g.N;
+                float v[4];
+                uint16_t ymask[4] = {0, 0, 0, 0};
+                if (g.epi == BEPI_MASK) {
+                    if (full) {
+                        const u32x2 yv = *reinterpret_cast<const u32x2*>(g.Y + row * g.ldy + col);
+                        ymask[0] = (uint16_t)yv.x; ymask[1] = (uint16_t)(yv.x >> 16);
+                        ymask[2] = (uint16_t)yv.y; ymask[3] = (uint16_t)(yv.y >> 16);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < g.N) ymask[j] = g.Y[row * g.ldy + col + j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[mi][ni][4 * q + j];
+                    if (g.epi == BEPI_BIAS_ACT) {
+                        x += (g.bias && col + j < g.N) ? g.bias[col + j] : 0.f;
+                        if (g.act == TNN_ACT_RELU) x = x < 0.f ? (g.relu_sign ? -0.0f : 0.f) : fabsf(x);
+                    } else if (g.epi == BEPI_MASK) {
+                        if (ymask[j] & 0x8000u) x = 0.f;
+                    }
+                    v[j] = x;
+                }
+                if (g.c_bf16) {
+                    bf16_t* dst = reinterpret_cast<bf16_t*>(g.C) + row * g.ldc + col;
+                    if (full) {
+                        u32x2 pk;
+                        pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                        pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                        *reinterpret_cast<u32x2*>(dst) = pk;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < g.N) dst[j] = f2bf(v[j]);
+                    }
+                } else {
+                    float* dst = reinterpret_cast<float*>(g.C) + row * g.ldc + col;
+                    if (full) {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (col + j < g.N) dst[j] = v[j];
+                    }
+                }
+            }
+    }
+    emit_trace();
+}
+
+}  // namespace sk
