@@ -23,8 +23,17 @@ What `value` is:
             weak_scaling    128 rows per rank (global batch 128 N)
             strong_scaling  configs[3] taken literally: global batch 1024 split over the N ranks (N = 1: bs 1024 on one
                             GPU = `--workload A --rows 1024`), with its own `speedup_vs_n1` against `single_gpu_bs1024`
+            weak_scaling_1024  1024 rows per rank (global batch 1024 N), speedup against `single_gpu_bs1024` — the only one of
+                            the three definitions under which north_star's >= 6x at 8 GPUs is arithmetically reachable
+                            (DESIGN.md §7 states the three ceilings)
             batch_sizes     (N = 1) the same net at 256 and 512 rows on the one GPU — the per-rank batches of N = 4 / 2
-          so both curves can be drawn from the driver's N = 1/2/4/8 lines.
+          so all curves can be drawn from the driver's N = 1/2/4/8 lines.  N > 1 lines also carry
+            parity_vs_reference_fixture  the trainer + transport against the reference's own per-step losses (traj_A / traj_D)
+            parity_at_timed_rows         the step form actually TIMED (its rows per rank) against the single-GPU trainer on the
+                                         concatenated global batch, replicas identical
+            multi_gpu       RCCL version, hipDeviceCanAccessPeer / link-type matrix, both transports' self-test verdicts before
+                            and after the timed runs, us per collective at this N (940,588-B all-reduce, 2-float all-gather)
+                            per transport, which transport `value` came from and the rule that chose it
   Transports at N > 1: RCCL (north_star's named transport) is timed FIRST, the xGMI peer-to-peer path second; both are
   reported unconditionally under config.collectives.  `value` is the peer-to-peer run when that transport passed its
   bit-exact self-test before and after the run, no barrier timed out and all replicas hold identical parameters —
@@ -38,6 +47,10 @@ Extra objects on the N = 1 line:
   roofline_gemm4096  north_star's ">= 50 % of fp32 MFMA roofline" target: the five 512x4096x4096 GEMMs of config C,
                      HIP events on the library stream, peak 157.3 TFLOP/s, traffic from the PMC passes in profiles/
   config_C           whole-step samples/s of configs[2] (4096-4096-4096, bs 512)
+  epoch_loop         the reference's LOOP end to end (examples/mnist_run.train: shuffle, device gather, graph capture, 391
+                     steps, loss read-back; eval timed separately) on the trainer / captured-ops / eager-ops paths
+  dp_world1          the data-parallel step forms behind a one-rank communicator (128 / 1024 rows per rank)
+  reference_example_net  the reference's OWN net 784-200-100-70-30-10: bs 128, batch_sizes 256 / 512 / 1024, dp_world1
   paths              the same config-A step on the drop-in Tensor/ops/Model API: eager and captured (tn.capture)
   cpu_baseline       the numpy port of the reference (oracle/ref_nn.py) on this host, all BLAS threads and 1 thread
   box                what THIS box's MFMA pipes (fp32; bf16 with random / zero operands), clocks and HBM (float4 copy) do,
@@ -597,6 +610,157 @@ def fixture_check(widths, rows, kind, rank, world, comm, force_dp, use_graph):
             "max_rel_err": float("%.3g" % err), "rtol": 1e-5, "ok": bool(err <= 1e-5)}
 
 
+def timed_rows_check(widths, rows, kind, rank, world, comm, force_dp, use_graph, torch, steps=5):
+    """Parity of the step form being TIMED (its rows per rank, its transport): a fresh data-parallel trainer runs `steps`
+    steps on seeded global batches of rows x world rows (this rank's row block), rank 0 also runs the SINGLE-GPU trainer on
+    the whole concatenated batches — the arithmetic the ranks must reproduce (examples/mnist/run.py:79-83 at that batch
+    size) — and the per-step losses are compared (rtol 1e-5); replicas must hold identical parameters afterwards."""
+    dp = FusedRun(widths, rows, kind, steps, rank, world, comm, force_dp, use_graph=use_graph, seed=4321)
+    if dp.chunk is not None:
+        losses = np.asarray(dp.chunk.launch(), dtype=np.float64)
+    else:
+        losses = np.array([float(dp.trainer.step(*b)) for b in dp.batches])
+    crc = dp.params_crc()
+    same = True
+    if world > 1:
+        import torch.distributed as dist
+        box = [None] * world
+        dist.all_gather_object(box, crc)
+        same = bool(all(c == box[0] for c in box))
+    out = None
+    if rank == 0:
+        solo = FusedRun(widths, rows * world, kind, steps, 0, 1, None, False, use_graph=False, seed=4321)
+        ref = np.array([float(solo.trainer.step(*b)) for b in solo.batches])
+        err = float(np.max(np.abs(losses - ref) / np.abs(ref)))
+        blocks = (rows + 127) // 128
+        out = {"against": "the single-GPU trainer on the concatenated global batch of %d rows, %d steps" % (rows * world, steps),
+               "rows_per_rank": rows, "global_batch": rows * world, "max_rel_err": float("%.3g" % err), "rtol": 1e-5,
+               "replicas_identical": same, "ok": bool(err <= 1e-5 and same),
+               "step_form": "merged 2L - 2 launch data-parallel step, %d block(s) of <= 128 rows per rank" % blocks}
+        del solo
+    del dp
+    return out
+
+
+def rccl_version_string():
+    try:
+        v = ctypes.c_int(0)
+        lib = ctypes.CDLL("librccl.so.1")
+        lib.ncclGetVersion(ctypes.byref(v))
+        n = v.value
+        return "%d.%d.%d" % (n // 10000, (n // 100) % 100, n % 100)
+    except Exception as exc:                              # noqa: BLE001
+        return "unavailable (%s)" % type(exc).__name__
+
+
+def topology_object(torch):
+    """hipDeviceCanAccessPeer and hipExtGetLinkTypeAndHopCount for every pair of visible devices (rank 0; no device is
+    initialised by either call).  link types: HSA_AMD_LINK_INFO_TYPE_* (0 HyperTransport, 1 QPI, 2 PCIe, 3 InfiniBand, 4 xGMI)."""
+    out = {}
+    try:
+        n = torch.cuda.device_count()
+        out["visible_devices"] = n
+        out["can_access_peer"] = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
+        hip = None
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                if "libamdhip64" in ln:
+                    hip = ctypes.CDLL(ln.split()[-1])
+                    break
+        if hip is not None and n > 1:
+            lt, hops = [], []
+            for i in range(n):
+                lt.append([]); hops.append([])
+                for j in range(n):
+                    a, b = ctypes.c_uint32(0), ctypes.c_uint32(0)
+                    rc = hip.hipExtGetLinkTypeAndHopCount(i, j, ctypes.byref(a), ctypes.byref(b)) if i != j else 0
+                    lt[-1].append(int(a.value) if (i != j and rc == 0) else None)
+                    hops[-1].append(int(b.value) if (i != j and rc == 0) else 0)
+            out["link_type"], out["hops"] = lt, hops
+            out["link_type_names"] = {"2": "PCIe", "4": "xGMI"}
+    except Exception as exc:                              # noqa: BLE001 - diagnostics never cost the line
+        out["error"] = "%s: %s" % (type(exc).__name__, exc)
+    return out
+
+
+def collective_selftest(comm, world, rank, all_ranks):
+    """Both transports against known answers, voted over the ranks: RCCL — an all-reduce of rank-dependent integers (exact
+    in f32) and the 2-float all-gather; the peer-to-peer transport — its own bit-exact self-test."""
+    out = {}
+    was = bool(getattr(comm, "_p2p", False))
+    if getattr(comm, "_rccl", False):
+        if was:
+            comm.set_p2p(False)
+        try:
+            n = 235147
+            v = da.asarray(((np.arange(n) % 97) + rank + 1).astype(np.float32))
+            comm.allreduce(v)
+            want = world * (np.arange(n) % 97).astype(np.float64) + world * (world + 1) / 2.0
+            ok = bool(np.array_equal(np.asarray(v, dtype=np.float64), want))
+            g = comm.allgather(da.asarray(np.array([rank + 0.5, 2.0 * rank], dtype=np.float32)))
+            ok = ok and bool(np.array_equal(np.asarray(g), np.array([[r + 0.5, 2.0 * r] for r in range(world)], dtype=np.float32)))
+        except Exception as exc:                          # noqa: BLE001
+            sys.stderr.write("bench: RCCL self-test raised: %s\n" % exc)
+            ok = False
+        out["rccl"] = all_ranks(ok)
+        if was:
+            comm.set_p2p(True)
+    if hasattr(comm, "p2p_status"):
+        st = comm.p2p_status()
+        if st and st["connected"] and not st["dead"]:
+            comm.set_p2p(True)
+            try:
+                ok = bool(comm.p2p_selftest(sizes=(235147, 4099, 2), rounds=2))
+            except Exception as exc:                      # noqa: BLE001
+                sys.stderr.write("bench: peer-to-peer self-test raised: %s\n" % exc)
+                ok = False
+            out["xgmi_p2p"] = all_ranks(ok)
+            comm.set_p2p(was)
+    return out
+
+
+def collective_latency_table(comm, clock, reps=100):
+    """us per collective at this world size, replayed from one hipGraph of `reps` back-to-back calls (max over ranks):
+    the 940,588-byte all-reduce of the gradient arena + loss slot (C1) and the 2-float statistics all-gather (C2), per
+    transport."""
+    lib = _lib.get()
+    world = comm.world
+    table = {}
+    was = bool(getattr(comm, "_p2p", False))
+    legs = []
+    if getattr(comm, "_rccl", False):
+        legs.append(("rccl", False))
+    st = comm.p2p_status() if hasattr(comm, "p2p_status") else None
+    if st and st["connected"] and not st["dead"]:
+        legs.append(("xgmi_p2p", True))
+    for name, p2p in legs:
+        comm.set_p2p(p2p)
+        row = {}
+        try:
+            buf = da.asarray(np.zeros(235147, np.float32))
+            st2, out2 = da.asarray(np.array([1.0, 2.0], np.float32)), da.empty((world, 2), np.float32)
+            for key, fn in (("allreduce_940588_B", lambda: comm.allreduce(buf)),
+                            ("allgather_2_floats_per_rank", lambda: lib.allgather(st2._ptr, out2._ptr, 2, _lib.F32))):
+                g = _lib.Graph()
+                with g:
+                    for _ in range(reps):
+                        fn()
+                g.launch()
+                clock.fence()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    g.launch()
+                clock.fence()
+                row[key] = round(clock.max_over_ranks(time.perf_counter() - t0) / (3 * reps) * 1e6, 2)
+                del g
+        except Exception as exc:                          # noqa: BLE001 - diagnostics never cost the line
+            row["error"] = "%s: %s" % (type(exc).__name__, exc)
+        table[name] = row
+    comm.set_p2p(was)
+    table["unit"] = "us per collective, %d back-to-back calls per hipGraph launch, max over ranks" % reps
+    return table
+
+
 class _OpsGraph(object):
     def __init__(self, captured):
         self.captured = captured
@@ -893,12 +1057,15 @@ def main():
         st = comm.p2p_status() if comm is not None and hasattr(comm, "p2p_status") else None
         return all_ranks(bool(st and st["enabled"] and not st["dead"]))
 
+    selftest_before = None
+    if comm is not None and args.path == "fused":
+        selftest_before = collective_selftest(comm, world, rank, all_ranks)
     if comm is not None and args.path == "fused" and isinstance(runner, FusedRun):
         # Data-parallel run.  RCCL first (north_star's named transport), the xGMI peer-to-peer path second; both are
         # reported.  The latency path carries f32 sums up to its mapped capacity: config A's 0.94 MB arena, not C's
         # 134 MB or E's 1 GB — those go to RCCL whatever the transport's state.
         transports = {}
-        arena_bytes = (int(runner.trainer.params.size) + 1) * 4
+        arena_bytes = (int(runner.trainer.arena_size) + 1) * 4
         have_rccl = bool(getattr(comm, "_rccl", False))
         have_p2p = p2p_alive() and arena_bytes <= getattr(comm, "p2p_bytes", 0)
         res_rccl = res_p2p = None
@@ -969,7 +1136,7 @@ def main():
 
     if comm is not None and transports is not None:
         comm.set_p2p(transports["used"] == "xgmi-p2p")       # everything below runs on the primary transport
-    check = None
+    check = check_timed = None
     if args.path == "fused" and args.workload == "A":
         # the reference's fixtures exist at global batches 128 and 1024: a weak-scaling line at N = 2 / 4 (global batch 256 /
         # 512) checks the same trainer + transport at config D's split instead (1024 / N rows per rank, the step form its
@@ -981,12 +1148,24 @@ def main():
         if check is not None:
             check["ok"] = all_ranks(check["ok"])
             check["rows_per_rank"], check["global_batch"] = rows_chk, rows_chk * world
+            check["step_form"] = ("single-GPU 2L - 2 launch step" if comm is None else
+                                  "merged 2L - 2 launch data-parallel step, %d block(s) of <= 128 rows per rank" % ((rows_chk + 127) // 128))
+        if comm is not None and not args.no_extras:
+            # ... and the step form actually TIMED (its own rows per rank), against the single-GPU trainer on the whole batch
+            check_timed = timed_rows_check(widths, rows, kind, rank, world, comm, force_dp, use_graph, torch)
+            ok_t = all_ranks(check_timed["ok"] if check_timed is not None else True)
+            if check_timed is not None:
+                check_timed["ok"] = ok_t
     if rank == 0:
         line = make_line(args, widths, rows, kind, world, warmup, steps, res, runner, transports, force_dp)
         if check is not None:
             line["parity_vs_reference_fixture"] = check
             if not check["ok"]:
                 exit_code = line["exit_code"] = 4            # a fast step with the wrong losses is not a result
+        if args.path == "fused" and args.workload == "A" and check_timed is not None:
+            line["parity_at_timed_rows"] = check_timed
+            if not check_timed["ok"]:
+                exit_code = line["exit_code"] = 4
 
     # ---------------------------------------------------------------- scaling curves (workload A)
     if args.workload == "A" and args.path == "fused" and not args.no_extras and args.rows is None:
@@ -1025,6 +1204,15 @@ def main():
                                                         widths="-".join(map(str, ex_widths)), rows=128,
                                                         launches_per_step=ex_run.launches_per_step())
                 del ex_run
+                ex_sizes = {}
+                for rows_b in (256, 512, 1024):              # the generic merged head walking 2 / 4 / 8 blocks of 128 rows
+                    rb_run = FusedRun(ex_widths, rows_b, kind, 32, 0, 1, None, False, use_graph=use_graph)
+                    ex_sizes[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
+                                                  launches_per_step=rb_run.launches_per_step())
+                    del rb_run
+                curves["reference_example_net"]["batch_sizes"] = ex_sizes
+            curves["weak_scaling_1024"] = dict(curves["strong_scaling"], note="N = 1 point of the third curve (1024 rows per rank): "
+                                               "the same measurement as strong_scaling's N = 1 point")
         elif other_rows != rows:
             other = FusedRun(widths, other_rows, kind, 64 if other_rows <= 256 else 32, rank, world, comm, False,
                              use_graph=use_graph)
@@ -1034,7 +1222,14 @@ def main():
                 replicas_identical=replicas_identical(other))
             del other
         if world > 1:
-            # the single-GPU references of BOTH curves, measured in THIS run on rank 0 while the others wait; each curve's
+            # third curve: 1024 rows per rank (global batch 1024 N) — the definition under which the step is long enough for the
+            # exchange to amortise (ceilings of the three curves)
+            w1024 = FusedRun(widths, 1024, kind, 32, rank, world, comm, False, use_graph=use_graph)
+            rw = measure(clock, w1024, warmup, steps, 3, args.min_ms, 1024 * world)
+            curves["weak_scaling_1024"] = brief(rw, global_batch=1024 * world, rows_per_rank=1024, transport=transports["used"],
+                                                replicas_identical=replicas_identical(w1024))
+            del w1024
+            # the single-GPU references of ALL curves, measured in THIS run on rank 0 while the others wait; each curve's
             # speedup is computed on its own definition (weak: 128 rows on one GPU; strong: the whole 1024 rows on one GPU)
             if rank == 0:
                 for rows_1 in (128, GLOBAL_BATCH_D):
@@ -1042,7 +1237,7 @@ def main():
                     r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, rows_1)
                     curves["single_gpu_bs%d" % rows_1] = brief(r1, note="rank 0 alone, no communicator")
                     del d1
-                for name, rows_1 in (("weak_scaling", 128), ("strong_scaling", GLOBAL_BATCH_D)):
+                for name, rows_1 in (("weak_scaling", 128), ("strong_scaling", GLOBAL_BATCH_D), ("weak_scaling_1024", 1024)):
                     if name in curves:
                         curves[name]["speedup_vs_n1"] = round(
                             curves[name]["value"] / curves["single_gpu_bs%d" % rows_1]["value"], 4)
@@ -1054,6 +1249,44 @@ def main():
             curves["strong_scaling"].setdefault("note", strong_note)
         if line is not None:
             line.update(curves)
+
+    # ---------------------------------------------------------------- what the communicator ran on (every line with one)
+    if comm is not None and args.path == "fused" and not args.no_extras:
+        after = collective_selftest(comm, world, rank, all_ranks)
+        table = collective_latency_table(comm, clock)
+        if line is not None:
+            used = transports["used"] if transports else None
+            line["multi_gpu"] = {
+                "world": world, "rccl_version": rccl_version_string(), "topology": topology_object(torch),
+                "selftest_before_timed_runs": selftest_before, "selftest_after_timed_runs": after,
+                "collective_latency": table,
+                "value_from": used,
+                "why": (transports or {}).get("rule"),
+                "ranks_share_a_device": os.environ.get("TNN_DEVICE") is not None,
+            }
+        if transports is not None:
+            comm.set_p2p(transports["used"] == "xgmi-p2p")
+
+    # ---------------------------------------------------------------- forced communicator at world 1: the step forms of N > 1
+    if comm is not None and world == 1 and args.workload == "A" and args.path == "fused" and not args.no_extras and args.rows is None:
+        dp_sizes = {}
+        for rows_b in (256, 512, 1024):                      # the per-rank batches of the strong curve and of weak_scaling_1024
+            rb_run = FusedRun(widths, rows_b, kind, 32, 0, 1, comm, True, use_graph=use_graph)
+            dp_sizes[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
+                                          graph_captured=rb_run.chunk is not None)
+            del rb_run
+        ex_widths = [784, 200, 100, 70, 30, 10]
+        ex_dp = {}
+        for rows_b in (128, 1024):
+            rb_run = FusedRun(ex_widths, rows_b, kind, 32, 0, 1, comm, True, use_graph=use_graph)
+            ex_dp[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
+                                       graph_captured=rb_run.chunk is not None)
+            del rb_run
+        if line is not None:
+            line["dp_world1_batch_sizes"] = dict(dp_sizes, note="the data-parallel step (both collectives issued, world 1) at the "
+                                                 "per-rank batches of the strong curve (256 / 512) and of weak_scaling_1024; transport: %s"
+                                                 % (transports["used"] if transports else "rccl"))
+            line.setdefault("reference_example_net", {"widths": "-".join(map(str, ex_widths))})["dp_world1"] = ex_dp
 
     # ---------------------------------------------------------------- configs[4] (bf16, 8 GPUs) on the data-parallel line
     if (comm is not None and getattr(comm, "_rccl", False) and args.workload == "A" and args.path == "fused"
@@ -1125,6 +1358,34 @@ def main():
         if not args.no_cpu_baseline and args.workload != "E":
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
 
+    if (rank == 0 and world == 1 and comm is None and line is not None and not args.no_extras and args.workload == "A"
+            and args.path == "fused" and args.rows is None):
+        # the data-parallel step forms with a one-rank communicator (every collective issued; what N > 1 runs per rank), AFTER
+        # every other measurement of this line
+        os.environ["TNN_FORCE_COMM"] = "1"
+        comm1 = None
+        try:
+            comm1 = tn.dist.init_from_env()
+            used1 = "xgmi-p2p" if getattr(comm1, "_p2p", False) else "rccl"
+            dp1 = {"transport": used1, "note": "one-rank communicator, both collectives issued; rows per rank as on the N > 1 curves"}
+            for rows_b in (128, 1024):
+                rb_run = FusedRun(widths, rows_b, kind, 32, 0, 1, comm1, True, use_graph=use_graph)
+                dp1[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b), graph_captured=rb_run.chunk is not None)
+                del rb_run
+            line["dp_world1"] = dp1
+            ex_widths = [784, 200, 100, 70, 30, 10]
+            ex_dp = {"transport": used1}
+            for rows_b in (128, 1024):
+                rb_run = FusedRun(ex_widths, rows_b, kind, 32, 0, 1, comm1, True, use_graph=use_graph)
+                ex_dp[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b), graph_captured=rb_run.chunk is not None)
+                del rb_run
+            line.setdefault("reference_example_net", {})["dp_world1"] = ex_dp
+        except Exception as exc:                             # noqa: BLE001 - an extra object never costs the line
+            line["dp_world1"] = "unavailable: %s: %s" % (type(exc).__name__, exc)
+        finally:
+            os.environ.pop("TNN_FORCE_COMM", None)
+            if comm1 is not None and hasattr(comm1, "close"):
+                comm1.close()
     if rank == 0 and world == 1 and line is not None and not args.no_extras:
         line["box"] = box_object(line)
     emit(line)

@@ -208,13 +208,19 @@ def run_config_e_small(tn, comm, calls, rank, world, dist):
     # and a checkpoint (a collective) holds WHOLE, rank-identical arenas from which a fresh trainer continues bit for bit
     if world > 1:
         assert trainer.masters_sharded() == world
-        try:
-            trainer.param_view(0, "w")
-            raise AssertionError("param_view on sharded masters did not raise")
-        except RuntimeError:
-            pass
+        # ... the moment arenas included, and the implicit collectives (state_dict / save / get_parameters) refuse to start
+        # unless told collective=True: `if rank == 0: trainer.save(path)` must raise, not hang in the all-gather
+        for reader in (lambda: trainer.param_view(0, "w"), lambda: trainer.param_view(0, "w", arena=trainer.arena_m),
+                       lambda: trainer.param_view(1, "w", arena=trainer.arena_v), trainer.state_dict, trainer.get_parameters,
+                       lambda: trainer.save("/tmp/never_written.npz")):
+            try:
+                reader()
+                raise AssertionError("a reader of sharded masters did not raise")
+            except RuntimeError:
+                pass
+        assert trainer.grad_view(0, "w").shape == (widths[0], widths[1])          # the gradient arena is not sharded
     calls["seq"] = []
-    state = trainer.state_dict()
+    state = trainer.state_dict(collective=True)
     if world > 1:
         shard = [widths[l] // world * widths[l + 1] for l in range(2)]
         assert calls["seq"] == [("allgather", shard[l], F32) for l in range(2) for _ in range(3)], calls["seq"]
@@ -230,7 +236,7 @@ def run_config_e_small(tn, comm, calls, rank, world, dist):
     la, lb = float(trainer.step(x16, x16)), float(resumed.step(x16, x16))
     assert la == lb, (la, lb)
     assert np.array_equal(np.asarray(trainer.weights_bf16()), np.asarray(resumed.weights_bf16()))
-    sa, sb = trainer.state_dict(), resumed.state_dict()
+    sa, sb = trainer.state_dict(collective=True), resumed.state_dict(collective=True)
     for k in ("params", "m", "v", "pows"):
         assert np.array_equal(sa[k], sb[k]), k
 

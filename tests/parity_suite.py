@@ -247,6 +247,47 @@ def trainer_R_example_row_blocks_take_the_2L_minus_2_launch_step():
             assert not full[w[l]:, :].any() and not full[:, w[l + 1]:].any(), (rows, l)       # the padding stays exactly zero
 
 
+def trainer_padded_api_is_logical():
+    """A trainer whose hidden widths are padded inside the arenas (the reference's own 784-200-100-70-30-10) presents the
+    LOGICAL parameters: n_params = the reference's count, params / grads / adam_m in the reference optimizer's flat order
+    (core/optimizer.py:14-15), param_view = the logical block as a read-only copy (assignment raises instead of silently
+    writing a temporary), set_param writes the padded block; the stored arenas are arena_params / arena_size."""
+    cfg, _ = H.load_traj("R_example")
+    model, _ = H.build_model(cfg)
+    w = cfg["widths"]
+    trainer = trainer_from_net(model.net, max_rows=cfg["m"], loss=cfg["loss"], optimizer=cfg["opt"], lr=cfg["lr"], use_graph=False)
+    assert trainer.padded
+    assert trainer.n_params == sum(w[i] * w[i + 1] + w[i + 1] for i in range(5)) == 186610 and trainer.arena_size == 198650
+    flat = np.concatenate([np.asarray(l.params[k].values).ravel() for l in H.dense_layers(model) for k in ("w", "b")])
+    assert trainer.params.shape == (186610,) and np.array_equal(np.asarray(trainer.params), flat)
+    assert np.asarray(trainer.arena_params).shape == (198650,)
+    x, y = H.batches(cfg["data_seed"], 1, cfg["m"], w[0], w[-1], cfg["loss"])[0]
+    trainer.step(tn.asarray(x), tn.asarray(y))
+    assert trainer.grads.shape == trainer.adam_m.shape == trainer.adam_v.shape == (186610,)
+    g = np.concatenate([np.asarray(trainer.grad_view(l, k)).ravel() for l in range(5) for k in ("w", "b")])
+    assert np.array_equal(np.asarray(trainer.grads), g) and np.abs(g).max() > 0
+    view = trainer.param_view(1, "w")
+    assert view.shape == (200, 100)
+    for bad in (lambda: view.__setitem__(Ellipsis, 0.0), lambda: trainer.params.__setitem__(slice(0, 4), 1.0)):
+        try:
+            bad()
+            raise AssertionError("assignment into a read-only copy must raise")
+        except ValueError:
+            pass
+    new = np.full((200, 100), 0.25, np.float32)
+    trainer.set_param(1, "w", new)
+    assert np.array_equal(np.asarray(trainer.param_view(1, "w")), new)
+    full = np.asarray(trainer._view(1, "w"))
+    assert full.shape == (208, 112) and not full[200:, :].any() and not full[:, 100:].any()
+    # an unpadded trainer's views stay views
+    cfg_a, _ = H.load_traj("A_adam")
+    model_a, _ = H.build_model(cfg_a)
+    t_a = trainer_from_net(model_a.net, max_rows=8, lr=1e-3)
+    assert not t_a.padded and t_a.n_params == t_a.arena_size == 235146
+    t_a.param_view(2, "b")[...] = 0.5
+    assert np.array_equal(np.asarray(t_a.params)[-10:], np.full(10, 0.5, np.float32))
+
+
 def trainer_A_adam_multi_step_graph():
     """All 20 steps captured into ONE hipGraph (each step bound to its own resident batch), replayed once;
     then a second replay must continue the optimizer (device-side Adam state), not restart it."""

@@ -208,6 +208,21 @@ def test_bench_two_ranks_under_torchrun_share_the_gpu():
     # both curves on the one line: this N's weak point (= value), the strong point, the single-GPU references of both
     assert d["weak_scaling"]["global_batch"] == 256 and d["weak_scaling"]["value"] == d["value"]
     assert d["strong_scaling"]["global_batch"] == 1024 and d["strong_scaling"]["rows_per_rank"] == 512
+    # the third curve (1024 rows per rank) with its own single-GPU reference and speedup
+    w3 = d["weak_scaling_1024"]
+    assert w3["global_batch"] == 2048 and w3["rows_per_rank"] == 1024 and w3["replicas_identical"] and w3["speedup_vs_n1"] > 0
+    assert abs(w3["speedup_vs_n1"] - w3["value"] / d["single_gpu_bs1024"]["value"]) < 1e-3
+    # the step form that was TIMED (128 rows per rank) is checked too, against the single-GPU trainer on the whole batch
+    pt = d["parity_at_timed_rows"]
+    assert pt["ok"] and pt["rows_per_rank"] == 128 and pt["global_batch"] == 256 and pt["replicas_identical"] and pt["max_rel_err"] <= 1e-5
+    assert "512" not in chk["step_form"] and "4 block" in chk["step_form"] and "1 block" in pt["step_form"]
+    # what the run stood on: RCCL version, peer access, self-tests before and after, per-collective latencies, which transport and why
+    mg = d["multi_gpu"]
+    assert mg["world"] == 2 and mg["value_from"] == "xgmi-p2p" and mg["why"] and mg["ranks_share_a_device"]
+    assert mg["selftest_before_timed_runs"] == {"xgmi_p2p": True} and mg["selftest_after_timed_runs"] == {"xgmi_p2p": True}
+    lat = mg["collective_latency"]["xgmi_p2p"]
+    assert lat["allreduce_940588_B"] > 0 and lat["allgather_2_floats_per_rank"] > 0
+    assert "can_access_peer" in mg["topology"] and isinstance(mg["rccl_version"], str)
     assert d["strong_scaling"]["replicas_identical"] and d["single_gpu_bs1024"]["value"] > 0 and d["single_gpu_bs128"]["value"] > 0
     assert abs(d["value"] / d["single_gpu_bs128"]["value"] - d["speedup_vs_n1"]) <= 1e-3 * d["speedup_vs_n1"]
 

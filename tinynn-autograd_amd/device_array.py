@@ -32,6 +32,7 @@ _CODE = {np.dtype(np.float32): F32, np.dtype(np.float64): F64, np.dtype(np.int64
          np.dtype(np.bool_): U8,
          np.dtype(np.uint16): _lib.BF16}     # raw bf16 bit patterns: storage only (tinynn_autograd_amd.bf16)
 _default_float = np.dtype(np.float32)
+READONLY_COPY = "readonly-copy"      # DeviceArray._tag of a snapshot that must not be mistaken for a view (fused.MLPTrainer.param_view)
 MAX_NDIM = 6
 
 
@@ -473,6 +474,9 @@ class DeviceArray(object):
     def __setitem__(self, key, value):
         if self._t or self._hv is not None:
             raise TypeError("cannot assign into a transposed view or host scalar")
+        if self._tag is READONLY_COPY:
+            raise ValueError("assignment destination is a read-only COPY (a padded trainer's logical parameter block): "
+                             "use MLPTrainer.set_param(layer, key, value)")
         lib = _lib.get()
         if DeviceArray._is_advanced(key):
             idx = self._index_array(key)

@@ -63,18 +63,38 @@ class MLPTrainer(object):
         n = ctypes.c_int64(0)
         self._lib.mlp_arena(self._h, ctypes.byref(p), ctypes.byref(g), ctypes.byref(m), ctypes.byref(v),
                             ctypes.byref(n))
-        self.n_params = n.value
-        self.params = da.from_ptr(p.value, (self.n_params,), self.dtype, self)
-        self.grads = da.from_ptr(g.value, (self.n_params,), self.dtype, self)
-        self._grads_and_loss = da.from_ptr(g.value, (self.n_params + 1,), self.dtype, self)
-        self.loss_slot = da.from_ptr(g.value + self.n_params * self.dtype.itemsize, (), self.dtype, self)
-        self.adam_m = da.from_ptr(m.value, (self.n_params,), self.dtype, self)
-        self.adam_v = da.from_ptr(v.value, (self.n_params,), self.dtype, self)
+        # The four arenas AS STORED (padded widths): what the kernels, the collectives and a checkpoint work on.  `params` /
+        # `grads` / `adam_m` / `adam_v` / `n_params` below are the LOGICAL view (the reference optimizer's flat order and
+        # count, core/optimizer.py:14-15): the arenas themselves unless hidden widths are padded, read-only copies then.
+        self.arena_size = n.value
+        self.arena_params = da.from_ptr(p.value, (self.arena_size,), self.dtype, self)
+        self.arena_grads = da.from_ptr(g.value, (self.arena_size,), self.dtype, self)
+        self._grads_and_loss = da.from_ptr(g.value, (self.arena_size + 1,), self.dtype, self)
+        self.loss_slot = da.from_ptr(g.value + self.arena_size * self.dtype.itemsize, (), self.dtype, self)
+        self.arena_m = da.from_ptr(m.value, (self.arena_size,), self.dtype, self)
+        self.arena_v = da.from_ptr(v.value, (self.arena_size,), self.dtype, self)
+        self.n_params = sum(self.widths[l] * self.widths[l + 1] + self.widths[l + 1] for l in range(self.n_layers))
         self._graph = None
         self._graph_rows = None
         self._x_stage = None
         self._y_stage = None
         self._stats = da.empty((2,), self.dtype)
+
+    @property
+    def params(self):
+        return self.flat_parameters()
+
+    @property
+    def grads(self):
+        return self.flat_parameters(self.arena_grads)
+
+    @property
+    def adam_m(self):
+        return self.flat_parameters(self.arena_m)
+
+    @property
+    def adam_v(self):
+        return self.flat_parameters(self.arena_v)
 
     def keep_grads(self, keep=True):
         """keep=False: `step` may consume weight gradients where they are produced (bf16 trainer: Adam in the epilogue of
@@ -107,19 +127,44 @@ class MLPTrainer(object):
 
     def gather_masters(self):
         """COLLECTIVE (every rank calls it): make the fp32 parameter / Adam arenas whole on every rank after
-        sharded-optimizer steps.  `state_dict`, `save` and `get_parameters` call it themselves."""
+        sharded-optimizer steps.  `state_dict`, `save` and `get_parameters` refuse to run on sharded masters unless told
+        `collective=True` (then they call this themselves — on EVERY rank, or the ranks that did call hang)."""
         self._lib.mlp_gather_masters(self._h)
         return self
 
+    def _whole_masters(self, collective, what):
+        if self.masters_sharded():
+            if not collective:
+                raise RuntimeError("%s: the fp32 masters are sharded over %d ranks (sharded-optimizer steps) — making them "
+                                   "whole is a COLLECTIVE.  Call it with collective=True on every rank, or call "
+                                   "gather_masters() on every rank first (an `if rank == 0: trainer.save(...)` would hang in "
+                                   "the all-gather)" % (what, self.masters_sharded()))
+            self.gather_masters()
+
     def param_view(self, layer, key, arena=None):
-        if arena is None and key == "w" and self.masters_sharded():
-            raise RuntimeError("the fp32 master weights are sharded over %d ranks (sharded-optimizer steps): call "
-                               "gather_masters() on every rank first, or read weights_bf16()" % self.masters_sharded())
+        if key == "w" and arena is not self.arena_grads and self.masters_sharded():      # master weights AND both moments
+            raise RuntimeError("the fp32 master weights / Adam moments are sharded over %d ranks (sharded-optimizer steps): "
+                               "call gather_masters() on every rank first, or read weights_bf16()" % self.masters_sharded())
         view = self._view(layer, key, arena)
         if self.padded and view.shape != self._shape(layer, key, self.widths):
             rows, cols = self._shape(layer, key, self.widths)
-            view = view[:rows, :cols]                  # a COPY of the logical block (the padding is zeros)
+            view = view[:rows, :cols]                  # a COPY of the logical block (the padding is zeros) ...
+            view._tag = da.READONLY_COPY               # ... that refuses assignment: write through set_param
         return view
+
+    def set_param(self, layer, key, value, arena=None):
+        """Write one parameter block ("w" [in, out] or "b" [1, out], logical shape; host or device values) — the way to assign
+        on a padded trainer, where `param_view` hands out read-only copies (an unpadded trainer's views can also be assigned
+        in place).  bf16 trainers: call sync() afterwards (or use set_parameters)."""
+        view = self._view(layer, key, arena)
+        rows, cols = self._shape(layer, key, self.widths)
+        src = value.values if hasattr(value, "values") and not isinstance(value, np.ndarray) else value
+        if view.shape != (rows, cols):                 # padded block: zeros around the logical values
+            host = np.zeros(view.shape, self.dtype)
+            host[:rows, :cols] = np.asarray(src, dtype=self.dtype).reshape(rows, cols)
+            view[...] = da.asarray(host)
+        else:
+            view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
 
     @staticmethod
     def _shape(layer, key, widths):
@@ -128,49 +173,43 @@ class MLPTrainer(object):
     def _view(self, layer, key, arena=None):
         """The parameter's block of the arena as stored (padded widths)."""
         off, cnt = self._offset(layer, 0 if key == "w" else 1)
-        base = self.params if arena is None else arena
+        base = self.arena_params if arena is None else arena
         return base[off:off + cnt].reshape(self._shape(layer, key, self._pwidths))
 
     def flat_parameters(self, arena=None):
         """The parameters (or another arena) as ONE flat vector in the reference optimizer's order (layer by layer, "w" then
         "b": core/optimizer.py:14-15) with the logical shapes — the arena itself unless hidden widths are padded."""
         if not self.padded:
-            return self.params if arena is None else arena
-        return da.asarray(np.concatenate([np.asarray(self.param_view(l, k, arena)).ravel()
+            return self.arena_params if arena is None else arena
+        flat = da.asarray(np.concatenate([np.asarray(self.param_view(l, k, arena)).ravel()
                                           for l in range(self.n_layers) for k in ("w", "b")]))
+        flat._tag = da.READONLY_COPY
+        return flat
 
     def grad_view(self, layer, key):
-        return self.param_view(layer, key, arena=self.grads)
+        return self.param_view(layer, key, arena=self.arena_grads)
 
     def set_parameters(self, layers):
         """layers: list of {"w": array [in,out], "b": array [1,out]} (host or device)."""
         for i, layer in enumerate(layers):
             for key in ("w", "b"):
-                src = layer[key]
-                src = src.values if hasattr(src, "values") and not isinstance(src, np.ndarray) else src
-                view = self._view(i, key)             # the whole arena is rewritten: no need for it to be whole before
-                rows, cols = self._shape(i, key, self.widths)
-                if view.shape != (rows, cols):         # padded block: zeros around the logical values
-                    host = np.zeros(view.shape, self.dtype)
-                    host[:rows, :cols] = np.asarray(src, dtype=self.dtype).reshape(rows, cols)
-                    view[...] = da.asarray(host)
-                else:
-                    view[...] = da.asarray(src, dtype=self.dtype).reshape(view.shape)
+                self.set_param(i, key, layer[key])    # the whole arena is rewritten: no need for it to be whole before
         self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies W, W^T
 
     # ------------------------------------------------------------------ checkpoint / resume
-    def state_dict(self):
+    def state_dict(self, collective=False):
         """Everything a resumed run needs, as host arrays: parameters, the optimizer's two state arenas and Adam's
         beta powers (the reference's Model.save only pickles the parameters and its load is broken).  After
-        sharded-optimizer steps (bf16 data-parallel trainer) this is a COLLECTIVE: every rank must call it (the owned
-        fp32 slices are all-gathered first)."""
-        self.gather_masters()                         # collective when the optimizer is sharded: every rank saves
+        sharded-optimizer steps (bf16 data-parallel trainer) the masters must be made whole first — a COLLECTIVE: pass
+        collective=True on EVERY rank (or call gather_masters() on every rank beforehand); without it this raises instead of
+        hanging the ranks that did call."""
+        self._whole_masters(collective, "state_dict")
         pows = ctypes.c_void_p()
         self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
         return {"widths": list(self.widths), "padded_widths": list(self._pwidths),
                 "dtype": "bfloat16" if self.bf16 else self.dtype.name,
-                "params": np.asarray(self.params).copy(), "m": np.asarray(self.adam_m).copy(),
-                "v": np.asarray(self.adam_v).copy(),
+                "params": np.asarray(self.arena_params).copy(), "m": np.asarray(self.arena_m).copy(),
+                "v": np.asarray(self.arena_v).copy(),
                 "pows": np.asarray(da.from_ptr(pows.value, (4,), np.float64, self)).copy()}
 
     def load_state_dict(self, state):
@@ -181,23 +220,23 @@ class MLPTrainer(object):
                              % (list(state.get("padded_widths", state["widths"])), self._pwidths))
         pows = ctypes.c_void_p()
         self._lib.mlp_optimizer_state(self._h, ctypes.byref(pows))
-        self.params[...] = da.asarray(np.asarray(state["params"]), dtype=self.dtype)
-        self.adam_m[...] = da.asarray(np.asarray(state["m"]), dtype=self.dtype)
-        self.adam_v[...] = da.asarray(np.asarray(state["v"]), dtype=self.dtype)
+        self.arena_params[...] = da.asarray(np.asarray(state["params"]), dtype=self.dtype)
+        self.arena_m[...] = da.asarray(np.asarray(state["m"]), dtype=self.dtype)
+        self.arena_v[...] = da.asarray(np.asarray(state["v"]), dtype=self.dtype)
         da.from_ptr(pows.value, (4,), np.float64, self)[...] = da.asarray(np.asarray(state["pows"]), dtype=np.float64)
         self._lib.mlp_sync_params(self._h)           # bf16 mode: refresh the working copies
         self._graph = None                            # a captured single-step graph holds no state, but be safe
 
-    def save(self, path):
-        np.savez(path, **{k: np.asarray(v) for k, v in self.state_dict().items()})
+    def save(self, path, collective=False):
+        np.savez(path, **{k: np.asarray(v) for k, v in self.state_dict(collective=collective).items()})
 
     def load(self, path):
         with np.load(path, allow_pickle=False) as f:
             self.load_state_dict({k: (f[k].tolist() if k in ("widths", "padded_widths") else (str(f[k]) if k == "dtype" else f[k]))
                                   for k in f.files})
 
-    def get_parameters(self):
-        self.gather_masters()                         # collective when the optimizer is sharded
+    def get_parameters(self, collective=False):
+        self._whole_masters(collective, "get_parameters")
         return [{"w": self.param_view(i, "w"), "b": self.param_view(i, "b")} for i in range(self.n_layers)]
 
     def weights_bf16(self, layer=None):
@@ -207,7 +246,7 @@ class MLPTrainer(object):
         then authoritative for its own row slice of every weight matrix only."""
         p = ctypes.c_void_p()
         self._lib.mlp_bf16_weights(self._h, ctypes.byref(p))
-        arena = da.from_ptr(p.value, (self.n_params,), np.uint16, self)
+        arena = da.from_ptr(p.value, (self.arena_size,), np.uint16, self)
         if layer is None:
             return arena
         off, cnt = self._offset(layer, 0)
