@@ -278,6 +278,10 @@ TNN_API int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes,
  * generic kernel takes any head with n_hidden %% 16 == 0, 16 <= n_hidden <= 256, n_classes <= 16 — both need f32,
  * rows <= 128 and n_in %% 16 == 0 (the reference's own 70 -> 30 -> 10 tail once the trainer has padded the hidden widths). */
 TNN_API int tnn_mlp_head_bwd_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, int dtype, int* fits);
+/* Allocate, outside any hipGraph capture, the hand-off memory tnn_mlp_head_bwd_tick_ext uses to work on the 128-row blocks of
+ * a batch in parallel (generic heads only; the trainer calls it when it is created, so that the first step may already be
+ * inside a capture).  No reference counterpart (new). */
+TNN_API int tnn_mlp_head_bwd_reserve(int64_t max_rows, int64_t n_in, int64_t n_hidden, int64_t n_classes);
 TNN_API int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x,
                                   const void* w1, const void* a, const void* w, const void* b, const void* y,
                                   const void* logit_partials, void* logits, void* dz, void* stats, void* loss, void* dw,

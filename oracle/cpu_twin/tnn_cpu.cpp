@@ -630,6 +630,7 @@ int tnn_mlp_head_fits(int64_t rows, int64_t nh, int64_t nc, int dtype, int* fits
     *fits = (dtype == TNN_F32 && nc == 10 && nh == 128 && rows >= 1 && rows <= 128) ? 1 : 0;    // the HIP kernel's shapes
     return 0;
 }
+int tnn_mlp_head_bwd_reserve(int64_t, int64_t, int64_t, int64_t) { return 0; }
 int tnn_mlp_head_bwd_fits(int64_t rows, int64_t n_in, int64_t nh, int64_t nc, int dtype, int* fits) {
     REQ(fits != nullptr, "tnn_mlp_head_bwd_fits: fits is NULL");
     *fits = (dtype == TNN_F32 && rows >= 1 && rows <= 128 && nh % 16 == 0 && nh >= 16 && nh <= 256 && nc >= 1 && nc <= 16 &&

@@ -91,6 +91,7 @@ _SIGNATURES = {
     "tnn_softmax_nll_fused_tick": [_p, _p, c_int64, c_int64, c_int64, c_int, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
     "tnn_mlp_head_fits": [c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
+    "tnn_mlp_head_bwd_reserve": [c_int64, c_int64, c_int64, c_int64],
     "tnn_mlp_head_bwd_fits": [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
     "tnn_mlp_head_tick": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_mlp_head_bwd_tick": [c_int64, c_int64, c_int64, c_int64] + [_p] * 16 + [c_int, _p, c_double, c_double],

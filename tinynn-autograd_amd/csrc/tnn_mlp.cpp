@@ -501,6 +501,8 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     if (!rc) rc |= tnn_memset(h->ticket, 0, 256);
     if (n_layers >= 2 && dtype == TNN_F32)
         rc |= tnn_malloc((size_t)((widths[n_layers - 1] + 15) / 16 * max_rows * widths[n_layers]) * 4, &h->zpart);
+    if (n_layers >= 3 && dtype == TNN_F32 && loss_kind == 0 && max_rows > 128 && !rc)     // (the merged head's row-block hand-off memory)
+        rc |= tnn_mlp_head_bwd_reserve(max_rows, widths[n_layers - 2], widths[n_layers - 1], widths[n_layers]);
     const size_t act_esz = h->bf16 ? 2 : h->esz;
     for (int l = 0; l < n_layers && !rc; ++l) {
         void *a = nullptr, *d = nullptr;
