@@ -337,6 +337,15 @@ TNN_API int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const
                                           int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
                                           const void* head_w, int64_t head_c, void* head_z_full, const void* head_b,
                                           void* pairs_f32, int dtype);
+/* ... whose workgroups also MERGE the panels' pairs inside the launch (the data-parallel step at more than 128 rows per rank):
+ * the last workgroup to finish (arrival counter ticket_u32[0]: zero on entry, left zero) merges the ceil(M / 16) pairs in panel
+ * order and leaves ONE pair in out_pair_f32 [2] — exchanged and merged with the other ranks' first when `exchange` is set
+ * (xGMI peer-to-peer transport; tnn_dense_fwd_head_partials_stats's exchange).  head_z_full as above: hand it to
+ * tnn_mlp_head_bwd_tick_ext with n_pairs = -1 (own merged pair) or -world (the all-gathered pairs).  core/losses.py:26-27. */
+TNN_API int tnn_dense_fwd_rows_head_stats_merged(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
+                                                 int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
+                                                 const void* head_w, int64_t head_c, void* head_z_full, const void* head_b,
+                                                 void* pairs_f32, void* ticket_u32, void* out_pair_f32, int exchange, int dtype);
 
 /* Sum-of-squares loss used by config C and test/test_autograd.py:119-121:
  * loss_out[0] = sum((pred - y)**2) / m_global over this shard, dpred = 2 (pred - y) / m_global

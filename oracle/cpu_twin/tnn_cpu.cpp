@@ -729,6 +729,19 @@ int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const void* A
     }
     return 0;
 }
+int tnn_lse_merge(const void*, int, void*, int);
+int tnn_dense_fwd_rows_head_stats_merged(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                         const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* head_w,
+                                         int64_t head_c, void* head_z_full, const void* head_b, void* pairs, void* ticket, void* out_pair,
+                                         int exchange, int dtype) {
+    NEED_INIT();
+    REQ(ticket && out_pair, "cpu twin: tnn_dense_fwd_rows_head_stats_merged needs the ticket and out_pair");
+    RECORD(tnn_dense_fwd_rows_head_stats_merged(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z_full, head_b,
+                                                pairs, ticket, out_pair, exchange, dtype));
+    if (int rc = tnn_dense_fwd_rows_head_stats(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z_full, head_b,
+                                               pairs, dtype)) return rc;
+    return tnn_lse_merge(pairs, (int)((M + 15) / 16), out_pair, dtype);            // a one-rank exchange is the identity
+}
 int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
                               const void* a, const void* w, const void* b, const void* y, const void* zpart, const void* pairs,
                               int n_pairs, void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,

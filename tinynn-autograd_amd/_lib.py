@@ -102,6 +102,8 @@ _SIGNATURES = {
                                           _p, c_int64, _p, _p, _p, _p, _p, c_int, c_int],
     "tnn_dense_fwd_rows_head_stats": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64, _p,
                                       c_int64, _p, _p, _p, c_int],
+    "tnn_dense_fwd_rows_head_stats_merged": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64, _p,
+                                             c_int64, _p, _p, _p, _p, _p, c_int, c_int],
     "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
     "tnn_mse_fwd_bwd_tick": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, _p, c_double, c_double],
     "tnn_sgd": [_p, _p, c_int64, c_double, c_int],

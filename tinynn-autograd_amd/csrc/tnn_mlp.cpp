@@ -496,7 +496,7 @@ int tnn_mlp_create(int n_layers, const int64_t* widths, int64_t max_rows, int lo
     rc |= tnn_malloc(bytes, (void**)&h->m);
     rc |= tnn_malloc(bytes, (void**)&h->v);
     rc |= tnn_malloc(4 * sizeof(double), &h->pows);
-    rc |= tnn_malloc(64 * 2 * 8, &h->stats);        // {max, sum-exp}: one pair, or one per 16-row panel (<= 64) of the row-panel forward
+    rc |= tnn_malloc(64 * 2 * 8 + 64, &h->stats);   // {max, sum-exp}: one pair, or one per 16-row panel (<= 64) of the row-panel forward (behind a merged pair: + 16 B)
     rc |= tnn_malloc(256, &h->ticket);          // 16 arrival counters + the row blocks' {max, sum-exp} pairs (tnn_dense_fwd_head_partials_stats)
     if (!rc) rc |= tnn_memset(h->ticket, 0, 256);
     if (n_layers >= 2 && dtype == TNN_F32)
@@ -899,12 +899,25 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
         //   | RCCL only: tnn_allgather of the pairs | head + hidden layer's backward taking the pair(s) from memory
         //   (tnn_mlp_head_bwd_tick_ext; advances Adam's beta powers) | remaining backward | all-reduce + Adam
         MLP_TRY(mlp_forward(h, x, rows, L - 2));
-        MLP_TRY(tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
-                                                  at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
-                                                  at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
-                                                  h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
-                                                  at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats,
-                                                  p2p_on ? 1 : 0, h->dtype));
+        // more than 128 rows of the tuned 128 -> 10 head: the hidden layer's forward in its ROW-PANEL form (a workgroup finishes
+        // 16 whole rows: logits + their statistics), the panels' pairs merged [+ exchanged] by the last workgroup of the launch
+        // (tnn_dense_fwd_rows_head_stats_merged; pairs live behind the merged one in h->stats); otherwise the tiled forward whose
+        // tail re-reads the partial logits per 128-row block behind arrival counters
+        const bool row_panels = rows > 128 && h->w[L - 1] == 128 && h->w[L] == 10 && h->w[L - 2] % 4 == 0;
+        if (row_panels)
+            MLP_TRY(tnn_dense_fwd_rows_head_stats_merged(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                         at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                         at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                         h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                         at(h->params, h->b_off[L - 1], h->esz), (char*)h->stats + 16, h->ticket,
+                                                         h->stats, p2p_on ? 1 : 0, h->dtype));
+        else
+            MLP_TRY(tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                      at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                      at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                      h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                      at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats,
+                                                      p2p_on ? 1 : 0, h->dtype));
         const void* pairs = h->stats;
         int n_pairs = 1;
         if (!p2p_on) {
@@ -912,6 +925,7 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
             pairs = h->stats_all;
             n_pairs = world;
         }
+        if (row_panels) n_pairs = -n_pairs;              // whole logits (without the bias) instead of per-tile partials
         MLP_TRY(tnn_mlp_head_bwd_tick_ext(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
                                           at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
                                           at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
