@@ -85,7 +85,7 @@ WIDTHS_A = [784, 256, 128, 10]
 WIDTHS_C = [4096, 4096, 4096]
 WIDTHS_E = [8192, 8192, 8192, 8192, 8192]
 GLOBAL_BATCH_D = 1024
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 # ------------------------------------------------------------------------------------------------ data / nets
@@ -317,7 +317,7 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
 def load_traffic_table():
     """HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 correction
     + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command; tools/traffic_from_pmc.py)."""
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(path):
             return json.load(open(path)), os.path.relpath(path, ROOT)

@@ -62,6 +62,7 @@ struct GemmArgs {
     const double* ad_pows;
     const int* ad_guard;
     int staged_c;          // tiled kernel: interior tiles store through an LDS image of the tile (row-major 16-B stores)
+    int group_m;           // tiled kernel: M-tiles per raster group (8; 1 = an M panel per XCD range, tiles_m = N-major sweep)
     // tiled TN kernel with EPI_ADAM (tnn_gemm_tn_adam_bias): the workgroups of tile row 0 also produce the column sums of B
     // (= the bias gradient, core/ops.py:52-54) in their epilogue -> cs_db [N], and apply Adam to the bias block
     // cs_p / cs_m / cs_v [N] when those are given
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(GemmArgs g) 
     // 16 MB of inputs, every A panel was evicted between its reuses)
     const int nb = g.tiles_m * g.tiles_n;
     const int t = xcd_remap((int)blockIdx.x, nb);
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = g.group_m;                     // 8 (TNN_GEMM_GROUP_M: the raster sweep of tools/gemm_sweep.py)
     const int per_group = GROUP_M * g.tiles_n;
     const int first_m = (t / per_group) * GROUP_M;
     const int gsz = min(g.tiles_m - first_m, GROUP_M);
@@ -1841,6 +1842,8 @@ int launch_cfg(GemmArgs& g, int transA, int transB, int splits) {
     g.k_per_split = tiles_per_split * BK;
     g.splits = splits;
     g.ws = nullptr;
+    g.group_m = 8;
+    if (const char* e = getenv("TNN_GEMM_GROUP_M")) g.group_m = atoi(e) > 0 ? atoi(e) : 8;       // tuning override (sweeps)
 #ifdef TNN_GEMM_TRACE
     g.trace = nullptr;
     if (const char* e = getenv("TNN_GEMM_TRACE_PTR"))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of one profiling pass (gpurun_out/<round>prof/, produced by tools/profile_round.sh) into profiles/ under
 # the round's prefix:  bash tools/collect_profiles.sh r03
-R=${1:-r04}
+R=${1:-r05}
 S=gpurun_out/${R}prof
 D=profiles
 cp $S/benchA.json $D/${R}_benchA.json
@@ -31,4 +31,7 @@ cp $S/soak.txt $D/${R}_soak.txt
 cp $S/soak_e.txt $D/${R}_soak_e.txt
 cp $S/step256_timeline.txt $D/${R}_step256_timeline.txt
 cp $S/eager_phases.txt $D/${R}_eager_phases.txt
+for f in epoch_loop.json mnist_run_trainer.txt mnist_run_ops.txt e_step_ab.txt e_kernels_ab.txt gemm_f32_cfg_ab.txt e_overlap_probe.txt exnet_launches.txt stepC_timeline.txt; do
+  [ -f $S/$f ] && cp $S/$f $D/${R}_$f
+done
 ls -la $D/${R}_*

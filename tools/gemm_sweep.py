@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sweep the LDS-tiled MFMA GEMM's tile configurations (TNN_GEMM_CFG) and split-K on the config-C shapes."""
+"""Sweep the LDS-tiled MFMA GEMM's tile configurations (TNN_GEMM_CFG), split-K and the tile raster (TNN_GEMM_GROUP_M: M-tiles
+per group; SWEEP_GROUP_M=1,2,4,8,16 — 1 gives every XCD's id range whole M panels) on the config-C shapes."""
 import os
 import sys
 
@@ -21,9 +22,10 @@ def main():
         b = da.asarray(rs.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32))
         c = da.empty((M, N), np.float32)
         lda, ldb = (M if ta else K), (K if tb else N)
-        for cfg in extra_cfgs():
-            for sk in [int(x) for x in os.environ.get("SWEEP_SPLITK", "1,2").split(",")]:
-                os.environ["TNN_GEMM_CFG"], os.environ["TNN_GEMM_SPLITK"] = str(cfg), str(sk)
+        for cfg, sk, gm in [(c_, s_, g_) for c_ in extra_cfgs() for s_ in [int(x) for x in os.environ.get("SWEEP_SPLITK", "1,2").split(",")]
+                            for g_ in [int(x) for x in os.environ.get("SWEEP_GROUP_M", "8").split(",")]]:
+            if True:
+                os.environ["TNN_GEMM_CFG"], os.environ["TNN_GEMM_SPLITK"], os.environ["TNN_GEMM_GROUP_M"] = str(cfg), str(sk), str(gm)
                 try:
                     for _ in range(2):
                         lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32)
@@ -37,8 +39,8 @@ def main():
                     lib.gemm(ta, tb, M, N, K, 1.0, a._ptr, lda, b._ptr, ldb, 0.0, c._ptr, N, _lib.F32)
                 e1.record()
                 ms = e0.elapsed_ms(e1) / reps
-                print("%-7s cfg %d (%-8s) splitK %d : %8.1f us  %6.1f TFLOP/s" % (
-                    name, cfg, CFGS.get(cfg, "?"), sk, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
+                print("%-7s cfg %d (%-8s) splitK %d group_m %2d : %8.1f us  %6.1f TFLOP/s" % (
+                    name, cfg, CFGS.get(cfg, "?"), sk, gm, ms * 1e3, 2.0 * M * N * K / ms / 1e9))
 
 
 def extra_cfgs():

@@ -4,7 +4,7 @@
 # Bench lines, rocprofv3 kernel traces of the same commands, separate --pmc passes (FETCH_SIZE / WRITE_SIZE for the HBM-side
 # traffic, SQ counters for the bf16 GEMM).  Everything lands under gpurun_out/<round>prof/; tools/rocpd_summary.py,
 # tools/rocpd_pmc.py and tools/traffic_from_pmc.py turn the databases into the text files committed under profiles/.
-R=${1:-r04}
+R=${1:-r05}
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/${R}prof
@@ -29,9 +29,18 @@ timeout 900 python3 tools/probes/eager_phases.py < /dev/null > $OUT/eager_phases
 # round 4: the skinny bf16 GEMM's variants / ablations / timelines, the box probe, the counter calibration
 timeout 900 tools/probes/bin/gemm_bf16_sk_probe < /dev/null > $OUT/gemm_bf16_sk_probe.txt 2>> $OUT/log.txt
 timeout 900 python3 -c "
-import json
-from tinynn_autograd_amd import _lib
-for i in range(3): print(json.dumps(_lib.box_probe()))" < /dev/null > $OUT/box_probe.txt 2>> $OUT/log.txt
+import json, bench
+for i in range(3): print(json.dumps(bench.box_probe()))" < /dev/null > $OUT/box_probe.txt 2>> $OUT/log.txt
+# round 5: the loop end to end, in-process A/B probes (config E step forms and kernels, fp32 tile / raster), the overlap probe,
+# per-launch times of the reference's own net
+timeout 900 python3 bench.py --epoch-loop-only < /dev/null > $OUT/epoch_loop.json 2>> $OUT/log.txt
+timeout 900 python3 -m tinynn_autograd_amd.examples.mnist_run --trainer --num_ep 3 --seed 0 < /dev/null > $OUT/mnist_run_trainer.txt 2>> $OUT/log.txt
+timeout 900 python3 -m tinynn_autograd_amd.examples.mnist_run --num_ep 2 --seed 0 < /dev/null > $OUT/mnist_run_ops.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/e_step_ab.py < /dev/null > $OUT/e_step_ab.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/e_kernels_ab.py < /dev/null > $OUT/e_kernels_ab.txt 2>> $OUT/log.txt
+timeout 900 python3 tools/probes/gemm_f32_cfg_ab.py < /dev/null > $OUT/gemm_f32_cfg_ab.txt 2>> $OUT/log.txt
+timeout 300 python3 tools/probes/e_overlap_probe.py < /dev/null 2>> $OUT/log.txt | grep -v "version\|Hostname\|Librccl" > $OUT/e_overlap_probe.txt
+timeout 900 python3 tools/probes/exnet_launches.py < /dev/null > $OUT/exnet_launches.txt 2>> $OUT/log.txt
 timeout 900 python3 tools/probes/gemm_f32_data_ab.py < /dev/null > $OUT/gemm_f32_data_ab.txt 2>> $OUT/log.txt
 mkdir -p $OUT/cal
 timeout 900 tools/probes/bin/fetch_calibration < /dev/null > $OUT/cal/known.txt 2>> $OUT/log.txt
