@@ -206,6 +206,10 @@ TNN_API int tnn_gather_rows(const void* src, const void* idx_i64, void* out, int
 TNN_API int tnn_scatter_rows(const void* src, const void* idx_i64, void* dst, int64_t n_idx,
                              int64_t row_elems, int64_t dst_rows, int dtype);
 /* onehot[i, labels[i]] = 1 — examples/mnist/run.py:27-28 (np.eye(n)[targets]) */
+/* out[i] = *(T*)ptrs_u64[i], i < n: n scalars living in n separate device buffers gathered into one vector by ONE launch (the
+ * per-step 0-d losses of a training loop, examples/mnist/run.py:84, read back once per epoch).  ptrs_u64: device array of n
+ * device addresses.  dtype float32 / float64.  No reference counterpart (new). */
+TNN_API int tnn_gather_scalars(const void* ptrs_u64, void* out, int64_t n, int dtype);
 TNN_API int tnn_one_hot(const void* labels_i64, void* out, int64_t n, int64_t classes, int dtype);
 
 /* ------------------------------------------------------------------ fused hot-path ops -------- */

@@ -17,6 +17,7 @@
 
 #include <functional>
 #include <unordered_map>
+#include <set>
 #include <vector>
 
 #include "tnn_hip.h"
@@ -158,11 +159,13 @@ int tnn_device_props(int* cu, int* clk, int64_t* hbm, char* name, int n) {
     if (name && n > 0) snprintf(name, n, "cpu-twin (tests only)");
     return 0;
 }
+static std::set<void*> g_graph_blocks;
 int tnn_malloc(size_t bytes, void** out) {
     NEED_INIT();
     void* p = nullptr;
     if (posix_memalign(&p, 64, bytes ? bytes : 1)) { tnn::set_error("tnn_malloc: out of memory"); return 1; }
     g_blocks[p] = bytes;
+    if (g_capturing) g_graph_blocks.insert(p);      // handed out during a capture: owned by that graph, like in the HIP library
     g_live += (int64_t)bytes;
     g_allocs++;
     *out = p;
@@ -174,7 +177,9 @@ int tnn_free(void* p) {
     REQ(it != g_blocks.end(), "tnn_free: %p was not allocated by tnn_malloc", p);
     g_live -= (int64_t)it->second;
     g_blocks.erase(it);
-    if (!g_capturing) free(p);   // buffers touched by a recorded graph stay valid (leaked in tests)
+    // buffers touched by a recorded graph stay valid (leaked in tests): freed while a capture is open, or allocated during one
+    // (the HIP library never recycles a graph-owned buffer outside its graph either)
+    if (!g_capturing && !g_graph_blocks.count(p)) free(p);
     return 0;
 }
 int tnn_pool_stats(int64_t* live, int64_t* cached, int64_t* allocs) {
@@ -531,6 +536,17 @@ int tnn_scatter_rows(const void* src, const void* idx, void* dst, int64_t n, int
         if (j < 0) j += rows;
         if (j < 0 || j >= rows) continue;
         memcpy((char*)dst + j * re * es, (const char*)src + i * re * es, re * es);
+    }
+    return 0;
+}
+int tnn_gather_scalars(const void* ptrs, void* out, int64_t n, int dtype) {
+    NEED_INIT();
+    REQ(dtype == TNN_F32 || dtype == TNN_F64, "tnn_gather_scalars: dtype %d is not a float type", dtype);
+    RECORD(tnn_gather_scalars(ptrs, out, n, dtype));
+    for (int64_t i = 0; i < n; ++i) {
+        const void* src = reinterpret_cast<const void*>(((const uint64_t*)ptrs)[i]);
+        if (dtype == TNN_F32) ((float*)out)[i] = *(const float*)src;
+        else ((double*)out)[i] = *(const double*)src;
     }
     return 0;
 }

@@ -1241,6 +1241,24 @@ def other_optimizers_on_device():
             np.testing.assert_allclose(np.asarray(step), r, rtol=2e-4, atol=1e-7, err_msg=kind)
 
 
+def gather_scalars_of_separate_buffers():
+    """tnn_gather_scalars: n 0-d device arrays in n separate buffers -> one vector in ONE launch (the per-step losses of the
+    epoch loop, examples/mnist/run.py:84), with the address list reusable for buffers that keep their place."""
+    vals = [tn.asarray(np.array([v], np.float32)).sum() for v in (0.5, -2.25, 3.0, 7.125, 1e-3)]     # five separate 0-d device buffers
+    out, ptrs = da.gather_scalars(vals)
+    assert out.shape == (5,) and np.array_equal(np.asarray(out), np.array([0.5, -2.25, 3.0, 7.125, 1e-3], np.float32))
+    for v in vals:
+        v *= 2.0                                             # in place: same buffers, new contents
+    again, ptrs2 = da.gather_scalars(None, out=out, pointers=ptrs)
+    assert again is out and ptrs2 is ptrs
+    assert np.array_equal(np.asarray(out), np.array([1.0, -4.5, 6.0, 14.25, 2e-3], np.float32))
+    try:
+        da.gather_scalars([tn.asarray(np.zeros(3, np.float32))])
+        raise AssertionError("a 3-element array is not a scalar")
+    except TypeError:
+        pass
+
+
 def batch_iterator_on_device_tensors():
     """utils/data_iterator.py:22-34 on device Tensors: one global-RNG shuffle per epoch, a row-gather kernel for
     inputs[idx], zero-copy row slices per batch, ragged last batch."""

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "tnn_strided_scatter": [_p, _p, _i64p, c_int, _i64p, c_int],
     "tnn_gather_rows": [_p, _p, _p, c_int64, c_int64, c_int64, c_int],
     "tnn_scatter_rows": [_p, _p, _p, c_int64, c_int64, c_int64, c_int],
+    "tnn_gather_scalars": [_p, _p, c_int64, c_int],
     "tnn_one_hot": [_p, _p, c_int64, c_int64, c_int],
     "tnn_bias_act": [_p, _p, c_int, _p, c_int64, c_int64, c_int],
     "tnn_softmax_nll_stats": [_p, c_int64, c_int64, _p, c_int],

@@ -595,6 +595,14 @@ int rows_move(const void* src, const void* idx, void* dst, int64_t n_idx, int64_
     return 0;
 }
 
+// out[i] = *ptrs[i]: n scalars that live in n separate device buffers (a training loop's per-step 0-d losses, core/tensor.py
+// values of examples/mnist/run.py:84's loss_list) into one vector — ONE launch instead of n 4-byte device copies
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gather_scalars_kernel(const uint64_t* __restrict__ ptrs, T* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = *reinterpret_cast<const T*>(ptrs[i]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void one_hot_kernel(const int64_t* __restrict__ labels,
                                                            T* __restrict__ out, int64_t n,
@@ -781,6 +789,20 @@ int tnn_scatter_rows(const void* src, const void* idx_i64, void* dst, int64_t n_
     TNN_NEED_INIT();
     TNN_ANY_SWITCH(dtype, "tnn_scatter_rows",
                    (rows_move<T>(src, idx_i64, dst, n_idx, row_elems, dst_rows, true)));
+}
+
+int tnn_gather_scalars(const void* ptrs_u64, void* out, int64_t n, int dtype) {
+    TNN_NEED_INIT();
+    if (n <= 0) return 0;
+    TNN_REQUIRE(ptrs_u64 && out, "tnn_gather_scalars: NULL argument");
+    unsigned grid = tnn::stream_grid(n, kThreads);
+    switch (dtype) {
+        case TNN_F32: hipLaunchKernelGGL((gather_scalars_kernel<float>), grid, kThreads, 0, tnn::stream(), (const uint64_t*)ptrs_u64, (float*)out, n); break;
+        case TNN_F64: hipLaunchKernelGGL((gather_scalars_kernel<double>), grid, kThreads, 0, tnn::stream(), (const uint64_t*)ptrs_u64, (double*)out, n); break;
+        default: tnn::set_error("tnn_gather_scalars: dtype %d is not a float type", dtype); return 2;
+    }
+    TNN_LAUNCH_OK();
+    return 0;
 }
 
 int tnn_one_hot(const void* labels_i64, void* out, int64_t n, int64_t classes, int dtype) {

@@ -747,6 +747,24 @@ def take_capture_lazies():
     return out
 
 
+def gather_scalars(arrays, out=None, pointers=None):
+    """One vector from n 0-d device arrays that live in n separate buffers (a loop's per-step losses): ONE launch
+    (tnn_gather_scalars) instead of n 4-byte copies.  `pointers`: a device array of their addresses from an earlier call
+    (returned as the second value) — the arrays of a replayed hipGraph keep their addresses, so the list is uploaded once.
+    Returns (vector, pointers)."""
+    if pointers is None:
+        arrays = [asarray(a) for a in arrays]
+        if any(a._hv is not None or a.size != 1 for a in arrays) or len({a.dtype for a in arrays}) != 1:
+            raise TypeError("gather_scalars: n one-element device arrays of one dtype are required")
+        pointers = asarray(np.array([a._dev() for a in arrays], dtype=np.int64))
+        pointers._aux = arrays                       # the buffers stay alive as long as their address list does
+    n = pointers.size
+    if out is None:
+        out = DeviceArray._new((n,), pointers._aux[0].dtype)
+    _lib.get().gather_scalars(pointers._ptr, out._ptr, n, out._code())
+    return out, pointers
+
+
 def from_ptr(ptr, shape, dtype, owner):
     """View over memory owned by something else (e.g. the trainer's arenas); `owner` is kept alive."""
     return DeviceArray._raw(ptr, shape, dtype, base=owner)

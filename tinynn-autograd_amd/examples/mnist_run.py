@@ -27,6 +27,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(_HERE)))
 
 import tinynn_autograd_amd as tn                                             # noqa: E402
+from tinynn_autograd_amd import device_array as da                           # noqa: E402
 from tinynn_autograd_amd.core.evaluator import AccEvaluator                  # noqa: E402
 from tinynn_autograd_amd.core.layers import Dense, ReLU                      # noqa: E402
 from tinynn_autograd_amd.core.losses import SoftmaxCrossEntropyLoss         # noqa: E402
@@ -92,18 +93,17 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
     evaluator = AccEvaluator()
     n_batches = iterator.num_batches(len(train_x))
     loss_hist = tn.empty((n_batches,), tn.get_default_float())   # this epoch's per-step losses, in HBM
-    step_trainer = epoch_graph = epoch_key = None
+    step_trainer = epoch_graph = epoch_key = loss_ptrs = None
     bound = False
     loss_list, preds, results = [], [], []
 
-    def one_step(i, batch):
+    def one_step(batch):
         model.zero_grad()
         pred = model.forward(batch.inputs)
         loss = loss_layer.loss(pred, batch.targets)
         loss.backward()
         model.step()
-        loss_hist[i:i + 1] = loss.values                   # a 4-byte device copy: no host sync inside the loop
-        return loss
+        return loss.values                                 # a 0-d DeviceArray: no host sync inside the loop
 
     for epoch in range(num_ep):
         tn.synchronize()
@@ -133,16 +133,17 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
                 bound = True
         elif capture and epoch > 0:
             if epoch_graph is None or epoch_key != key:
-                epoch_graph = tn.capture(lambda: [one_step(i, b) for i, b in enumerate(batches)], warmup=0)
-                epoch_key = key
+                epoch_graph = tn.capture(lambda: [one_step(b) for b in batches], warmup=0)
+                epoch_key, loss_ptrs = key, None           # (the graph's loss buffers keep their addresses: listed once)
                 t_capture = time.time()
-            epoch_graph()
+            step_losses = epoch_graph()
             if more:
                 iterator.prefetch_order(len(train_x))
+            _, loss_ptrs = da.gather_scalars(step_losses, out=loss_hist, pointers=loss_ptrs)
             losses = np.asarray(loss_hist)
         else:
-            for i, batch in enumerate(batches):
-                one_step(i, batch)
+            step_losses = [one_step(batch) for batch in batches]
+            da.gather_scalars(step_losses, out=loss_hist)  # the epoch's 391 losses: ONE launch + ONE device-to-host copy
             losses = np.asarray(loss_hist)
         loss_list.extend(losses.tolist())
         tn.synchronize()
