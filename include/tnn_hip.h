@@ -410,6 +410,9 @@ TNN_API int tnn_gemm_bf16_nt_t(int64_t M, int64_t N, int64_t K, const void* A, i
  * kernel.  No reference counterpart (new). */
 TNN_API int tnn_gemm_bf16_reserve(int64_t M, int64_t N, int64_t K);
 TNN_API int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols);     /* [R,C] -> [C,R] */
+/* two independent transposes in ONE launch: the K-contiguous operands a^T and dz^T of a dW product written just in front of it */
+TNN_API int tnn_transpose2_bf16(const void* in1, void* out1, int64_t rows1, int64_t cols1, const void* in2, void* out2,
+                                int64_t rows2, int64_t cols2);
 TNN_API int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16);              /* f32 <-> bf16 (RNE) */
 TNN_API int tnn_colsum_bf16(const void* in, void* out_f32, int64_t rows, int64_t cols);    /* bias gradient */
 TNN_API int tnn_mse_bf16(const void* pred, const void* y, int64_t n, int64_t m_global, void* loss_out_f32,

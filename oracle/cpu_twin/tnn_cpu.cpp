@@ -980,6 +980,10 @@ int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols) {
         for (int64_t c = 0; c < cols; ++c) ((bf16_t*)out)[c * rows + r] = ((const bf16_t*)in)[r * cols + c];
     return 0;
 }
+int tnn_transpose2_bf16(const void* in1, void* out1, int64_t r1, int64_t c1, const void* in2, void* out2, int64_t r2, int64_t c2) {
+    if (int rc = tnn_transpose_bf16(in1, out1, r1, c1)) return rc;
+    return tnn_transpose_bf16(in2, out2, r2, c2);
+}
 int tnn_cast_bf16(const void* in, void* out, int64_t n, int to_bf16) {
     NEED_INIT();
     RECORD(tnn_cast_bf16(in, out, n, to_bf16));

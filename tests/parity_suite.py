@@ -1911,6 +1911,46 @@ def trainer_row_blocks_random_batch_sizes():
         np.testing.assert_allclose(np.asarray(trainer.params), flat, rtol=0, atol=0.1 * 1e-3, err_msg="rows=%d" % rows)
 
 
+def trainer_generic_heads_random_shapes_and_rows():
+    """The generic merged head (any hidden width that is a multiple of 16 up to 256 — or padded to one —, <= 16 classes) across its
+    whole range: random nets x random batch sizes from 1 to 1024 rows (one block with the statistics inside; 2 .. 8 blocks of
+    128 rows with the statistics from memory, worked on in parallel), each against the float64 closed form of the reference's
+    step (oracle/closed_form.py): loss, every weight gradient of the first step, loss of the second step, 2L - 2 launches."""
+    import ctypes
+    from oracle.closed_form import ClosedFormMLP
+    rs = np.random.RandomState(2025)
+    nets = [[40, 64, 16, 16], [100, 48, 256, 3], [30, 50, 33, 7], [64, 32, 240, 112, 16], [20, 16, 16, 1], [784, 200, 100, 70, 30, 10]]
+    rows_list = [1, 17, 128, 129, 200, 256, 300, 511, 640, 1000, 1024]
+    for widths in nets:
+        L = len(widths) - 1
+        for rows in [int(r) for r in rs.choice(rows_list, 4, replace=False)]:
+            Ws = [(rs.randn(widths[i], widths[i + 1]) * (1.5 / np.sqrt(widths[i]))).astype(np.float32) for i in range(L)]
+            Bs = [(rs.randn(1, widths[i + 1]) * 0.1).astype(np.float32) for i in range(L)]
+            trainer = MLPTrainer(widths, rows, loss="softmax_nll", optimizer="adam", lr=1e-3)
+            trainer.set_parameters([{"w": Ws[i], "b": Bs[i]} for i in range(L)])
+            oracle = ClosedFormMLP(Ws, Bs, lr=1e-3)
+            tag = "widths %s rows %d" % (widths, rows)
+            for step in range(2):
+                x = (rs.rand(rows, widths[0]) * (rs.rand(rows, widths[0]) < 0.5)).astype(np.float32)
+                y = np.eye(widths[-1], dtype=np.float32)[rs.randint(0, widths[-1], rows)]
+                loss = float(trainer.step(tn.asarray(x), tn.asarray(y)))
+                if step == 0:
+                    n = ctypes.c_int(0)
+                    trainer._lib.mlp_launch_window(trainer._h, 0, -1, ctypes.byref(n))
+                    assert n.value == 2 * L - 2, (tag, n.value)
+                    grads = [np.asarray(trainer.grad_view(l, "w")) for l in range(L)]
+                    gb = [np.asarray(trainer.grad_view(l, "b")) for l in range(L)]
+                ref_loss, _, gW, gB = oracle.step(x, y)
+                np.testing.assert_allclose(loss, ref_loss, rtol=2e-5, err_msg="%s step %d" % (tag, step))
+                if step == 0:
+                    for l in range(L):
+                        np.testing.assert_allclose(grads[l], gW[l], rtol=0, atol=max(2e-5 * np.abs(gW[l]).max(), 2e-7),
+                                                   err_msg="%s dW%d" % (tag, l))
+                        np.testing.assert_allclose(gb[l], gB[l], rtol=0, atol=max(2e-5 * np.abs(gB[l]).max(), 2e-7),
+                                                   err_msg="%s db%d" % (tag, l))      # (one class: every gradient is 0 up to rounding)
+            del trainer
+
+
 def trainer_keep_grads_off_is_bit_identical():
     """MLPTrainer.keep_grads(False) on the MNIST-size step (what bench.py times on one GPU): the first layer's weight
     gradient is consumed by Adam in the launch that produces it and not stored — losses, parameters and both moments are

@@ -156,6 +156,18 @@ def test_bf16_prep_launch_and_multi_layer_bias_launch():
 
 
 @pytest.mark.gpu
+def test_bf16_two_transposes_in_one_launch():
+    from tinynn_autograd_amd import _lib
+    lib = _lib.get()
+    rs = np.random.RandomState(46)
+    for (r1, c1, r2, c2) in ((512, 8192, 512, 8192), (128, 256, 128, 384), (64, 64, 320, 192), (36, 20, 100, 52), (30, 7, 64, 64)):
+        a, b = bf16.to_bf16(rs.randn(r1, c1).astype(np.float32)), bf16.to_bf16(rs.randn(r2, c2).astype(np.float32))
+        at_, bt_ = tn.empty((c1, r1), np.uint16), tn.empty((c2, r2), np.uint16)
+        lib.transpose2_bf16(a._ptr, at_._ptr, r1, c1, b._ptr, bt_._ptr, r2, c2)
+        assert np.array_equal(np.asarray(at_), np.asarray(a).T) and np.array_equal(np.asarray(bt_), np.asarray(b).T), (r1, c1, r2, c2)
+
+
+@pytest.mark.gpu
 def test_bf16_transpose_colsum_mse_adam():
     from tinynn_autograd_amd import _lib
     rs = np.random.RandomState(42)
@@ -298,11 +310,16 @@ def test_bf16_trainer_fused_step_equals_separate_launches(monkeypatch):
     B = [(rs.randn(1, widths[i + 1]) * 0.05).astype(np.float32) for i in range(3)]
     x16 = bf16.to_bf16(bf16.round_to_bf16(rs.rand(m, 256).astype(np.float32)))
     runs = []
-    for mode in ("separate", "step", "step_nokeep"):
+    for mode in ("separate", "step", "step_nokeep", "step_nokeep_ct", "step_nokeep_long"):
         t = MLPTrainer(widths, m, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16")
         t.set_parameters([{"w": W[i], "b": B[i]} for i in range(3)])
-        if mode == "step_nokeep":
+        if mode.startswith("step_nokeep"):
             t.keep_grads(False)                                          # -> Adam in the dW epilogues
+            # the three launch sequences of that step (tnn_mlp.cpp mlp16_step_form): 4L + 1 launches (default), 3L + 1 with the
+            # transposed operands from the GEMM epilogues, the long sequence
+            monkeypatch.delenv("TNN_E_STEP", raising=False)
+            if mode != "step_nokeep":
+                monkeypatch.setenv("TNN_E_STEP", mode.rsplit("_", 1)[1])
         losses = []
         for _ in range(3):
             if mode == "separate":
@@ -315,6 +332,7 @@ def test_bf16_trainer_fused_step_equals_separate_launches(monkeypatch):
         runs.append((losses, np.asarray(t.params).copy(), np.asarray(t.adam_m).copy(), np.asarray(t.adam_v).copy(),
                      [np.asarray(t.grad_view(l, "w")).copy() for l in range(3)],
                      np.asarray(t.forward(x16)).copy()))
+    monkeypatch.delenv("TNN_E_STEP", raising=False)
     for got in runs[1:]:
         assert got[0] == runs[0][0]
         for k in (1, 2, 3, 5):

@@ -11,6 +11,8 @@ is float64 numpy on the SAME bf16-rounded operands:
   * adam_master_bf16_2d at 8192 x 8192: bit-equal to the flat kernel, W^T copy == W.T.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -197,10 +199,22 @@ def test_config_E_trainer_step_at_full_size():
     t2.set_parameters([{"w": W[i], "b": B[i]} for i in range(L)])
     assert float(t2.step(x16, x16)) == loss and float(t2.step(x16, x16)) == loss2
     assert np.array_equal(np.asarray(t2.params), p_ref) and np.array_equal(np.asarray(t2.adam_m), m_ref)
-    # ... in 3 L + 1 = 13 launches: 4 forward GEMMs (the hidden ones writing a^T from their epilogues), the prep launch (loss, dz,
-    # dz^T, x^T, beta powers), 3 dX GEMMs (writing dz^T), 4 dW GEMMs with Adam in the epilogue, one launch for the four biases
-    # (25 launches before)
+    # ... in 4 L + 1 = 17 launches: 4 forward GEMMs, the prep launch (loss, dz, dz^T, beta powers), per layer one launch for both
+    # transposed operands of its dW product + the dX GEMM + the dW GEMM with Adam in the epilogue, one launch for the four biases
+    # (25 launches before; DESIGN §5 for why the transposes stay launches)
     import ctypes
     n = ctypes.c_int(0)
     t2._lib.mlp_launch_window(t2._h, 0, -1, ctypes.byref(n))
-    assert n.value == 3 * L + 1 == 13, n.value
+    assert n.value == 4 * L + 1 == 17, n.value
+    del t2
+    # ... and the 13-launch form (transposed operands from the producing GEMMs' epilogues; kept for the A/B probe) gives the same bits
+    os.environ["TNN_E_STEP"] = "ct"
+    try:
+        t3 = MLPTrainer(widths, M8, loss="mse", optimizer="adam", lr=1e-3, dtype="bfloat16").keep_grads(False)
+        t3.set_parameters([{"w": W[i], "b": B[i]} for i in range(L)])
+        assert float(t3.step(x16, x16)) == loss and float(t3.step(x16, x16)) == loss2
+        assert np.array_equal(np.asarray(t3.params), p_ref) and np.array_equal(np.asarray(t3.adam_m), m_ref)
+        t3._lib.mlp_launch_window(t3._h, 0, -1, ctypes.byref(n))
+        assert n.value == 3 * L + 1 == 13, n.value
+    finally:
+        os.environ.pop("TNN_E_STEP", None)

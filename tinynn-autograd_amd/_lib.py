@@ -123,6 +123,7 @@ _SIGNATURES = {
     "tnn_mse_bf16_prep": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, c_int64, _p, _p, _p, _p, c_double, c_double],
     "tnn_bias_bf16_adam_multi": [c_int, _p, c_int64, _i64p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
     "tnn_transpose_bf16": [_p, _p, c_int64, c_int64],
+    "tnn_transpose2_bf16": [_p, _p, c_int64, c_int64, _p, _p, c_int64, c_int64],
     "tnn_cast_bf16": [_p, _p, c_int64, c_int],
     "tnn_colsum_bf16": [_p, _p, c_int64, c_int64],
     "tnn_mse_bf16": [_p, _p, c_int64, c_int64, _p, _p],

@@ -4,7 +4,7 @@ Same constructor, attributes (`values`, `grad`, `requires_grad`, `dependency`, `
 (including the non-autograd in-place forms that replace `values` and drop `grad`, core/tensor.py:35-38,
 66-68) and `backward` / `zero_grad` semantics, but `values` and `grad` are DeviceArrays in HBM.
 
-Differences that are deliberate (DESIGN.md "dtype policy" and "backward schedule"):
+Differences that are deliberate:
   * floating data defaults to float32 on device (the reference silently promotes everything to float64,
     SURVEY F4); `set_default_float(np.float64)` restores bit-for-bit behaviour for the known-answer tests.
   * `backward()` called on a root schedules every reachable node ONCE in topological order and hands each

@@ -274,10 +274,9 @@ bool sk_workspace(hipStream_t s, int tiles, int slices, size_t slab_bytes_per_sl
 // every thread loads a 4x4 block with four 8-B loads, transposes it in registers, writes the four transposed
 // 8-B rows into an LDS image of the OUTPUT tile, and after the barrier the tile leaves with 16-B stores, eight
 // lanes per 128-B output row.  Requires R % 4 == 0 and C % 4 == 0 (else the element-wise fallback below).
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in,
-                                                             bf16_t* __restrict__ out, int64_t R, int64_t C) {
+__device__ __forceinline__ void transpose_bf16_tile(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int64_t R, int64_t C,
+                                                    const int64_t r0, const int64_t c0) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];     // [c][r], 144-B rows
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;             // 16 x 16 threads, 4x4 elements each
     u32x2 row[4];
 #pragma unroll
@@ -312,6 +311,25 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
                 *reinterpret_cast<u32x2*>(out + oc * R + orow) = u32x2{v.x, v.y};
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in,
+                                                             bf16_t* __restrict__ out, int64_t R, int64_t C) {
+    transpose_bf16_tile(in, out, R, C, (int64_t)blockIdx.y * 64, (int64_t)blockIdx.x * 64);
+}
+// two independent transposes in ONE launch (tnn_transpose2_bf16: the two K-contiguous operands of a dW product, a^T and dz^T,
+// written just in front of it): blocks [0, n1) work on the first matrix, the rest on the second
+__global__ __launch_bounds__(256) void transpose2_bf16_kernel(const bf16_t* __restrict__ in1, bf16_t* __restrict__ out1, int64_t R1,
+                                                              int64_t C1, const bf16_t* __restrict__ in2, bf16_t* __restrict__ out2,
+                                                              int64_t R2, int64_t C2, int n1) {
+    const int b = (int)blockIdx.x;
+    if (b < n1) {                                           // block-uniform
+        const int tc = (int)((C1 + 63) / 64);
+        transpose_bf16_tile(in1, out1, R1, C1, (int64_t)(b / tc) * 64, (int64_t)(b % tc) * 64);
+    } else {
+        const int tc = (int)((C2 + 63) / 64), bb = b - n1;
+        transpose_bf16_tile(in2, out2, R2, C2, (int64_t)(bb / tc) * 64, (int64_t)(bb % tc) * 64);
     }
 }
 
@@ -952,6 +970,24 @@ int tnn_transpose_bf16(const void* in, void* out, int64_t rows, int64_t cols) {
         hipLaunchKernelGGL(transpose_bf16_kernel, grid, 256, 0, tnn::stream(), (const bf16_t*)in, (bf16_t*)out, rows, cols);
     else
         hipLaunchKernelGGL(transpose_bf16_slow_kernel, grid, 256, 0, tnn::stream(), (const bf16_t*)in, (bf16_t*)out, rows, cols);
+    TNN_LAUNCH_OK();
+    return 0;
+}
+
+int tnn_transpose2_bf16(const void* in1, void* out1, int64_t rows1, int64_t cols1, const void* in2, void* out2, int64_t rows2,
+                        int64_t cols2) {
+    TNN_NEED_INIT();
+    auto fast = [](const void* a, const void* b, int64_t r, int64_t c) {
+        return r > 0 && c > 0 && r % 4 == 0 && c % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+    };
+    if (!fast(in1, out1, rows1, cols1) || !fast(in2, out2, rows2, cols2)) {          // odd shapes: the two launches
+        if (int rc = tnn_transpose_bf16(in1, out1, rows1, cols1)) return rc;
+        return tnn_transpose_bf16(in2, out2, rows2, cols2);
+    }
+    const int64_t n1 = ((rows1 + 63) / 64) * ((cols1 + 63) / 64), n2 = ((rows2 + 63) / 64) * ((cols2 + 63) / 64);
+    TNN_REQUIRE(n1 + n2 < (int64_t(1) << 31), "tnn_transpose2_bf16: too many tiles");
+    hipLaunchKernelGGL(transpose2_bf16_kernel, dim3((unsigned)(n1 + n2)), 256, 0, tnn::stream(), (const bf16_t*)in1, (bf16_t*)out1, rows1,
+                       cols1, (const bf16_t*)in2, (bf16_t*)out2, rows2, cols2, (int)n1);
     TNN_LAUNCH_OK();
     return 0;
 }

@@ -22,7 +22,7 @@
 //     DMA, 8 waves of 64x32, 4 stages (1 workgroup per CU)    "dma8"     806 / 353 / 745 / 771
 // Two resident workgroups matter more than the depth of the ring: one workgroup cannot overlap its own barrier, prologue
 // and epilogue.  The M = 512 shapes have exactly one 128 x 128 tile per CU whatever the kernel (~800 TFLOP/s, 32 % of
-// peak): more needs 256-wide tiles + split-K over this kernel's DMA / swizzle machinery.
+// peak): more needs 256-wide tiles + split-K over this kernel's DMA / swizzle machinery — built in round 4: tnn_gemm_bf16_sk.h (JOURNAL.md).
 namespace g8 {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int ROWB = BK * 2;                 // bytes per LDS row (no padding)

@@ -34,7 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //     workgroup 0              : loss, stats, db = column sums of dz, Adam's beta powers advanced (tick)
 //     workgroup G - 1          : logits (and dz, when asked for) written out
 // so the step's forward-of-last-layer / loss / backward-of-last-layer triple (three launches, ~9.4 us of launch
-// boundaries and first-load round trips around ~1 us of math) becomes one launch.  (DESIGN.md §8 of round 1 named this.)
+// boundaries and first-load round trips around ~1 us of math) becomes one launch.  (JOURNAL.md, round 1, named this.)
 //   * logits: thread (row r = t & 127, K-quarter kq = t >> 7) holds its 32 activations in registers (8 x 16-B loads,
 //     requested first thing) and multiplies them with W rows read through the SCALAR cache (kq is wave-uniform, so
 //     W[k][c] is an SGPR operand of v_fma: no LDS or vector traffic for W); the four K-quarter partials meet in LDS;

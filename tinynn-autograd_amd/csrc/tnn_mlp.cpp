@@ -160,47 +160,69 @@ int mlp16_forward(Mlp* h, const void* x16, int64_t rows, bool emit_t = false) {
     return 0;
 }
 
-// can the single-GPU bf16 step take its 3L + 1 launch form (mlp16_step_fused)?  The prep launch works on 64 x 64 tiles.
-bool mlp16_fused_fits(const Mlp* h, int64_t rows) {
-    // TNN_E_STEP=long: the 25-launch sequence of separate transposes / bias / loss launches (same-box A/B runs under profiles/)
-    // (read at every step: tools/probes/e_step_ab.py alternates the two forms inside ONE process, the only A/B this pool's
-    // +-3 % run-to-run clock drift leaves meaningful)
+// The single-GPU bf16 step with the weight gradients consumed where they are produced (tnn_mlp_keep_grads(h, 0)): which form?
+//   0  the 25-launch sequence (mlp16_forward + mlp16_backward: separate transposes, bias, loss and partial-sum launches) — shapes
+//      the prep launch does not take, or TNN_E_STEP=long
+//   1  17 launches (default): see mlp16_step_fused
+//   2  13 launches (TNN_E_STEP=ct): a^T / dz^T from the producing GEMMs' epilogues instead of transpose launches — built first,
+//      kept for tools/probes/e_step_ab.py, which alternates the forms inside one process (the variable is read at every step)
+int mlp16_step_form(const Mlp* h, int64_t rows) {
+    if (!(h->bf16 && h->opt_kind == 1 && h->loss_kind == 1 && rows % 64 == 0 && h->w[0] % 64 == 0 && h->w[h->L] % 64 == 0 &&
+          h->prep_ws != nullptr && h->L <= 16))
+        return 0;
     const char* form = getenv("TNN_E_STEP");
-    const bool long_form = form != nullptr && form[0] == 'l';
-    return !long_form && h->bf16 && h->opt_kind == 1 && h->loss_kind == 1 && rows % 64 == 0 && h->w[0] % 64 == 0 && h->w[h->L] % 64 == 0 &&
-           h->prep_ws != nullptr;
+    if (form != nullptr && form[0] == 'l') return 0;
+    return form != nullptr && form[0] == 'c' ? 2 : 1;
 }
 
-// Single-GPU bf16 step, weight gradients consumed where they are produced (tnn_mlp_keep_grads(h, 0)), 3L + 1 launches (13 for the
-// four 8192-wide layers of configs[4]; 25 before):
-//   L   forward GEMMs, the hidden ones also writing a_l^T from their epilogues
-//   1   prep: loss, dz_L, dz_L^T, x^T, Adam's beta powers (tnn_mse_bf16_prep)
-//   L-1 dz_{l-1} = (dz_l W_l^T) * mask, also writing dz_{l-1}^T — ALL of them before the first dW: each reads the bf16 W_l that
-//       dW_l's epilogue rewrites, and a skinny GEMM launched right behind a dW + Adam launch runs ~10 us slower (it starts behind
-//       that launch's 1.9 GB of writes still draining to HBM; measured in-step, profiles/r05_e_step_ab.txt)
-//   L   dW_l = a_{l-1}^T dz_l with Adam on W_l in the epilogue (tnn_gemm_bf16_nt_adam), back to back
-//   1   every layer's bias: db_l + Adam on b_l (tnn_bias_bf16_adam_multi) — last, so that the next step's first forward GEMM
-//       does not start right behind a dW + Adam launch either.  (The bias as a role of the dW launch's tile-row-0 workgroups
-//       was built and measured: + 7.6 us on the launch's critical path against 6.8 us for a launch of its own — dropped.)
-// Same arithmetic, element for element, as the 25-launch sequence (transposes are exact, the bias sums keep their order).
-int mlp16_step_fused(Mlp* h, const void* x16, const void* y16, int64_t rows, void* loss_out) {
+// Single-GPU bf16 step in 4L + 1 = 17 launches for the four 8192-wide layers of configs[4] (25 before):
+//   L   forward GEMMs
+//   1   prep: loss, dz_L, dz_L^T, Adam's beta powers (tnn_mse_bf16_prep; the loss + partial-sum + transpose launches it replaces)
+//   per layer, last to first:
+//     1   BOTH K-contiguous operands of dW_l in one launch, just in front of their use: a_{l-1}^T (x^T for the first layer) and
+//         dz_l^T (tnn_transpose2_bf16; the last layer's dz^T comes from prep)
+//     1   dz_{l-1} = (dz_l W_l^T) * mask (l > 0) — BEFORE dW_l, it reads the bf16 W_l that dW_l's epilogue rewrites
+//     1   dW_l = a_{l-1}^T dz_l with Adam on W_l in the epilogue (tnn_gemm_bf16_nt_adam)
+//   1   every layer's bias: db_l + Adam on b_l (tnn_bias_bf16_adam_multi; 5.8 us against 16.2 for four launches)
+// Why the transposes stay launches (form 2 writes a^T / dz^T from the epilogues of the GEMMs that produce a / dz: + 1.5 us per
+// GEMM against 5.9 us per transpose launch, 13 launches): step against step, alternating segments in one process on five boxes,
+// form 2 is 0 / 6 / 57 / 84 / 88 us SLOWER than the 25-launch sequence, this form 13 - 22 us FASTER
+// (profiles/r05_e_step_ab.txt, r05_e_step_ab_kernels.txt, r05_e_kernels_ab.txt).  The kernel trace says where: the HBM-bound
+// dW + Adam launch (1.9 GB, 70 % of the step) takes 25-29 us longer when its operands were written long before (by the forward
+// pass; by the dX launch in front of the PREVIOUS dW) than when a transpose launch wrote them just in front of it — those
+// launches leave 16 MB of operands in the memory-side cache exactly when a consumer at the HBM roofline is about to re-read them
+// from eight XCDs: they are a prefetch.  Also measured and not kept: every dX before the first dW (dW directly behind dW: + 25 us
+// each), a bias launch behind each dW, the split-K partners of a tile on one XCD, the bias as a role of the dW launch's
+// tile-row-0 workgroups (+ 7.6 us on its critical path — 8 exactly equal rounds of tiles — against 6.8 us for a launch).
+// Same arithmetic, element for element, in every form (transposes are exact, the bias sums keep their order).
+int mlp16_step_fused(Mlp* h, const void* x16, const void* y16, int64_t rows, void* loss_out, bool ct) {
     const int L = h->L;
     auto f32 = [](void* base, int64_t off) { return (void*)((float*)base + off); };
-    MLP_TRY(mlp16_forward(h, x16, rows, true));
+    MLP_TRY(mlp16_forward(h, x16, rows, ct));
     STEP_CALL(h, tnn_mse_bf16_prep(h->act[L - 1], y16, rows, h->w[L], rows, at(h->grads, h->n_params, 4), loss_out, h->dact[L - 1],
-                                   h->dactT16[L - 1], x16, h->w[0], h->xT16, h->prep_ws, h->ticket, h->pows, h->b1, h->b2));
-    for (int l = L - 1; l > 0; --l)
-        STEP_CALL(h, tnn_gemm_bf16_nt_t(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, h->w_off[l]), h->w[l + 1],
-                                        h->dact[l - 1], h->w[l], nullptr, TNN_ACT_NONE, 0, h->act[l - 1], h->w[l],
-                                        h->dactT16[l - 1], rows));
+                                   h->dactT16[L - 1], ct ? x16 : nullptr, h->w[0], ct ? h->xT16 : nullptr, h->prep_ws, h->ticket,
+                                   h->pows, h->b1, h->b2));
     for (int l = L - 1; l >= 0; --l) {
+        const void* in = l == 0 ? x16 : h->act[l - 1];
         void* inT = l == 0 ? h->xT16 : h->actT16[l - 1];
         const int64_t wo = h->w_off[l];
+        if (!ct) {
+            if (l < L - 1) STEP_CALL(h, tnn_transpose2_bf16(in, inT, rows, h->w[l], h->dact[l], h->dactT16[l], rows, h->w[l + 1]));
+            else STEP_CALL(h, tnn_transpose_bf16(in, inT, rows, h->w[l]));
+        }
+        if (l > 0) {
+            if (ct)
+                STEP_CALL(h, tnn_gemm_bf16_nt_t(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, wo), h->w[l + 1],
+                                                h->dact[l - 1], h->w[l], nullptr, TNN_ACT_NONE, 0, h->act[l - 1], h->w[l],
+                                                h->dactT16[l - 1], rows));
+            else
+                STEP_CALL(h, tnn_gemm_bf16_nt(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, wo), h->w[l + 1],
+                                              h->dact[l - 1], h->w[l], TNN_BF16, nullptr, TNN_ACT_NONE, 0, h->act[l - 1], h->w[l]));
+        }
         STEP_CALL(h, tnn_gemm_bf16_nt_adam(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows, nullptr, f32(h->params, wo),
                                            f32(h->m, wo), f32(h->v, wo), at16(h->w16, wo), h->wT16[l], h->lr, h->b1, h->b2, h->eps,
                                            h->pows));
     }
-    if (L > 16) { tnn::set_error("bf16 trainer: more than 16 layers"); return 2; }
     const void* dz[16];
     int64_t cols[16];
     void *db[16], *bp[16], *bm[16], *bv[16], *bw[16];
@@ -678,7 +700,7 @@ int tnn_mlp_step(void* handle, const void* x, const void* y, int64_t rows, void*
         // round trip through HBM (8 of the 36 bytes per parameter and step; measured 8192 x 8192 x 512: 385-405 us against
         // 450-495 for GEMM + optimizer).  With the gradient ALSO stored the fused launch is slower than the two (517 us):
         // keep_grads stays on the separate launches.
-        if (mlp16_fused_fits(h, rows)) return mlp16_step_fused(h, x, y, rows, loss_out);
+        if (const int form = mlp16_step_form(h, rows)) return mlp16_step_fused(h, x, y, rows, loss_out, form == 2);
         MLP_TRY(mlp16_forward(h, x, rows));
         return mlp16_backward(h, x, y, rows, rows, loss_out, false, true, true);
     }

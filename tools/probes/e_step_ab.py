@@ -1,8 +1,10 @@
-"""configs[4] step, A/B inside ONE process: the 3L + 1 = 13 launch form (mlp16_step_fused: transposes from the producing GEMMs'
-epilogues, loss + operand preparation in one launch, every dX before the first dW, one launch for the four biases) against the
-25-launch sequence it replaces (TNN_E_STEP=long, read at every step).  Segments of STEPS steps alternate between the two forms on the same trainer
-and the same batches, HIP events on the library stream; back-to-back bench.py runs differ by +-3 % on this pool (clock drift),
-alternating segments do not.  Prints per-form median / min over the segments and the paired difference."""
+"""configs[4] step, A/B inside ONE process.  Three forms of the single-GPU bf16 step on the same trainer and the same batches, in
+alternating segments of STEPS steps, HIP events on the library stream (TNN_E_STEP is read at every step; back-to-back bench.py runs
+differ by +-3 % on this pool — clock drift —, alternating segments repeat to +-3 us):
+  default  17 launches: prep launch, one transpose launch for both operands of each dW product just in front of it, one bias launch
+  ct       13 launches: the transposed operands written by the epilogues of the GEMMs that produce a / dz (TNN_E_STEP=ct)
+  long     25 launches: the sequence of separate transposes / bias / loss / partial-sum launches (TNN_E_STEP=long)
+Prints per-form median / min / max over the segments and the paired differences."""
 import os
 import sys
 
@@ -14,17 +16,19 @@ from tinynn_autograd_amd import _lib
 
 STEPS = int(os.environ.get("AB_STEPS", "20"))
 ROUNDS = int(os.environ.get("AB_ROUNDS", "12"))
+FORMS = tuple(os.environ.get("AB_FORMS", "default,ct,long").split(","))
+NAMES = {"default": "17 launches (shipped): prep, one transpose launch per dW, one bias launch",
+         "ct": "13 launches: a^T / dz^T from the producing GEMMs' epilogues",
+         "long": "25 launches: separate transposes / bias / loss launches"}
 
 run = bench.FusedRun(bench.WIDTHS_E, 512, "mse", 2, dtype="bfloat16")
-lib = _lib.get()
 ev0, ev1 = _lib.Event(), _lib.Event()
 
 
 def segment(form):
-    if form == "long":
-        os.environ["TNN_E_STEP"] = "long"
-    else:
-        os.environ.pop("TNN_E_STEP", None)
+    os.environ.pop("TNN_E_STEP", None)
+    if form != "default":
+        os.environ["TNN_E_STEP"] = form
     for i in range(3):
         run.eager_step(i)
     ev0.record()
@@ -34,18 +38,21 @@ def segment(form):
     return ev0.elapsed_ms(ev1) / STEPS * 1e3
 
 
-segment("fused"), segment("long")            # warm-up of both forms
-res = {"fused": [], "long": []}
+for f_ in FORMS:
+    segment(f_)                                # warm-up of every form
+res = {f_: [] for f_ in FORMS}
 for r in range(ROUNDS):
-    order = ("fused", "long") if r % 2 == 0 else ("long", "fused")
-    for form in order:
+    for form in (FORMS if r % 2 == 0 else FORMS[::-1]):
         res[form].append(segment(form))
 os.environ.pop("TNN_E_STEP", None)
-f, l = np.array(res["fused"]), np.array(res["long"])
 print("configs[4] step, %d rounds of %d-step segments alternating on one trainer (us per step)" % (ROUNDS, STEPS))
-print("  fused (13 launches): median %.1f  min %.1f  max %.1f" % (np.median(f), f.min(), f.max()))
-print("  long  (25 launches): median %.1f  min %.1f  max %.1f" % (np.median(l), l.min(), l.max()))
-print("  paired difference long - fused: median %.1f us  (%.2f %% of the long form), min %.1f, max %.1f"
-      % (np.median(l - f), 100.0 * np.median(l - f) / np.median(l), (l - f).min(), (l - f).max()))
-print("  segments fused:", " ".join("%.0f" % v for v in f))
-print("  segments long: ", " ".join("%.0f" % v for v in l))
+for f_ in FORMS:
+    v = np.array(res[f_])
+    print("  %-78s median %7.1f  min %7.1f  max %7.1f" % (NAMES[f_], np.median(v), v.min(), v.max()))
+for f_ in FORMS:
+    if f_ != "default" and "default" in res:
+        d = np.array(res[f_]) - np.array(res["default"])
+        print("  paired difference %-7s - default: median %6.1f us  (%.2f %% of %s), min %.1f, max %.1f"
+              % (f_, np.median(d), 100.0 * np.median(d) / np.median(res[f_]), f_, d.min(), d.max()))
+for f_ in FORMS:
+    print("  segments %-8s" % f_, " ".join("%.0f" % v for v in res[f_]))

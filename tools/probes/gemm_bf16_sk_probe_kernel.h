@@ -6,7 +6,7 @@
 //
 // Why: with 128 x 128 tiles a 512 x 8192 x 8192 product has exactly one tile per CU and every CU pulls 2 x 2 MB of operands
 // through the L2 -> LDS path (1 GB per product, 12 TB/s at the measured 87 us); three kernels with different LDS traffic,
-// ring depth and occupancy all landed within 1 % of each other — the operand stream INTO the CU bounds the
+// ring depth and occupancy all landed within 1 % of each other (JOURNAL.md, former §5b) — the operand stream INTO the CU bounds the
 // shape.  A 256 x 256 tile halves the bytes per flop; to still fill 256 CUs the K range is split over S workgroups per tile
 // (64 tiles x 4 slices) and the fp32 partial tiles are combined inside the launch:
 // (S = 2, the shipped form, hands over SYMMETRICALLY — each partner finishes half the rows; see SYM at the kernel.  The ticket
