@@ -37,6 +37,12 @@ timeout 900 python3 bench.py --epoch-loop-only < /dev/null > $OUT/epoch_loop.jso
 timeout 900 python3 -m tinynn_autograd_amd.examples.mnist_run --trainer --num_ep 3 --seed 0 < /dev/null > $OUT/mnist_run_trainer.txt 2>> $OUT/log.txt
 timeout 900 python3 -m tinynn_autograd_amd.examples.mnist_run --num_ep 2 --seed 0 < /dev/null > $OUT/mnist_run_ops.txt 2>> $OUT/log.txt
 timeout 900 python3 tools/probes/e_step_ab.py < /dev/null > $OUT/e_step_ab.txt 2>> $OUT/log.txt
+# ... and where the forms differ, kernel by kernel and position by position (two traces: the shipped form and the epilogue-transpose form, each against the 25-launch sequence)
+for f in default ct; do
+  AB_FORMS=$f,long AB_ROUNDS=4 timeout 900 rocprofv3 --kernel-trace -d $OUT/abtrace_$f -o ab -- python3 tools/probes/e_step_ab.py >> $OUT/log.txt 2>&1 < /dev/null
+  db=$(find $OUT/abtrace_$f -name "*.db" | head -1)
+  [ -n "$db" ] && { echo "== AB_FORMS=$f,long (the 'prep' form below is '$f')"; python3 tools/probes/e_step_ab_kernels.py $db; } >> $OUT/e_step_ab_kernels.txt 2>> $OUT/log.txt
+done
 timeout 900 python3 tools/probes/e_kernels_ab.py < /dev/null > $OUT/e_kernels_ab.txt 2>> $OUT/log.txt
 timeout 900 python3 tools/probes/gemm_f32_cfg_ab.py < /dev/null > $OUT/gemm_f32_cfg_ab.txt 2>> $OUT/log.txt
 timeout 300 python3 tools/probes/e_overlap_probe.py < /dev/null 2>> $OUT/log.txt | grep -v "version\|Hostname\|Librccl" > $OUT/e_overlap_probe.txt
