@@ -1280,6 +1280,50 @@ def batch_iterator_on_device_tensors():
     assert batches[1].inputs.values._ptr == batches[0].inputs.values._ptr + 32 * 7 * 4
 
 
+def batch_iterator_persistent_epoch_buffers():
+    """BatchIterator(reuse_buffers=True): every epoch's permutation lands in the SAME buffers (same Batch objects, same device
+    addresses, new rows), `buffers_token` changes only when the buffers are re-allocated (another dataset shape), a permutation
+    drawn ahead with `prefetch_order` consumes the global RNG exactly like the draw at the epoch's start would — the index
+    order of three epochs equals utils/data_iterator.py:22-34's on the same seed — and plain ndarrays take the same path."""
+    from tinynn_autograd_amd.utils.data_iterator import BatchIterator
+    rs = np.random.RandomState(33)
+    x = rs.rand(103, 7).astype(np.float32)
+    y = np.eye(5)[rs.randint(0, 5, 103)].astype(np.float32)
+    np.random.seed(11)
+    want = []
+    for _ in range(3):
+        idx = np.arange(103); np.random.shuffle(idx); want.append(idx)
+    for make in (Tensor, np.asarray):
+        tx, ty = make(x), make(y)
+        it = BatchIterator(batch_size=32, reuse_buffers=True)
+        np.random.seed(11)
+        seen, ptrs, token = [], None, None
+        for ep in range(3):
+            batches = list(it(tx, ty))
+            assert [len(b.inputs) for b in batches] == [32, 32, 32, 7]
+            got_x = np.concatenate([np.asarray(getattr(b.inputs, "values", b.inputs)) for b in batches])
+            got_y = np.concatenate([np.asarray(getattr(b.targets, "values", b.targets)) for b in batches])
+            assert np.array_equal(got_x, x[want[ep]]) and np.array_equal(got_y, y[want[ep]]), ep
+            if make is Tensor:
+                now = [(b.inputs.values._ptr, b.targets.values._ptr) for b in batches]
+                assert ptrs is None or now == ptrs
+                ptrs = now
+            assert token is None or it.buffers_token == token
+            token = it.buffers_token
+            seen.append(batches)
+            if ep < 2:
+                it.prefetch_order(103)                     # drawn ahead: the same RNG stream position as the next epoch's own draw
+        assert all(a is b for a, b in zip(seen[0], seen[2]))       # the very same Batch objects every epoch
+        # another dataset shape: new buffers, new token
+        list(it(make(x[:64]), make(y[:64])))
+        assert it.buffers_token != token
+    # reuse_buffers=False (the reference's behaviour): fresh arrays every epoch, the token moves every epoch
+    it = BatchIterator(batch_size=32)
+    t0 = it.buffers_token
+    list(it(Tensor(x), Tensor(y))); list(it(Tensor(x), Tensor(y)))
+    assert it.buffers_token == t0 + 2
+
+
 def host_side_callers_match_reference():
     """SURVEY §8 a24 / a25 — the host code either side of the path, draw for draw against the reference itself
     (tests/golden/host_side.npz, written by oracle/gen_golden.py from core/initializer.py and utils/data_iterator.py):
