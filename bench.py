@@ -458,6 +458,16 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
             "steps_per_epoch": last["n_steps"], "first_loss": round(losses[0], 6), "last_loss": round(losses[-1], 6),
             "frac_of_headline": round(n_train / last["train"] / headline_value, 4),
         }
+    # the same loop with the reference's OWN example net (examples/mnist/run.py:59-69: hidden widths 200-100-70-30)
+    ex = {}
+    for name, kw in (("trainer", {"trainer": True}), ("ops_eager", {})):
+        np.random.seed(0)
+        stats = []
+        losses, preds, results = mnist_run.train(train_x, train_y, test_x, test_y, [200, 100, 70, 30], num_ep, batch_size, 1e-3,
+                                                 stats=stats, **kw)
+        ex[name] = {"value": round(n_train / stats[-1]["train"], 1), "epoch_ms": [ms(st["train"]) for st in stats],
+                    "eval_ms": ms(stats[-1]["eval"]), "last_loss": round(losses[-1], 6), "accuracy": results[-1]["accuracy"]}
+    out["reference_example_net"] = ex
     out["note"] = ("headline = the timed replay of pre-captured step graphs over resident batches (`value` of this line); this object "
                    "is the loop a user of examples/mnist/run.py runs.  trainer: epoch 0 pays lazy init + trainer creation + the "
                    "capture of the epoch graph (phases_per_epoch.capture[0]); epochs >= 1 replay it (capture 0.0).")
