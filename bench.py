@@ -422,7 +422,7 @@ def cpu_baseline(widths, rows, kind, budget_s=8.0):
     return out
 
 
-def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=128, num_ep=3):
+def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=128, num_ep=4):
     """The reference's LOOP end to end (examples/mnist/run.py:76-93 + utils/data_iterator.py:22-34), wall clock, through
     this build's counterpart `examples/mnist_run.train`: per epoch np.random.shuffle of the row order, its upload, the
     device gather of inputs and one-hot targets, [graph capture + instantiation], 390 steps of 128 rows + the ragged 80-row
@@ -430,9 +430,13 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
     AccEvaluator).  Three paths: `trainer` (whole-step trainer, the epoch as ONE hipGraph captured in epoch 0 and replayed),
     `ops_captured` (the drop-in Tensor / ops / Model loop body recorded with tn.capture in epoch 1 and replayed), `ops_eager`
     (the same loop body issued op by op from Python: what a user of the reference's loop gets with no opt-in).
-    `value` of a path = rows / wall time of its LAST epoch's training part (a replayed epoch on the graph paths);
+    `value` of a path = rows / the MEDIAN wall time of the training part of its steady epochs (the replayed ones on the graph
+    paths: epochs >= 1 for the trainer, >= 2 for the recorded op-level loop; every epoch is listed in `epoch_ms`);
     `all_epochs` is everything from the first shuffle to the last loss, captures included."""
+    import gc
     from tinynn_autograd_amd.examples import mnist_run
+    gc.collect()                                           # (what earlier measurements of this process left behind goes now)
+    _lib.synchronize()
     (train_x, train_y), (test_x, test_y), source = mnist_run.prepare_dataset("/nonexistent", n_train=n_train, n_test=n_test)
     out = {"workload": "%d epochs x %d rows, bs %d (%d full batches + a ragged %d-row batch), eval on %d rows; %s"
                        % (num_ep, n_train, batch_size, n_train // batch_size, n_train % batch_size, n_test, source),
@@ -447,8 +451,10 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
         wall = time.perf_counter() - t0
         last = stats[-1]
         train_all = sum(st["train"] for st in stats)
+        steady = [st["train"] for st in stats[(2 if name == "ops_captured" else 1):]]
+        t_steady = float(np.median(steady))
         out[name] = {
-            "value": round(n_train / last["train"], 1),
+            "value": round(n_train / t_steady, 1), "steady_epoch_ms": ms(t_steady),
             "epoch_ms": [ms(st["train"]) for st in stats],
             "phases_last_epoch": {k: ms(last[k]) for k in ("data", "capture", "steps")},
             "phases_per_epoch": {k: [ms(st[k]) for st in stats] for k in ("data", "capture", "steps", "eval")},
@@ -456,7 +462,7 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
             "eval": {"ms": ms(last["eval"]), "value": round(n_test / last["eval"], 1), "accuracy": results[-1]["accuracy"]},
             "wall_s_incl_setup": round(wall, 3),
             "steps_per_epoch": last["n_steps"], "first_loss": round(losses[0], 6), "last_loss": round(losses[-1], 6),
-            "frac_of_headline": round(n_train / last["train"] / headline_value, 4),
+            "frac_of_headline": round(n_train / t_steady / headline_value, 4),
         }
     # the same loop with the reference's OWN example net (examples/mnist/run.py:59-69: hidden widths 200-100-70-30)
     ex = {}
@@ -465,7 +471,7 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
         stats = []
         losses, preds, results = mnist_run.train(train_x, train_y, test_x, test_y, [200, 100, 70, 30], num_ep, batch_size, 1e-3,
                                                  stats=stats, **kw)
-        ex[name] = {"value": round(n_train / stats[-1]["train"], 1), "epoch_ms": [ms(st["train"]) for st in stats],
+        ex[name] = {"value": round(n_train / float(np.median([st["train"] for st in stats[1:]])), 1), "epoch_ms": [ms(st["train"]) for st in stats],
                     "eval_ms": ms(stats[-1]["eval"]), "last_loss": round(losses[-1], 6), "accuracy": results[-1]["accuracy"]}
     out["reference_example_net"] = ex
     out["note"] = ("headline = the timed replay of pre-captured step graphs over resident batches (`value` of this line); this object "
@@ -1357,6 +1363,9 @@ def main():
                 paths["host_modules"] = ("compiled ahead of time from the .py sources (tinynn-autograd_amd/_host_build.py)"
                                          if tn.host_modules_compiled() else "interpreted")
                 line["paths"] = paths
+                # (before the large configurations: releasing their GBs of buffers stalls the GPU once, ~70 ms, some 50 ms later —
+                # tools/probes/epoch_stall.py; the object's `value` is a median over the steady epochs anyway)
+                line["epoch_loop"] = epoch_loop_object(res["value"])
                 c = FusedRun(WIDTHS_C, 512, "mse", 2, use_graph=use_graph)
                 rc = measure(solo, c, 3, 20, 3, 0.0, 512)
                 line["config_C"] = brief(rc, workload="configs[2]: Dense 4096-4096-4096 autoencoder, bs 512, sum-of-squares/m, Adam",
@@ -1364,7 +1373,6 @@ def main():
                                          mfma_frac_of_whole_step=round(85.8993e9 / (rc["ms_per_step"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
                 del c
                 line["config_E"] = config_e_object(solo)
-                line["epoch_loop"] = epoch_loop_object(res["value"])
         if not args.no_cpu_baseline and args.workload != "E":
             line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
 

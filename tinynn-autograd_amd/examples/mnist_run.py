@@ -113,6 +113,7 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
         more = epoch + 1 < num_ep
         t_data = time.time()
         t_capture = t_data
+        t_sub = []
         if trainer:
             if step_trainer is None:
                 model.forward(Tensor(batches[0].inputs.values[:1]))   # lazy Dense init from the first batch's width
@@ -123,9 +124,12 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
                 epoch_key = key
                 t_capture = time.time()
             device_losses = epoch_graph.launch()           # asynchronous: the GPU works through the epoch ...
+            t_sub.append(time.time())
             if more:
                 iterator.prefetch_order(len(train_x))      # ... while the host draws the next epoch's permutation
+            t_sub.append(time.time())
             losses = np.asarray(device_losses)             # the one synchronising read-back of the epoch
+            t_sub.append(time.time())
             if not bound or step_trainer.padded:           # (views of the trainer's arena: bound once; padded nets: copies)
                 for i, layer in enumerate(l for l in net.layers if isinstance(l, Dense)):
                     layer.params["w"].values = step_trainer.param_view(i, "w")
@@ -162,7 +166,9 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
         if stats is not None:
             stats.append({"data": t_data - t_start, "capture": t_capture - t_data, "steps": t_train - t_capture,
                           "train": t_train - t_start, "eval": time.time() - t_train, "n_rows": len(train_x),
-                          "n_steps": len(batches)})
+                          "n_steps": len(batches),
+                          **({"launch": t_sub[0] - t_capture, "prefetch": t_sub[1] - t_sub[0], "readback": t_sub[2] - t_sub[1]}
+                             if len(t_sub) == 3 else {})})
     return loss_list, preds, results
 
 

@@ -23,7 +23,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "spread", "run*.js
     rows.append(dict(
         run=os.path.basename(path)[:-5], A_us=d["ms_per_step"] * 1e3, A_Msps=d["value"] / 1e6,
         R_us=d.get("reference_example_net", {}).get("ms_per_step", float("nan")) * 1e3,
-        loop_ms=d.get("epoch_loop", {}).get("trainer", {}).get("epoch_ms", [float("nan")])[-1],
+        loop_ms=d.get("epoch_loop", {}).get("trainer", {}).get("steady_epoch_ms", float("nan")),
         dp1024_us=(d.get("dp_world1", {}).get("1024", {}).get("ms_per_step", float("nan")) if isinstance(d.get("dp_world1"), dict) else float("nan")) * 1e3,
         C_ms=d.get("config_C", {}).get("ms_per_step", float("nan")), g32_TF=g.get("achieved", float("nan")),
         g32_frac=g.get("frac", float("nan")), g32_box=g.get("frac_of_box", float("nan")),
@@ -34,7 +34,7 @@ for path in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "spread", "run*.js
 cols = ["run", "A_us", "A_Msps", "R_us", "loop_ms", "dp1024_us", "C_ms", "g32_TF", "g32_frac", "g32_box", "E_ms", "E_gemm_TF", "E_dw_frac", "E_dw_box",
         "box_f32", "box_bf16", "box_copy", "box_4r3w"]
 print("# one row per bench.py run (fresh box each): A = configs[1] step (us, M samples/s); R = the reference's own net (us/step);")
-print("# loop_ms = one replayed 50,000-row epoch of the reference's loop on the trainer path (ms); dp1024_us = the data-parallel step at 1024 rows per rank, one rank;")
+print("# loop_ms = the median replayed 50,000-row epoch of the reference's loop on the trainer path (ms); dp1024_us = the data-parallel step at 1024 rows per rank, one rank;")
 print("# C = configs[2] step (ms); g32 = the five fp32 GEMMs of C (TFLOP/s, fraction of 157.3, fraction of the box's MFMA-only loop);")
 print("# E = configs[4] step (ms), its GEMMs in aggregate (TFLOP/s), its dW + Adam launch against 8 TB/s and against the box's")
 print("# 4-read / 3-write stream; box = the probe inside the same run (fp32 / bf16 MFMA-only TFLOP/s, float4 copy and 4R/3W GB/s)")
