@@ -217,3 +217,47 @@ def test_example_learns_the_teacher_labels():
     assert r.returncode == 0, r.stdout[-3000:]
     acc = [float(a) for a in re.findall(r"'accuracy': ([0-9.]+)", r.stdout)]
     assert len(acc) == 2 and acc[-1] > 0.7, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_epoch_loop_at_full_size_properties():
+    """The reference's loop (examples/mnist/run.py:76-93, utils/data_iterator.py:22-34) at BASELINE's size — 50,000 rows,
+    bs 128: 390 full batches + the ragged 80-row batch, 2 epochs — through size-independent properties: the epoch buffer
+    is a PERMUTATION of the dataset (row checksums as a multiset) drawn from numpy's global RNG exactly like the reference's
+    shuffle; a seeded run is deterministic bit for bit (two runs, the replayed epoch graph included); the trainer path,
+    the recorded op-level loop and the eager op-level loop tell the same story (first-epoch losses within 1e-4 over the first 30
+    float32 Adam steps and within 1e-2 over all 391, identical step counts, accuracies within a point); the loss falls and the accuracy rises."""
+    from tinynn_autograd_amd.core.tensor import Tensor
+    from tinynn_autograd_amd.examples import mnist_run
+    from tinynn_autograd_amd.utils.data_iterator import BatchIterator
+    (train_x, train_y), (test_x, test_y), _ = mnist_run.prepare_dataset("/nonexistent", n_train=50000, n_test=10000)
+    # ---- the gather is a permutation, and the one the reference would draw
+    it = BatchIterator(batch_size=128, reuse_buffers=True)
+    tx, ty = Tensor(train_x), Tensor(mnist_run.get_one_hot(train_y, 10))
+    np.random.seed(5)
+    want = np.arange(50000); np.random.shuffle(want)
+    np.random.seed(5)
+    batches = list(it(tx, ty))
+    assert len(batches) == 391 and len(batches[-1].inputs) == 80
+    got = np.concatenate([np.asarray(b.inputs.values) for b in batches])
+    assert np.array_equal(got, train_x[want])
+    words = lambda a: np.sort(np.ascontiguousarray(a).view(np.uint32).sum(axis=1, dtype=np.uint64))   # one integer checksum per row
+    assert np.array_equal(words(got), words(train_x))
+    del batches, it, tx, ty
+    # ---- determinism and agreement of the three paths
+    runs = {}
+    for name, kw in (("trainer", {"trainer": True}), ("trainer_again", {"trainer": True}), ("capture", {"capture": True}), ("eager", {})):
+        np.random.seed(0)
+        runs[name] = mnist_run.train(train_x, train_y, test_x, test_y, [256, 128], 2, 128, 1e-3, **kw)
+    losses, preds, results = runs["trainer"]
+    assert len(losses) == 2 * 391 and np.isfinite(losses).all()
+    assert losses == runs["trainer_again"][0] and all(np.array_equal(a, b) for a, b in zip(preds, runs["trainer_again"][1]))
+    assert np.mean(losses[-50:]) < np.mean(losses[:50]) and results[1]["accuracy"] > results[0]["accuracy"] > 0.5
+    for other in ("capture", "eager"):
+        o_losses, _, o_results = runs[other]
+        assert len(o_losses) == 2 * 391
+        np.testing.assert_allclose(o_losses[:30], losses[:30], rtol=1e-4, err_msg=other)      # same arithmetic, other summation order:
+        np.testing.assert_allclose(o_losses[:391], losses[:391], rtol=1e-2, err_msg=other)    # ... amplified by 391 float32 Adam steps
+        for ep in range(2):
+            assert o_results[ep]["total_num"] == 10000 and abs(o_results[ep]["accuracy"] - results[ep]["accuracy"]) < 0.01, (other, ep)
+    assert runs["capture"][0][:391] == runs["eager"][0][:391]          # epoch 0 of the recorded path IS the eager path
