@@ -276,7 +276,8 @@ def time_dw_adam_bf16(widths, rows, reps=10):
             "algorithmic_bytes": int(alg), "us": round(us, 1), "launches_per_step": len(widths) - 1,
             "mfma_tflops": round(2.0 * M * N * K / us / 1e6, 1),
             "model": "28 B per parameter (p, m, v read; p, m, v, bf16 copy, bf16 transpose written) + the operands; the "
-                     "gradient itself never leaves the accumulators"}
+                     "gradient itself never leaves the accumulators.  Timed here: the 28-B form (3 of the step's 4 launches); "
+                     "the first layer's launch writes no [in, out] bf16 copy (nothing reads it: dX stops at the input) = 26 B"}
 
 
 def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):

@@ -448,8 +448,8 @@ TNN_API int tnn_adam_master_bf16_2d(void* p_master, const void* g, void* m, void
                                     void* pows_f64, int advance);
 /* dW = A B^T (A [M, K], B [N, K], bf16, K-contiguous, fp32 accumulation — core/ops.py:160 with the transposed copies of
  * tnn_transpose_bf16 as operands) CONSUMED by Adam in the GEMM epilogue (core/optimizer.py:67-79, the maths of
- * tnn_adam_master_bf16_2d): p / m / v [M, N] fp32 updated in place, w_bf16 [M, N] and wT_bf16 [N, M] (NULL = skip)
- * refreshed.  g_out_f32 [M, N] receives the gradient itself when not NULL; NULL saves its 4 B write and the 4 B re-read
+ * tnn_adam_master_bf16_2d): p / m / v [M, N] fp32 updated in place, w_bf16 [M, N] and wT_bf16 [N, M] refreshed (either
+ * may be NULL = skip: the first layer's [in, out] copy has no reader — no dX is formed for the input).  g_out_f32 [M, N] receives the gradient itself when not NULL; NULL saves its 4 B write and the 4 B re-read
  * of the separate optimizer launch per parameter (of 36).  pows_f64 = {b1^t, b2^t} ALREADY advanced (tnn_adam_tick).
  * Single-GPU step only: a data-parallel step reduces the gradients between the two. */
 TNN_API int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,

@@ -331,11 +331,15 @@ def test_bf16_trainer_fused_step_equals_separate_launches(monkeypatch):
                 losses.append(float(t.step(x16, x16)))
         runs.append((losses, np.asarray(t.params).copy(), np.asarray(t.adam_m).copy(), np.asarray(t.adam_v).copy(),
                      [np.asarray(t.grad_view(l, "w")).copy() for l in range(3)],
-                     np.asarray(t.forward(x16)).copy()))
+                     np.asarray(t.forward(x16)).copy(), np.asarray(t.weights_bf16()).copy()))
+        # the bf16 working copy IS the rounded masters — also W_0's [in, out] copy, which the default step does not write (it
+        # has no reader inside a step) and the accessor re-derives
+        for l in range(3):
+            assert np.array_equal(np.asarray(t.weights_bf16(l)), np.asarray(bf16.to_bf16(np.asarray(t.param_view(l, "w"))))), (mode, l)
     monkeypatch.delenv("TNN_E_STEP", raising=False)
     for got in runs[1:]:
         assert got[0] == runs[0][0]
-        for k in (1, 2, 3, 5):
+        for k in (1, 2, 3, 5, 6):
             assert np.array_equal(got[k], runs[0][k]), k
     for l in range(3):
         assert np.array_equal(runs[1][4][l], runs[0][4][l])              # stored gradients of the default step

@@ -879,7 +879,7 @@ int tnn_gemm_bf16_nt_adam(int64_t M, int64_t N, int64_t K, const void* A, int64_
                 "tnn_gemm_bf16_nt_adam: operands must be 16-byte aligned");
     TNN_REQUIRE(M * lda * 2 < (int64_t(1) << 32) && N * ldb * 2 < (int64_t(1) << 32),
                 "tnn_gemm_bf16_nt_adam: operands of 4 GiB or more are not supported (32-bit buffer offsets)");
-    TNN_REQUIRE(p_master && m && v && w_bf16 && pows_f64, "tnn_gemm_bf16_nt_adam: p, m, v, w_bf16 and pows are required");
+    TNN_REQUIRE(p_master && m && v && pows_f64, "tnn_gemm_bf16_nt_adam: p, m, v and pows are required");
     TNN_REQUIRE(wT_bf16 == nullptr || (M % 4 == 0 && (reinterpret_cast<uintptr_t>(wT_bf16) & 7) == 0),
                 "tnn_gemm_bf16_nt_adam: the transposed copy needs M %% 4 == 0 and 8-byte alignment");
     BfArgs g = {};

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
                         __builtin_nontemporal_store(pv[buf][jj], reinterpret_cast<f32x4*>(g.ap + o));
                         hp[j][0] = h[0] | (h[1] << 16);
                         hp[j][1] = h[2] | (h[3] << 16);
-                        *reinterpret_cast<u32x2*>(g.aw16 + o) = u32x2{hp[j][0], hp[j][1]};
+                        if (g.aw16) *reinterpret_cast<u32x2*>(g.aw16 + o) = u32x2{hp[j][0], hp[j][1]};
                         if (gout) *reinterpret_cast<f32x4*>(gout + o) = gv;
                     }
                     if (half == 1 && g.awT16 != nullptr) {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_bf16_dma_kernel(BfArgs g) {
                             __builtin_nontemporal_store(m1, g.am + o);
                             __builtin_nontemporal_store(v1, g.av + o);
                             __builtin_nontemporal_store(p1, g.ap + o);
-                            g.aw16[o] = h;
+                            if (g.aw16) g.aw16[o] = h;
                             if (gout) gout[o] = gi;
                         }
                     }

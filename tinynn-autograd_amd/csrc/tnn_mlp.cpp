@@ -54,6 +54,7 @@ struct Mlp {
     // the GEMMs consume bf16 working copies, every operand K-contiguous (see tnn_gemm_bf16.hip)
     bool bf16 = false;
     char* w16 = nullptr;             // bf16 copy of the whole parameter arena (W_l at w_off[l], [in,out])
+    bool w16_first_stale = false;    // a step form that does not refresh W_0's copy has run (or been recorded)
     std::vector<void*> wT16;         // W_l^T [out,in]  (forward operand)
     std::vector<void*> actT16;       // act[l]^T [w[l+1], max_rows]   (dW operand of layer l+1)
     std::vector<void*> dactT16;      // dact[l]^T [w[l+1], max_rows]  (dW operand of layer l)
@@ -219,9 +220,11 @@ int mlp16_step_fused(Mlp* h, const void* x16, const void* y16, int64_t rows, voi
                 STEP_CALL(h, tnn_gemm_bf16_nt(rows, h->w[l], h->w[l + 1], h->dact[l], h->w[l + 1], at16(h->w16, wo), h->w[l + 1],
                                               h->dact[l - 1], h->w[l], TNN_BF16, nullptr, TNN_ACT_NONE, 0, h->act[l - 1], h->w[l]));
         }
+        // (W_0's [in, out] bf16 copy has no reader inside a step — dX stops at the input —: not written, 2 of 28 B/param of
+        // that layer; tnn_mlp_bf16_weights re-derives it from the masters on request)
         STEP_CALL(h, tnn_gemm_bf16_nt_adam(h->w[l], h->w[l + 1], rows, inT, rows, h->dactT16[l], rows, nullptr, f32(h->params, wo),
-                                           f32(h->m, wo), f32(h->v, wo), at16(h->w16, wo), h->wT16[l], h->lr, h->b1, h->b2, h->eps,
-                                           h->pows));
+                                           f32(h->m, wo), f32(h->v, wo), l == 0 ? nullptr : at16(h->w16, wo), h->wT16[l], h->lr,
+                                           h->b1, h->b2, h->eps, h->pows));
     }
     const void* dz[16];
     int64_t cols[16];
@@ -232,6 +235,7 @@ int mlp16_step_fused(Mlp* h, const void* x16, const void* y16, int64_t rows, voi
         db[l] = f32(h->grads, bo); bp[l] = f32(h->params, bo); bm[l] = f32(h->m, bo); bv[l] = f32(h->v, bo); bw[l] = at16(h->w16, bo);
     }
     STEP_CALL(h, tnn_bias_bf16_adam_multi(L, dz, rows, cols, db, bp, bm, bv, bw, h->lr, h->b1, h->b2, h->eps, h->pows));
+    h->w16_first_stale = true;
     return 0;
 }
 
@@ -1053,6 +1057,8 @@ int tnn_mlp_gather_masters(void* handle) {
 int tnn_mlp_bf16_weights(void* handle, void** w16) {
     Mlp* h = (Mlp*)handle;
     if (!h || !w16 || !h->bf16) { tnn::set_error("tnn_mlp_bf16_weights: not a bf16 trainer"); return 2; }
+    if (h->w16_first_stale)          // (stays set: a recorded step replays without coming back through the host code)
+        if (int rc = tnn_cast_bf16((float*)h->params + h->w_off[0], h->w16 + 2 * h->w_off[0], h->w[0] * h->w[1], 1)) return rc;
     *w16 = h->w16;
     return 0;
 }

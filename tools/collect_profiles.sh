@@ -31,7 +31,7 @@ cp $S/soak.txt $D/${R}_soak.txt
 cp $S/soak_e.txt $D/${R}_soak_e.txt
 cp $S/step256_timeline.txt $D/${R}_step256_timeline.txt
 cp $S/eager_phases.txt $D/${R}_eager_phases.txt
-for f in e_step_ab_kernels.txt epoch_loop.json mnist_run_trainer.txt mnist_run_ops.txt e_step_ab.txt e_kernels_ab.txt gemm_f32_cfg_ab.txt e_overlap_probe.txt exnet_launches.txt stepC_timeline.txt; do
+for f in e_step_ab_kernels.txt epoch_loop.json mnist_run_trainer.txt mnist_run_ops.txt e_step_ab.txt e_kernels_ab.txt gemm_f32_cfg_ab.txt e_overlap_probe.txt exnet_launches.txt stepC_timeline.txt dw_adam_k.txt dw_adam_stride_ab.txt; do
   [ -f $S/$f ] && cp $S/$f $D/${R}_$f
 done
 ls -la $D/${R}_*

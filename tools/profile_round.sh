@@ -48,6 +48,9 @@ timeout 900 python3 tools/probes/gemm_f32_cfg_ab.py < /dev/null > $OUT/gemm_f32_
 timeout 300 python3 tools/probes/e_overlap_probe.py < /dev/null 2>> $OUT/log.txt | grep -v "version\|Hostname\|Librccl" > $OUT/e_overlap_probe.txt
 timeout 900 python3 tools/probes/exnet_launches.py < /dev/null > $OUT/exnet_launches.txt 2>> $OUT/log.txt
 timeout 900 python3 tools/probes/gemm_f32_data_ab.py < /dev/null > $OUT/gemm_f32_data_ab.txt 2>> $OUT/log.txt
+# the bf16 dW + Adam launch taken apart: K sweep / bf16 copies / stand-alone optimizer on the same box; row stride A/B
+timeout 600 python3 tools/probes/dw_adam_k.py < /dev/null 2>> $OUT/log.txt | grep "^W " > $OUT/dw_adam_k.txt
+timeout 600 python3 tools/probes/dw_adam_stride_ab.py < /dev/null 2>> $OUT/log.txt | grep "bf16 copies\|median" > $OUT/dw_adam_stride_ab.txt
 mkdir -p $OUT/cal
 timeout 900 tools/probes/bin/fetch_calibration < /dev/null > $OUT/cal/known.txt 2>> $OUT/log.txt
 run rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/cal/fetch -o cal -- tools/probes/bin/fetch_calibration
