@@ -1259,6 +1259,34 @@ def gather_scalars_of_separate_buffers():
         pass
 
 
+def row_gather_vector_and_scalar_paths():
+    """tnn_gather_rows (utils/data_iterator.py:26-28 `inputs[idx]`; np.take(..., axis=0, out=...)): rows whose byte length and bases
+    are multiples of 16 move as 16-B pieces read with streaming loads, everything else element by element — both against numpy
+    fancy indexing, bit for bit, for every dtype of the seam, with negative and repeated indices, one row and the 157 MB-style shape."""
+    rs = np.random.RandomState(91)
+    for dtype in (np.float32, np.float64, np.int64, np.bool_):
+        for n_src, row in ((37, 784), (37, 783), (5, 4), (5, 3), (64, 16), (3, 1), (300, 48)):
+            if dtype == np.bool_:
+                src = rs.rand(n_src, row) < 0.5
+            elif dtype == np.int64:
+                src = rs.randint(-2 ** 40, 2 ** 40, (n_src, row)).astype(np.int64)
+            else:
+                src = rs.randn(n_src, row).astype(dtype)
+            idx = rs.randint(-n_src, n_src, 2 * n_src + 1)
+            d = tn.asarray(src, dtype=dtype)
+            got = d[tn.asarray(idx)]
+            assert got.dtype == dtype and np.array_equal(np.asarray(got), src[idx]), (dtype, n_src, row)
+            out = tn.empty((len(idx), row), dtype)
+            res = np.take(d, tn.asarray(idx), axis=0, out=out)
+            assert res is out and np.array_equal(np.asarray(out), src[idx])
+            # a source that starts 4 / 8 bytes into its buffer (a row-sliced view is still aligned; a column slice is not dense)
+            one = d[tn.asarray(np.array([n_src - 1]))]
+            assert np.array_equal(np.asarray(one), src[[n_src - 1]])
+    big = rs.rand(2000, 784).astype(np.float32)
+    order = rs.permutation(2000)
+    assert np.array_equal(np.asarray(tn.asarray(big)[tn.asarray(order)]), big[order])
+
+
 def batch_iterator_on_device_tensors():
     """utils/data_iterator.py:22-34 on device Tensors: one global-RNG shuffle per epoch, a row-gather kernel for
     inputs[idx], zero-copy row slices per batch, ragged last batch."""
