@@ -18,7 +18,9 @@ import weakref
 
 import numpy as np
 
+from .. import _lib
 from .. import device_array as da
+from .layers import Dense
 
 
 _PENDING = weakref.WeakSet()      # models with a deferred first-layer backward
@@ -130,7 +132,6 @@ class Model(object):
 
     def _first_dense_params(self, tensors):
         """(w, b) of the net's first layer when that is a Dense whose parameters head the arena, else ()."""
-        from .layers import Dense
         layers = getattr(self.net, "layers", None)
         if not layers or type(layers[0]) is not Dense or not layers[0].fused or len(tensors) < 2:
             return ()
@@ -167,7 +168,6 @@ class Model(object):
             return
         x, dz, w, rows, n_in, n_out = pend
         dw, db = ts[0]._grad_home, ts[1]._grad_home
-        from .. import _lib
         _lib.get().dense_bwd(rows, n_in, n_out, x._ptr, dz._ptr, w._ptr, dw.fulfilled_ptr(), db.fulfilled_ptr(), None, None,
                              dz._code())
 
@@ -220,7 +220,6 @@ class Model(object):
             # op-level updates are ordinary array expressions: nothing on the device ties them to the collective, so a
             # peer-to-peer transport is asked (after a stream sync) whether it timed out BEFORE the update is issued
             if getattr(self.comm, "_p2p", False):
-                from .. import _lib
                 _lib.synchronize()
                 self.comm.check(collective=False)
 

@@ -2,6 +2,7 @@
 iteration over parameter tensors in the optimizer's flattening order, parameter counting and the Dense/ReLU
 structure query the whole-step trainer uses."""
 
+from .layers import Dense, ReLU
 
 
 class Net(object):
@@ -17,7 +18,6 @@ class Net(object):
         """Thread the input through the layers (core/nn.py:10-13).  A fused `Dense` directly followed by a `ReLU` runs
         as ONE node (GEMM + bias + clip(., 0) epilogue, ops.dense_(relu=True)); the ReLU layer object is then skipped —
         its `inputs` attribute (cached but never read by the reference, core/layers.py:67) holds the fused output."""
-        from .layers import Dense, ReLU
         layers, i, activations = self.layers, 0, inputs
         n = len(layers)
         # TRAIN mode, ... Dense -> ReLU -> Dense(classifier): the hidden layer's launch also emits the classifier's logits as

@@ -19,9 +19,15 @@ from .. import _lib
 from .. import device_array as da
 
 
+_AS_TENSOR = None
+
+
 def as_tensor(obj):
-    from .tensor import as_tensor as _as_tensor   # lazy: tensor imports ops
-    return _as_tensor(obj)
+    global _AS_TENSOR
+    if _AS_TENSOR is None:
+        from .tensor import as_tensor as _as_tensor   # lazy: tensor imports ops (resolved once, not on every call)
+        _AS_TENSOR = _as_tensor
+    return _AS_TENSOR(obj)
 
 
 # ---------------------------------------------------------------------- graph construction

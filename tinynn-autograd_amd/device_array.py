@@ -65,6 +65,9 @@ def _dense_strides(shape):
 
 
 def _is_scalar_like(x):
+    tx = type(x)
+    if tx is float or tx is int:                     # (no ABC instance check for the exact Python types)
+        return True
     return isinstance(x, (numbers.Number, np.generic)) or (isinstance(x, np.ndarray) and x.ndim == 0)
 
 
@@ -97,7 +100,7 @@ def trim_cache():
 
 
 class DeviceArray(object):
-    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "_own", "_aux", "__weakref__")
+    __slots__ = ("_ptr", "shape", "dtype", "_base", "_hv", "_t", "_tag", "_own", "_aux", "_sc", "__weakref__")
     __array_priority__ = 1000.0
 
     # ------------------------------------------------------------------ construction
@@ -108,12 +111,16 @@ class DeviceArray(object):
     def _raw(cls, ptr, shape, dtype, base=None, hv=None, t=False):
         self = object.__new__(cls)
         self._ptr = ptr
-        self.shape = tuple(map(int, shape))
+        # (shapes reach this point as tuples of Python ints from every internal caller: checked, not rebuilt)
+        if type(shape) is not tuple or any(type(v) is not int for v in shape):
+            shape = tuple(map(int, shape))
+        self.shape = shape
         self.dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
         self._base = base
         self._hv = hv
         self._t = t
         self._own = 0                # 0: the native pool's (or not owned), 1: recyclable through _cache, 2: graph-owned
+        self._sc = 0                 # size class of an owned buffer (bytes), set by _new
         self._aux = None             # by-product of the producing launch riding along (core/ops.py: the partial logits)
         self._tag = None             # free-form marker: RELU_SIGN on a fused Dense+ReLU output; the producer's output array
                                      # on a gradient whose ReLU mask has already been applied (core/ops.py dense_)
@@ -131,24 +138,28 @@ class DeviceArray(object):
                 self = cls._raw(ptrs.pop(), shape, dtype)
                 _cache_bytes -= sc
                 self._own = 1
+                self._sc = sc
                 return self
         p = ctypes.c_void_p()
         _lib.get().malloc(sc, ctypes.byref(p))
         self = cls._raw(p.value, shape, dtype)
         self._own = 2 if _lib.capturing else 1
+        self._sc = sc
         return self
 
     @classmethod
     def _scalar(cls, value):
         """Host scalar (weakly typed, like a Python number under numpy promotion)."""
-        if isinstance(value, np.ndarray):
-            value = value[()]
-        if isinstance(value, (bool, np.bool_)):
-            value = float(value)
-        elif isinstance(value, (numbers.Integral, np.integer)):
-            value = int(value)
-        else:
-            value = float(value)
+        tv = type(value)
+        if tv is not float and tv is not int:        # (exact Python floats / ints: nothing to normalise, no ABC instance checks)
+            if isinstance(value, np.ndarray):
+                value = value[()]
+            if isinstance(value, (bool, np.bool_)):
+                value = float(value)
+            elif isinstance(value, (numbers.Integral, np.integer)):
+                value = int(value)
+            else:
+                value = float(value)
         return cls._raw(None, (), _default_float, hv=value)
 
     def __del__(self):
@@ -156,7 +167,7 @@ class DeviceArray(object):
         try:
             if self._base is None and self._ptr is not None and _lib._lib is not None:
                 if self._own == 1 and not _lib.capturing:
-                    sc = _size_class(_prod(self.shape) * self.dtype.itemsize)
+                    sc = self._sc or _size_class(_prod(self.shape) * self.dtype.itemsize)
                     if sc <= _CACHE_MAX_BLOCK and _cache_bytes + sc <= _CACHE_LIMIT:
                         _cache.setdefault(sc, []).append(self._ptr)
                         _cache_bytes += sc
@@ -270,6 +281,8 @@ class DeviceArray(object):
 
     # ------------------------------------------------------------------ dtype handling
     def astype(self, dtype):
+        if dtype is self.dtype:                      # (np.dtype objects are singletons per type: the common no-op case)
+            return self
         dtype = np.dtype(dtype)
         if dtype == self.dtype:
             return self
@@ -600,9 +613,9 @@ class DeviceArray(object):
 
 # ---------------------------------------------------------------------- creation helpers
 def empty(shape, dtype=None):
-    if isinstance(shape, numbers.Integral):
-        shape = (shape,)
-    return DeviceArray._new(tuple(shape), dtype or _default_float)
+    if type(shape) is not tuple:                     # (the hot callers pass tuples: no ABC instance check for them)
+        shape = (shape,) if isinstance(shape, numbers.Integral) else tuple(shape)
+    return DeviceArray._new(shape, dtype or _default_float)
 
 
 def full(shape, value, dtype=None):
@@ -638,7 +651,7 @@ def asarray(obj, dtype=None):
     numpy scalars stay on the host as kernel arguments.
     """
     if isinstance(obj, DeviceArray):
-        if dtype is not None and np.dtype(dtype) != obj.dtype:
+        if dtype is not None and dtype is not obj.dtype and np.dtype(dtype) != obj.dtype:
             return obj.astype(dtype)
         return obj
     if _is_scalar_like(obj):
