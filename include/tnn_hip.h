@@ -426,7 +426,7 @@ TNN_API int tnn_mse_bf16_tick(const void* pred, const void* y, int64_t n, int64_
  * when not NULL), dpred = 2 (pred - y) / m_global [rows, cols] AND its transpose dpred_t [cols, rows] (NULL = skip), x_t
  * [x_cols, rows] = the transpose of the batch x [rows, x_cols] (x / x_t NULL = skip), Adam's {b1^t, b2^t} advanced when
  * adam_pows_f64 != NULL.  rows, cols, x_cols multiples of 64.  partials_f64: workspace of rows / 64 * cols / 64 doubles;
- * ticket_u32: one word that is ZERO on entry and is left zero (arrival counter of the loss reduction).
+ * ticket_u32: 64 words that are ZERO on entry and are left zero (two-level arrival counters of the loss reduction).
  * core/losses.py (sum-of-squares form), core/ops.py:159-160 for the transposed operands. */
 TNN_API int tnn_mse_bf16_prep(const void* pred, const void* y, int64_t rows, int64_t cols, int64_t m_global,
                               void* loss_out_f32, void* loss_out2_f32, void* dpred, void* dpred_t, const void* x,

@@ -470,9 +470,19 @@ __global__ __launch_bounds__(256) void mse_prep_bf16_kernel(const bf16_t* __rest
         // line of this XCD's L2 — the dz / dz^T tiles just stored — once per workgroup (34 us for the launch, measured)
         __hip_atomic_store(partial + b, ((lds4[0] + lds4[1]) + (lds4[2] + lds4[3])) * inv_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == (unsigned)n_loss - 1 ? 1 : 0;
-        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // graph replays start from 0
+        // Two-level arrival: the tiles draw tickets in groups of G >= 32 (word 1 + group), the last of a group draws one of the
+        // launch (word 0) — a thousand agent-scope atomics on ONE word serialise to ~25 us (measured on the data-parallel
+        // step's counters, csrc/tnn_gemm.hip), 32 + 32 do not.  Every word is back at 0 when the launch ends (graph replays).
+        const int G = max(32, (n_loss + 62) / 63), n_groups = (n_loss + G - 1) / G, grp = b / G;
+        const unsigned members = (unsigned)min(G, n_loss - grp * G);
+        int last = 0;
+        if (__hip_atomic_fetch_add(ticket + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+            __hip_atomic_store(ticket + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)n_groups - 1) {
+                __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
         is_last = last;
     }
     __syncthreads();
@@ -937,7 +947,7 @@ int tnn_mse_bf16_prep(const void* pred, const void* y, int64_t rows, int64_t col
     TNN_REQUIRE(rows % 64 == 0 && cols % 64 == 0 && (x == nullptr || x_cols % 64 == 0),
                 "tnn_mse_bf16_prep: rows, cols and x_cols must be multiples of 64");
     TNN_REQUIRE((x == nullptr) == (x_t == nullptr), "tnn_mse_bf16_prep: x and x_t go together");
-    TNN_REQUIRE(partials_f64 && ticket_u32, "tnn_mse_bf16_prep: the partial-sum workspace (rows / 64 * cols / 64 doubles) and the zeroed ticket word are required");
+    TNN_REQUIRE(partials_f64 && ticket_u32, "tnn_mse_bf16_prep: the partial-sum workspace (rows / 64 * cols / 64 doubles) and the 64 zeroed ticket words are required");
     TNN_REQUIRE(loss_out_f32 != nullptr || loss_out2_f32 == nullptr, "tnn_mse_bf16_prep: loss_out2 needs loss_out");
     auto al = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     TNN_REQUIRE(al(pred, 8) && al(y, 8) && al(dpred, 8) && al(dpred_t, 16) && al(x, 8) && al(x_t, 16), "tnn_mse_bf16_prep: misaligned operand");

@@ -119,7 +119,7 @@ ab("bias gradient + Adam of four 8192-wide layers", {"four launches": bias_four,
 pred, y, x = rnd16((M, W)), rnd16((M, W)), rnd16((M, W), 0.0, 1.0)
 dzo, dzt, xt = tn.empty((M, W), np.uint16), tn.empty((W, M), np.uint16), tn.empty((W, M), np.uint16)
 loss = tn.empty((2,), np.float32)
-ws, ticket = tn.empty((M // 64 * (W // 64),), np.float64), tn.asarray(np.zeros(2, np.int64))
+ws, ticket = tn.empty((M // 64 * (W // 64),), np.float64), tn.asarray(np.zeros(32, np.int64))
 
 
 def prep_new(i):
