@@ -58,3 +58,42 @@ def test_compiled_host_modules_follow_their_sources(tmp_path):
     got, warned = _probe(str(copy))
     assert got == [n for n in names if n != "core.nn"]
     assert "core/nn.py" in warned
+
+
+def test_call_wrappers_match_the_signature_table_and_behave_like_ctypes():
+    """The generated C call wrappers (_fastcall_gen.py, built by _host_build.py): one per entry point with plain integer /
+    double / address parameters, bound to the SAME functions of the SAME shared object — used by _lib when their hash matches
+    the signature table, ignored with TNN_HOST_COMPILED=0; errors, arity and argument types behave like the ctypes binding."""
+    import numpy as np
+    import tinynn_autograd_amd as tn
+    from tinynn_autograd_amd import _fastcall_gen, _lib
+    hb = _host_build()
+    hb.build_host()
+    assert not hb.fastcall_stale() and hb.read_manifest()[hb.FASTCALL] == _fastcall_gen.signature_hash(_lib._SIGNATURES)
+    elig = _fastcall_gen.eligible(_lib._SIGNATURES)
+    assert len(elig) > 100 and "tnn_gemm_bias_act" in elig and "tnn_mlp_step" in elig
+    assert "tnn_malloc" not in elig and "tnn_device_props" not in elig            # typed out-pointers / strings stay on ctypes
+    fast = _lib._fast_wrappers(_lib.get().path)
+    if os.environ.get("TNN_HOST_COMPILED", "1") == "0":
+        assert fast == {}
+        return
+    assert sorted(fast) == sorted(elig) and _lib.get().fast_calls == len(elig)
+    a = tn.asarray(np.arange(16, dtype=np.float32).reshape(4, 4))
+    lib = _lib.get()
+    assert lib.fill is fast["tnn_fill"] or lib.fill.__name__ == "tnn_fill"
+    import ctypes
+    for call in (fast["tnn_fill"], lib._wrap("tnn_fill", lib.cdll.tnn_fill)):       # the wrapper, then the ctypes binding
+        call(a._ptr, 2.5, 16, a._code())
+        assert (np.asarray(a) == 2.5).all()
+        with pytest.raises(_lib.TnnError, match="tnn_fill failed .rc=2.: tnn_fill: unknown dtype 9"):
+            call(a._ptr, 1.0, 16, 9)
+        with pytest.raises(TypeError):
+            call(a._ptr, 1.0, 16)
+        with pytest.raises((TypeError, ctypes.ArgumentError)):
+            call(a._ptr, 1.0, 16.5, a._code())
+    fast["tnn_fill"](a._ptr, np.float32(1.5), np.int64(16), a._code())              # (the wrapper also takes numpy scalars)
+    assert (np.asarray(a) == 1.5).all()
+    # a c_void_p INSTANCE passes its value (event / graph handles), None passes NULL
+    ev = _lib.Event().record()
+    fast["tnn_event_record"](ev._h)
+    lib.stream_sync()

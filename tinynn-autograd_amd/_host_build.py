@@ -53,11 +53,67 @@ def stale_modules():
             if have.get(rel_name(m)) != source_hash(m) or not os.path.exists(compiled_path(m))]
 
 
+FASTCALL = "_tnn_fastcall"            # the C-ABI's call wrappers (_fastcall_gen.py): plain C generated from _lib._SIGNATURES
+
+
+def fastcall_path():
+    return os.path.join(OUT_DIR, FASTCALL + EXT_SUFFIX)
+
+
+def _fastcall_gen():
+    """(_fastcall_gen module, the signature table) loaded from their files — this script also runs outside the package."""
+    import importlib.util
+    mods = []
+    for name in ("_fastcall_gen", "_signatures"):
+        spec = importlib.util.spec_from_file_location("_tnn_" + name, os.path.join(PKG_DIR, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mods.append(mod)
+    return mods[0], mods[1]._SIGNATURES
+
+
+def fastcall_stale():
+    gen, sigs = _fastcall_gen()
+    return read_manifest().get(FASTCALL) != gen.signature_hash(sigs) or not os.path.exists(fastcall_path())
+
+
+def build_fastcall(verbose=False):
+    """Generate and compile the call wrappers; returns True when it was (re)built."""
+    from setuptools import Extension
+    from setuptools.dist import Distribution
+    from setuptools.command.build_ext import build_ext
+    gen, sigs = _fastcall_gen()
+    tmp = os.path.join(OUT_DIR, "_tmp_fastcall")
+    os.makedirs(tmp, exist_ok=True)
+    src = os.path.join(tmp, FASTCALL + ".c")
+    with open(src, "w") as f:
+        f.write(gen.generate(sigs))
+    ext = Extension(FASTCALL, [src], extra_compile_args=["-O2", "-g0", "-w"], libraries=["dl"])
+    dist = Distribution(dict(ext_modules=[ext], script_name="_host_build", script_args=[]))
+    cmd = build_ext(dist)
+    cmd.build_lib, cmd.build_temp, cmd.inplace, cmd.force = os.path.join(tmp, "lib"), os.path.join(tmp, "obj"), False, True
+    cmd.ensure_finalized()
+    if not verbose:
+        dist.verbose = cmd.verbose = 0
+    cmd.run()
+    os.replace(os.path.join(tmp, "lib", FASTCALL + EXT_SUFFIX), fastcall_path())
+    have = read_manifest()
+    have[FASTCALL] = gen.signature_hash(sigs)
+    with open(MANIFEST, "w") as f:
+        json.dump(have, f, indent=1, sort_keys=True)
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return True
+
+
 def build_host(force=False, verbose=False):
-    """Compile the stale modules; returns the list that was (re)built.  Raises if Cython or the compiler fails."""
+    """Compile the stale modules (and the call wrappers); returns the list that was (re)built.  Raises if Cython or the
+    compiler fails."""
+    os.makedirs(OUT_DIR, exist_ok=True)
+    extra = [FASTCALL] if (force or fastcall_stale()) and build_fastcall(verbose) else []
     todo = list(MODULES) if force else stale_modules()
     if not todo:
-        return []
+        return extra
     from Cython.Build import cythonize
     from setuptools import Extension
     from setuptools.dist import Distribution
@@ -97,7 +153,7 @@ def build_host(force=False, verbose=False):
         json.dump(have, f, indent=1, sort_keys=True)
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)        # generated C + objects: several MB nobody needs afterwards
-    return built
+    return extra + built
 
 
 if __name__ == "__main__":

@@ -27,163 +27,35 @@ NEG, EXP, LOG, SQRT, SQUARE, ABS, RECIP, SIGMOID, TANH, COPY = range(10)
 RSUM, RMAX, RMIN = range(3)
 ACT_NONE, ACT_RELU = 0, 1
 
-_p = c_void_p
-_i64p = POINTER(c_int64)
-
-# name -> argtypes; every entry point returns int except tnn_last_error
-_SIGNATURES = {
-    "tnn_init": [c_int],
-    "tnn_shutdown": [],
-    "tnn_backend_kind": [],
-    "tnn_device_props": [POINTER(c_int), POINTER(c_int), _i64p, c_char_p, c_int],
-    "tnn_malloc": [c_size_t, POINTER(c_void_p)],
-    "tnn_free": [_p],
-    "tnn_pool_stats": [_i64p, _i64p, _i64p],
-    "tnn_pool_trim": [],
-    "tnn_memcpy_h2d": [_p, _p, c_size_t],
-    "tnn_memcpy_d2h": [_p, _p, c_size_t],
-    "tnn_memcpy_d2d": [_p, _p, c_size_t],
-    "tnn_memset": [_p, c_int, c_size_t],
-    "tnn_fill": [_p, c_double, c_int64, c_int],
-    "tnn_stream_sync": [],
-    "tnn_event_create": [POINTER(c_void_p)],
-    "tnn_event_record": [_p],
-    "tnn_event_elapsed_ms": [_p, _p, POINTER(ctypes.c_float)],
-    "tnn_event_destroy": [_p],
-    "tnn_graph_capture_begin": [],
-    "tnn_graph_capture_end": [POINTER(c_void_p)],
-    "tnn_graph_launch": [_p],
-    "tnn_graph_destroy": [_p],
-    "tnn_gemm": [c_int, c_int, c_int64, c_int64, c_int64, c_double, _p, c_int64, _p, c_int64,
-                 c_double, _p, c_int64, c_int],
-    "tnn_gemm_bias_act": [c_int, c_int, c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p,
-                          c_int, c_int, _p, c_int64, c_int],
-    "tnn_gemm_mask": [c_int, c_int, c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p,
-                      c_int64, _p, c_int64, c_int],
-    "tnn_gemm_tn_colsum": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, _p, c_int],
-    "tnn_gemm_tn_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p, c_int],
-    "tnn_gemm_tn_adam_bias": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p, c_int],
-    "tnn_dense_bwd": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, c_int],
-    "tnn_ewise_binary": [c_int, _p, _i64p, _p, _i64p, _p, c_int, _i64p, c_int],
-    "tnn_ewise_scalar": [c_int, _p, c_double, c_int, _p, c_int64, c_int],
-    "tnn_ewise_compare": [c_int, _p, _i64p, _p, _i64p, _p, c_int, _i64p, c_int],
-    "tnn_compare_scalar": [c_int, _p, c_double, _p, c_int64, c_int],
-    "tnn_ewise_unary": [c_int, _p, _p, c_int64, c_int],
-    "tnn_clip": [_p, c_int, c_double, c_int, c_double, _p, c_int64, c_int],
-    "tnn_clip_bwd": [_p, _p, c_int, c_double, c_int, c_double, _p, c_int64, c_int],
-    "tnn_mul_mask": [_p, _p, _p, c_int64, c_int],
-    "tnn_mul_signmask": [_p, _p, _p, c_int64, c_int],
-    "tnn_axpy": [_p, c_double, _p, c_int64, c_int],
-    "tnn_cast": [_p, c_int, _p, c_int, c_int64],
-    "tnn_reduce": [c_int, _p, _p, c_int64, c_int64, c_int64, c_int],
-    "tnn_argmax_rows": [_p, _p, c_int64, c_int64, c_int],
-    "tnn_strided_copy": [_p, _i64p, _p, c_int, _i64p, c_int],
-    "tnn_strided_scatter": [_p, _p, _i64p, c_int, _i64p, c_int],
-    "tnn_gather_rows": [_p, _p, _p, c_int64, c_int64, c_int64, c_int],
-    "tnn_scatter_rows": [_p, _p, _p, c_int64, c_int64, c_int64, c_int],
-    "tnn_gather_scalars": [_p, _p, c_int64, c_int],
-    "tnn_one_hot": [_p, _p, c_int64, c_int64, c_int],
-    "tnn_bias_act": [_p, _p, c_int, _p, c_int64, c_int64, c_int],
-    "tnn_softmax_nll_stats": [_p, c_int64, c_int64, _p, c_int],
-    "tnn_lse_merge": [_p, c_int, _p, c_int],
-    "tnn_softmax_nll_fwd_bwd": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
-    "tnn_softmax_nll_fused": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int],
-    "tnn_softmax_nll_fused_sharded": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int],
-    "tnn_softmax_nll_fused_tick": [_p, _p, c_int64, c_int64, c_int64, c_int, _p, _p, _p, c_int, _p, c_double, c_double],
-    "tnn_mlp_head": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int],
-    "tnn_mlp_head_fits": [c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
-    "tnn_mlp_head_bwd_reserve": [c_int64, c_int64, c_int64, c_int64],
-    "tnn_mlp_head_bwd_fits": [c_int64, c_int64, c_int64, c_int64, c_int, POINTER(c_int)],
-    "tnn_mlp_head_tick": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int, _p, c_double, c_double],
-    "tnn_mlp_head_bwd_tick": [c_int64, c_int64, c_int64, c_int64] + [_p] * 16 + [c_int, _p, c_double, c_double],
-    "tnn_mlp_head_bwd_tick_ext": [c_int64, c_int64, c_int64, c_int64, c_int64] + [_p] * 8 + [c_int] + [_p] * 9 + [c_int, _p, c_double, c_double],
-    "tnn_dense_fwd_head_partials": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
-                                    _p, c_int64, _p, c_int],
-    "tnn_dense_fwd_head_partials_stats": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
-                                          _p, c_int64, _p, _p, _p, _p, _p, c_int, c_int],
-    "tnn_dense_fwd_rows_head_stats": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64, _p,
-                                      c_int64, _p, _p, _p, c_int],
-    "tnn_dense_fwd_rows_head_stats_merged": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64, _p,
-                                             c_int64, _p, _p, _p, _p, _p, c_int, c_int],
-    "tnn_mse_fwd_bwd": [_p, _p, c_int64, c_int64, _p, _p, c_int],
-    "tnn_mse_fwd_bwd_tick": [_p, _p, c_int64, c_int64, _p, _p, _p, c_int, _p, c_double, c_double],
-    "tnn_sgd": [_p, _p, c_int64, c_double, c_int],
-    "tnn_dense_bwd_first_adam": [c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, c_int64,
-                                 c_double, c_double, c_double, c_double, _p, c_int],
-    "tnn_dense_bwd_first_allreduce_adam": [c_int64, c_int64, c_int64, _p, _p, _p, c_int64, c_int64, c_int64, _p, _p, _p, c_int64,
-                                           c_double, c_double, c_double, c_double, _p, c_int64, _p, c_int],
-    "tnn_optim_step": [c_int, _p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, c_int],
-    "tnn_adam": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int],
-    "tnn_adam_ex": [_p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, _p, c_int, c_int, _p, _p],
-    "tnn_gemm_bf16_nt": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, c_int, _p, c_int, c_int,
-                         _p, c_int64],
-    "tnn_gemm_bf16_nt_t": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, c_int64, _p, c_int, c_int, _p, c_int64,
-                           _p, c_int64],
-    "tnn_gemm_bf16_reserve": [c_int64, c_int64, c_int64],
-    "tnn_mse_bf16_prep": [_p, _p, c_int64, c_int64, c_int64, _p, _p, _p, _p, _p, c_int64, _p, _p, _p, _p, c_double, c_double],
-    "tnn_bias_bf16_adam_multi": [c_int, _p, c_int64, _i64p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
-    "tnn_transpose_bf16": [_p, _p, c_int64, c_int64],
-    "tnn_transpose2_bf16": [_p, _p, c_int64, c_int64, _p, _p, c_int64, c_int64],
-    "tnn_cast_bf16": [_p, _p, c_int64, c_int],
-    "tnn_colsum_bf16": [_p, _p, c_int64, c_int64],
-    "tnn_mse_bf16": [_p, _p, c_int64, c_int64, _p, _p],
-    "tnn_mse_bf16_tick": [_p, _p, c_int64, c_int64, _p, _p, _p, _p, c_double, c_double],
-    "tnn_bias_bf16_adam": [_p, c_int64, c_int64, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
-    "tnn_adam_master_bf16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
-    "tnn_adam_master_bf16_2d": [_p, _p, _p, _p, _p, _p, c_int64, c_int64, c_double, c_double, c_double, c_double, _p, c_int],
-    "tnn_gemm_bf16_nt_adam": [c_int64, c_int64, c_int64, _p, c_int64, _p, c_int64, _p, _p, _p, _p, _p, _p, c_double, c_double, c_double, c_double, _p],
-    "tnn_adam_tick": [_p, c_double, c_double],
-    "tnn_adam_master_g16": [_p, _p, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p],
-    "tnn_mlp_create": [c_int, _i64p, c_int64, c_int, c_int, c_double, c_double, c_double, c_double,
-                       c_int, POINTER(c_void_p)],
-    "tnn_mlp_destroy": [_p],
-    "tnn_mlp_arena": [_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                      POINTER(c_void_p), _i64p],
-    "tnn_mlp_optimizer_state": [_p, POINTER(ctypes.c_void_p)],
-    "tnn_mlp_param_offset": [_p, c_int, c_int, _i64p, _i64p],
-    "tnn_mlp_forward": [_p, _p, c_int64, _p],
-    "tnn_mlp_forward_stats": [_p, _p, c_int64, _p],
-    "tnn_mlp_backward": [_p, _p, _p, c_int64, c_int64, _p, _p],
-    "tnn_mlp_update": [_p],
-    "tnn_mlp_step": [_p, _p, _p, c_int64, _p],
-    "tnn_mlp_step_sharded": [_p, _p, _p, c_int64, _p],
-    "tnn_mlp_launch_window": [_p, c_int, c_int, POINTER(c_int)],
-    "tnn_mlp_keep_grads": [_p, c_int],
-    "tnn_mlp_sync_params": [_p],
-    "tnn_mlp_activation": [_p, c_int, POINTER(c_void_p)],
-    "tnn_mlp_bf16_weights": [_p, POINTER(c_void_p)],
-    "tnn_mlp_masters_sharded": [_p, POINTER(c_int)],
-    "tnn_mlp_gather_masters": [_p],
-    "tnn_comm_unique_id": [_p],
-    "tnn_comm_init": [c_int, c_int, _p],
-    "tnn_comm_destroy": [],
-    "tnn_comm_world": [POINTER(c_int), POINTER(c_int)],
-    "tnn_allreduce": [_p, c_int64, c_int, c_int],
-    "tnn_allgather": [_p, _p, c_int64, c_int],
-    "tnn_allreduce_async": [_p, c_int64, c_int, c_int],
-    "tnn_comm_join": [],
-    "tnn_reduce_scatter": [_p, _p, c_int64, c_int],
-    "tnn_comm_chain_begin": [],
-    "tnn_comm_chain_end": [],
-    "tnn_comm_wait_oldest": [],
-    "tnn_allreduce_adam": [_p, c_int64, _p, _p, _p, c_int64, c_double, c_double, c_double, c_double, _p, c_int, c_int,
-                           c_int64, _p],
-    "tnn_p2p_create": [c_int, c_int, c_int64, _p],
-    "tnn_p2p_connect": [_p],
-    "tnn_p2p_enable": [c_int],
-    "tnn_p2p_tune": [c_int],
-    "tnn_p2p_status": [POINTER(c_int), POINTER(c_int), POINTER(c_int)],
-    "tnn_p2p_poll_failed": [POINTER(c_int)],
-    "tnn_p2p_debug": [POINTER(c_int)],
-    "tnn_p2p_guard_updates": [c_int],
-    "tnn_p2p_destroy": [],
-}
+from ._signatures import _SIGNATURES, _i64p, _p        # noqa: E402  (name -> argtypes; every entry point returns int except tnn_last_error)
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ["tnn_last_error"])
 
 
 class TnnError(RuntimeError):
     """A native call returned non-zero; the message is tnn_last_error()."""
+
+
+def _fast_wrappers(path):
+    """{entry point: callable} from the compiled call-wrapper module (_host_build.py builds it; TNN_HOST_COMPILED=0 or a
+    signature table that has changed since it was built -> {}: every call goes through ctypes)."""
+    if os.environ.get("TNN_HOST_COMPILED", "1") == "0":
+        return {}
+    try:
+        import importlib.util
+        import sysconfig
+        so = os.path.join(_HERE, "_compiled", "_tnn_fastcall" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+        if not os.path.exists(so):
+            return {}
+        from . import _fastcall_gen
+        spec = importlib.util.spec_from_file_location("_tnn_fastcall", so)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.SIGNATURE_HASH != _fastcall_gen.signature_hash(_SIGNATURES):
+            return {}
+        return mod.bind(path, TnnError)
+    except (ImportError, OSError):
+        return {}
 
 
 class _Lib(object):
@@ -199,11 +71,15 @@ class _Lib(object):
         self.cdll = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
         self.cdll.tnn_last_error.restype = c_char_p
         self.cdll.tnn_last_error.argtypes = []
+        fast = _fast_wrappers(path)
         for name, argtypes in _SIGNATURES.items():
             fn = getattr(self.cdll, name)     # AttributeError here = header/library mismatch
             fn.argtypes = argtypes
             fn.restype = c_int
-            setattr(self, name[4:], self._wrap(name, fn))
+            # the compiled call wrapper of this entry point when there is one (same function, same error behaviour,
+            # arguments converted in C: _fastcall_gen.py), else the ctypes binding
+            setattr(self, name[4:], fast.get(name) or self._wrap(name, fn))
+        self.fast_calls = len(fast)
         self.kind = self.cdll.tnn_backend_kind()
 
     def _wrap(self, name, fn):
