@@ -112,7 +112,17 @@ class DeviceArray(object):
         self = object.__new__(cls)
         self._ptr = ptr
         # (shapes reach this point as tuples of Python ints from every internal caller: checked, not rebuilt)
-        if type(shape) is not tuple or any(type(v) is not int for v in shape):
+        if type(shape) is tuple:
+            n = len(shape)
+            if n == 2:
+                ok = type(shape[0]) is int and type(shape[1]) is int
+            elif n == 1:
+                ok = type(shape[0]) is int
+            else:
+                ok = n == 0 or all(type(v) is int for v in shape)
+        else:
+            ok = False
+        if not ok:
             shape = tuple(map(int, shape))
         self.shape = shape
         self.dtype = dtype if type(dtype) is np.dtype else np.dtype(dtype)
