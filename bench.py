@@ -1363,6 +1363,8 @@ def main():
                                  "recorded with tn.capture, 16 steps on their resident batches per hipGraph, and replayed (graph)")
                 paths["host_modules"] = ("compiled ahead of time from the .py sources (tinynn-autograd_amd/_host_build.py)"
                                          if tn.host_modules_compiled() else "interpreted")
+                paths["host_call_wrappers"] = ("%d of %d entry points called through generated C wrappers instead of ctypes "
+                                               "(tinynn-autograd_amd/_fastcall_gen.py)" % (_lib.get().fast_calls, len(_lib._SIGNATURES)))
                 line["paths"] = paths
                 # (before the large configurations: releasing their GBs of buffers stalls the GPU once, ~70 ms, some 50 ms later —
                 # tools/probes/epoch_stall.py; the object's `value` is a median over the steady epochs anyway)
