@@ -1490,6 +1490,26 @@ def latency_roofline(widths, rows, res, runner):
     roof["traffic"] = traffic
     if src:
         roof["traffic_unit"] = "HBM-side bytes per step, all kernels of the step (PMC, %s)" % src
+    if "per_launch_us" in roof and len(widths) >= 3:
+        # the step's largest launch against the roofline that would bound it if anything but latency did: the first layer's
+        # backward with the whole optimizer step in it (HBM: x, dz0, every parameter's p / m / v read and written)
+        n_params = sum(widths[l] * widths[l + 1] + widths[l + 1] for l in range(len(widths) - 1))
+        rest = n_params - (widths[0] * widths[1] + widths[1])
+        alg = 4 * (rows * widths[0] + rows * widths[1]) + 24 * n_params + 4 * rest
+        us = roof["per_launch_us"][-1]
+        dom = {"kernel": "dense_bwd0_adam_kernel<4> (dW0 = x^T dz0 + db0 with Adam over the whole parameter arena in the launch)",
+               "bound": "hbm", "achieved": round(alg / us / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": round(alg / us / 1e3 / PEAK_HBM_GBS, 4), "traffic": None, "algorithmic_bytes": int(alg), "us": round(us, 3),
+               "us_note": "HIP events over back-to-back replays of this launch alone (boundary + kernel)",
+               "model": "x [rows, n_in] and dz0 [rows, n_1] read; p, m, v of every parameter read and written (24 B/param); the other "
+                        "layers' gradients read (4 B/param); dW0 itself never stored"}
+        table, tsrc = load_traffic_table()
+        if table is not None:
+            for name, per in table["kernels"].items():
+                if "A" in per and name.startswith("dense_bwd0_adam_kernel<"):
+                    dom["traffic"] = per["A"]["fetch_bytes"] + per["A"]["write_bytes"]
+                    dom["traffic_unit"] = "HBM-side bytes per launch (PMC: FETCH_SIZE x 2 + WRITE_SIZE, %s)" % tsrc
+        roof["dominant_kernel"] = dom
     roof.update({"algorithmic_bytes": int(gemm_bytes + adam_bytes), "algorithmic_gflop_per_step": round(flops / 1e9, 4),
                  "hbm_frac": round((gemm_bytes + adam_bytes) / (step_us * 1e-6) / (PEAK_HBM_TBS * 1e12), 4),
                  "mfma_frac_of_whole_step": round(flops / (step_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
