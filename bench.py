@@ -477,7 +477,10 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
     out["reference_example_net"] = ex
     out["note"] = ("headline = the timed replay of pre-captured step graphs over resident batches (`value` of this line); this object "
                    "is the loop a user of examples/mnist/run.py runs.  trainer: epoch 0 pays lazy init + trainer creation + the "
-                   "capture of the epoch graph (phases_per_epoch.capture[0]); epochs >= 1 replay it (capture 0.0).")
+                   "capture of the epoch graph (phases_per_epoch.capture[0]); epochs >= 1 replay it (capture 0.0).  One early epoch of "
+                   "the first path may carry a one-off 50-80 ms GPU-side pause (a light load following this line's heavy GEMM "
+                   "measurements: not a Python collection, not a HIP call — tools/probes/epoch_stall*.py, JOURNAL.md); `value` is the "
+                   "median of the steady epochs and every epoch is listed.")
     return out
 
 
