@@ -307,6 +307,9 @@ def test_bench_single_gpu_line_has_the_contract_objects():
     assert ex["widths"] == "784-200-100-70-30-10" and ex["value"] > 0 and ex["launches_per_step"] == 8     # 2 L - 2
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["single_thread"]["cores"] == 1 and cpu["cpu_model"]
+    # `value` is the host's best leg (all BLAS threads / 8 / 1), every leg stays on the line with its thread count
+    assert cpu["value"] >= cpu["single_thread"]["value"] and cpu["value"] >= cpu["all_threads"]["value"]
+    assert cpu["cores"] == cpu[cpu["best_leg"]]["cores"]
     # `--workload A --rows 1024` is the same measurement as the strong-scaling N = 1 point
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5",
                          "--rows", "1024", "--no-extras"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
