@@ -1799,6 +1799,11 @@ def deferred_first_layer_backward_semantics():
             l_.loss(m_.forward(x_stage), y_stage).backward()
             m_.step()
     pows_before = np.asarray(model.optimizer._pows).copy()
+    # the unrelated model has an eager loss pending (its powers stand advanced for a step that has not run): capturing `model`
+    # must leave that advance exactly as it is — bit for bit, no take-back-and-redo (round-5 advisor finding)
+    other.zero_grad()
+    other_loss.loss(other.forward(x_stage), y_stage).backward()
+    assert other.optimizer._ticked
     other_before = np.asarray(other.optimizer._pows).copy()
 
     def partial2():
@@ -1807,7 +1812,8 @@ def deferred_first_layer_backward_semantics():
         out.backward()
         return out
     replay = tn.capture(partial2)                          # warmup=2
-    assert not model.optimizer._ticked and not other.optimizer._ticked
+    assert not model.optimizer._ticked and other.optimizer._ticked
+    assert np.array_equal(np.asarray(other.optimizer._pows), other_before)
     np.testing.assert_allclose(np.asarray(model.optimizer._pows)[:2], pows_before[:2], rtol=1e-12)
     ref_model, ref_loss = build(False)
     for i in range(2):
@@ -1824,7 +1830,9 @@ def deferred_first_layer_backward_semantics():
         ref_model.step()
         np.testing.assert_allclose(np.asarray(model.optimizer._pows)[:2],
                                    pows_before[:2] * np.array([0.9, 0.999]) ** (i + 1), rtol=1e-12)
-    np.testing.assert_allclose(np.asarray(other.optimizer._pows)[:2], other_before[:2], rtol=1e-12)
+    assert np.array_equal(np.asarray(other.optimizer._pows), other_before) and other.optimizer._ticked
+    other.step()                                           # ... and its own step consumes it without a second advance
+    assert np.array_equal(np.asarray(other.optimizer._pows), other_before) and not other.optimizer._ticked
     for lg, lr_ in zip(H.dense_layers(model), H.dense_layers(ref_model)):
         for k in ("w", "b"):
             np.testing.assert_allclose(np.asarray(lg.params[k].values), np.asarray(lr_.params[k].values), rtol=0, atol=0.1 * 1e-3)

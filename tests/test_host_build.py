@@ -93,6 +93,19 @@ def test_call_wrappers_match_the_signature_table_and_behave_like_ctypes():
             call(a._ptr, 1.0, 16.5, a._code())
     fast["tnn_fill"](a._ptr, np.float32(1.5), np.int64(16), a._code())              # (the wrapper also takes numpy scalars)
     assert (np.asarray(a) == 1.5).all()
+    # an address given as a numpy integer is an ADDRESS (never the scalar's own storage); exporters of the buffer protocol
+    # other than bytes / bytearray / ctypes arrays are refused with TypeError as ctypes refuses them
+    fast["tnn_fill"](np.int64(a._ptr), 3.5, 16, a._code())
+    assert (np.asarray(a) == 3.5).all()
+    b = tn.asarray(np.zeros(8, np.float32))
+    fast["tnn_memcpy_d2d"](np.int64(b._ptr), np.uint64(a._ptr), 32)
+    assert (np.asarray(b) == 3.5).all()
+    for bad in (np.zeros(16, np.float32), np.float32(1.0), ctypes.pointer(ctypes.c_int(0)), "text", 1.5):
+        with pytest.raises(TypeError):
+            fast["tnn_fill"](bad, 1.0, 16, a._code())
+    host = (ctypes.c_float * 8)()                                                    # a ctypes array passes its storage
+    fast["tnn_memcpy_d2h"](host, b._ptr, 32)
+    assert list(host) == [3.5] * 8
     # a c_void_p INSTANCE passes its value (event / graph handles), None passes NULL
     ev = _lib.Event().record()
     fast["tnn_event_record"](ev._h)

@@ -77,6 +77,12 @@ def take_capture_ticks():
     cleared here; the captured function sets them after every replay (the replay's loss launch has then really advanced the
     powers and the eager step that follows must not advance them again — exact, no extra launch in the graph).  A captured
     WHOLE step has consumed its tick: nothing to hand over."""
+    # the capture is closed: the eager advances its own launches superseded are taken back NOW (nothing of the captured function
+    # has executed, so the order "eager advance, roll back, replay advances" is what the device sees)
+    for opt in _ROLLBACK:
+        if opt._pows is not None:
+            _lib.get().adam_tick(opt._pows._ptr, 1.0 / opt._b1, 1.0 / opt._b2)
+    del _ROLLBACK[:]
     out = [opt for opt in list(_TICKED) if opt._ticked and opt._tick_captured and opt._pows is not None]
     for opt in out:
         opt._ticked = opt._tick_captured = False
@@ -84,14 +90,15 @@ def take_capture_ticks():
     return out
 
 
+_ROLLBACK = []                    # Adam instances whose pending EAGER advance was superseded inside the open capture
+
+
 def settle_eager_ticks():
-    """Start of a hipGraph capture (graph.py): an advance that an EAGER loss launch has made and no step has consumed yet
-    (a warm-up call of a loss-only function, another model's pending loss) is taken back, so that the captured function's own
-    loss launch records its advance in the graph and `take_capture_ticks` hands over exactly the optimizers that ticked while
-    the capture was open."""
-    for opt in list(_TICKED):
-        opt.untick()
-    _TICKED.clear()
+    """Start of a hipGraph capture (graph.py).  An advance that an EAGER loss launch has made and no step has consumed yet (a
+    warm-up call of a loss-only function, ANOTHER model's pending loss) is NOT touched here: only an optimizer that ticks or
+    steps again inside the captured function has its eager advance taken back — lazily, see `Adam._supersede_eager_tick` and
+    `take_capture_ticks` — so capturing one model never perturbs the bias-correction powers of an unrelated one."""
+    del _ROLLBACK[:]              # (left over from an aborted capture)
 
 
 def _flat_pair_ok(params, grads):
@@ -124,11 +131,21 @@ class Adam(BaseOptimizer):
         v_hat = self._v / (1 - self._b2 ** self._t)
         return -self.lr * m_hat / (v_hat ** 0.5 + self._eps)
 
+    def _supersede_eager_tick(self):
+        """Inside an open hipGraph capture with an EAGER advance of the powers still pending (a loss evaluated before the capture
+        whose step never ran): the captured function must record its OWN advance — a replay cannot live on one that happened
+        once, outside the graph — so the eager one is forgotten here and taken back when the capture closes
+        (`take_capture_ticks`; 1 / b is not the exact inverse in float64: an ulp at most, on this optimizer only)."""
+        if self._ticked and not self._tick_captured and _lib.capturing:
+            self._ticked = False
+            _ROLLBACK.append(self)
+
     def apply_flat(self, params, grads):
         if not (self.fused and _flat_pair_ok(params, grads)):
             return False
         self._t += 1
         self._ensure_state(grads)
+        self._supersede_eager_tick()
         if self._ticked:                             # the loss launch advanced the powers for this step
             _lib.get().adam_ex(params._ptr, grads._ptr, self._m._ptr, self._v._ptr, grads.size, self.lr, self._b1, self._b2,
                                self._eps, self._pows._ptr, None, grads._code(), 0, None, None)
@@ -143,6 +160,8 @@ class Adam(BaseOptimizer):
         the bias-correction powers for the coming step — once per optimizer step, however many losses are evaluated in
         between — else None.  The whole-step trainer does the same in its head launch; it is what lets the step's LAST launch
         carry the optimizer (apply_with_first_layer) without a launch or an arrival counter for the advance."""
+        if self.fused and self._pows is not None:
+            self._supersede_eager_tick()
         if not self.fused or self._pows is None or self._ticked:
             return None
         self._ticked = True
@@ -165,6 +184,7 @@ class Adam(BaseOptimizer):
         if not (self.fused and _flat_pair_ok(params, grads)) or grads.dtype != np.float32:
             return False
         self._ensure_state(grads)
+        self._supersede_eager_tick()
         lib = _lib.get()
         if not self._ticked:                         # no loss launch advanced the powers: a launch of its own
             lib.adam_tick(self._pows._ptr, self._b1, self._b2)
@@ -190,6 +210,7 @@ class Adam(BaseOptimizer):
         lib = _lib.get()
         self._ensure_state(grad)
         step = da.empty(grad.shape, grad.dtype)
+        self._supersede_eager_tick()
         if self._ticked:                             # see take_tick
             lib.adam_ex(None, grad._ptr, self._m._ptr, self._v._ptr, grad.size, self.lr, self._b1, self._b2,
                         self._eps, self._pows._ptr, step._ptr, grad._code(), 0, None, None)

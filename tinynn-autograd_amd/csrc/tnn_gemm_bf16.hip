@@ -230,8 +230,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_nt_kernel(BfArgs g) {
 #include "tnn_gemm_bf16_sk.h"      // sk::gemm_bf16_sk_kernel: 256-row tiles + split-K for the skinny (M = 512) products
 
 // Hand-off memory of the split-K kernel: fp32 slabs [tile][slice][256 x 128] + two counter words per tile, one set per stream
-// (two such GEMMs on different streams must not share counters).  Allocated on first use outside a capture and never
-// returned (32 MB for config E's shapes); the counters are zeroed once — every launch leaves them at zero.
+// (two such GEMMs on different streams must not share counters).  Allocated ONCE per stream, on first use outside a capture,
+// at its upper bound — sk_shape() admits at most num_cus (tile, slice) pairs, i.e. 32 MB of slabs on 256 CUs — and never
+// returned or regrown: the pointers are kernel arguments of every hipGraph captured since, so they must stay valid whatever
+// shapes later trainers ask for (growing by hipFree + hipMalloc left earlier captures replaying into freed memory).  The
+// counters are zeroed once — every launch leaves them at zero.
 struct SkWorkspace {
     float* slabs = nullptr;
     unsigned* counters = nullptr;
@@ -245,18 +248,17 @@ bool sk_workspace(hipStream_t s, int tiles, int slices, size_t slab_bytes_per_sl
     std::lock_guard<std::mutex> lk(g_sk_mu);
     SkWorkspace& w = g_sk_ws[s];
     const size_t need = (size_t)tiles * slices * slab_bytes_per_slice;
-    if (w.slab_bytes >= need && w.tiles >= tiles) {
+    constexpr int n_cnt = 4096;
+    if (w.slabs != nullptr) {                       // fixed size: a request beyond it is refused, never served by regrowing
+        if (w.slab_bytes < need || w.tiles < tiles) return false;
         *out = w;
         return true;
     }
+    const size_t cap = (size_t)tnn::num_cus() * slab_bytes_per_slice;      // tiles x slices <= CUs (sk_shape)
+    if (need > cap || tiles > n_cnt) return false;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;   // not inside a capture
-    if (hipStreamSynchronize(s) != hipSuccess) return false;          // nobody still reads the old buffers
-    if (w.slabs) (void)hipFree(w.slabs);
-    if (w.counters) (void)hipFree(w.counters);
-    w = SkWorkspace();
-    const int n_cnt = tiles > 4096 ? tiles : 4096;
-    if (hipMalloc(&w.slabs, need) != hipSuccess) { (void)hipGetLastError(); w = SkWorkspace(); return false; }
+    if (hipMalloc(&w.slabs, cap) != hipSuccess) { (void)hipGetLastError(); w = SkWorkspace(); return false; }
     if (hipMalloc(&w.counters, (size_t)n_cnt * 2 * sizeof(unsigned)) != hipSuccess ||
         hipMemset(w.counters, 0, (size_t)n_cnt * 2 * sizeof(unsigned)) != hipSuccess) {
         (void)hipGetLastError();
@@ -264,7 +266,7 @@ bool sk_workspace(hipStream_t s, int tiles, int slices, size_t slab_bytes_per_sl
         w = SkWorkspace();
         return false;
     }
-    w.slab_bytes = need;
+    w.slab_bytes = cap;
     w.tiles = n_cnt;
     *out = w;
     return true;

@@ -1306,9 +1306,11 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
     }
 }
 
-// Workspace of the generic kernel's parallel row blocks: slots + arrival counters, one set per stream, allocated outside a capture
-// (tnn_mlp_head_bwd_reserve at trainer creation, or the first eager call) and never returned; the counters are zeroed once — every
-// launch leaves them at zero.  Capped at 16 MB: wider hidden layers walk the blocks serially.
+// Workspace of the generic kernel's parallel row blocks: slots + arrival counters, one set per stream, allocated ONCE at its
+// upper bound (the 16 MB cap; wider hidden layers walk the blocks serially) outside a capture — tnn_mlp_head_bwd_reserve at
+// trainer creation, or the first eager call — and never returned or regrown: the pointers are kernel arguments of every
+// hipGraph captured since (growing by hipFree + hipMalloc left earlier captures replaying into freed memory).  The counters
+// are zeroed once — every launch leaves them at zero.
 struct HeadWs {
     float* slots = nullptr;
     unsigned* tickets = nullptr;
@@ -1321,24 +1323,22 @@ std::unordered_map<hipStream_t, HeadWs> g_head_ws;
 bool head_workspace(hipStream_t st, int units, int nblk, HeadWs* out) {
     std::lock_guard<std::mutex> lk(g_head_ws_mu);
     HeadWs& w = g_head_ws[st];
+    constexpr size_t CAP_FLOATS = ((size_t)16 << 20) / 4;
+    constexpr int MAX_UNITS = (int)(CAP_FLOATS / (2 * 288));       // a request has at least two row blocks
     const size_t need = (size_t)units * nblk * 288;
-    if (need * 4 > ((size_t)16 << 20)) return false;
-    if (w.slot_floats >= need && w.units >= units) { *out = w; return true; }
+    if (need > CAP_FLOATS || units > MAX_UNITS) return false;
+    if (w.slots != nullptr) { *out = w; return true; }
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
-    if (hipStreamSynchronize(st) != hipSuccess) return false;
-    if (w.slots) (void)hipFree(w.slots);
-    if (w.tickets) (void)hipFree(w.tickets);
-    w = HeadWs();
-    if (hipMalloc(&w.slots, need * 4) != hipSuccess) { (void)hipGetLastError(); w = HeadWs(); return false; }
-    if (hipMalloc(&w.tickets, (size_t)units * 4) != hipSuccess || hipMemset(w.tickets, 0, (size_t)units * 4) != hipSuccess) {
+    if (hipMalloc(&w.slots, CAP_FLOATS * 4) != hipSuccess) { (void)hipGetLastError(); w = HeadWs(); return false; }
+    if (hipMalloc(&w.tickets, (size_t)MAX_UNITS * 4) != hipSuccess || hipMemset(w.tickets, 0, (size_t)MAX_UNITS * 4) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipFree(w.slots);
         w = HeadWs();
         return false;
     }
-    w.slot_floats = need;
-    w.units = units;
+    w.slot_floats = CAP_FLOATS;
+    w.units = MAX_UNITS;
     *out = w;
     return true;
 }

@@ -74,8 +74,11 @@ class BatchIterator(BaseIterator):
     def _reused_epoch(self, inputs, targets, order):
         """One epoch through the persistent buffers: the same gather, written over the previous epoch's rows; the Batch
         objects (and the arrays behind them) are created once and yielded again every epoch."""
-        key = tuple((type(a), getattr(a, "shape", None), str(getattr(getattr(a, "values", a), "dtype", "")))
-                    for a in (inputs, targets))
+        # the cached Batch views were cut with the batch size of their first epoch: a changed `batch_size` attribute rebuilds
+        # them (and bumps buffers_token, so a captured epoch graph is not taken for valid).  A DIFFERENT dataset of the same
+        # type / shape / dtype is gathered into the same buffers on purpose (that is what "persistent" means here).
+        key = (self.batch_size,) + tuple((type(a), getattr(a, "shape", None), str(getattr(getattr(a, "values", a), "dtype", "")))
+                                         for a in (inputs, targets))
         if self._epoch_buffers is None or self._epoch_buffers[0] != key:
             gx, gy = inputs[order], targets[order]                 # first epoch: the ordinary gather allocates them
             n_rows = len(gx)
