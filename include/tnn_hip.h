@@ -307,6 +307,20 @@ TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_
                                       const void* y, const void* logit_partials, const void* stats_pairs, int n_pairs,
                                       void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1,
                                       void* db1, void* dx, int dtype, void* adam_pows_f64, double b1, double b2);
+/* The data-parallel form on the xGMI peer-to-peer transport with the statistics exchange DEFERRED into this launch
+ * (core/losses.py:26-27; needs tnn_p2p_connect): the forward launch in front is issued with exchange = 2
+ * (tnn_dense_fwd_head_partials_stats / tnn_dense_fwd_rows_head_stats_merged below) and has NO statistics tail; here every
+ * workgroup reduces this SHARD's {max, sum-exp} itself — n_pairs = 0: from the partial logits, rows <= 128, exactly as
+ * tnn_mlp_head_bwd_tick does on one GPU; n_pairs < 0: by merging the -n_pairs panel pairs in shard_pairs, logit_partials =
+ * whole logits (row-panel forward, 128 hidden units x 10 classes, rows <= 1024) — ONE workgroup pushes the pair to every peer
+ * (tagged 16-byte stores), and every workgroup merges the ranks' pairs, in rank order, from its own tagged slots.  Outputs as
+ * tnn_mlp_head_bwd_tick_ext (contributions to the global gradients, this rank's share of the global loss).  A peer that never
+ * sends: bounded wait, sticky failure word (tnn_p2p_status), the update behind the launch is discarded. */
+TNN_API int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
+                                       const void* x, const void* w1, const void* a, const void* w, const void* b,
+                                       const void* y, const void* logit_partials, const void* shard_pairs, int n_pairs,
+                                       void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1,
+                                       void* db1, void* dx, int dtype, void* adam_pows_f64, double b1, double b2);
 /* Forward of the hidden Dense layer in front of the classifier, C = act(A B + bias) like tnn_gemm_bias_act (NN form,
  * core/layers.py:49,98), which ALSO emits the next layer's logits as per-tile partial sums:
  *   head_z[tn][row][c] = sum_{col in [16 tn, 16 tn + 16)} C[row][col] * head_w[col][c]      (head_z: [ceil(N/16)][M][head_c])
@@ -323,6 +337,9 @@ TNN_API int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const v
  * [head_c]) and writes them to out_pair_f32[2]; exchange != 0 (needs tnn_p2p_connect): it exchanges the pair with the
  * peers over xGMI and writes the MERGED pair instead.  y [M, head_c] (labels) rides along for symmetry with the head
  * kernels' staging.  No statistics launch and nobody waits for a peer inside the head launch that follows.
+ * exchange == 2 (M <= 128; needs tnn_p2p_connect): the DEFERRED form — no statistics tail at all, ticket_u32 / out_pair_f32
+ * untouched; the launch is tnn_dense_fwd_head_partials plus one thread that advances the sequence number tagging the pairs
+ * tnn_mlp_head_bwd_tick_xchg (which must follow) exchanges.
  * f32, M <= 1024, N == 128, head_c == 10, 16-B aligned operands. */
 TNN_API int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                               int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
@@ -345,7 +362,9 @@ TNN_API int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const
  * the last workgroup to finish (arrival counter ticket_u32[0]: zero on entry, left zero) merges the ceil(M / 16) pairs in panel
  * order and leaves ONE pair in out_pair_f32 [2] — exchanged and merged with the other ranks' first when `exchange` is set
  * (xGMI peer-to-peer transport; tnn_dense_fwd_head_partials_stats's exchange).  head_z_full as above: hand it to
- * tnn_mlp_head_bwd_tick_ext with n_pairs = -1 (own merged pair) or -world (the all-gathered pairs).  core/losses.py:26-27. */
+ * tnn_mlp_head_bwd_tick_ext with n_pairs = -1 (own merged pair) or -world (the all-gathered pairs).  core/losses.py:26-27.
+ * exchange == 2 (needs tnn_p2p_connect): the DEFERRED form — the panels' pairs only (tnn_dense_fwd_rows_head_stats: no ticket,
+ * no merge, out_pair_f32 untouched) plus the sequence advance for tnn_mlp_head_bwd_tick_xchg with n_pairs = -ceil(M / 16). */
 TNN_API int tnn_dense_fwd_rows_head_stats_merged(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B,
                                                  int64_t ldb, const void* bias, int act, int relu_sign, void* C, int64_t ldc,
                                                  const void* head_w, int64_t head_c, void* head_z_full, const void* head_b,

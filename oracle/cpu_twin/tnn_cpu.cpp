@@ -712,6 +712,7 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
     RECORD(tnn_dense_fwd_head_partials_stats(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z, head_b, y,
                                              ticket, out_pair, exchange, dtype));
     if (int rc = tnn_dense_fwd_head_partials(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z, dtype)) return rc;
+    if (exchange == 2) return 0;                      // deferred exchange: no statistics tail (tnn_mlp_head_bwd_tick_xchg follows)
     std::vector<float> logits((size_t)(M * head_c));
     twin_logits_from_partials(M, N, head_c, head_b, head_z, logits.data());
     return tnn_softmax_nll_stats(logits.data(), M, head_c, out_pair, dtype);      // a one-rank exchange is the identity
@@ -756,6 +757,7 @@ int tnn_dense_fwd_rows_head_stats_merged(int64_t M, int64_t N, int64_t K, const 
                                                 pairs, ticket, out_pair, exchange, dtype));
     if (int rc = tnn_dense_fwd_rows_head_stats(M, N, K, A, lda, B, ldb, bias, act, relu_sign, C, ldc, head_w, head_c, head_z_full, head_b,
                                                pairs, dtype)) return rc;
+    if (exchange == 2) return 0;                      // deferred exchange: the panels' pairs only
     return tnn_lse_merge(pairs, (int)((M + 15) / 16), out_pair, dtype);            // a one-rank exchange is the identity
 }
 int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
@@ -783,6 +785,35 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
     std::vector<float> da((size_t)(rows * nh));
     if (int rc = tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da.data(), a, dtype)) return rc;
     return tnn_dense_bwd(rows, n_in, nh, x, da.data(), w1, dw1, db1, dx, x, dtype);
+}
+int tnn_allgather(const void*, void*, int64_t, int);
+int tnn_comm_world(int*, int*);
+int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
+                               const void* a, const void* w, const void* b, const void* y, const void* zpart, const void* shard_pairs,
+                               int n_pairs, void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
+                               void* dx, int dtype, void* pows, double b1, double b2) {
+    // the deferred statistics exchange of the HIP library (tnn_p2p.h: XchgCtx) restated with the twin's collective: the shard's
+    // pair (from the partial logits, or merged from the row-panel forward's pairs) -> all-gather over the ranks -> the form that
+    // takes every rank's pair from memory
+    NEED_INIT();
+    REQ(x && w1 && zpart && logits && dz && dw && db && dw1 && db1 && dx && dtype == TNN_F32 && n_pairs <= 0 &&
+            (n_pairs == 0 || shard_pairs),
+        "cpu twin: tnn_mlp_head_bwd_tick_xchg needs every buffer, f32, n_pairs <= 0");
+    float mine[2];
+    if (n_pairs < 0) {
+        if (int rc = tnn_lse_merge(shard_pairs, -n_pairs, mine, dtype)) return rc;
+    } else {
+        std::vector<float> z((size_t)(rows * nc));
+        twin_logits_from_partials(rows, nh, nc, b, zpart, z.data());
+        if (int rc = tnn_softmax_nll_stats(z.data(), rows, nc, mine, dtype)) return rc;
+    }
+    int rank = 0, world = 1;
+    if (int rc = tnn_comm_world(&rank, &world)) return rc;
+    std::vector<float> all((size_t)world * 2);
+    if (world > 1) { if (int rc = tnn_allgather(mine, all.data(), 2, dtype)) return rc; }
+    else { all[0] = mine[0]; all[1] = mine[1]; }
+    return tnn_mlp_head_bwd_tick_ext(rows, m_global, n_in, nh, nc, x, w1, a, w, b, y, zpart, all.data(), n_pairs < 0 ? -world : world,
+                                     logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype, pows, b1, b2);
 }
 int tnn_dense_fwd_head_partials(int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* B, int64_t ldb,
                                 const void* bias, int act, int relu_sign, void* C, int64_t ldc, const void* hw, int64_t hc,

@@ -124,7 +124,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_p2p_workers(world, traj="D_adam"):
+def _run_p2p_workers(world, traj="D_adam", **extra_env):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -132,6 +132,7 @@ def _run_p2p_workers(world, traj="D_adam"):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNN_P2P_TIMEOUT_MS="3000",
                    TNN_P2P_TEST_TIMEOUT="1", TNN_P2P_TEST_TRAJ=traj,
                    HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+        env.update(extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -162,6 +163,25 @@ def test_p2p_two_processes_five_launch_step():
     replicas identical, and the timeout drill.  One workgroup per rank waits for a peer, so ranks sharing a GPU cannot
     starve each other (`TNN_P2P_TEST_TRAJ=D_adam` with 8 workers runs the N = 8 shape on one GPU the same way)."""
     _run_p2p_workers(2, "A_adam")
+
+
+@pytest.mark.gpu
+def test_p2p_statistics_exchange_at_the_tail_of_the_forward_launch_still_works():
+    """The data-parallel step takes the DEFERRED statistics exchange by default (round 6: the head launch pushes the shard's
+    {max, sum-exp} pair and merges the ranks' pairs itself, tnn_mlp_head_bwd_tick_xchg).  TNN_DP_XCHG=0 selects the round-5
+    form — reduced, exchanged and merged by the last workgroup of the forward launch — which stays the form of generic heads
+    above 128 rows per rank: both must reproduce the reference's trajectories (128 rows per rank at 8 ranks, 512 at 2)."""
+    _run_p2p_workers(2, "A_adam", TNN_DP_XCHG="0")
+    _run_p2p_workers(2, "D_adam", TNN_DP_XCHG="0")
+
+
+@pytest.mark.gpu
+def test_p2p_four_processes_quarter_batches():
+    """configs[3] split over FOUR ranks sharing the box's GPU (256 rows per rank: the row-panel forward leaves 16 panel pairs,
+    the row-blocked head launch merges them, pushes the shard's pair and merges the four ranks' pairs) and the bs-128
+    trajectory split four ways (32 rows per rank)."""
+    _run_p2p_workers(4, "D_adam")
+    _run_p2p_workers(4, "A_adam")
 
 
 @pytest.mark.gpu

@@ -55,6 +55,9 @@ struct GemmArgs {
     const float* head_w;
     float* head_z;
     int head_c;
+    // small/latency kernel, FAST form only (tnn_dense_fwd_head_partials_stats with exchange = 2): a launch sequence that ONE
+    // thread of the launch advances — the tag of the deferred statistics exchange in the head launch behind it (tnn_p2p.h: XchgCtx)
+    unsigned int* bump;
     // EPI_ADAM (tiled kernel, tnn_gemm_tn_adam): the product is a weight gradient that Adam consumes in the epilogue;
     // C (may be NULL) receives the gradient itself
     float *ad_p, *ad_m, *ad_v;
@@ -1021,6 +1024,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_small_f32_kernel(GemmArgs g, 
     __shared__ float bsum[WAVES][64];
     if constexpr (FAST) {
         __shared__ __attribute__((aligned(16))) float head_lds[16 * 20];   // tnn_dense_fwd_head_partials: the finished tile
+        if (g.bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *g.bump += 1u;     // single writer; read by the NEXT launch
         small_tile_fast<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum, head_lds);
     } else {
         small_tile<AKC, BKC, WAVES>(g, colsum, (int)blockIdx.x, red, bsum);
@@ -1194,6 +1198,7 @@ struct RowPanelArgs {
     int M, K, relu_sign;
     const float *head_w, *head_b;    // [128][10], [10]
     float *zfull, *pairs;
+    unsigned int* bump;              // !MERGE: launch sequence of the deferred statistics exchange (GemmArgs::bump), or NULL
 };
 
 // MERGE (data-parallel step, rows > 128): the panels' pairs also meet inside the launch — every workgroup stores its pair at
@@ -1213,6 +1218,9 @@ __global__ __launch_bounds__(512) void dense_fwd_rowpanel_head_kernel(RowPanelAr
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i16 = lane & 15, grp = lane >> 4;
     const int m0 = 16 * (int)blockIdx.x, n0 = 16 * wid;
+    if constexpr (!MERGE) {
+        if (g.bump != nullptr && blockIdx.x == 0 && tid == 0) *g.bump += 1u;       // single writer; read by the NEXT launch
+    }
     const uint32_t K = (uint32_t)g.K, lda4 = (uint32_t)g.lda * 4u, ldb4 = (uint32_t)g.ldb * 4u;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(g.A), 0, (uint32_t)(((int64_t)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
@@ -2327,11 +2335,21 @@ int tnn_dense_fwd_head_partials_stats(int64_t M, int64_t N, int64_t K, const voi
     g.tiles_n = (int)(N / 16);
     g.splits = 1;
     pick_xcd_cut(g);
+    tnn::p2p::LaunchCtx ctx = {};
+    if (exchange == 2) {
+        // DEFERRED exchange (round 6): this launch has no statistics tail at all — the plain forward with its partial logits —
+        // and only advances the launch sequence that tags the pairs the head launch behind it exchanges itself
+        // (tnn_mlp_head_bwd_tick_xchg).  M <= 128: the head launch's workgroups reduce the shard's pair from the partial logits.
+        TNN_REQUIRE(M <= 128, "tnn_dense_fwd_head_partials_stats: exchange = 2 is the <= 128-row form (rows %lld)", (long long)M);
+        if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_fwd_head_partials_stats")) return rc;
+        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_head_partials_stats: the peer-to-peer transport is not enabled");
+        g.bump = ctx.xchg_seq;
+        return gemm_small(g, 0, 0, nullptr);
+    }
     HeadTail ta;
     ta.ticket = (unsigned int*)ticket_u32;
     ta.zpart = (const float*)head_z; ta.bias = (const float*)head_b; ta.y = (const float*)y;
     ta.out_pair = (float*)out_pair_f32; ta.m = (int)M; ta.exchange = exchange ? 1 : 0;
-    tnn::p2p::LaunchCtx ctx = {};
     if (exchange) {
         if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_fwd_head_partials_stats")) return rc;
         TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_head_partials_stats: the peer-to-peer transport is not enabled");
@@ -2362,7 +2380,7 @@ int tnn_dense_fwd_rows_head_stats(int64_t M, int64_t N, int64_t K, const void* A
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = (int)M; g.K = (int)K; g.relu_sign = relu_sign;
     g.head_w = (const float*)head_w; g.head_b = (const float*)head_b;
-    g.zfull = (float*)head_z_full; g.pairs = (float*)pairs_f32;
+    g.zfull = (float*)head_z_full; g.pairs = (float*)pairs_f32; g.bump = nullptr;
     hipLaunchKernelGGL(dense_fwd_rowpanel_head_kernel<false>, dim3((unsigned)((M + 15) / 16)), 512, 0, tnn::stream(), g, HeadTail{},
                        tnn::p2p::LaunchCtx{});
     TNN_LAUNCH_OK();
@@ -2388,11 +2406,22 @@ int tnn_dense_fwd_rows_head_stats_merged(int64_t M, int64_t N, int64_t K, const 
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = (int)M; g.K = (int)K; g.relu_sign = relu_sign;
     g.head_w = (const float*)head_w; g.head_b = (const float*)head_b;
-    g.zfull = (float*)head_z_full; g.pairs = (float*)pairs_f32;
+    g.zfull = (float*)head_z_full; g.pairs = (float*)pairs_f32; g.bump = nullptr;
     HeadTail ta = {};
     ta.ticket = (unsigned int*)ticket_u32;
     ta.out_pair = (float*)out_pair_f32; ta.m = (int)M; ta.exchange = exchange ? 1 : 0;
     tnn::p2p::LaunchCtx ctx = {};
+    if (exchange == 2) {
+        // DEFERRED exchange (round 6): the panels' pairs only — no ticket, no merge, no exchange in this launch; it advances the
+        // launch sequence of the exchange the head launch behind it does itself (tnn_mlp_head_bwd_tick_xchg, n_pairs < 0)
+        if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_fwd_rows_head_stats_merged")) return rc;
+        TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_rows_head_stats_merged: the peer-to-peer transport is not enabled");
+        g.bump = ctx.xchg_seq;
+        hipLaunchKernelGGL(dense_fwd_rowpanel_head_kernel<false>, dim3((unsigned)((M + 15) / 16)), 512, 0, tnn::stream(), g, HeadTail{},
+                           tnn::p2p::LaunchCtx{});
+        TNN_LAUNCH_OK();
+        return 0;
+    }
     if (exchange) {
         if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_fwd_rows_head_stats_merged")) return rc;
         TNN_REQUIRE(tnn::p2p_launch_ctx(&ctx), "tnn_dense_fwd_rows_head_stats_merged: the peer-to-peer transport is not enabled");

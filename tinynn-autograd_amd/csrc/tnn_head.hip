@@ -48,8 +48,9 @@ struct HeadMArgs {
     int vec;                         // rows even, zpart / y 16-B aligned: the partial logits are staged with 16-B loads
     int nparts;                      // tiles of zpart that exist: H / 16 partial sums, or 1 = whole logits (bias still to be added)
     int m_global;                    // data-parallel (SH kernels): rows of the GLOBAL batch; the loss written is this rank's share
-    const float* ext_pairs;          // SH == 2: {M_q, S_q} pairs from an earlier launch (head_stats_kernel [+ all-gather])
+    const float* ext_pairs;          // SH >= 2: {M_q, S_q} pairs from an earlier launch (head_stats_kernel [+ all-gather])
     int ext_n;
+    const tnn::p2p::XchgCtx* xc;     // SH == 3: the peer-to-peer group this launch exchanges the shard's pair with (device memory)
     const float *a, *w, *b, *y;
     const float* zpart;              // [H / 16][m][C] partial logits from the previous layer's tiles, or NULL
     float *logits, *dz, *stats, *loss, *dw, *db, *da;
@@ -105,7 +106,10 @@ __device__ __forceinline__ void head_stage_store(const HeadMArgs& p, const int t
 // the statistics, 3 = after dz.
 // DA = false: the caller derives the hidden layer's dz itself (mlp_head_bwd_kernel below) — no da rows, no loads for them.
 // SH (data parallel): 0 single GPU; 2 the shards' softmax statistics were reduced (and, on the peer-to-peer transport,
-// exchanged and merged) at the tail of the previous launch (dense_fwd_head_kernel) and arrive through HeadMArgs::ext_pairs
+// exchanged and merged) at the tail of the previous launch (dense_fwd_head_kernel) and arrive through HeadMArgs::ext_pairs;
+// 3 DEFERRED exchange (round 6, tnn_p2p.h: XchgCtx): every workgroup reduces the SHARD's pair itself exactly as for SH = 0,
+// one workgroup of the launch pushes it to the peers and every workgroup merges the ranks' pairs from its own tagged slots —
+// the forward launch in front has no statistics tail and nobody extends its exit by a link latency
 template <int H, int C, bool PART, int CUT, bool DA, int SH = 0>
 __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
@@ -207,6 +211,12 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     HeadStats st;
     if constexpr (SH == 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, p.ext_pairs, p.ext_n);
     else head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
+    if constexpr (SH == 3) {                                                // the shard's pair -> the batch's (all ranks)
+        __shared__ float xm[2];
+        float Mx = st.M, Sx = (float)st.S;
+        tnn::p2p::xchg_merge<512>(p.xc, Mx, Sx, false, xm);
+        st.M = Mx; st.S = (double)Sx;
+    }
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
     const float mx = st.mx, urow = st.urow;
@@ -420,6 +430,12 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     HeadStats st;
     if constexpr (SH == 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, p.ext_pairs, p.ext_n);
     else head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
+    if constexpr (SH == 3) {                       // the first tile workgroup is the launch's sender (f32 statistics: the shortest path to the pair)
+        __shared__ float xm[2];
+        float Mx = st.M, Sx = (float)st.S;
+        tnn::p2p::xchg_merge<512>(p.xc, Mx, Sx, blk == 0, xm);
+        st.M = Mx; st.S = (double)Sx;
+    }
     if constexpr (CUT == 2) {
         q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
         return;
@@ -557,7 +573,7 @@ template <int H, int C, bool PART, int CUT, bool DA, int SH = 0, bool RB = false
 __device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
     constexpr int ROWS = 128, ZS = C + 1, WS = 12, JPB = 8, G = H / JPB, KC = H / 16, NP = H / 16;
     static_assert(H == ROWS && C <= 12 && (H * C) % 4 == 0, "thread (t & 127) doubles as the hidden-unit index of the da phase");
-    static_assert(!RB || (SH == 2 && PART && !DA && CUT == 0), "row blocks exist in the form that takes the statistics from memory only");
+    static_assert(!RB || (SH >= 2 && PART && !DA && CUT == 0), "row blocks exist in the form that takes the statistics from memory only");
     constexpr int TS = ROWS + 16;                  // row stride of the transposed images: (j or c, row chunk) -> distinct banks
     __shared__ float zs[ROWS * ZS];                // logits (MFMA form only); odd row stride: conflict-free with lane = row
     __shared__ __attribute__((aligned(16))) float ws[H * WS];      // W, rows padded to 12 (columns >= C hold 0)
@@ -584,8 +600,12 @@ __device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
 
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (PART) bias4 = head_stage_bias<C, NP>(p, t);
-    float ext_ms[2] = {0.f, 0.f};                  // SH == 2: the batch's {max, sum-exp}, merged once for all row blocks
-    if constexpr (SH == 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
+    float ext_ms[2] = {0.f, 0.f};                  // SH >= 2: the batch's {max, sum-exp}, merged once for all row blocks
+    if constexpr (SH >= 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
+    if constexpr (SH == 3) {                       // ... the pairs in memory were this SHARD's: exchange and merge with the peers'
+        __shared__ float xm[2];
+        tnn::p2p::xchg_merge<512>(p.xc, ext_ms[0], ext_ms[1], false, xm);
+    }
     float dws0 = 0.f, dws1 = 0.f;                  // this thread's dW partial sums (threads < JPB * C * 4)
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};            // workgroup 0, wave 7: db partial sums
     double Lsum = 0.0;
@@ -700,7 +720,7 @@ __device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
     }
 
     HeadStats st;
-    if constexpr (SH == 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, ext_ms, 0);
+    if constexpr (SH >= 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, ext_ms, 0);
     else head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
@@ -879,8 +899,12 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     const f32x4 bias4 = head_stage_bias<C, NP>(p, t);
-    float ext_ms[2] = {0.f, 0.f};                // SH == 2: the batch's {max, sum-exp}, merged once for all row blocks
-    if constexpr (SH == 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
+    float ext_ms[2] = {0.f, 0.f};                // SH >= 2: the batch's {max, sum-exp}, merged once for all row blocks
+    if constexpr (SH >= 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
+    if constexpr (SH == 3) {                     // the first tile workgroup is the launch's sender
+        __shared__ float xm[2];
+        tnn::p2p::xchg_merge<512>(p.xc, ext_ms[0], ext_ms[1], blk == 0, xm);
+    }
     // the global reads of one row block: staged logits / labels, the mask source rows of a1, (dW) the x fragment
     HeadStage<C, NP> stg_nx;
     float a1m_nx[4], af_nx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -923,7 +947,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
         return;
     }
     HeadStats st;
-    if constexpr (SH == 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, ext_ms, 0);
+    if constexpr (SH >= 2) head_stats<C, false, true>(zc, yc, slive, sub, lane, wid, red, st, false, ext_ms, 0);
     else head_stats<C, false>(zc, yc, slive, sub, lane, wid, red, st);
     if constexpr (CUT == 2) {
         q.dx[(size_t)(blk % 64) * 512 + t] = (float)st.S + st.M + st.ec[0] + st.eyc[1] + w2f[0] + w2f[1] + w2f[2] + a1m[0] + a1m[1] + a1m[2] + a1m[3] + af[0] + af[1] + af[2] + af[3] + bf[0] + e_pre;
@@ -1018,6 +1042,8 @@ struct HeadGenArgs {
     int m, H, C, n_in;
     int m_global, ext_n;             // ext_pairs != NULL: rows of the GLOBAL batch, number of pairs (<= 64)
     const float* ext_pairs;
+    const tnn::p2p::XchgCtx* xc;     // statistics inside + DEFERRED exchange (<= 128 rows per rank; tnn_p2p.h: XchgCtx): every workgroup
+                                     // reduces the shard's pair, workgroup 0 pushes it to the peers, all merge the ranks' pairs
     const float *a, *w, *b, *y, *zpart, *x, *w1;
     float *logits, *dz, *stats, *loss, *dw, *db, *dw1, *db1, *dx;
     double* tick;
@@ -1041,6 +1067,8 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
     const int G = H / 16, tiles_in = n_in / 16, n_dw = tiles_in * G, np = H / 16;
     const int blk = (int)blockIdx.x;
     const bool ext = p.ext_pairs != nullptr;         // block-uniform
+    const bool dp = ext || p.xc != nullptr;          // data parallel: 1 / m is the GLOBAL batch's, the loss written is this rank's share
+    __shared__ float xm[2];
     double pw0 = 0.0, pw1 = 0.0;
     if (blk == 0 && t == 0 && p.tick) { pw0 = p.tick[0]; pw1 = p.tick[1]; }
     float M = 0.f;
@@ -1051,7 +1079,7 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
         M = Mx;
         S = (double)Sx;
     }
-    const double inv_m = 1.0 / (double)(ext ? p.m_global : m);
+    const double inv_m = 1.0 / (double)(dp ? p.m_global : m);
     // W2 -> LDS (every role needs it except the head's, which needs only dz): coalesced
     for (int i = t; i < H * C; i += 256) w2s[i] = p.w[i];
 
@@ -1114,6 +1142,11 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
             M = (float)red[0];
             S = red[1];
             L = red[2];
+            if (p.xc != nullptr) {                        // block-uniform: the shard's pair -> the batch's (all ranks)
+                float Sx = (float)S;
+                tnn::p2p::xchg_merge<256>(p.xc, M, Sx, blk == 0, xm);
+                S = (double)Sx;
+            }
         }
         if (t < n) {
             const float sf = live ? expf(mx - M) / (float)S : 0.f, uf = live ? (float)inv_m / qy : 0.f;
@@ -1214,8 +1247,8 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
             if (t < C) p.db[t] = dbs;
             if (t == 0) {
                 // data parallel: this rank's SHARE of the global loss (the all-reduce of the gradient arena sums the shares)
-                if (p.loss) p.loss[0] = ext ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
-                                            : (float)((double)logf((float)S) + (double)M - L * inv_m);
+                if (p.loss) p.loss[0] = dp ? (float)((((double)logf((float)S) + (double)M) * (double)m - L) * inv_m)
+                                           : (float)((double)logf((float)S) + (double)M - L * inv_m);
                 if (p.stats) { p.stats[0] = M; p.stats[1] = (float)S; }
                 if (p.tick) {
                     if (par) { pw0 = p.tick[0]; pw1 = p.tick[1]; }       // (this workgroup is not necessarily block 0)
@@ -1354,6 +1387,7 @@ bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtyp
 }
 
 int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whole_logits, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
+                          const tnn::p2p::XchgCtx* xc,
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
@@ -1368,7 +1402,9 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
         TNN_REQUIRE(ext_pairs == nullptr || (m_global >= rows && ext_n >= 1 && ext_n <= 64), "%s: m_global < rows or bad pair count", fn);
         HeadGenArgs ga;
         ga.m = (int)rows; ga.H = (int)n_hidden; ga.C = (int)n_classes; ga.n_in = (int)n_in;
-        ga.m_global = (int)m_global; ga.ext_n = ext_n; ga.ext_pairs = ext_pairs;
+        ga.m_global = (int)m_global; ga.ext_n = ext_n; ga.ext_pairs = ext_pairs; ga.xc = xc;
+        TNN_REQUIRE(xc == nullptr || (ext_pairs == nullptr && m_global >= rows),
+                    "%s: the deferred exchange of a generic head is the <= 128-row form (statistics inside)", fn);
         ga.a = (const float*)a; ga.w = (const float*)w; ga.b = (const float*)b; ga.y = (const float*)y;
         ga.zpart = (const float*)logit_partials; ga.x = (const float*)x; ga.w1 = (const float*)w1;
         ga.logits = (float*)logits; ga.dz = (float*)dz; ga.stats = (float*)stats; ga.loss = (float*)loss;
@@ -1396,7 +1432,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = (int)m_global;
-    p.ext_pairs = ext_pairs; p.ext_n = ext_n;
+    p.ext_pairs = ext_pairs; p.ext_n = ext_n; p.xc = xc;
     TNN_REQUIRE(!whole_logits || rows > 128, "%s: whole logits (n_pairs < 0) come from the row-panel forward, i.e. with more than 128 rows", fn);
     p.nparts = whole_logits ? 1 : 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
@@ -1408,6 +1444,16 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
     q.xcd = 1;
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
+    if (xc != nullptr) {
+        // data parallel, DEFERRED exchange: <= 128 rows — statistics inside as on one GPU, then exchanged; more — the panels' pairs
+        // of THIS shard from memory (row-panel forward), merged, then exchanged
+        TNN_REQUIRE(m_global >= rows && (rows <= 128 ? ext_pairs == nullptr : (ext_pairs != nullptr && ext_n >= 1 && ext_n <= 64)),
+                    "%s: m_global < rows, or the pairs do not match the row count", fn);
+        if (rows > 128) hipLaunchKernelGGL((mlp_head_bwd_rb_kernel<128, 10, 0, 3, true>), grid, 512, 0, tnn::stream(), p, q);
+        else hipLaunchKernelGGL((mlp_head_bwd_kernel<128, 10, 0, 3>), grid, 512, 0, tnn::stream(), p, q);
+        TNN_LAUNCH_OK();
+        return 0;
+    }
     if (ext_pairs != nullptr) {          // data parallel: the statistics come from the tail of the previous launch [+ all-gather]
         TNN_REQUIRE(m_global >= rows && ext_n >= 1 && ext_n <= 64, "%s: m_global < rows or bad pair count", fn);
         if (rows > 128) hipLaunchKernelGGL((mlp_head_bwd_rb_kernel<128, 10, 0, 2, true>), grid, 512, 0, tnn::stream(), p, q);
@@ -1478,7 +1524,7 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = 0;
-    p.ext_pairs = nullptr; p.ext_n = 0;
+    p.ext_pairs = nullptr; p.ext_n = 0; p.xc = nullptr;
     p.nparts = 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
@@ -1494,7 +1540,7 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
-    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, false, 0, rows, n_in, n_hidden, n_classes, x, w1, a, w, b, y, logit_partials, logits,
+    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, false, 0, rows, n_in, n_hidden, n_classes, x, w1, nullptr, a, w, b, y, logit_partials, logits,
                            dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
@@ -1507,8 +1553,29 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
     // n_pairs < 0: logit_partials holds WHOLE logits [rows][classes] without the bias (tnn_dense_fwd_rows_head_stats) and
     // there are -n_pairs pairs
     return head_bwd_launch("tnn_mlp_head_bwd_tick_ext", (const float*)stats_pairs, n_pairs < 0 ? -n_pairs : n_pairs, n_pairs < 0, m_global, rows, n_in, n_hidden,
-                           n_classes, x, w1, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
+                           n_classes, x, w1, nullptr, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
                            adam_pows_f64, b1, b2);
+}
+
+int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
+                               const void* x, const void* w1, const void* a, const void* w, const void* b, const void* y,
+                               const void* logit_partials, const void* shard_pairs, int n_pairs, void* logits, void* dz,
+                               void* stats, void* loss, void* dw, void* db, void* dw1, void* db1, void* dx, int dtype,
+                               void* adam_pows_f64, double b1, double b2) {
+    // The merged head + hidden-backward launch of a data-parallel step on the peer-to-peer transport with the DEFERRED statistics
+    // exchange (tnn_p2p.h: XchgCtx): the shard's {max, sum-exp} is reduced inside (n_pairs = 0: <= 128 rows, from the partial
+    // logits) or merged from the row-panel forward's pairs (n_pairs < 0: -n_pairs pairs, logit_partials = whole logits), pushed
+    // to the peers by one workgroup, and every workgroup merges the ranks' pairs.  The forward launch in front MUST have been
+    // issued with exchange = 2 (it advances the sequence that tags the pairs).
+    TNN_NEED_INIT();
+    TNN_REQUIRE(m_global >= 1 && n_pairs <= 0 && (n_pairs == 0 || shard_pairs != nullptr),
+                "tnn_mlp_head_bwd_tick_xchg: m_global >= 1, n_pairs = 0 (statistics inside) or < 0 (row-panel pairs of this shard)");
+    if (int rc = tnn::p2p_refuse_if_failed("tnn_mlp_head_bwd_tick_xchg")) return rc;
+    const tnn::p2p::XchgCtx* xc = tnn::p2p_xchg_ctx();
+    TNN_REQUIRE(xc != nullptr, "tnn_mlp_head_bwd_tick_xchg: the peer-to-peer transport is not enabled");
+    return head_bwd_launch("tnn_mlp_head_bwd_tick_xchg", n_pairs < 0 ? (const float*)shard_pairs : nullptr, -n_pairs, n_pairs < 0, m_global,
+                           rows, n_in, n_hidden, n_classes, x, w1, xc, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1,
+                           db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
 }  // extern "C"

@@ -930,6 +930,41 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
         // (tnn_dense_fwd_rows_head_stats_merged; pairs live behind the merged one in h->stats); otherwise the tiled forward whose
         // tail re-reads the partial logits per 128-row block behind arrival counters
         const bool row_panels = rows > 128 && h->w[L - 1] == 128 && h->w[L] == 10 && h->w[L - 2] % 4 == 0;
+        // Peer-to-peer transport (round 6): the statistics exchange is DEFERRED into the head launch — the forward launch is the
+        // single-GPU one (no acknowledgement wait, arrival ticket, system-scope re-read of the partial logits or exchange at its
+        // tail: 8.4 -> 5.2 us at 128 rows), the head launch's workgroups reduce the shard's pair as they do on one GPU, one of
+        // them pushes it to the peers and all merge the ranks' pairs from their own tagged slots (tnn_mlp_head_bwd_tick_xchg).
+        // <= 128 rows (any head the merged launch takes), or the tuned head's row-panel form above 128 rows; a generic head with
+        // more than 128 rows keeps the counter tail.  TNN_DP_XCHG=0 selects the round-5 form (A/B measurements).
+        static const bool xchg_allowed = !(getenv("TNN_DP_XCHG") && atoi(getenv("TNN_DP_XCHG")) == 0);
+        if (p2p_on && xchg_allowed && h->dtype == TNN_F32 && (rows <= 128 || row_panels)) {
+            const int n_panels = (int)((rows + 15) / 16);
+            if (row_panels)
+                MLP_TRY(tnn_dense_fwd_rows_head_stats_merged(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                             at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                             at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                             h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                             at(h->params, h->b_off[L - 1], h->esz), (char*)h->stats + 16, h->ticket,
+                                                             h->stats, 2, h->dtype));
+            else
+                MLP_TRY(tnn_dense_fwd_head_partials_stats(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
+                                                          at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],
+                                                          at(h->params, h->b_off[L - 2], h->esz), TNN_ACT_RELU, 1, h->act[L - 2],
+                                                          h->w[L - 1], at(h->params, h->w_off[L - 1], h->esz), h->w[L], h->zpart,
+                                                          at(h->params, h->b_off[L - 1], h->esz), y, h->ticket, h->stats, 2, h->dtype));
+            MLP_TRY(tnn_mlp_head_bwd_tick_xchg(rows, rows * world, h->w[L - 2], h->w[L - 1], h->w[L], h->act[L - 3],
+                                               at(h->params, h->w_off[L - 2], h->esz), h->act[L - 2],
+                                               at(h->params, h->w_off[L - 1], h->esz), at(h->params, h->b_off[L - 1], h->esz),
+                                               y, h->zpart, row_panels ? (char*)h->stats + 16 : nullptr, row_panels ? -n_panels : 0,
+                                               h->act[L - 1], h->dact[L - 1], nullptr, loss_slot,
+                                               at(h->grads, h->w_off[L - 1], h->esz), at(h->grads, h->b_off[L - 1], h->esz),
+                                               at(h->grads, h->w_off[L - 2], h->esz), at(h->grads, h->b_off[L - 2], h->esz),
+                                               h->dact[L - 3], h->dtype, h->pows, h->b1, h->b2));
+            MLP_TRY(mlp_backward_layers(h, x, rows, L - 3, 1));
+            return tnn_dense_bwd_first_allreduce_adam(rows, h->w[0], h->w[1], x, h->dact[0], h->grads, h->n_params + 1,
+                                                      h->w_off[0], h->b_off[0], h->params, h->m, h->v, h->n_params, h->lr,
+                                                      h->b1, h->b2, h->eps, h->pows, h->n_params, loss_out, h->dtype);
+        }
         if (row_panels)
             MLP_TRY(tnn_dense_fwd_rows_head_stats_merged(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],
                                                          at(h->params, h->w_off[L - 2], h->esz), h->w[L - 1],

@@ -62,6 +62,29 @@ struct LaunchCtx {                                // what a kernel embedding an 
                                                   // ar_grid polling workgroups, so the entries stay equal whichever kind runs
     unsigned* ar_gate;                            // [MAXB][GATE_STRIDE] arrival counters of such a kernel's producer workgroups
     int ar_grid;
+    uint32_t* xchg_seq;                           // launch sequence of the DEFERRED statistics exchange (XchgCtx::seq below)
+};
+
+// ---- deferred exchange of the shards' {max, sum-exp} pairs (core/losses.py:26-27 couples the shards) --------------------
+// The merged head + hidden-backward launch of a data-parallel step does the exchange ITSELF: every workgroup reduces the
+// shard's pair from the logits as the single-GPU launch does, ONE workgroup pushes it to every peer (tagged 16-byte stores,
+// one per polling row and peer), and every workgroup polls its row of its own region for the peers' pairs and merges them in
+// rank order.  The forward launch in front then has no statistics tail at all (no acknowledgement wait, arrival ticket,
+// system-scope re-read of the partial logits, no exchange: 3.2 us of an 8.4 us launch at world 1), and the link latency
+// overlaps the head launch's own start-up instead of extending the forward launch.  Nobody waits on a workgroup of its OWN
+// launch except through data it needs anyway, and a sender never waits at all — ranks that share a GPU cannot deadlock.
+//   tag   = *seq, a launch sequence advanced by the FORWARD launch of the same step (one thread of it; kernel boundary in
+//           between), so every workgroup of the head launch reads the same value however late it starts;
+//   slots = Header::flag[0][row] (a 4096-B row per polling row): [parity][source rank] x 16 B = {M, tag, S, tag}.
+// Reuse: a rank sends step k + 1's pair after its step-k all-reduce, which needs every rank's step-k gradients, which are
+// produced behind every rank's step-k head launch — so the slots of step k have been read everywhere.  A reader that finds
+// any other tag keeps polling until the bounded wait gives up (sticky `dead` word): wrong statistics are never consumed.
+constexpr int XCHG_ROWS = 32;
+struct XchgCtx {                                  // lives in DEVICE memory (tnn_p2p.hip keeps it current), kernels take a pointer
+    Peers peers;
+    uint32_t* seq;
+    int* dead;
+    int64_t timeout_ticks;
 };
 
 // Signal `val` to every peer's word [.. + rank] and wait until every peer's signal arrived in mine.
@@ -152,6 +175,7 @@ __device__ __forceinline__ void loads_landed(T (&v)[N]) {
 __device__ __forceinline__ float ll_exchange2(const Peers& p, uint32_t epoch, float mine, int* dead, int64_t timeout_ticks,
                                               size_t slots = offsetof(Header, ll)) {
     const int t = threadIdx.x, q = t >> 1, idx = t & 1;
+    if (q == p.rank) return mine;                 // this rank's own pair never travels (at world 1 nothing does)
     const uint32_t tag = epoch + 1;
     const size_t base = slots + (size_t)(epoch & 1) * MAXW * 16;
     store_sys(reinterpret_cast<uint64_t*>(p.base[q] + base + (size_t)p.rank * 16) + idx,
@@ -323,45 +347,8 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
 #ifdef TNN_AR_TRACE
     if (skip.trace && threadIdx.x == 0) skip.trace[1] = wall_clock64();
 #endif
-    // (B) reduce my slice in rank order and broadcast the result.  The (element, source) pairs of this thread are walked in
-    // order, four slots requested together (eight at once spilled registers): a thread with several elements and few
-    // sources polls them side by side instead of paying one memory round trip per element; the sum of an element still
-    // runs over the sources in rank order.
-    {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; ok && j0 < items; j0 += 4) {
-            const char* src[4];
-            bool live[4];
-            f32x4 part[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                live[u] = j < items;
-                src[u] = p.base[r] + ll_recv_off(p, live[u] ? j % W : 0, first + (live[u] ? j / W : 0) * stride);
-            }
-            ok = ll_poll<4>(src, live, part, tag, p, dead, timeout_ticks);
-            if (!ok) break;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!live[u]) continue;
-                const int x = (j0 + u) % W;
-                acc = x == 0 ? part[u] : acc + part[u];
-                if (x == W - 1) {
-                    const int64_t i = first + ((j0 + u) / W) * stride;
-                    for (int y = 0; y < W; ++y) {
-                        const int q = (r + 1 + y) % W;
-                        ll_send(p.base[q] + ll_out_off(p, r, i), acc, tag);
-                    }
-                }
-            }
-        }
-    }
-
-#ifdef TNN_AR_TRACE
-    if (skip.trace && threadIdx.x == 0) skip.trace[2] = wall_clock64();
-#endif
-    // (C) gathered result -> caller's buffer (+ the optimizer update when ADAM).  A thread that lost a poll (timeout, dead
-    // transport) updates nothing; with a peer missing that is every thread of every rank (see above).
+    // What becomes of a finished float4 of the sum (element offset i0 of buf; n = nothing): the caller's buffer, and with ADAM
+    // the optimizer update on the spot (pm / mm / vm: the parameter and moments, requested before the wait that produced g).
     float ic1 = 0.f, ic2 = 0.f, omb1 = 0.f, omb2 = 0.f;
     if constexpr (ADAM) {
         ic1 = (float)(1.0 / (1.0 - t.pows[0]));
@@ -375,7 +362,95 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
         const float mh = mi * ic1, vh = vi * ic2;
         pi = pi + (-t.lr * mh / (sqrtf(vh) + t.eps));
     };
-    for (int j0 = 0; ok && j0 < items; j0 += UN) {
+    auto consume = [&](const int64_t i0, const f32x4 g, f32x4 pm, f32x4 mm, f32x4 vm) {
+        if (i0 >= n) return;
+        if constexpr (ADAM) {
+            if (i0 + 4 <= t.n_params) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float mi = mm[k], vi = vm[k], pi = pm[k];
+                    adam1(g[k], mi, vi, pi);
+                    mm[k] = mi; vm[k] = vi; pm[k] = pi;
+                }
+                *reinterpret_cast<f32x4*>(t.m + i0) = mm;
+                *reinterpret_cast<f32x4*>(t.v + i0) = vm;
+                *reinterpret_cast<f32x4*>(t.p + i0) = pm;
+                *reinterpret_cast<f32x4*>(buf + i0) = g;
+            } else {                                         // the arena's ragged end and the slots behind it
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t i = i0 + k;
+                    if (i >= n) break;
+                    if (i < t.n_params) {
+                        float mi = t.m[i], vi = t.v[i], pi = t.p[i];
+                        adam1(g[k], mi, vi, pi);
+                        t.m[i] = mi; t.v[i] = vi; t.p[i] = pi;
+                    }
+                    buf[i] = g[k];
+                    if (i == t.scalar_index) *t.scalar_dst = g[k];
+                }
+            }
+        } else {
+            store_guarded(buf, i0, n, g);
+        }
+    };
+
+    // (B) reduce my slice in rank order and broadcast the result.  The (element, source) pairs of this thread are walked in
+    // order, GB slots requested together (eight at once spilled registers): a thread with several elements and few
+    // sources polls them side by side instead of paying one memory round trip per element; the sum of an element still
+    // runs over the sources in rank order.  The finished sum goes to every PEER's out slots — and is consumed right here for
+    // this rank itself (round 6): the owner of a slice has the sum in registers, so its own copy neither travels through an
+    // out slot nor waits for stage (C)'s poll; at world 1 stage (C) disappears, at world W the owner's share of the optimizer
+    // pass (1 / W of it) runs while the other owners' sums are still on the links.
+    {
+        constexpr int GB = ADAM ? (UN < 4 ? UN : 4) : 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; ok && j0 < items; j0 += GB) {
+            const char* src[GB];
+            bool live[GB];
+            f32x4 part[GB];
+            f32x4 pm[GB] = {}, mm[GB] = {}, vm[GB] = {};
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                const int j = j0 + u;
+                live[u] = j < items;
+                const int64_t i = first + (live[u] ? j / W : 0) * stride;
+                src[u] = p.base[r] + ll_recv_off(p, live[u] ? j % W : 0, i);
+                if constexpr (ADAM) {
+                    // the parameter / moment loads of an element this group finishes do not depend on the peers: issued under
+                    // the same wait
+                    const int64_t e = (int64_t)r * slice + 4 * i;
+                    if (live[u] && j % W == W - 1 && e + 4 <= t.n_params) {
+                        pm[u] = *reinterpret_cast<const f32x4*>(t.p + e);
+                        mm[u] = *reinterpret_cast<const f32x4*>(t.m + e);
+                        vm[u] = *reinterpret_cast<const f32x4*>(t.v + e);
+                    }
+                }
+            }
+            ok = ll_poll<GB>(src, live, part, tag, p, dead, timeout_ticks);
+            if (!ok) break;
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                if (!live[u]) continue;
+                const int x = (j0 + u) % W;
+                acc = x == 0 ? part[u] : acc + part[u];
+                if (x == W - 1) {
+                    const int64_t i = first + ((j0 + u) / W) * stride;
+                    for (int y = 0; y + 1 < W; ++y) {
+                        const int q = (r + 1 + y) % W;
+                        ll_send(p.base[q] + ll_out_off(p, r, i), acc, tag);
+                    }
+                    consume((int64_t)r * slice + 4 * i, acc, pm[u], mm[u], vm[u]);
+                }
+            }
+        }
+    }
+
+#ifdef TNN_AR_TRACE
+    if (skip.trace && threadIdx.x == 0) skip.trace[2] = wall_clock64();
+#endif
+    // (C) the other owners' results -> caller's buffer (+ the optimizer update when ADAM).  A thread that lost a poll (timeout,
+    // dead transport) updates nothing; with a peer missing that is every thread of every rank (see above).
+    for (int j0 = 0; ok && W > 1 && j0 < items; j0 += UN) {
         f32x4 g[UN] = {};
         const char* gsrc[UN];
         bool glive[UN];
@@ -383,15 +458,15 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = j0 + u;
-            glive[u] = j < items;
-            const int q = glive[u] ? j % W : 0;
-            const int64_t i = first + (glive[u] ? j / W : 0) * stride;
+            const int q = j < items ? j % W : 0;
+            glive[u] = j < items && q != r;           // this rank's own slice was consumed in stage (B)
+            const int64_t i = first + (j < items ? j / W : 0) * stride;
             gsrc[u] = p.base[r] + ll_out_off(p, q, i);
             at[u] = glive[u] ? (int64_t)q * slice + 4 * i : n;
         }
+        f32x4 pm[UN] = {}, mm[UN] = {}, vm[UN] = {};
         if constexpr (ADAM) {
             // the parameter / moment loads do not depend on the peers: issue them under the same wait
-            f32x4 pm[UN] = {}, mm[UN] = {}, vm[UN] = {};
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 if (at[u] + 4 <= t.n_params) {
@@ -400,44 +475,11 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
                     vm[u] = *reinterpret_cast<const f32x4*>(t.v + at[u]);
                 }
             }
-            ok = ll_poll<UN>(gsrc, glive, g, tag, p, dead, timeout_ticks);
-            if (!ok) break;
-#pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int64_t i0 = at[u];
-                if (i0 >= n) continue;
-                if (i0 + 4 <= t.n_params) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float mi = mm[u][k], vi = vm[u][k], pi = pm[u][k];
-                        adam1(g[u][k], mi, vi, pi);
-                        mm[u][k] = mi; vm[u][k] = vi; pm[u][k] = pi;
-                    }
-                    *reinterpret_cast<f32x4*>(t.m + i0) = mm[u];
-                    *reinterpret_cast<f32x4*>(t.v + i0) = vm[u];
-                    *reinterpret_cast<f32x4*>(t.p + i0) = pm[u];
-                    *reinterpret_cast<f32x4*>(buf + i0) = g[u];
-                } else {                                         // the arena's ragged end and the slots behind it
-                    for (int k = 0; k < 4; ++k) {
-                        const int64_t i = i0 + k;
-                        if (i >= n) break;
-                        if (i < t.n_params) {
-                            float mi = t.m[i], vi = t.v[i], pi = t.p[i];
-                            adam1(g[u][k], mi, vi, pi);
-                            t.m[i] = mi; t.v[i] = vi; t.p[i] = pi;
-                        }
-                        buf[i] = g[u][k];
-                        if (i == t.scalar_index) *t.scalar_dst = g[u][k];
-                    }
-                }
-            }
-        } else {
-            ok = ll_poll<UN>(gsrc, glive, g, tag, p, dead, timeout_ticks);
-            if (!ok) break;
-#pragma unroll
-            for (int u = 0; u < UN; ++u)
-                if (at[u] < n) store_guarded(buf, at[u], n, g[u]);
         }
+        ok = ll_poll<UN>(gsrc, glive, g, tag, p, dead, timeout_ticks);
+        if (!ok) break;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) consume(at[u], g[u], pm[u], mm[u], vm[u]);
     }
 #ifdef TNN_AR_TRACE
     if (skip.trace && threadIdx.x == 0) skip.trace[3] = wall_clock64();
@@ -468,8 +510,69 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
 
 }
 
+// ---- deferred statistics exchange (XchgCtx above): device side ------------------------------------------------------------
+__device__ __forceinline__ size_t xchg_off(const int row, const int par, const int src) {
+    return offsetof(Header, flag) + (size_t)row * FLAG_ROW + (size_t)par * MAXW * 16 + (size_t)src * 16;
+}
+// {M, S}: this shard's pair, the same in every thread of the workgroup on entry; the batch's pair (all ranks merged in rank
+// order) in every thread on return.  `sender`: block-uniform, true in exactly ONE workgroup of the launch.  lds2: two floats of
+// shared memory.  One workgroup barrier inside when world > 1; at world 1 nothing at all happens.  NT = threads per workgroup.
+template <int NT>
+__device__ __forceinline__ void xchg_merge(const XchgCtx* __restrict__ xc, float& M, float& S, const bool sender, float* lds2) {
+    if (xc == nullptr) return;
+    const int W = xc->peers.world;
+    if (W <= 1) return;
+    const int rank = xc->peers.rank, tid = threadIdx.x;
+    const uint32_t tag = *xc->seq;
+    const int par = (int)(tag & 1u);
+    if (sender) {
+        for (int s = tid; s < XCHG_ROWS * W; s += NT) {
+            const int q = s % W, row = s / W;
+            if (q != rank)
+                ll_store16(xc->peers.base[q] + xchg_off(row, par, rank), u32x4{__float_as_uint(M), tag, __float_as_uint(S), tag});
+        }
+    }
+    if (tid < 64) {
+        float mq = -INFINITY, sq = 0.f;
+        if (tid < W) {
+            if (tid == rank) {
+                mq = M; sq = S;
+            } else if (__hip_atomic_load(xc->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                const char* src = xc->peers.base[rank] + xchg_off((int)(blockIdx.x % XCHG_ROWS), par, tid);
+                uint64_t t0 = 0;
+                uint32_t polls = 0;
+                for (;;) {
+                    u32x4 v;
+                    ll_load16(v, src);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("" : "+v"(v));
+                    if (v[1] == tag && v[3] == tag) { mq = __uint_as_float(v[0]); sq = __uint_as_float(v[2]); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++polls & 63u) == 0) {
+                        const uint64_t now = wall_clock64();
+                        if (t0 == 0) t0 = now;
+                        if (__hip_atomic_load(xc->dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                        if ((int64_t)(now - t0) > xc->timeout_ticks) {
+                            mark_dead(xc->peers, xc->dead, 2, tag, v[1], (uint32_t)tid, (uint32_t)par);
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        // (a rank whose wait gave up contributes {-inf, 0}: the update behind this launch is discarded with the dead word)
+        const float Mg = tnn::wave_max_dpp(mq);
+        const float Sg = tnn::wave_sum_dpp(mq > -INFINITY ? sq * expf(mq - Mg) : 0.f);
+        if (tid == 0) { lds2[0] = Mg; lds2[1] = Sg; }
+    }
+    __syncthreads();
+    M = lds2[0];
+    S = lds2[1];
+}
+
 }  // namespace p2p
 
+const p2p::XchgCtx* p2p_xchg_ctx();                          // device pointer, NULL when the transport is not enabled
 bool p2p_world(int* rank, int* world);                       // false when no peer group exists
 bool p2p_failed();                                           // a peer barrier timed out (host mirror, no stream sync)
 int p2p_refuse_if_failed(const char* who);                   // 0, or 3 + tnn_last_error() once the transport is dead

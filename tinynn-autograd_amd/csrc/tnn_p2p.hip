@@ -39,7 +39,8 @@ namespace {
 
 using namespace tnn::p2p;
 
-// the local (cached) block: [MAXB + 1] epochs | 64 spare bytes (the sticky dead word at + 28) | the gate counters
+// the local (cached) block: [MAXB + 1] epochs | 64 spare bytes (the sticky dead word at + 28, the deferred statistics
+// exchange's launch sequence at + 32) | the gate counters
 constexpr size_t LOCAL_GATES = ((MAXB + 1) * sizeof(uint32_t) + 64 + 255) / 256 * 256;
 constexpr size_t LOCAL_BYTES = LOCAL_GATES + (size_t)MAXB * GATE_STRIDE * sizeof(uint32_t);
 
@@ -51,6 +52,8 @@ struct State {
     uint32_t* epoch = nullptr;                    // [MAXB + 1] per-block epochs, the all-gather / statistics-exchange epoch
                                                   // (local, cached)
     int* dead = nullptr;                          // sticky timeout word (local)
+    uint32_t* xchg_seq = nullptr;                 // launch sequence of the deferred statistics exchange (local; tnn_p2p.h: XchgCtx)
+    XchgCtx* xchg_dev = nullptr;                  // device copy of the XchgCtx the head kernels take a pointer to
     int* host_dead = nullptr;                     // its host-pinned mirror (hipHostMalloc, mapped): host address
     int64_t max_floats = 0;
     int64_t timeout_ticks = 0;
@@ -190,8 +193,11 @@ bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
     ctx->ar_epoch = S.epoch;
     ctx->ar_gate = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(S.epoch) + LOCAL_GATES);
     ctx->ar_grid = S.grid;
+    ctx->xchg_seq = S.xchg_seq;
     return true;
 }
+
+const p2p::XchgCtx* p2p_xchg_ctx() { return S.enabled && !p2p_failed() ? S.xchg_dev : nullptr; }
 
 bool p2p_can_allgather(int64_t n_per_rank, int dtype) {
     const int64_t bytes = n_per_rank * esize(dtype);
@@ -243,6 +249,7 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     S.p.dead_host = (int*)host_dead_dev;
     S.epoch = (uint32_t*)local;
     S.dead = (int*)((char*)local + (MAXB + 1) * sizeof(uint32_t) + 28);
+    S.xchg_seq = (uint32_t*)((char*)local + (MAXB + 1) * sizeof(uint32_t) + 32);
     S.p.rank = rank;
     S.p.world = world;
     S.p.slice_cap = cap;
@@ -272,6 +279,14 @@ int tnn_p2p_connect(const void* handles) {
         S.mapped[q] = ptr;
         S.p.base[q] = (char*)ptr;
     }
+    // what the head kernels of the deferred statistics exchange read through a pointer (fixed from here on)
+    XchgCtx xc;
+    xc.peers = S.p;
+    xc.seq = S.xchg_seq;
+    xc.dead = S.dead;
+    xc.timeout_ticks = S.timeout_ticks;
+    TNN_CHECK_HIP(hipMalloc((void**)&S.xchg_dev, sizeof(XchgCtx)));
+    TNN_CHECK_HIP(hipMemcpy(S.xchg_dev, &xc, sizeof(XchgCtx), hipMemcpyHostToDevice));
     S.enabled = true;
     return 0;
 }
@@ -339,6 +354,7 @@ int tnn_p2p_destroy(void) {
         if (S.mapped[q]) (void)hipIpcCloseMemHandle(S.mapped[q]);
     (void)hipFree(S.own);
     (void)hipFree(S.epoch);
+    if (S.xchg_dev) (void)hipFree(S.xchg_dev);
     if (S.host_dead) (void)hipHostFree(S.host_dead);
     S = State();
     return 0;
