@@ -316,6 +316,9 @@ TNN_API int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_
  * (tagged 16-byte stores), and every workgroup merges the ranks' pairs, in rank order, from its own tagged slots.  Outputs as
  * tnn_mlp_head_bwd_tick_ext (contributions to the global gradients, this rank's share of the global loss).  A peer that never
  * sends: bounded wait, sticky failure word (tnn_p2p_status), the update behind the launch is discarded. */
+/* tnn_mlp_head_bwd_xchg_fits: the shapes above, the transport enabled, and — because EVERY workgroup of that launch waits for
+ * the peers — all ranks whose launches run on this GPU fit the device together (always true with one process per GPU). */
+TNN_API int tnn_mlp_head_bwd_xchg_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, int dtype, int* fits);
 TNN_API int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
                                        const void* x, const void* w1, const void* a, const void* w, const void* b,
                                        const void* y, const void* logit_partials, const void* shard_pairs, int n_pairs,
@@ -596,6 +599,13 @@ TNN_API int tnn_allreduce_adam(void* grads, int64_t n_reduce, void* p, void* m, 
  * max_bytes) and tnn_allgather (<= 256 B per rank) are single kernels of posted peer stores and flag barriers on
  * the library stream, hipGraph-capturable, bit-identical on every rank; anything else still goes to RCCL.
  * rank/world here also serve tnn_comm_world when no RCCL communicator exists. */
+/* Before tnn_p2p_create: reserve `slot_bytes` (a multiple of 4096; 0 = none, the default) of staging per (parity, source rank)
+ * in the region the NEXT group creates — 2 x world x slot_bytes in all.  With it, and without an RCCL communicator
+ * (tnn_comm_init), tnn_reduce_scatter (bf16 / f32 sums: fp32 accumulation in rank order, one rounding) and tnn_allgather of
+ * any size go over the mapped regions (direct exchange, a flag barrier per workgroup, messages beyond a slot in chunks) — the
+ * sharded-optimizer step of configs[4] (tnn_mlp_step_sharded on a bf16 trainer) then runs on a peer-to-peer-only group, e.g.
+ * several ranks on ONE GPU, which RCCL refuses.  No reference counterpart (new). */
+TNN_API int tnn_p2p_set_bulk_bytes(int64_t slot_bytes);
 TNN_API int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64_out);
 TNN_API int tnn_p2p_connect(const void* handles /* world x 64 bytes, rank order */);
 /* workgroups of the all-reduce kernel (0 = pick from the message size; TNN_P2P_BLOCKS sets the initial value).

@@ -786,6 +786,11 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
     if (int rc = tnn_dense_bwd(rows, nh, nc, a, dz, w, dw, db, da.data(), a, dtype)) return rc;
     return tnn_dense_bwd(rows, n_in, nh, x, da.data(), w1, dw1, db1, dx, x, dtype);
 }
+int tnn_mlp_head_bwd_xchg_fits(int64_t, int64_t, int64_t, int64_t, int, int* fits) {
+    REQ(fits != nullptr, "tnn_mlp_head_bwd_xchg_fits: fits is NULL");
+    *fits = 0;                                           // no peer-to-peer transport on the twin: the step takes the all-gather form
+    return 0;
+}
 int tnn_allgather(const void*, void*, int64_t, int);
 int tnn_comm_world(int*, int*);
 int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int64_t nh, int64_t nc, const void* x, const void* w1,
@@ -1284,6 +1289,7 @@ int tnn_p2p_create(int rank, int world, int64_t, void* h) {
 int tnn_p2p_connect(const void*) { g_comm = 1; return 0; }
 int tnn_p2p_enable(int) { return 0; }
 int tnn_p2p_tune(int) { return 0; }
+int tnn_p2p_set_bulk_bytes(int64_t) { return 0; }          // (no peer-to-peer transport on the twin: tnn_p2p_create refuses)
 int tnn_p2p_status(int* c, int* e, int* d) {
     // with the collective callbacks installed there is no peer-to-peer transport: the step takes the RCCL-shaped path
     const int on = g_comm && !g_hook_allreduce;

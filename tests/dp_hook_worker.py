@@ -150,18 +150,22 @@ def main():
     print("dp_hook_worker %s rank %d/%d ok" % (mode, rank, world))
 
 
-def run_config_e_small(tn, comm, calls, rank, world, dist):
+def run_config_e_small(tn, comm, calls, rank, world, dist, width=512):
+    """calls: the collective log of the twin's hooks, or None on the HIP library (tests/p2p_zero_worker.py: the same checks with
+    the collectives on the peer-to-peer transport's bulk path, several ranks on one GPU)."""
     from oracle.closed_form import ClosedFormMLP                 # the checker
     from tinynn_autograd_amd import bf16
     from tinynn_autograd_amd.fused import MLPTrainer
     BF16, F32 = 4, 0
-    widths, rows, lr, steps = [512, 512, 512], 64, 1e-3, 3
+    widths, rows, lr, steps = [width, width, width], 64, 1e-3, 3
     m = rows * world
     rs = np.random.RandomState(91)
-    a = np.sqrt(6.0 / 1024)
-    W = [bf16.round_to_bf16(rs.uniform(-a, a, (512, 512)).astype(np.float32)) for _ in range(2)]
-    B = [bf16.round_to_bf16((rs.randn(1, 512) * 0.02).astype(np.float32)) for _ in range(2)]
-    x = bf16.round_to_bf16(rs.rand(m, 512).astype(np.float32))
+    a = np.sqrt(6.0 / (2 * width))
+    W = [bf16.round_to_bf16(rs.uniform(-a, a, (width, width)).astype(np.float32)) for _ in range(2)]
+    B = [bf16.round_to_bf16((rs.randn(1, width) * 0.02).astype(np.float32)) for _ in range(2)]
+    x = bf16.round_to_bf16(rs.rand(m, width).astype(np.float32))
+    if calls is None:
+        calls = {"seq": None}
     sl = slice(rank * rows, (rank + 1) * rows)
     trainer = MLPTrainer(widths, rows, loss="mse", optimizer="adam", lr=lr, dtype="bfloat16", comm=comm)
     trainer.set_parameters([{"w": W[i], "b": B[i]} for i in range(2)])
@@ -169,7 +173,8 @@ def run_config_e_small(tn, comm, calls, rank, world, dist):
     x16 = bf16.to_bf16(x[sl])
     losses, ref = [], []
     for s in range(steps):
-        calls["seq"] = []
+        if calls["seq"] is not None:
+            calls["seq"] = []
         losses.append(float(trainer.step(x16, x16)))
         ref.append(oracle.step(x, x)[0])
         # last layer first: reduce-scatter of the bf16 gradient slice, all-gather of the refreshed bf16 rows; then ONE
@@ -178,7 +183,7 @@ def run_config_e_small(tn, comm, calls, rank, world, dist):
         want = [("reduce_scatter", shard[1], BF16), ("allgather", shard[1], BF16),
                 ("reduce_scatter", shard[0], BF16), ("allgather", shard[0], BF16),
                 ("allreduce", widths[1] + widths[2] + 1, F32)]
-        assert calls["seq"] == want, (calls["seq"], want)
+        assert calls["seq"] is None or calls["seq"] == want, (calls["seq"], want)
     # bf16 activations / dz / dW add ~2^-9 relative noise per tensor (same bar as tests/test_gpu_bf16.py)
     np.testing.assert_allclose(losses, ref, rtol=2e-2)
     assert losses[-1] < losses[0]
@@ -219,9 +224,10 @@ def run_config_e_small(tn, comm, calls, rank, world, dist):
             except RuntimeError:
                 pass
         assert trainer.grad_view(0, "w").shape == (widths[0], widths[1])          # the gradient arena is not sharded
-    calls["seq"] = []
+    if calls["seq"] is not None:
+        calls["seq"] = []
     state = trainer.state_dict(collective=True)
-    if world > 1:
+    if world > 1 and calls["seq"] is not None:
         shard = [widths[l] // world * widths[l + 1] for l in range(2)]
         assert calls["seq"] == [("allgather", shard[l], F32) for l in range(2) for _ in range(3)], calls["seq"]
     assert trainer.masters_sharded() == 0

@@ -38,6 +38,14 @@ def main():
     sl = slice(rank * rows, (rank + 1) * rows)
     model, _ = H.build_model(cfg)
     trainer = tn.trainer_from_net(model.net, max_rows=rows, loss="softmax_nll", optimizer="adam", lr=cfg["lr"], comm=comm)
+    # which form of the statistics exchange this run takes: deferred into the head launch (every workgroup of which waits for the
+    # peers, so all ranks sharing this GPU must fit it together: tnn_mlp_head_bwd_xchg_fits) or at the tail of the forward launch
+    pw = trainer._pwidths
+    deferred = _xchg_fits(rows, pw[-3], pw[-2], pw[-1])
+    want = os.environ.get("TNN_P2P_TEST_EXPECT_XCHG")
+    if want is not None:
+        assert deferred == (want == "1"), "expected the %s form of the statistics exchange (ranks %d, rows %d)" % (
+            "deferred" if want == "1" else "forward-tail", world, rows)
     data = list(H.batches(cfg["data_seed"], 5, m, w[0], w[-1], cfg["loss"]))
     for s in range(3):                                                      # eager sharded steps
         x, y = data[s]
@@ -58,6 +66,8 @@ def main():
         buf *= 1.0 / world
     want = np.float32(sum(1.0 + r for r in range(world))) / np.float32(world)
     np.testing.assert_allclose(np.asarray(buf), want, rtol=1e-5)
+    comm.barrier()
+    _row_blocked_deferred_exchange(tn, comm, rank, world, dist)
     comm.barrier()
     # a peer that never shows up must not hang the GPU and must not corrupt training: rank 0 alone enters one more
     # sharded training step (loss exchange + all-reduce with the Adam tail).  Its barriers time out (TNN_P2P_TIMEOUT_MS),
@@ -95,6 +105,45 @@ def main():
         assert not comm.p2p_status()["enabled"]
     comm.close()
     print("p2p_worker rank %d/%d ok" % (rank, world))
+
+
+def _xchg_fits(rows, n_in, n_hidden, n_classes):
+    import ctypes
+    from tinynn_autograd_amd import _lib
+    fits = ctypes.c_int(0)
+    _lib.get().mlp_head_bwd_xchg_fits(rows, n_in, n_hidden, n_classes, _lib.F32, ctypes.byref(fits))
+    return bool(fits.value)
+
+
+def _row_blocked_deferred_exchange(tn, comm, rank, world, dist):
+    """The deferred exchange in the ROW-BLOCKED head launch (more than 128 rows per rank: the row-panel forward leaves one pair per
+    16-row panel, the head launch merges them, pushes the shard's pair and merges the ranks' pairs) with `world` ranks on one GPU.
+    A 16-wide layer in front of the 128 -> 10 head keeps the launch small enough (8 + 16 + rows / 16 workgroups per rank) that the
+    ranks fit the GPU together whatever their number — the co-residency rule of tnn_mlp_head_bwd_xchg_fits holds.  Checked against
+    the float64 closed-form oracle on the GLOBAL batch: losses to 1e-5, replicas identical."""
+    from oracle.closed_form import ClosedFormMLP             # the checker
+    from tinynn_autograd_amd.fused import MLPTrainer
+    widths, rows, lr, steps = [40, 16, 128, 10], 320, 1e-3, 4
+    assert _xchg_fits(rows, 16, 128, 10), "the small row-blocked launch must fit the GPU %d times" % world
+    m = rows * world
+    rs = np.random.RandomState(77)
+    layers = [{"w": rs.uniform(-0.3, 0.3, (a, b)).astype(np.float32), "b": rs.uniform(-0.1, 0.1, (1, b)).astype(np.float32)}
+              for a, b in zip(widths[:-1], widths[1:])]
+    data = [(rs.uniform(-1, 1, (m, widths[0])).astype(np.float32), np.eye(10, dtype=np.float32)[rs.randint(0, 10, m)])
+            for _ in range(steps)]
+    oracle = ClosedFormMLP([l["w"] for l in layers], [l["b"] for l in layers], lr=lr)
+    dp = MLPTrainer(widths, rows, loss="softmax_nll", optimizer="adam", lr=lr, comm=comm)
+    dp.set_parameters(layers)
+    sl = slice(rank * rows, (rank + 1) * rows)
+    for s, (x, y) in enumerate(data):
+        got = float(dp.step(tn.asarray(x[sl]), tn.asarray(y[sl])))
+        want = oracle.step(x, y)[0]
+        np.testing.assert_allclose(got, want, rtol=1e-5, err_msg="row-blocked deferred exchange, step %d" % s)
+    flat = np.asarray(dp.params)
+    parts = [None] * world
+    dist.all_gather_object(parts, flat.tobytes())
+    assert all(p == parts[0] for p in parts), "parameters diverged across ranks (row-blocked deferred exchange)"
+    assert not comm.p2p_status()["dead"]
 
 
 if __name__ == "__main__":

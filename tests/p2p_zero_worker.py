@@ -1,0 +1,92 @@
+"""Worker of tests/test_gpu_p2p.py::test_sharded_optimizer_step_with_ranks_sharing_the_gpu: one rank of configs[4]'s
+SHARDED-OPTIMIZER step (csrc/tnn_mlp.cpp mlp16_step_zero: per layer reduce-scatter of the bf16 weight gradient, Adam on the
+owned rows of the fp32 masters, all-gather of the refreshed bf16 rows; one small fp32 all-reduce for biases + loss) with
+rank > 0 on the HIP library.  RCCL refuses ranks that share a device, so the collectives run on the peer-to-peer transport's
+bulk path (tnn_p2p_set_bulk_bytes: direct exchange over the IPC-mapped regions).  The checks are those of the CPU twin's
+world-4 run (tests/dp_hook_worker.py mode "E"): losses against oracle/closed_form.py on bf16-rounded operands, bf16 weights
+identical on every rank and the rounding of the owner's fp32 rows, sharded masters refused / gathered / resumed bit for bit —
+here at 1024-wide x 2 layers, and first the two bulk collectives on their own against numpy."""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def bf16_bits(f):
+    u = np.ascontiguousarray(f, dtype=np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_f32(h):
+    return (np.asarray(h).astype(np.uint32) << 16).view(np.float32)
+
+
+def main():
+    import torch                        # noqa: F401  (first: one HIP runtime per process)
+    import torch.distributed as dist
+    import tinynn_autograd_amd as tn
+    from tinynn_autograd_amd import _lib
+    from tinynn_autograd_amd.dist import XgmiCommunicator
+    from dp_hook_worker import run_config_e_small
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # 1 MiB of staging per (parity, source): the fp32 master shards of the 1024-wide layers (2 MiB at world 2) go in two chunks
+    comm = XgmiCommunicator(rank, world, p2p_bytes=4 << 20, bulk_bytes=1 << 20)
+    assert comm.p2p_selftest(sizes=(1, 1000, 65536), rounds=2), "self-test failed"
+    lib = _lib.get()
+
+    # ---- the two bulk collectives against numpy: every rank can reproduce every rank's input
+    for n, rounds in ((8, 3), (4096, 3), (1 << 19, 2), (786432 + 8, 2)):      # 16 B; one chunk; exactly a slot (bf16); chunked with a ragged last chunk
+        for k in range(rounds):
+            contrib = [np.random.RandomState(1000 * k + 10 * n % 9973 + q).uniform(-2, 2, n * world).astype(np.float32) for q in range(world)]
+            # bf16 sums: fp32 accumulation in rank order, ONE rounding
+            send = tn.asarray(bf16_bits(contrib[rank]))
+            recv = tn.asarray(np.zeros(n, np.uint16))
+            lib.reduce_scatter(send._ptr, recv._ptr, n, _lib.BF16)
+            acc = bf16_f32(bf16_bits(contrib[0]))[rank * n:(rank + 1) * n].copy()
+            for q in range(1, world):
+                acc = acc + bf16_f32(bf16_bits(contrib[q]))[rank * n:(rank + 1) * n]
+            assert np.array_equal(np.asarray(recv), bf16_bits(acc)), ("reduce_scatter bf16", n, k)
+            # f32 sums in rank order
+            send = tn.asarray(contrib[rank])
+            recv = tn.asarray(np.zeros(n, np.float32))
+            lib.reduce_scatter(send._ptr, recv._ptr, n, _lib.F32)
+            acc = contrib[0][rank * n:(rank + 1) * n].copy()
+            for q in range(1, world):
+                acc = acc + contrib[q][rank * n:(rank + 1) * n]
+            assert np.array_equal(np.asarray(recv), acc), ("reduce_scatter f32", n, k)
+            # all-gather, in place like the trainer's (the rank's shard already sits at its position of the output)
+            whole = tn.asarray(np.zeros(n * world, np.float32))
+            mine = contrib[rank][:n]
+            whole[rank * n:(rank + 1) * n] = tn.asarray(mine)
+            lib.allgather(whole._ptr + rank * n * 4, whole._ptr, n, _lib.F32)
+            assert np.array_equal(np.asarray(whole), np.concatenate([contrib[q][:n] for q in range(world)])), ("allgather", n, k)
+    # captured and replayed: launch counts live in device memory
+    n = 4096
+    send = tn.asarray(bf16_bits(np.full(n * world, 1.0 + rank, np.float32)))
+    recv = tn.asarray(np.zeros(n, np.uint16))
+    graph = _lib.Graph()
+    with graph:
+        lib.reduce_scatter(send._ptr, recv._ptr, n, _lib.BF16)
+        lib.allgather(recv._ptr, send._ptr, n, _lib.BF16)
+    for _ in range(3):
+        graph.launch()
+    total = float(sum(1.0 + q for q in range(world)))
+    assert np.array_equal(bf16_f32(np.asarray(send)), np.full(n * world, total * world ** 2, np.float32)), "replayed bulk collectives"
+    assert not comm.p2p_status()["dead"]
+    comm.barrier()
+
+    # ---- configs[4] in small: the sharded-optimizer step with rank > 0 on the HIP kernels (owned-row offsets included)
+    run_config_e_small(tn, comm, None, rank, world, dist, width=1024)
+    comm.barrier()
+    comm.close()
+    print("p2p_zero_worker rank %d/%d ok" % (rank, world))
+
+
+if __name__ == "__main__":
+    main()

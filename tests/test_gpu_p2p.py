@@ -115,7 +115,38 @@ def test_p2p_eight_processes_the_n8_point():
     one GPU: the 5-launch sharded step (statistics reduced and exchanged by the last workgroup of the forward launch, tagged
     all-reduce with the Adam tail) reproduces the reference's bs-1024 trajectory, replicas identical, timeout drill green.
     Only one workgroup per rank ever waits for a peer outside the all-reduce, so the ranks cannot starve each other."""
-    _run_p2p_workers(8, "D_adam")
+    # (8 x 272 workgroups of the head launch do not fit the GPU together: on a SHARED device the step keeps the exchange at the tail of
+    # the forward launch, where one workgroup per rank waits; with one process per GPU it takes the deferred form)
+    _run_p2p_workers(8, "D_adam", TNN_P2P_TEST_EXPECT_XCHG="0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_optimizer_step_with_ranks_sharing_the_gpu(world):
+    """configs[4]'s multi-rank leg ON THE HIP LIBRARY with rank > 0: the bf16 trainer's sharded-optimizer step (mlp16_step_zero —
+    reduce-scatter of the bf16 dW, Adam on the owned rows, all-gather of the bf16 rows) at 1024-wide x 2 layers with 2 and 4 ranks on
+    the box's one GPU, collectives on the peer-to-peer transport's bulk path (RCCL refuses ranks that share a device).  The GPU
+    twin of tests/dp_hook_worker.py mode "E": see tests/p2p_zero_worker.py."""
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), TNN_DEVICE="0", WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TNN_P2P_TIMEOUT_MS="20000",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONDONTWRITEBYTECODE="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_zero_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
+        assert "p2p_zero_worker rank %d/%d ok" % (rank, world) in out
 
 
 def _free_port():
@@ -162,7 +193,7 @@ def test_p2p_two_processes_five_launch_step():
     (tnn_dense_fwd_head_partials_stats), the head launch only reads the merged pair — eager, replayed from a hipGraph,
     replicas identical, and the timeout drill.  One workgroup per rank waits for a peer, so ranks sharing a GPU cannot
     starve each other (`TNN_P2P_TEST_TRAJ=D_adam` with 8 workers runs the N = 8 shape on one GPU the same way)."""
-    _run_p2p_workers(2, "A_adam")
+    _run_p2p_workers(2, "A_adam", TNN_P2P_TEST_EXPECT_XCHG="1")      # 2 x 208 workgroups fit the GPU: the DEFERRED exchange
 
 
 @pytest.mark.gpu
@@ -190,8 +221,8 @@ def test_p2p_reference_example_net_two_and_eight_ranks():
     2 ranks (512 rows each: the generic merged head walks four blocks of 128) and 8 ranks (128 rows each) sharing the box's
     one GPU — the merged 2L - 2 launch data-parallel step for a head that is NOT the benchmark's 128 -> 10, eager and captured,
     replicas identical, timeout drill."""
-    _run_p2p_workers(2, "R_example_D")
-    _run_p2p_workers(8, "R_example_D")
+    _run_p2p_workers(2, "R_example_D")                                   # 512 rows per rank: a generic head above 128 rows keeps the forward tail
+    _run_p2p_workers(8, "R_example_D", TNN_P2P_TEST_EXPECT_XCHG="1")     # 128 rows per rank, 8 x 52 workgroups: the DEFERRED exchange, generic kernel
 
 
 @pytest.mark.gpu

@@ -248,7 +248,10 @@ int tnn_reduce_scatter(const void* send, void* recv, int64_t n_per_rank, int dty
     if (R.comm == nullptr) {
         int rank = 0, world = 1;
         (void)tnn_comm_world(&rank, &world);
-        TNN_REQUIRE(world == 1, "tnn_reduce_scatter: tnn_comm_init() has not been called");
+        // a peer-to-peer group without an RCCL communicator (TNN_COMM=xgmi): the bulk path of tnn_p2p.hip
+        if (world > 1 && tnn::p2p_can_bulk(n_per_rank, dtype, true)) return tnn::p2p_reduce_scatter(send, recv, n_per_rank, dtype);
+        TNN_REQUIRE(world == 1, "tnn_reduce_scatter: no RCCL communicator (tnn_comm_init) and no peer-to-peer bulk staging "
+                                "(tnn_p2p_set_bulk_bytes) that takes %lld elements of dtype %d", (long long)n_per_rank, dtype);
         if (recv != send) TNN_CHECK_HIP(hipMemcpyAsync(recv, send, (size_t)n_per_rank * esz, hipMemcpyDeviceToDevice, tnn::stream()));
         return 0;
     }
@@ -336,7 +339,9 @@ int tnn_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
     if (R.comm == nullptr) {
         int rank = 0, world = 1;
         (void)tnn_comm_world(&rank, &world);
-        TNN_REQUIRE(world == 1, "tnn_allgather: tnn_comm_init() has not been called");
+        if (world > 1 && tnn::p2p_can_bulk(n_per_rank, dtype, false)) return tnn::p2p_allgather_bulk(send, recv, n_per_rank, dtype);
+        TNN_REQUIRE(world == 1, "tnn_allgather: no RCCL communicator (tnn_comm_init) and no peer-to-peer bulk staging "
+                                "(tnn_p2p_set_bulk_bytes) that takes %lld elements of dtype %d", (long long)n_per_rank, dtype);
         const size_t esz = dtype == TNN_F64 || dtype == TNN_I64 ? 8 : dtype == TNN_BF16 ? 2 : dtype == TNN_U8 ? 1 : 4;
         if (recv != send) TNN_CHECK_HIP(hipMemcpyAsync(recv, send, (size_t)n_per_rank * esz, hipMemcpyDeviceToDevice, tnn::stream()));
         return 0;

@@ -1557,6 +1557,43 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
                            adam_pows_f64, b1, b2);
 }
 
+// Does the merged head launch with the DEFERRED statistics exchange take this shape — and may it be launched here?  In that
+// launch EVERY workgroup waits for the peers' pairs, so all ranks whose launches run on THIS GPU (the tests' shared-GPU groups;
+// one in a one-process-per-GPU job) must fit the device together: ranks_on_my_device x grid <= resident workgroups of the
+// kernel, which always leaves a lagging rank's earlier launches room to run.  TNN_DP_XCHG=2 skips that rule (experiments).
+int tnn_mlp_head_bwd_xchg_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, int dtype, int* fits) {
+    TNN_REQUIRE(fits != nullptr, "tnn_mlp_head_bwd_xchg_fits: fits is NULL");
+    *fits = 0;
+    if (!tnn::initialised() || tnn::p2p_xchg_ctx() == nullptr || dtype != TNN_F32 || rows < 1 || n_in < 16 || n_in % 16) return 0;
+    const bool tuned = head_multi_fits(1, n_hidden, n_classes, dtype);
+    int grid = 0, per_cu = 0;
+    if (tuned && rows <= 1024) {
+        grid = 16 + (int)(n_in / 16) * 8 + (int)((rows + 15) / 16) * (int)(n_in / 16);
+        static int per_cu_small = -1, per_cu_rb = -1;
+        if (per_cu_small < 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_small, mlp_head_bwd_kernel<128, 10, 0, 3>, 512, 0) != hipSuccess) per_cu_small = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_rb, mlp_head_bwd_rb_kernel<128, 10, 0, 3, true>, 512, 0) != hipSuccess) per_cu_rb = 0;
+            (void)hipGetLastError();
+        }
+        per_cu = rows <= 128 ? per_cu_small : per_cu_rb;
+    } else if (!tuned && head_bwd_generic_fits(rows, n_in, n_hidden, n_classes, dtype, false)) {
+        const int gh = (int)(n_hidden / 16), ti = (int)(n_in / 16);
+        grid = gh + ti * gh + (int)((rows + 15) / 16) * ti;
+        static int per_cu_gen = -1;
+        if (per_cu_gen < 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_gen, mlp_head_bwd_generic_kernel, 256, 0) != hipSuccess) per_cu_gen = 0;
+            (void)hipGetLastError();
+        }
+        per_cu = per_cu_gen;
+    } else {
+        return 0;
+    }
+    const int shared = tnn::p2p_ranks_on_my_device();
+    static const bool force = getenv("TNN_DP_XCHG") && atoi(getenv("TNN_DP_XCHG")) == 2;
+    if (shared <= 1 || force || (int64_t)shared * grid <= (int64_t)per_cu * tnn::num_cus()) *fits = 1;
+    return 0;
+}
+
 int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int64_t n_hidden, int64_t n_classes,
                                const void* x, const void* w1, const void* a, const void* w, const void* b, const void* y,
                                const void* logit_partials, const void* shard_pairs, int n_pairs, void* logits, void* dz,

@@ -936,8 +936,13 @@ static int step_sharded_impl(void* handle, const void* x, const void* y, int64_t
         // them pushes it to the peers and all merge the ranks' pairs from their own tagged slots (tnn_mlp_head_bwd_tick_xchg).
         // <= 128 rows (any head the merged launch takes), or the tuned head's row-panel form above 128 rows; a generic head with
         // more than 128 rows keeps the counter tail.  TNN_DP_XCHG=0 selects the round-5 form (A/B measurements).
+        // (every workgroup of that head launch waits for the peers: tnn_mlp_head_bwd_xchg_fits also checks that the ranks whose
+        // launches share THIS GPU — the tests' groups; never more than one in a one-process-per-GPU job — fit it together)
         static const bool xchg_allowed = !(getenv("TNN_DP_XCHG") && atoi(getenv("TNN_DP_XCHG")) == 0);
-        if (p2p_on && xchg_allowed && h->dtype == TNN_F32 && (rows <= 128 || row_panels)) {
+        int xchg_fits = 0;
+        if (p2p_on && xchg_allowed && (rows <= 128 || row_panels))
+            MLP_TRY(tnn_mlp_head_bwd_xchg_fits(rows, h->w[L - 2], h->w[L - 1], h->w[L], h->dtype, &xchg_fits));
+        if (xchg_fits) {
             const int n_panels = (int)((rows + 15) / 16);
             if (row_panels)
                 MLP_TRY(tnn_dense_fwd_rows_head_stats_merged(rows, h->w[L - 1], h->w[L - 2], h->act[L - 3], h->w[L - 2],

@@ -25,6 +25,8 @@ struct Header {                                   // start of every rank's uncac
     uint32_t ag_flag[MAXW];                       // [source rank]
     uint32_t ag_slot[2][MAXW][AG_BYTES / 4];      // [epoch parity][source rank][word]
     uint64_t ll[2][MAXW][2];                      // [epoch parity][source rank][word]: (tag << 32) | payload, see ll_exchange2
+    int32_t devid[4];                             // PCI {domain, bus, device} of the owner's GPU + 1 (written before the region is
+                                                  // exported): how a rank learns which peers share ITS device (p2p_ranks_on_my_device)
 };
 constexpr size_t HEADER_BYTES = (sizeof(Header) + 4095) / 4096 * 4096;
 
@@ -573,6 +575,7 @@ __device__ __forceinline__ void xchg_merge(const XchgCtx* __restrict__ xc, float
 }  // namespace p2p
 
 const p2p::XchgCtx* p2p_xchg_ctx();                          // device pointer, NULL when the transport is not enabled
+int p2p_ranks_on_my_device();                                // ranks of the group whose region lives on this rank's GPU (>= 1); 0 = no group
 bool p2p_world(int* rank, int* world);                       // false when no peer group exists
 bool p2p_failed();                                           // a peer barrier timed out (host mirror, no stream sync)
 int p2p_refuse_if_failed(const char* who);                   // 0, or 3 + tnn_last_error() once the transport is dead
@@ -584,4 +587,8 @@ int p2p_allreduce_adam(float* buf, int64_t n, float* p, float* m, float* v, int6
 bool p2p_can_allgather(int64_t n_per_rank, int dtype);       // enabled, <= 256 B per rank
 int p2p_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype);
 bool p2p_launch_ctx(p2p::LaunchCtx* ctx);                    // false when the transport is not enabled
+// bulk collectives over the mapped regions (tnn_p2p.hip; staging reserved with tnn_p2p_set_bulk_bytes before the group was made)
+bool p2p_can_bulk(int64_t n_per_rank, int dtype, bool sum);  // enabled, staging exists, whole 16-byte units, (sum: bf16 / f32)
+int p2p_reduce_scatter(const void* send, void* recv, int64_t n_per_rank, int dtype);
+int p2p_allgather_bulk(const void* send, void* recv, int64_t n_per_rank, int dtype);
 }  // namespace tnn

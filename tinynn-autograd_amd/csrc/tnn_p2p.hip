@@ -42,7 +42,9 @@ using namespace tnn::p2p;
 // the local (cached) block: [MAXB + 1] epochs | 64 spare bytes (the sticky dead word at + 28, the deferred statistics
 // exchange's launch sequence at + 32) | the gate counters
 constexpr size_t LOCAL_GATES = ((MAXB + 1) * sizeof(uint32_t) + 64 + 255) / 256 * 256;
-constexpr size_t LOCAL_BYTES = LOCAL_GATES + (size_t)MAXB * GATE_STRIDE * sizeof(uint32_t);
+constexpr int BULK_BLOCKS = 64;                  // workgroups of every bulk-collective launch (flag rows Header::flag[1][b])
+constexpr size_t LOCAL_BULK = LOCAL_GATES + (size_t)MAXB * GATE_STRIDE * sizeof(uint32_t);    // [BULK_BLOCKS] launch counts
+constexpr size_t LOCAL_BYTES = LOCAL_BULK + (size_t)BULK_BLOCKS * sizeof(uint32_t);
 
 struct State {
     bool open = false, enabled = false;
@@ -58,7 +60,21 @@ struct State {
     int64_t max_floats = 0;
     int64_t timeout_ticks = 0;
     int grid = MAXB;                              // workgroups of EVERY all-reduce launch (see p2p_allreduce_kernel)
+    size_t bulk_off = 0, bulk_slot = 0;           // bulk staging: region + bulk_off + (parity * W + source) * bulk_slot
+    uint32_t* bulk_epoch = nullptr;               // [BULK_BLOCKS] launch counts of the bulk collectives' workgroups (local)
+    int32_t devid[4] = {};                        // this GPU's identity (Header::devid)
+    int on_my_device = 1;                         // ranks whose region lives on this GPU, this one included
 } S;
+
+int device_identity(int32_t (&id)[4]) {
+    int dev = 0, dom = 0, bus = 0, devn = 0;
+    TNN_CHECK_HIP(hipGetDevice(&dev));
+    TNN_CHECK_HIP(hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, dev));
+    TNN_CHECK_HIP(hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, dev));
+    TNN_CHECK_HIP(hipDeviceGetAttribute(&devn, hipDeviceAttributePciDeviceId, dev));
+    id[0] = dom; id[1] = bus; id[2] = devn; id[3] = 1;
+    return 0;
+}
 
 // buf[0:n] <- sum over ranks, in place.  slice = floats per rank slice (multiple of 4, W*slice >= n).
 //   (A) my copy of slice q -> rank q's recv slots [me]         (tagged stores, nothing waits)
@@ -115,6 +131,96 @@ __global__ __launch_bounds__(THREADS) void p2p_allgather_kernel(Peers p, const u
         recv[t] = v[0];
     }
     if (threadIdx.x == 0) *epoch = e + 1;
+}
+
+// ---- bulk collectives: reduce-scatter (bf16 / f32 sums) and all-gather of bandwidth-sized messages over the same mapped
+// regions, for groups WITHOUT an RCCL communicator (TNN_COMM=xgmi; RCCL refuses ranks that share a device, and the
+// sharded-optimizer step of configs[4] — csrc/tnn_mlp.cpp mlp16_step_zero: reduce-scatter of the bf16 weight gradient, Adam
+// on the owned rows, all-gather of the bf16 rows — must be runnable with rank > 0 on a one-GPU box).  Direct exchange, every
+// byte crosses one link once: (A) rank r pushes its copy of shard q into rank q's staging slot [r] (16-byte write-through
+// stores); one flag barrier per workgroup (exchange_flags on Header::flag[1][b]: workgroup b of every rank owns the same 16-byte
+// units, so it only needs workgroup b of the peers); (B) rank q sums the W copies of its shard in rank order — fp32
+// accumulation, ONE rounding to the wire type at the end — into recv.  The all-gather pushes the rank's shard into every
+// peer's slot [r] and copies the W slots out.  Slots are double-buffered on the launch count's parity: passing barrier k + 1
+// means every peer has finished launch k, so launch k + 2 may overwrite what launch k read.  Messages larger than a slot
+// go in chunks (one launch each).  hipGraph-replayable: launch counts live in device memory.
+template <int KIND>          // 0: reduce-scatter bf16, 1: reduce-scatter f32, 2: all-gather (bytes)
+__global__ __launch_bounds__(THREADS) void p2p_bulk_kernel(Peers p, const char* __restrict__ send, char* __restrict__ recv,
+                                                           int64_t shard_bytes, int64_t off_bytes, int64_t chunk_bytes,
+                                                           size_t bulk_off, size_t bulk_slot, uint32_t* __restrict__ epoch,
+                                                           int* dead, int64_t timeout_ticks) {
+    const int W = p.world, r = p.rank, b = blockIdx.x;
+    const uint32_t e = epoch[b];
+    const size_t par_off = bulk_off + (size_t)(e & 1u) * W * bulk_slot;
+    const int64_t units = chunk_bytes / 16, first = (int64_t)b * THREADS + threadIdx.x, stride = (int64_t)gridDim.x * THREADS;
+    // (A) push
+    for (int64_t u = first; u < units; u += stride) {
+        if constexpr (KIND == 2) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(send + off_bytes + u * 16);
+            for (int y = 0; y < W; ++y) {
+                const int q = (r + 1 + y) % W;
+                store_sys(reinterpret_cast<float*>(p.base[q] + par_off + (size_t)r * bulk_slot + u * 16), v);
+            }
+        } else {
+            for (int y = 0; y < W; ++y) {
+                const int q = (r + 1 + y) % W;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(send + (int64_t)q * shard_bytes + off_bytes + u * 16);
+                store_sys(reinterpret_cast<float*>(p.base[q] + par_off + (size_t)r * bulk_slot + u * 16), v);
+            }
+        }
+    }
+    const bool ok = exchange_flags(p, offsetof(Header, flag) + ((size_t)MAXB + b) * FLAG_ROW, e + 1, dead, timeout_ticks);
+    // (B) reduce / copy out
+    for (int64_t u = first; ok && u < units; u += stride) {
+        f32x4 v[MAXW];                                    // (loops unrolled to MAXW with a predicate: the array stays in registers)
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+            if (q < W) load_sys(v[q], reinterpret_cast<const float*>(p.base[r] + par_off + (size_t)q * bulk_slot + u * 16));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < MAXW; ++q)
+            if (q < W) asm volatile("" : "+v"(v[q]));
+        if constexpr (KIND == 2) {
+#pragma unroll
+            for (int q = 0; q < MAXW; ++q)
+                if (q < W) *reinterpret_cast<f32x4*>(recv + (int64_t)q * shard_bytes + off_bytes + u * 16) = v[q];
+        } else if constexpr (KIND == 1) {
+            f32x4 acc = v[0];
+#pragma unroll
+            for (int q = 1; q < MAXW; ++q)
+                if (q < W) acc += v[q];
+            *reinterpret_cast<f32x4*>(recv + off_bytes + u * 16) = acc;
+        } else {
+            float acc[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w = __float_as_uint(v[0][k]);
+                acc[2 * k] = __uint_as_float(w << 16);
+                acc[2 * k + 1] = __uint_as_float(w & 0xffff0000u);
+            }
+#pragma unroll
+            for (int q = 1; q < MAXW; ++q) {
+                if (q >= W) continue;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = __float_as_uint(v[q][k]);
+                    acc[2 * k] += __uint_as_float(w << 16);
+                    acc[2 * k + 1] += __uint_as_float(w & 0xffff0000u);
+                }
+            }
+            f32x4 out;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t lo = __float_as_uint(acc[2 * k]), hi = __float_as_uint(acc[2 * k + 1]);
+                lo = (lo + 0x7fffu + ((lo >> 16) & 1u)) >> 16;                     // round to nearest even (finite sums)
+                hi = (hi + 0x7fffu + ((hi >> 16) & 1u)) & 0xffff0000u;
+                out[k] = __uint_as_float(hi | lo);
+            }
+            *reinterpret_cast<f32x4*>(recv + off_bytes + u * 16) = out;
+        }
+    }
+    __syncthreads();                                      // every thread has read epoch[b]
+    if (threadIdx.x == 0) epoch[b] = e + 1;
 }
 
 int esize(int dtype) {
@@ -198,6 +304,7 @@ bool p2p_launch_ctx(p2p::LaunchCtx* ctx) {
 }
 
 const p2p::XchgCtx* p2p_xchg_ctx() { return S.enabled && !p2p_failed() ? S.xchg_dev : nullptr; }
+int p2p_ranks_on_my_device() { return S.open ? S.on_my_device : 0; }
 
 bool p2p_can_allgather(int64_t n_per_rank, int dtype) {
     const int64_t bytes = n_per_rank * esize(dtype);
@@ -213,9 +320,52 @@ int p2p_allgather(const void* send, void* recv, int64_t n_per_rank, int dtype) {
     return 0;
 }
 
+bool p2p_can_bulk(int64_t n_per_rank, int dtype, bool sum) {
+    if (!S.enabled || S.bulk_slot == 0 || n_per_rank <= 0) return false;
+    const int64_t es = dtype == TNN_BF16 ? 2 : esize(dtype);
+    if (es == 0 || (n_per_rank * es) % 16 != 0) return false;
+    return !sum || dtype == TNN_BF16 || dtype == TNN_F32;
+}
+
+static int bulk_launch(int kind, const void* send, void* recv, int64_t shard_bytes) {
+    if (int rc = p2p_refuse_if_failed(kind == 2 ? "tnn_allgather" : "tnn_reduce_scatter")) return rc;
+    TNN_REQUIRE(((reinterpret_cast<uintptr_t>(send) | reinterpret_cast<uintptr_t>(recv)) & 15) == 0,
+                "peer-to-peer bulk collective: buffers must be 16-byte aligned");
+    const int64_t slot = (int64_t)S.bulk_slot;
+    for (int64_t off = 0; off < shard_bytes; off += slot) {
+        const int64_t chunk = shard_bytes - off < slot ? shard_bytes - off : slot;
+#define TNN_BULK(K)                                                                                                          \
+        hipLaunchKernelGGL(p2p_bulk_kernel<K>, dim3(BULK_BLOCKS), dim3(THREADS), 0, tnn::stream(), S.p, (const char*)send,    \
+                           (char*)recv, shard_bytes, off, chunk, S.bulk_off, S.bulk_slot, S.bulk_epoch, S.dead, S.timeout_ticks)
+        if (kind == 0) TNN_BULK(0);
+        else if (kind == 1) TNN_BULK(1);
+        else TNN_BULK(2);
+#undef TNN_BULK
+        TNN_LAUNCH_OK();
+    }
+    return 0;
+}
+
+int p2p_reduce_scatter(const void* send, void* recv, int64_t n_per_rank, int dtype) {
+    return bulk_launch(dtype == TNN_BF16 ? 0 : 1, send, recv, n_per_rank * (dtype == TNN_BF16 ? 2 : 4));
+}
+
+int p2p_allgather_bulk(const void* send, void* recv, int64_t n_per_rank, int dtype) {
+    return bulk_launch(2, send, recv, n_per_rank * (dtype == TNN_BF16 ? 2 : esize(dtype)));
+}
+
 }  // namespace tnn
 
+static int64_t g_bulk_request = 0;            // tnn_p2p_set_bulk_bytes: staging bytes per (parity, source) slot of the NEXT group
+
 extern "C" {
+
+int tnn_p2p_set_bulk_bytes(int64_t slot_bytes) {
+    TNN_REQUIRE(slot_bytes >= 0 && slot_bytes % 4096 == 0, "tnn_p2p_set_bulk_bytes: a multiple of 4096 (0 = no bulk staging)");
+    g_bulk_request = slot_bytes;
+    return 0;
+}
+
 
 int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     TNN_NEED_INIT();
@@ -227,10 +377,15 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     const int64_t max_floats = max_bytes / 4;
     int64_t cap = (max_floats + world - 1) / world;
     cap = (cap + 3) / 4 * 4;
-    const size_t bytes = HEADER_BYTES + (size_t)2 * world * cap * 8;      // recv + out halves, every payload word next to its tag
+    const size_t ll_bytes = HEADER_BYTES + (size_t)2 * world * cap * 8;   // recv + out halves, every payload word next to its tag
+    const size_t bulk_off = (ll_bytes + 4095) / 4096 * 4096;
+    const size_t bytes = bulk_off + (size_t)2 * world * (size_t)g_bulk_request;      // + the bulk collectives' staging slots
     void* region = nullptr;
     TNN_CHECK_HIP(hipExtMallocWithFlags(&region, bytes, hipDeviceMallocUncached));
     TNN_CHECK_HIP(hipMemset(region, 0, bytes));
+    int32_t devid[4];
+    if (int rc = device_identity(devid)) return rc;
+    TNN_CHECK_HIP(hipMemcpy((char*)region + offsetof(Header, devid), devid, sizeof(devid), hipMemcpyHostToDevice));
     void* local = nullptr;
     TNN_CHECK_HIP(hipMalloc(&local, LOCAL_BYTES));
     TNN_CHECK_HIP(hipMemset(local, 0, LOCAL_BYTES));
@@ -254,6 +409,10 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     S.p.world = world;
     S.p.slice_cap = cap;
     S.max_floats = max_floats;
+    memcpy(S.devid, devid, sizeof(devid));
+    S.bulk_off = bulk_off;
+    S.bulk_slot = (size_t)g_bulk_request;
+    S.bulk_epoch = (uint32_t*)((char*)local + LOCAL_BULK);
     const char* to = getenv("TNN_P2P_TIMEOUT_MS");
     const double ms = to ? atof(to) : 20000.0;
     S.timeout_ticks = (int64_t)(ms * 1e5);                      // wall_clock64(): 100 MHz
@@ -278,6 +437,15 @@ int tnn_p2p_connect(const void* handles) {
         TNN_CHECK_HIP(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
         S.mapped[q] = ptr;
         S.p.base[q] = (char*)ptr;
+    }
+    // which peers live on THIS GPU (the tests' shared-GPU groups; never in a one-process-per-GPU job): kernels in which EVERY
+    // workgroup waits for a peer are only launched when all such ranks' launches fit the device together (tnn_mlp_head_bwd_xchg_fits)
+    S.on_my_device = 1;
+    for (int q = 0; q < S.p.world; ++q) {
+        if (q == S.p.rank) continue;
+        int32_t theirs[4] = {};
+        TNN_CHECK_HIP(hipMemcpy(theirs, S.p.base[q] + offsetof(Header, devid), sizeof(theirs), hipMemcpyDeviceToHost));
+        if (theirs[3] == 1 && memcmp(theirs, S.devid, sizeof(theirs)) == 0) ++S.on_my_device;
     }
     // what the head kernels of the deferred statistics exchange read through a pointer (fixed from here on)
     XchgCtx xc;

@@ -85,13 +85,16 @@ class DeviceCommunicator(Communicator):
         self._rccl = True
         return self
 
-    def enable_p2p(self, max_bytes=8 << 20, exchange=None):
+    def enable_p2p(self, max_bytes=8 << 20, exchange=None, bulk_bytes=0):
         """Create this rank's region, swap the 64-byte IPC handles (`exchange(bytes) -> [bytes] * world`, default:
-        torch.distributed.all_gather_object on the gloo control plane) and map every peer."""
+        torch.distributed.all_gather_object on the gloo control plane) and map every peer.  bulk_bytes > 0 also reserves staging
+        for bandwidth-sized reduce-scatter / all-gather over the same regions (tnn_p2p_set_bulk_bytes: what a group WITHOUT an
+        RCCL communicator needs for the bf16 trainer's sharded-optimizer step)."""
         lib = _lib.get()
         mine = ctypes.create_string_buffer(64)
         created, failure = False, None
         try:
+            lib.p2p_set_bulk_bytes((int(bulk_bytes) + 4095) // 4096 * 4096)
             lib.p2p_create(self.rank, self.world, int(max_bytes), mine)
             created = True
         except Exception as e:                  # noqa: BLE001 - still take part in the exchange below
@@ -123,6 +126,7 @@ class DeviceCommunicator(Communicator):
             raise
         self._p2p = True
         self.p2p_bytes = int(max_bytes)
+        self.p2p_bulk_bytes = int(bulk_bytes)
         return self
 
     def set_p2p(self, on):
@@ -253,9 +257,9 @@ class RcclCommunicator(DeviceCommunicator):
 class XgmiCommunicator(DeviceCommunicator):
     """Peer-to-peer transport only (no RCCL communicator): f32 sums up to `p2p_bytes` and small all-gathers."""
 
-    def __init__(self, rank, world, p2p_bytes=8 << 20, exchange=None):
+    def __init__(self, rank, world, p2p_bytes=8 << 20, exchange=None, bulk_bytes=0):
         DeviceCommunicator.__init__(self, rank, world)
-        self.enable_p2p(p2p_bytes, exchange)
+        self.enable_p2p(p2p_bytes, exchange, bulk_bytes)
 
 
 class GlooCommunicator(Communicator):
@@ -292,13 +296,13 @@ def _want_p2p(p2p):
     return bool(p2p)
 
 
-def _try_p2p(comm, dist):
+def _try_p2p(comm, dist, bulk_bytes=0):
     """Map the peers and prove the path before trusting it: any failure — IPC refused, a wrong sum, a barrier
     timeout — on ANY rank leaves every rank on RCCL.  Returns True when the peer-to-peer path is live."""
     import torch
     ok = 1
     try:
-        comm.enable_p2p(int(os.environ.get("TNN_P2P_BYTES", str(8 << 20))))
+        comm.enable_p2p(int(os.environ.get("TNN_P2P_BYTES", str(8 << 20))), bulk_bytes=bulk_bytes)
     except Exception as e:                      # noqa: BLE001 - every failure means "stay on RCCL"
         sys.stderr.write("[tinynn_autograd_amd] xGMI peer-to-peer path unavailable on rank %d: %s\n" % (comm.rank, e))
         ok = 0
@@ -354,7 +358,9 @@ def init_from_env(backend="rccl", p2p=None):
         # peer-to-peer transport only, no RCCL communicator: RCCL refuses ranks that share a GPU, this does not —
         # how the N > 1 code paths (bench.py included) are exercised on a one-GPU box (TNN_DEVICE=0 for every rank)
         comm = DeviceCommunicator(rank, world)
-        if not _try_p2p(comm, dist):
+        # no RCCL here: bandwidth-sized reduce-scatter / all-gather (the bf16 trainer's sharded optimizer) go over the mapped
+        # regions too — 4 MiB of staging per (parity, source) unless TNN_P2P_BULK_BYTES says otherwise
+        if not _try_p2p(comm, dist, bulk_bytes=int(os.environ.get("TNN_P2P_BULK_BYTES", str(4 << 20)))):
             raise RuntimeError("TNN_COMM=xgmi: the peer-to-peer transport is not available")
         return comm
     box = [RcclCommunicator.new_unique_id() if rank == 0 else None]
