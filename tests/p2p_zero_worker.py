@@ -45,8 +45,8 @@ def main():
         for k in range(rounds):
             contrib = [np.random.RandomState(1000 * k + 10 * n % 9973 + q).uniform(-2, 2, n * world).astype(np.float32) for q in range(world)]
             # bf16 sums: fp32 accumulation in rank order, ONE rounding
-            send = tn.asarray(bf16_bits(contrib[rank]))
-            recv = tn.asarray(np.zeros(n, np.uint16))
+            send = tn.asarray(bf16_bits(contrib[rank]), dtype=np.uint16)        # (integer host arrays default to int64)
+            recv = tn.asarray(np.zeros(n, np.uint16), dtype=np.uint16)
             lib.reduce_scatter(send._ptr, recv._ptr, n, _lib.BF16)
             acc = bf16_f32(bf16_bits(contrib[0]))[rank * n:(rank + 1) * n].copy()
             for q in range(1, world):
@@ -68,8 +68,8 @@ def main():
             assert np.array_equal(np.asarray(whole), np.concatenate([contrib[q][:n] for q in range(world)])), ("allgather", n, k)
     # captured and replayed: launch counts live in device memory
     n = 4096
-    send = tn.asarray(bf16_bits(np.full(n * world, 1.0 + rank, np.float32)))
-    recv = tn.asarray(np.zeros(n, np.uint16))
+    send = tn.asarray(bf16_bits(np.full(n * world, 1.0 + rank, np.float32)), dtype=np.uint16)
+    recv = tn.asarray(np.zeros(n, np.uint16), dtype=np.uint16)
     graph = _lib.Graph()
     with graph:
         lib.reduce_scatter(send._ptr, recv._ptr, n, _lib.BF16)
@@ -82,7 +82,10 @@ def main():
     comm.barrier()
 
     # ---- configs[4] in small: the sharded-optimizer step with rank > 0 on the HIP kernels (owned-row offsets included)
-    run_config_e_small(tn, comm, None, rank, world, dist, width=1024)
+    # (losses against the float64 oracle: bf16 activations / dz / dW put ~2^-9 of relative noise on every tensor and Adam's
+    # sign-like steps — lr = 1e-3 on weights of ~0.03 — amplify it: 2.05 % at step 3 measured, against 2 % at 512 wide on the
+    # twin; the sharded step is therefore ALSO held to 1 % of the unsharded bf16 trainer of the same library on the global batch)
+    run_config_e_small(tn, comm, None, rank, world, dist, width=1024, loss_rtol=4e-2, plain_rtol=1e-2)
     comm.barrier()
     comm.close()
     print("p2p_zero_worker rank %d/%d ok" % (rank, world))

@@ -82,7 +82,8 @@ def test_sharded_trainer_on_p2p_world1_equals_the_single_gpu_trainer():
     comm = XgmiCommunicator(0, 1, p2p_bytes=2 << 20)
     try:
         for widths, rows in (([784, 256, 128, 10], 128), ([784, 256, 128, 10], 80), ([784, 256, 128, 10], 37),
-                             ([60, 48, 64, 128, 10], 128), ([784, 256, 128, 10], 320), ([40, 16, 128, 10], 1)):
+                             ([60, 48, 64, 128, 10], 128), ([784, 256, 128, 10], 320), ([40, 16, 128, 10], 1),
+                             ([784, 256, 128, 10], 1024), ([784, 256, 128, 10], 520)):        # (32 x 32 tile form of the fused launch)
             rs = np.random.RandomState(rows + len(widths))
             batches = [(tn.asarray(rs.uniform(-1, 1, (rows, widths[0])).astype(np.float32)),
                         tn.asarray(np.eye(widths[-1], dtype=np.float32)[rs.randint(0, widths[-1], rows)])) for _ in range(6)]

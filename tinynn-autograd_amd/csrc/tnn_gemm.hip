@@ -1578,30 +1578,18 @@ int gemm_small(GemmArgs& g, int transA, int transB, float* colsum) {
 // up to 4 chunks of loads in flight per wave, partial tiles meet in LDS, coalesced epilogue.  Within an 8-deep chunk the
 // lane group g = lane / 32 owns k = 4 g .. 4 g + 3 and MFMA s contracts element s of both groups — a permutation of the
 // contraction index that lets K-contiguous operands arrive as ONE 16-B load per lane and chunk.
-template <bool AKC, bool BKC, bool ADAM>
-__global__ __launch_bounds__(512) void gemm_mid_f32_kernel(GemmArgs g, float* __restrict__ colsum, AdamEpi ad, int n_tiles) {
+// One 32 x 32 tile of the mid-size kernel (workgroup `block` of the tile grid).  TO_LDS: the finished tile goes to out_lds [32][32]
+// (row-major; entries outside the matrix are not written) and the column sums of the first tile row to out_lds[1024 .. 1056)
+// instead of memory — for a caller that sends them elsewhere itself (dense_bwd0_mid_allreduce_adam_kernel).
+template <bool AKC, bool BKC, bool ADAM, bool TO_LDS = false>
+__device__ __forceinline__ void mid_tile(const GemmArgs& g, float* __restrict__ colsum, const AdamEpi& ad, const int block,
+                                         float (*red)[16][64], float (*bsum)[64], float* out_lds = nullptr) {
     constexpr int WAVES = 8, MAXC = 4;
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     constexpr uint32_t OOB = 0xffffffffu;
-    if constexpr (ADAM) {
-        if ((int)blockIdx.x >= n_tiles) {               // trailing workgroups: Adam over the other layers' flat range
-            const float ic1 = (float)(1.0 / (1.0 - ad.pows[0])), ic2 = (float)(1.0 / (1.0 - ad.pows[1]));
-            const int64_t nth = (int64_t)(gridDim.x - n_tiles) * blockDim.x;
-            for (int64_t i = (int64_t)(blockIdx.x - n_tiles) * blockDim.x + threadIdx.x; i < ad.fn; i += nth) {
-                float m = ad.fm[i], v = ad.fv[i];
-                ad.fp[i] = adam_apply(ad, ic1, ic2, ad.fg[i], m, v, ad.fp[i]);
-                ad.fm[i] = m;
-                ad.fv[i] = v;
-            }
-            return;
-        }
-    }
-    __shared__ float red[WAVES][16][64];
-    __shared__ float bsum[WAVES][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int block = (int)blockIdx.x;
     int tm, tn;
     if (g.xg_m) {
         const int xcd = block & 7, idx = block >> 3, pm = g.tiles_m / g.xg_m, pn = g.tiles_n / g.xg_n;
@@ -1709,7 +1697,8 @@ __global__ __launch_bounds__(512) void gemm_mid_f32_kernel(GemmArgs g, float* __
         if (e_live[u]) {
             const float val = finish_epilogue(g, sres, e_pre[u]);
             const int64_t o = e_row[u] * g.ldc + e_col;
-            if (!ADAM || g.C != nullptr) g.C[o] = val;
+            if constexpr (TO_LDS) out_lds[(int)(e_row[u] - m0) * 32 + l31] = val;
+            else if (!ADAM || g.C != nullptr) g.C[o] = val;
             if constexpr (ADAM) {
                 ad.pw[o] = adam_apply(ad, ic1, ic2, val, a_m[u], a_v[u], a_p[u]);
                 ad.mw[o] = a_m[u];
@@ -1717,17 +1706,43 @@ __global__ __launch_bounds__(512) void gemm_mid_f32_kernel(GemmArgs g, float* __
             }
         }
     }
-    if (colsum != nullptr && tm == 0 && tid < 32 && n0 + tid < g.N) {
+    if ((TO_LDS || colsum != nullptr) && tm == 0 && tid < 32 && n0 + tid < g.N) {
         float sres = 0.f;
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) sres += bsum[w][tid] + bsum[w][32 + tid];
-        colsum[n0 + tid] = sres;
+        if constexpr (TO_LDS) out_lds[1024 + tid] = sres;
+        else colsum[n0 + tid] = sres;
         if constexpr (ADAM) {
             ad.pb[n0 + tid] = adam_apply(ad, ic1, ic2, sres, ab_m, ab_v, ab_p);
             ad.mb[n0 + tid] = ab_m;
             ad.vb[n0 + tid] = ab_v;
         }
     }
+}
+
+
+template <bool AKC, bool BKC, bool ADAM>
+__global__ __launch_bounds__(512) void gemm_mid_f32_kernel(GemmArgs g, float* __restrict__ colsum, AdamEpi ad, int n_tiles) {
+    constexpr int WAVES = 8, MAXC = 4;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    constexpr uint32_t OOB = 0xffffffffu;
+    if constexpr (ADAM) {
+        if ((int)blockIdx.x >= n_tiles) {               // trailing workgroups: Adam over the other layers' flat range
+            const float ic1 = (float)(1.0 / (1.0 - ad.pows[0])), ic2 = (float)(1.0 / (1.0 - ad.pows[1]));
+            const int64_t nth = (int64_t)(gridDim.x - n_tiles) * blockDim.x;
+            for (int64_t i = (int64_t)(blockIdx.x - n_tiles) * blockDim.x + threadIdx.x; i < ad.fn; i += nth) {
+                float m = ad.fm[i], v = ad.fv[i];
+                ad.fp[i] = adam_apply(ad, ic1, ic2, ad.fg[i], m, v, ad.fp[i]);
+                ad.fm[i] = m;
+                ad.fv[i] = v;
+            }
+            return;
+        }
+    }
+    __shared__ float red[WAVES][16][64];
+    __shared__ float bsum[WAVES][64];
+    mid_tile<AKC, BKC, ADAM>(g, colsum, ad, (int)blockIdx.x, red, bsum);
 }
 
 // the mid-size kernel takes 16-B loads on its K-contiguous operands: alignment, ld % 4 == 0, K % 4 == 0, extents below 2 GiB
@@ -1770,6 +1785,67 @@ int gemm_mid(GemmArgs& g, int transA, int transB, float* colsum) {
 #undef TNN_MID
     TNN_LAUNCH_OK();
     return 0;
+}
+
+// dense_bwd0_allreduce_adam_kernel for shards of more than 256 rows (the 32 x 32 tile form: 200 tiles of the 784 x 256 weight
+// gradient at 512 / 1024 rows per rank): blocks [0, n_dw) compute a tile and push its 256 float4 (+ 8 of the column sums in the
+// first tile row) straight into the owners' receive slots; blocks >= n_dw are the transport's polling workgroups (stage A for the
+// rest of the arena, stages B and C with Adam) — one launch instead of tnn_dense_bwd + tnn_allreduce_adam, and the pollers'
+// start-up and rest-of-arena sends hide behind the product (round 6; tags and gates as in the 16 x 16 form).
+__global__ __launch_bounds__(512) void dense_bwd0_mid_allreduce_adam_kernel(GemmArgs gw, ArTileArgs f, tnn::p2p::LaunchCtx ctx,
+                                                                            tnn::p2p::AdamTail t) {
+    using namespace tnn::p2p;
+    __shared__ float red[8][16][64];
+    __shared__ float bsum[8][64];
+    __shared__ __attribute__((aligned(16))) float tile[32 * 32 + 32];
+    const Peers& p = ctx.peers;
+    const int tid = threadIdx.x, P = ctx.ar_grid;
+    if ((int)blockIdx.x < f.n_dw) {
+        const int b = (int)blockIdx.x % P;
+        const uint32_t tag = ctx.ar_epoch[b] + 1;
+        const AdamEpi none = {};
+        mid_tile<false, false, false, true>(gw, nullptr, none, (int)blockIdx.x, red, bsum, tile);
+        __syncthreads();
+        if (tid < 264 && __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            int tm, tn;
+            small_tile_coords(gw, (int)blockIdx.x, tm, tn);            // (the same XCD-aware order as mid_tile)
+            const int64_t m0 = (int64_t)tm * 32, n0 = (int64_t)tn * 32;
+            int64_t e;
+            bool live;
+            f32x4 v;
+            if (tid < 256) {
+                const int row = tid >> 3, c4 = tid & 7;
+                live = m0 + row < gw.M && n0 + 4 * c4 < gw.N;
+                e = f.w_off + (m0 + row) * gw.ldc + n0 + 4 * c4;
+                v = *reinterpret_cast<const f32x4*>(tile + row * 32 + 4 * c4);
+            } else {
+                const int c4 = tid - 256;
+                live = tm == 0 && n0 + 4 * c4 < gw.N;
+                e = f.b_off + n0 + 4 * c4;
+                v = *reinterpret_cast<const f32x4*>(tile + 1024 + 4 * c4);
+            }
+            if (live) {
+                const int q = (int)(e / f.slice);
+                ll_send(p.base[q] + ll_recv_off(p, p.rank, (e - (int64_t)q * f.slice) / 4), v, tag);
+            }
+        }
+        __syncthreads();                                  // every thread has its tag, the stores are issued
+        if (tid == 0) __hip_atomic_fetch_add(ctx.ar_gate + b * GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int b = (int)blockIdx.x - f.n_dw;               // polling workgroup b of P
+    const uint32_t tag = ctx.ar_epoch[b] + 1;
+    unsigned* const gate = ctx.ar_gate + b * GATE_STRIDE;
+    SkipRanges skip;
+    skip.lo0 = f.w_off; skip.hi0 = f.w_off + gw.M * gw.N;
+    skip.lo1 = f.b_off; skip.hi1 = f.b_off + gw.N;
+    allreduce_body<true, 2>(p, f.buf, f.n, f.slice, tag, ctx.dead, ctx.timeout_ticks, t, (int64_t)b * 512 + tid, (int64_t)P * 512, skip,
+                            gate, b < f.n_dw ? (unsigned)((f.n_dw - b + P - 1) / P) : 0u);
+    __syncthreads();                                      // every thread has read epoch[b]
+    if (tid == 0) {
+        __hip_atomic_store(gate, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // its producers have all arrived
+        ctx.ar_epoch[b] = tag;
+    }
 }
 
 // ------------------------------------------------------------------------------ f64 (exact mode)
@@ -2250,6 +2326,27 @@ int tnn_dense_bwd_first_allreduce_adam(int64_t rows, int64_t n_in, int64_t n_out
             // the transport's polling workgroups (128 by default) behind the tiles, 256 threads each: with up to eight ranks'
             // launches on ONE GPU (the tests) they still leave half the wave slots to the producers
             hipLaunchKernelGGL((dense_bwd0_allreduce_adam_kernel<4>), f.n_dw + ctx.ar_grid, 256, 0, tnn::stream(), gw, f, ctx, t);
+            TNN_LAUNCH_OK();
+            return 0;
+        }
+        // more rows (512 / 1024 per rank): the same single launch on the 32 x 32 tile form of the product
+        if (aligned && use_small_path(gw) && use_mid_path(gw, 1, 0) && n_out % 4 == 0 && w_off % 4 == 0 && b_off % 4 == 0 &&
+            (!scalar_dst || scalar_index >= n_params) && tnn::p2p_can_allreduce(n_reduce, dtype, TNN_RSUM) && tnn::p2p_launch_ctx(&ctx)) {
+            if (int rc = tnn::p2p_refuse_if_failed("tnn_dense_bwd_first_allreduce_adam")) return rc;
+            mid_geometry(gw);
+            const int W = ctx.peers.world;
+            ArTileArgs f;
+            f.buf = (float*)grads; f.n = n_reduce;
+            f.slice = ((n_reduce + W - 1) / W + 3) / 4 * 4;
+            f.w_off = w_off; f.b_off = b_off;
+            f.n_dw = gw.tiles_m * gw.tiles_n;
+            tnn::p2p::AdamTail t;
+            t.p = (float*)p; t.m = (float*)m; t.v = (float*)v; t.n_params = n_params;
+            t.lr = (float)lr; t.b1 = (float)b1; t.b2 = (float)b2; t.eps = (float)eps;
+            t.pows = (const double*)pows_f64;
+            t.scalar_index = scalar_dst ? scalar_index : -1;
+            t.scalar_dst = (float*)scalar_dst;
+            hipLaunchKernelGGL(dense_bwd0_mid_allreduce_adam_kernel, f.n_dw + ctx.ar_grid, 512, 0, tnn::stream(), gw, f, ctx, t);
             TNN_LAUNCH_OK();
             return 0;
         }

@@ -36,7 +36,13 @@ struct Peers {
     int64_t slice_cap;                            // floats per slice the regions were sized for
     int* dead_host;                               // host-pinned mirror of the sticky `dead` word (device-visible address):
                                                   // written once when a barrier times out, read by the host WITHOUT a sync
+    int poll_gap, poll_first;                     // tagged polls: s_sleep units (64 clocks) between two polls of a slot group, and
+                                                  // before the FIRST poll of stage (B) (TNN_P2P_POLL_GAP / TNN_P2P_POLL_FIRST)
 };
+__device__ __forceinline__ void poll_pause(int units) {          // s_sleep takes an immediate: pauses of 1 .. 127 units
+    for (; units >= 8; units -= 8) __builtin_amdgcn_s_sleep(8);
+    for (; units > 0; --units) __builtin_amdgcn_s_sleep(1);
+}
 
 // A barrier timed out: the sticky device word stops every later wait, the host mirror lets the next host-side call fail
 // loudly (tnn_p2p.hip: p2p_failed) instead of running on partial sums.
@@ -287,7 +293,7 @@ __device__ __forceinline__ bool ll_poll(const char* const (&src)[N], const bool 
         }
         if (ok) return true;
         if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        __builtin_amdgcn_s_sleep(1);
+        poll_pause(p.poll_gap);
         if ((++polls & 63u) == 0) {
             const uint64_t now = wall_clock64();
             if (t0 == 0) t0 = now;
@@ -406,6 +412,7 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
     {
         constexpr int GB = ADAM ? (UN < 4 ? UN : 4) : 4;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (gate != nullptr) poll_pause(p.poll_first);        // producers of THIS launch: nothing can have arrived before their product
         for (int j0 = 0; ok && j0 < items; j0 += GB) {
             const char* src[GB];
             bool live[GB];

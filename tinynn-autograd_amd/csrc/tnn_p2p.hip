@@ -171,15 +171,16 @@ __global__ __launch_bounds__(THREADS) void p2p_bulk_kernel(Peers p, const char* 
     }
     const bool ok = exchange_flags(p, offsetof(Header, flag) + ((size_t)MAXB + b) * FLAG_ROW, e + 1, dead, timeout_ticks);
     // (B) reduce / copy out
+    const __amdgpu_buffer_rsrc_t stage = __builtin_amdgcn_make_buffer_rsrc(p.base[r] + par_off, 0, (uint32_t)((size_t)W * bulk_slot), 0x00020000);
     for (int64_t u = first; ok && u < units; u += stride) {
-        f32x4 v[MAXW];                                    // (loops unrolled to MAXW with a predicate: the array stays in registers)
+        // cache-bypassing loads the COMPILER can see (buffer loads with the sc0 sc1 policy bits, as in tnn_head_stats.h): behind a
+        // conditional inline-asm load the compiler inserts a register copy that reads the destination before the data has landed
+        // (measured: wrong sums).  Loops unrolled to MAXW with a predicate: the array stays in registers.
+        f32x4 v[MAXW];
 #pragma unroll
         for (int q = 0; q < MAXW; ++q)
-            if (q < W) load_sys(v[q], reinterpret_cast<const float*>(p.base[r] + par_off + (size_t)q * bulk_slot + u * 16));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < MAXW; ++q)
-            if (q < W) asm volatile("" : "+v"(v[q]));
+            if (q < W)
+                v[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(stage, (uint32_t)(u * 16), (uint32_t)((size_t)q * bulk_slot), 17));
         if constexpr (KIND == 2) {
 #pragma unroll
             for (int q = 0; q < MAXW; ++q)
@@ -361,7 +362,8 @@ static int64_t g_bulk_request = 0;            // tnn_p2p_set_bulk_bytes: staging
 extern "C" {
 
 int tnn_p2p_set_bulk_bytes(int64_t slot_bytes) {
-    TNN_REQUIRE(slot_bytes >= 0 && slot_bytes % 4096 == 0, "tnn_p2p_set_bulk_bytes: a multiple of 4096 (0 = no bulk staging)");
+    TNN_REQUIRE(slot_bytes >= 0 && slot_bytes % 4096 == 0 && slot_bytes <= ((int64_t)1 << 27),
+                "tnn_p2p_set_bulk_bytes: a multiple of 4096 up to 128 MiB (0 = no bulk staging)");
     g_bulk_request = slot_bytes;
     return 0;
 }
@@ -408,6 +410,10 @@ int tnn_p2p_create(int rank, int world, int64_t max_bytes, void* handle64) {
     S.p.rank = rank;
     S.p.world = world;
     S.p.slice_cap = cap;
+    S.p.poll_gap = getenv("TNN_P2P_POLL_GAP") ? atoi(getenv("TNN_P2P_POLL_GAP")) : 1;
+    // (measured at world 1, tools/probes/dp_poll_ab.py: 32 units before the first stage-B poll of the fused launch: - 0.3 us per
+    // step at 128 rows; the gap between polls makes no difference between 1 and 16 units)
+    S.p.poll_first = getenv("TNN_P2P_POLL_FIRST") ? atoi(getenv("TNN_P2P_POLL_FIRST")) : 32;
     S.max_floats = max_floats;
     memcpy(S.devid, devid, sizeof(devid));
     S.bulk_off = bulk_off;
