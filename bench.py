@@ -85,7 +85,7 @@ WIDTHS_A = [784, 256, 128, 10]
 WIDTHS_C = [4096, 4096, 4096]
 WIDTHS_E = [8192, 8192, 8192, 8192, 8192]
 GLOBAL_BATCH_D = 1024
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 # ------------------------------------------------------------------------------------------------ data / nets
@@ -280,6 +280,56 @@ def time_dw_adam_bf16(widths, rows, reps=10):
                      "the first layer's launch writes no [in, out] bf16 copy (nothing reads it: dX stops at the input) = 26 B"}
 
 
+def in_step_launch_us(run, positions, reps=4):
+    """HIP-event time of single launches INSIDE the step: launch k costs T(the step's launches 0 .. k) - T(launches 0 .. k - 1),
+    each prefix replayed `reps` times back to back from one hipGraph (tnn_mlp_launch_window restricts tnn_mlp_step to a window
+    of its primitive calls).  Unlike a stand-alone replay of one launch on one operand set, the launch finds the caches as the
+    step leaves them: its operands written by the launch in front of it, everything older evicted by the step's own traffic."""
+    lib, h = run.trainer._lib, run.trainer._h
+    x, y = run.batches[0]
+    prefix = {}
+    try:
+        for k in sorted(set(positions) | set(p + 1 for p in positions)):
+            if k == 0:
+                prefix[0] = 0.0
+                continue
+            lib.mlp_launch_window(h, 0, k, None)
+            prefix[k] = events_us(lambda: lib.mlp_step(h, x._ptr, y._ptr, run.rows, None), reps)
+    finally:
+        lib.mlp_launch_window(h, 0, -1, None)
+    return [prefix[p + 1] - prefix[p] for p in positions]
+
+
+def dw_adam_roofline_in_step(run, widths, rows, ms_per_step):
+    """config E's roofline object: the dW + Adam launch against 8 TB/s with its time taken INSIDE the step (in_step_launch_us);
+    the stand-alone replay on one operand set — which stays in the memory-side cache and reads 5-20 % faster — is kept as
+    isolated_*.  `run`: the bf16 FusedRun whose step is being reported."""
+    # where the dW + Adam launches sit in the step's launch sequence (csrc/tnn_mlp.cpp mlp16_step_fused): L forward, the
+    # loss / dz launch, then per layer, last first: transposes, dX (not for the first layer), dW + Adam; one bias launch
+    L, k, dw_pos = len(widths) - 1, len(widths), []
+    for l in reversed(range(L)):
+        k += 1 + (1 if l > 0 else 0)
+        dw_pos.append(k)
+        k += 1
+    in_step = in_step_launch_us(run, dw_pos) if run.launches_per_step() == k + 1 else None
+    roof = time_dw_adam_bf16(widths, rows, reps=6)
+    if in_step is None:
+        roof["frac_of_step_time"] = round(roof["us"] * L / (ms_per_step * 1e3), 3)
+        return roof
+    us28 = float(np.mean(in_step[:-1])) if L > 1 else float(in_step[0])
+    roof["isolated_us"], roof["isolated_achieved"], roof["isolated_frac"] = roof["us"], roof["achieved"], roof["frac"]
+    roof["us"] = round(us28, 1)
+    roof["achieved"] = round(roof["algorithmic_bytes"] / us28 / 1e3, 1)
+    roof["frac"] = round(roof["achieved"] / PEAK_HBM_GBS, 4)
+    roof["mfma_tflops"] = round(2.0 * widths[0] * widths[1] * rows / us28 / 1e6, 1)
+    roof["in_step_us_per_layer_last_first"] = [round(v, 1) for v in in_step]
+    roof["timed"] = ("inside the %d-launch step: T(launches 0 .. k) - T(launches 0 .. k - 1) with HIP events, the step restricted to "
+                     "a prefix of its launches (tnn_mlp_launch_window); us = mean of the 28-byte launches (every layer but the first, "
+                     "whose 26-byte launch is the last entry of in_step_us_per_layer_last_first)" % (k + 1))
+    roof["frac_of_step_time"] = round(float(np.sum(in_step)) / (ms_per_step * 1e3), 3)
+    return roof
+
+
 def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
     """configs[4] on the driver's line: the whole bf16 step (8192-wide x 4, 512 rows per GPU, Adam) — single GPU: Adam in
     the dW epilogues; data-parallel: the sharded-optimizer step (reduce-scatter bf16 dW / Adam on the owned rows /
@@ -296,6 +346,9 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
         obj["step_form"] = ("sharded optimizer: per layer reduce-scatter(bf16 dW) -> Adam on the owned rows -> all-gather(bf16 W) on "
                             "the communication stream, overlapping the remaining backward; one small fp32 all-reduce for biases + loss")
         obj["wire_bytes_per_step_per_gpu"] = int(2 * (world - 1) / max(world, 1) * 2 * n)
+        obj["collectives_on"] = ("rccl" if getattr(comm, "_rccl", False) else
+                                 "xgmi peer-to-peer bulk path (no RCCL communicator: direct exchange over the IPC-mapped regions, "
+                                 "%d MiB of staging per source)" % (getattr(comm, "p2p_bulk_bytes", 0) >> 20))
         w16 = np.asarray(e.trainer.weights_bf16())
         crc = int(np.frombuffer(w16.tobytes(), dtype=np.uint32).sum(dtype=np.uint64))
         if world > 1:
@@ -305,10 +358,10 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
             obj["replicas_identical_bf16_weights"] = bool(all(c == box[0] for c in box))
     else:
         obj["step_form"] = "single GPU: Adam in the epilogue of every dW GEMM (keep_grads off)"
+    if comm is None:
+        obj["dw_adam_roofline"] = dw_adam_roofline_in_step(e, WIDTHS_E, 512, re["ms_per_step"])
     del e
     if comm is None:
-        obj["dw_adam_roofline"] = time_dw_adam_bf16(WIDTHS_E, 512, reps=6)
-        obj["dw_adam_roofline"]["frac_of_step_time"] = round(obj["dw_adam_roofline"]["us"] * 4 / (re["ms_per_step"] * 1e3), 3)
         g = time_gemms_bf16(WIDTHS_E, 512, reps=6)
         g.pop("per_gemm", None)
         obj["gemm_roofline"] = g
@@ -318,7 +371,7 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
 def load_traffic_table():
     """HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 correction
     + WRITE_SIZE, separate rocprofv3 --pmc passes of this same command; tools/traffic_from_pmc.py)."""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(path):
             return json.load(open(path)), os.path.relpath(path, ROOT)
@@ -1321,7 +1374,7 @@ def main():
             line.setdefault("reference_example_net", {"widths": "-".join(map(str, ex_widths))})["dp_world1"] = ex_dp
 
     # ---------------------------------------------------------------- configs[4] (bf16, 8 GPUs) on the data-parallel line
-    if (comm is not None and getattr(comm, "_rccl", False) and args.workload == "A" and args.path == "fused"
+    if (comm is not None and (getattr(comm, "_rccl", False) or getattr(comm, "p2p_bulk_bytes", 0) > 0) and args.workload == "A" and args.path == "fused"
             and not args.no_extras and args.rows is None and os.environ.get("TNN_BENCH_CONFIG_E", "1") != "0"):
         # never at the price of the line: a watchdog on EVERY rank emits the line as it stands and ends the process if the
         # extra measurement does not come back (it is the first time this step form meets real links)
@@ -1339,7 +1392,9 @@ def main():
         dog_e = threading.Timer(limit_e, stop_e)
         dog_e.daemon = True
         dog_e.start()
-        comm.set_p2p(False)                                  # bandwidth-sized messages: RCCL
+        if getattr(comm, "_rccl", False):
+            comm.set_p2p(False)                              # bandwidth-sized messages: RCCL
+        # (a peer-to-peer-only group — TNN_COMM=xgmi, ranks sharing a GPU — carries them on the transport's bulk path)
         try:
             obj_e = config_e_object(clock, rank, world, comm, force_dp)
         except Exception as exc:                             # noqa: BLE001
@@ -1357,8 +1412,7 @@ def main():
     # ---------------------------------------------------------------- secondary objects (rank 0, N = 1)
     if line is not None and world == 1 and not args.no_extras:
         if args.workload == "E":
-            line["roofline"] = time_dw_adam_bf16(widths, rows)
-            line["roofline"]["frac_of_step_time"] = round(line["roofline"]["us"] * (len(widths) - 1) / (res["ms_per_step"] * 1e3), 3)
+            line["roofline"] = dw_adam_roofline_in_step(runner, widths, rows, res["ms_per_step"])
             line["gemm_roofline"] = time_gemms_bf16(widths, rows)
         elif args.workload == "C":
             line["roofline"] = time_gemms(widths, rows, reps=20)

@@ -51,6 +51,7 @@ struct HeadMArgs {
     const float* ext_pairs;          // SH >= 2: {M_q, S_q} pairs from an earlier launch (head_stats_kernel [+ all-gather])
     int ext_n;
     const tnn::p2p::XchgCtx* xc;     // SH == 3: the peer-to-peer group this launch exchanges the shard's pair with (device memory)
+    int xw;                          // ... and its size (by value: a one-rank group must not cost a load through xc)
     const float *a, *w, *b, *y;
     const float* zpart;              // [H / 16][m][C] partial logits from the previous layer's tiles, or NULL
     float *logits, *dz, *stats, *loss, *dw, *db, *da;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void head_block(const HeadMArgs& p, const int g) {
     if constexpr (SH == 3) {                                                // the shard's pair -> the batch's (all ranks)
         __shared__ float xm[2];
         float Mx = st.M, Sx = (float)st.S;
-        tnn::p2p::xchg_merge<512>(p.xc, Mx, Sx, false, xm);
+        tnn::p2p::xchg_merge<512>(p.xc, p.xw, Mx, Sx, false, xm);
         st.M = Mx; st.S = (double)Sx;
     }
     const bool (&valid)[3] = st.valid;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     if constexpr (SH == 3) {                       // the first tile workgroup is the launch's sender (f32 statistics: the shortest path to the pair)
         __shared__ float xm[2];
         float Mx = st.M, Sx = (float)st.S;
-        tnn::p2p::xchg_merge<512>(p.xc, Mx, Sx, blk == 0, xm);
+        tnn::p2p::xchg_merge<512>(p.xc, p.xw, Mx, Sx, blk == 0, xm);
         st.M = Mx; st.S = (double)Sx;
     }
     if constexpr (CUT == 2) {
@@ -604,7 +605,7 @@ __device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
     if constexpr (SH >= 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
     if constexpr (SH == 3) {                       // ... the pairs in memory were this SHARD's: exchange and merge with the peers'
         __shared__ float xm[2];
-        tnn::p2p::xchg_merge<512>(p.xc, ext_ms[0], ext_ms[1], false, xm);
+        tnn::p2p::xchg_merge<512>(p.xc, p.xw, ext_ms[0], ext_ms[1], false, xm);
     }
     float dws0 = 0.f, dws1 = 0.f;                  // this thread's dW partial sums (threads < JPB * C * 4)
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};            // workgroup 0, wave 7: db partial sums
@@ -903,7 +904,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
     if constexpr (SH >= 2) head_merge_pairs(p.ext_pairs, p.ext_n, lane, ext_ms[0], ext_ms[1]);
     if constexpr (SH == 3) {                     // the first tile workgroup is the launch's sender
         __shared__ float xm[2];
-        tnn::p2p::xchg_merge<512>(p.xc, ext_ms[0], ext_ms[1], blk == 0, xm);
+        tnn::p2p::xchg_merge<512>(p.xc, p.xw, ext_ms[0], ext_ms[1], blk == 0, xm);
     }
     // the global reads of one row block: staged logits / labels, the mask source rows of a1, (dW) the x fragment
     HeadStage<C, NP> stg_nx;
@@ -1042,6 +1043,7 @@ struct HeadGenArgs {
     int m, H, C, n_in;
     int m_global, ext_n;             // ext_pairs != NULL: rows of the GLOBAL batch, number of pairs (<= 64)
     const float* ext_pairs;
+    int xw;                          // size of that group (by value)
     const tnn::p2p::XchgCtx* xc;     // statistics inside + DEFERRED exchange (<= 128 rows per rank; tnn_p2p.h: XchgCtx): every workgroup
                                      // reduces the shard's pair, workgroup 0 pushes it to the peers, all merge the ranks' pairs
     const float *a, *w, *b, *y, *zpart, *x, *w1;
@@ -1144,7 +1146,7 @@ __global__ __launch_bounds__(256) void mlp_head_bwd_generic_kernel(HeadGenArgs p
             L = red[2];
             if (p.xc != nullptr) {                        // block-uniform: the shard's pair -> the batch's (all ranks)
                 float Sx = (float)S;
-                tnn::p2p::xchg_merge<256>(p.xc, M, Sx, blk == 0, xm);
+                tnn::p2p::xchg_merge<256>(p.xc, p.xw, M, Sx, blk == 0, xm);
                 S = (double)Sx;
             }
         }
@@ -1387,7 +1389,7 @@ bool head_multi_fits(int64_t rows, int64_t n_hidden, int64_t n_classes, int dtyp
 }
 
 int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whole_logits, int64_t m_global, int64_t rows, int64_t n_in, int64_t n_hidden, int64_t n_classes, const void* x, const void* w1,
-                          const tnn::p2p::XchgCtx* xc,
+                          const tnn::p2p::XchgCtx* xc, const int xw,
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
@@ -1402,7 +1404,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
         TNN_REQUIRE(ext_pairs == nullptr || (m_global >= rows && ext_n >= 1 && ext_n <= 64), "%s: m_global < rows or bad pair count", fn);
         HeadGenArgs ga;
         ga.m = (int)rows; ga.H = (int)n_hidden; ga.C = (int)n_classes; ga.n_in = (int)n_in;
-        ga.m_global = (int)m_global; ga.ext_n = ext_n; ga.ext_pairs = ext_pairs; ga.xc = xc;
+        ga.m_global = (int)m_global; ga.ext_n = ext_n; ga.ext_pairs = ext_pairs; ga.xc = xc; ga.xw = xw;
         TNN_REQUIRE(xc == nullptr || (ext_pairs == nullptr && m_global >= rows),
                     "%s: the deferred exchange of a generic head is the <= 128-row form (statistics inside)", fn);
         ga.a = (const float*)a; ga.w = (const float*)w; ga.b = (const float*)b; ga.y = (const float*)y;
@@ -1432,7 +1434,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = (int)m_global;
-    p.ext_pairs = ext_pairs; p.ext_n = ext_n; p.xc = xc;
+    p.ext_pairs = ext_pairs; p.ext_n = ext_n; p.xc = xc; p.xw = xw;
     TNN_REQUIRE(!whole_logits || rows > 128, "%s: whole logits (n_pairs < 0) come from the row-panel forward, i.e. with more than 128 rows", fn);
     p.nparts = whole_logits ? 1 : 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
@@ -1524,7 +1526,7 @@ int tnn_mlp_head_tick(int64_t rows, int64_t n_hidden, int64_t n_classes, const v
     p.zpart = (const float*)logit_partials;
     p.vec = (rows % 2 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(logit_partials)) & 15) == 0) ? 1 : 0;
     p.m_global = 0;
-    p.ext_pairs = nullptr; p.ext_n = 0; p.xc = nullptr;
+    p.ext_pairs = nullptr; p.ext_n = 0; p.xc = nullptr; p.xw = 1;
     p.nparts = 8;
     p.logits = (float*)logits; p.dz = (float*)dz; p.stats = (float*)stats; p.loss = (float*)loss;
     p.dw = (float*)dw; p.db = (float*)db; p.da = (float*)da;
@@ -1540,7 +1542,7 @@ int tnn_mlp_head_bwd_tick(int64_t rows, int64_t n_in, int64_t n_hidden, int64_t 
                           const void* a, const void* w, const void* b, const void* y, const void* logit_partials,
                           void* logits, void* dz, void* stats, void* loss, void* dw, void* db, void* dw1, void* db1,
                           void* dx, int dtype, void* adam_pows_f64, double b1, double b2) {
-    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, false, 0, rows, n_in, n_hidden, n_classes, x, w1, nullptr, a, w, b, y, logit_partials, logits,
+    return head_bwd_launch("tnn_mlp_head_bwd_tick", nullptr, 0, false, 0, rows, n_in, n_hidden, n_classes, x, w1, nullptr, 1, a, w, b, y, logit_partials, logits,
                            dz, stats, loss, dw, db, dw1, db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 
@@ -1553,7 +1555,7 @@ int tnn_mlp_head_bwd_tick_ext(int64_t rows, int64_t m_global, int64_t n_in, int6
     // n_pairs < 0: logit_partials holds WHOLE logits [rows][classes] without the bias (tnn_dense_fwd_rows_head_stats) and
     // there are -n_pairs pairs
     return head_bwd_launch("tnn_mlp_head_bwd_tick_ext", (const float*)stats_pairs, n_pairs < 0 ? -n_pairs : n_pairs, n_pairs < 0, m_global, rows, n_in, n_hidden,
-                           n_classes, x, w1, nullptr, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
+                           n_classes, x, w1, nullptr, 1, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1, db1, dx, dtype,
                            adam_pows_f64, b1, b2);
 }
 
@@ -1610,8 +1612,10 @@ int tnn_mlp_head_bwd_tick_xchg(int64_t rows, int64_t m_global, int64_t n_in, int
     if (int rc = tnn::p2p_refuse_if_failed("tnn_mlp_head_bwd_tick_xchg")) return rc;
     const tnn::p2p::XchgCtx* xc = tnn::p2p_xchg_ctx();
     TNN_REQUIRE(xc != nullptr, "tnn_mlp_head_bwd_tick_xchg: the peer-to-peer transport is not enabled");
+    int rank = 0, world = 1;
+    (void)tnn::p2p_world(&rank, &world);
     return head_bwd_launch("tnn_mlp_head_bwd_tick_xchg", n_pairs < 0 ? (const float*)shard_pairs : nullptr, -n_pairs, n_pairs < 0, m_global,
-                           rows, n_in, n_hidden, n_classes, x, w1, xc, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1,
+                           rows, n_in, n_hidden, n_classes, x, w1, xc, world, a, w, b, y, logit_partials, logits, dz, stats, loss, dw, db, dw1,
                            db1, dx, dtype, adam_pows_f64, b1, b2);
 }
 

@@ -526,9 +526,11 @@ __device__ __forceinline__ size_t xchg_off(const int row, const int par, const i
 // {M, S}: this shard's pair, the same in every thread of the workgroup on entry; the batch's pair (all ranks merged in rank
 // order) in every thread on return.  `sender`: block-uniform, true in exactly ONE workgroup of the launch.  lds2: two floats of
 // shared memory.  One workgroup barrier inside when world > 1; at world 1 nothing at all happens.  NT = threads per workgroup.
+// world: the group's size as a kernel ARGUMENT (HeadMArgs::xw) — at world 1 the call must not cost a dependent load through xc.
 template <int NT>
-__device__ __forceinline__ void xchg_merge(const XchgCtx* __restrict__ xc, float& M, float& S, const bool sender, float* lds2) {
-    if (xc == nullptr) return;
+__device__ __forceinline__ void xchg_merge(const XchgCtx* __restrict__ xc, const int world, float& M, float& S, const bool sender,
+                                           float* lds2) {
+    if (world <= 1 || xc == nullptr) return;
     const int W = xc->peers.world;
     if (W <= 1) return;
     const int rank = xc->peers.rank, tid = threadIdx.x;
