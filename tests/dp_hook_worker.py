@@ -139,7 +139,7 @@ def main():
     np.testing.assert_allclose(losses, gold["loss"], rtol=1e-5, err_msg="%s sharded over %d ranks" % (name, world))
     for l in range(n_layers):
         for k in ("w", "b"):
-            H.check_summary(np.asarray(trainer.param_view(l, k)), gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * cfg["lr"])
+            H.check_summary(np.asarray(trainer.param_view(l, k)), gold, "final_%d%s" % (l, k), rtol=0, atol=0.01 * cfg["lr"])       # (parity_suite.ADAM_GATE)
     flat = np.asarray(trainer.params)
     parts = [None] * world
     dist.all_gather_object(parts, flat.tobytes())

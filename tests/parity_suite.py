@@ -20,6 +20,8 @@ from tinynn_autograd_amd.core.tensor import Tensor
 from tinynn_autograd_amd.fused import MLPTrainer, trainer_from_net
 
 RTOL = 1e-5
+ADAM_GATE = 0.01           # |parameter - reference| <= ADAM_GATE * lr after an Adam trajectory (was 0.1 until round 6; measured 0.0003)
+ADAM_MARGINS = {}          # case -> worst |parameter - reference| / lr seen by the Adam trajectory checks of this process
 
 
 # ------------------------------------------------------------------------------------ op cases
@@ -81,7 +83,11 @@ def _check_traj(name, fused, use_arena=True):
         for k in ("w", "b"):
             p = np.asarray(layer.params[k].values)
             if cfg["opt"] == "adam":
-                H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * lr)
+                # gate ADAM_GATE lr (SURVEY H1 proposed 0.01 lr); the MEASURED worst deviation is recorded per case in ADAM_MARGINS
+                # (in units of lr; tools/probes/adam_margin.py prints them: <= 0.0003 lr on the MI355X, <= 0.0011 lr on the CPU twin)
+                worst = H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=ADAM_GATE * lr)
+                key = "%s/%s" % (name, "fused" if fused else "generic_ops")
+                ADAM_MARGINS[key] = max(ADAM_MARGINS.get(key, 0.0), worst / lr)
             else:
                 H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=RTOL * max(np.abs(p).max(), 1e-3))
 
@@ -152,8 +158,11 @@ def _check_trainer(name, use_graph):
     for l in range(trainer.n_layers):
         for k in ("w", "b"):
             p = np.asarray(trainer.param_view(l, k))
-            atol = 0.1 * lr if cfg["opt"] == "adam" else RTOL * max(np.abs(p).max(), 1e-3)
-            H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=atol)
+            atol = ADAM_GATE * lr if cfg["opt"] == "adam" else RTOL * max(np.abs(p).max(), 1e-3)
+            worst = H.check_summary(p, gold, "final_%d%s" % (l, k), rtol=0, atol=atol)
+            if cfg["opt"] == "adam":
+                key = "%s/trainer%s" % (name, "_graph" if use_graph else "")
+                ADAM_MARGINS[key] = max(ADAM_MARGINS.get(key, 0.0), worst / lr)
 
 
 def trainer_A_adam_eager():
@@ -301,7 +310,7 @@ def trainer_A_adam_multi_step_graph():
     np.testing.assert_allclose(losses, gold["loss"], rtol=RTOL)
     for l in range(trainer.n_layers):
         for k in ("w", "b"):
-            H.check_summary(np.asarray(trainer.param_view(l, k)), gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * cfg["lr"])
+            H.check_summary(np.asarray(trainer.param_view(l, k)), gold, "final_%d%s" % (l, k), rtol=0, atol=ADAM_GATE * cfg["lr"])
     # reference for the continuation: an eager trainer fed the same 40 batches
     model2, _ = H.build_model(cfg)
     eager = trainer_from_net(model2.net, max_rows=cfg["m"], lr=cfg["lr"])
@@ -346,7 +355,7 @@ def op_level_step_captured_in_graph():
     assert np.array_equal(np.argmax(state["pred"], axis=1), gold["argmax_19"])
     for l, layer in enumerate(H.dense_layers(model)):
         for k in ("w", "b"):
-            H.check_summary(np.asarray(layer.params[k].values), gold, "final_%d%s" % (l, k), rtol=0, atol=0.1 * cfg["lr"])
+            H.check_summary(np.asarray(layer.params[k].values), gold, "final_%d%s" % (l, k), rtol=0, atol=ADAM_GATE * cfg["lr"])
 
 
 def trainer_A_ragged():

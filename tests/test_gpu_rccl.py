@@ -65,7 +65,7 @@ def test_sharded_steps_captured_with_rccl_in_graph(comm):
     losses = np.asarray(graph.launch())
     np.testing.assert_allclose(losses, gold["loss"], rtol=1e-5)
     for l in range(trainer.n_layers):
-        H.check_summary(np.asarray(trainer.param_view(l, "w")), gold, "final_%dw" % l, rtol=0, atol=0.1 * cfg["lr"])
+        H.check_summary(np.asarray(trainer.param_view(l, "w")), gold, "final_%dw" % l, rtol=0, atol=0.01 * cfg["lr"])       # (parity_suite.ADAM_GATE)
 
 
 @pytest.mark.gpu

@@ -730,6 +730,10 @@ __device__ __forceinline__ float adam_apply(const AdamEpi& ad, float ic1, float 
 
 // TO_LDS: the finished tile goes to out_lds [16][16] (row-major; entries outside the matrix are not written) and the column
 // sums of the first tile row to out_lds[256 .. 272) instead of memory — for a caller that sends them elsewhere itself
+#ifdef TNN_STEP_TRACE
+__device__ unsigned long long g_step_trace[4 * 1024 * 4];        // tnn_internal.h: TNN_STEP_STAMP
+#endif
+
 template <bool AKC, bool BKC, int WAVES, bool ADAM = false, bool TO_LDS = false>
 __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict__ colsum, int block,
                                            float (*red)[4][64], float (*bsum)[64], const AdamEpi* ad = nullptr,
@@ -752,6 +756,7 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     float a_p = 0.f, a_m = 0.f, a_v = 0.f, ab_p = 0.f, ab_m = 0.f, ab_v = 0.f, ic1 = 0.f, ic2 = 0.f;
+    if constexpr (ADAM) TNN_STEP_STAMP(g_step_trace, 3, 0);
     if constexpr (ADAM) {
         ic1 = (float)(1.0 / (1.0 - ad->pows[0]));
         ic2 = (float)(1.0 / (1.0 - ad->pows[1]));
@@ -803,6 +808,7 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
                 for (int j = 0; j < 4; ++j) if (k + j < g.K) b[j] = g.B[(k + j) * g.ldb + bn];
             }
         }
+        if constexpr (ADAM) { if (c == wid) TNN_STEP_STAMP_ACKED(g_step_trace, 3, 1); }      // (first chunk's operands + the Adam state)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
         bs += (b[0] + b[1]) + (b[2] + b[3]);
@@ -811,6 +817,7 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
     for (int r = 0; r < 4; ++r) red[wid][r][lane] = acc[r];
     bsum[wid][lane] = bs;
     __syncthreads();
+    if constexpr (ADAM) TNN_STEP_STAMP(g_step_trace, 3, 2);
     if (tid < 256) {
         const int r = tid >> 6, ln = tid & 63;
         float s = 0.f;
@@ -841,6 +848,7 @@ __device__ __forceinline__ void small_tile(const GemmArgs& g, float* __restrict_
             ad->vb[n0 + tid] = ab_v;
         }
     }
+    if constexpr (ADAM) TNN_STEP_STAMP_ACKED(g_step_trace, 3, 3);
 }
 
 // the same epilogue with its operand (bias value / mask source / old C) already in a register
@@ -926,6 +934,8 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     constexpr int MAXC = 4;
+    constexpr int KID = WAVES == 16 ? 0 : 1;              // (trace build: fwd0 runs 16 waves, fwd1 4 — or 8 in the data-parallel tail form)
+    TNN_STEP_STAMP(g_step_trace, KID, 0);
     for (int c0 = wid; c0 < nchunks; c0 += WAVES * MAXC) {
         float a[MAXC][4], b[MAXC][4];
 #pragma unroll
@@ -962,6 +972,7 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
                 }
             }
         }
+        if (c0 == wid) TNN_STEP_STAMP_ACKED(g_step_trace, KID, 1);
 #pragma unroll
         for (int u = 0; u < MAXC; ++u) {
 #pragma unroll
@@ -973,6 +984,7 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
     for (int r = 0; r < 4; ++r) red[wid][r][lane] = acc[r];
     bsum[wid][lane] = bs;
     __syncthreads();
+    TNN_STEP_STAMP(g_step_trace, KID, 2);
     float e_val = 0.f;
     if (tid < 256) {
         float s = 0.f;
@@ -1016,6 +1028,7 @@ __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __rest
             }
         }
     }
+    TNN_STEP_STAMP_ACKED(g_step_trace, KID, 3);
 }
 
 template <bool AKC, bool BKC, int WAVES, bool FAST>
@@ -1564,6 +1577,9 @@ bool use_small_path(const GemmArgs& g) {
 
 int gemm_small(GemmArgs& g, int transA, int transB, float* colsum) {
     int nchunks = (int)((g.K + 15) / 16);
+    // (round 6, fwd0 of the MNIST net — 49 chunks — with 8 waves and all 7 chunks of a wave requested in one round instead of 16
+    // waves: 21.68 against 21.33 us per step, three alternating process pairs on one box; the 16-wave workgroups' slower placement
+    // — 1.5 us from the first to the last workgroup entry, profiles/r06_stepA_stamps.txt — costs less than the longer MFMA chain)
     if (nchunks <= 16) return launch_small<4>(g, transA, transB, colsum);
     if (nchunks <= 48) return launch_small<8>(g, transA, transB, colsum);
     return launch_small<16>(g, transA, transB, colsum);
@@ -2270,6 +2286,14 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
     return 0;
 }
 
+#ifdef TNN_STEP_TRACE
+// rows [kernel id][workgroup][4] of g_step_trace; `which` = 2 is served by tnn_head.hip's own buffer (tnn_debug_step_trace_head)
+extern "C" __attribute__((visibility("default"))) int tnn_debug_step_trace(unsigned long long* out, int n) {
+    TNN_CHECK_HIP(hipDeviceSynchronize());
+    TNN_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), (size_t)std::min(n, 4 * 1024 * 4) * 8));
+    return 0;
+}
+#endif
 #ifdef TNN_AR_TRACE
 __attribute__((visibility("default"))) int tnn_debug_fh_trace(unsigned long long* out, int n) {
     TNN_CHECK_HIP(hipDeviceSynchronize());

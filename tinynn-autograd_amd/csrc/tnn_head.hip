@@ -346,12 +346,18 @@ struct HeadBwdArgs {
 };
 
 // CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
+#ifdef TNN_STEP_TRACE
+__device__ unsigned long long g_step_trace_head[1024 * 4];       // tnn_internal.h: TNN_STEP_STAMP (kernel id 2 of the step)
+#endif
+
 template <int H, int C, int CUT = 0, int SH = 0>
 __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdArgs q) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
+    TNN_STEP_STAMP(g_step_trace_head, 0, 0);
     if ((int)blockIdx.x < G) {
         head_block<H, C, true, 0, false, SH>(p, (int)blockIdx.x);
+        TNN_STEP_STAMP_ACKED(g_step_trace_head, 0, 3);            // (head workgroups: entry and end only)
         return;
     }
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     if (grp >= 2) w2f[2] = 0.f;                  // classes 10, 11 do not exist (the clamped address read class 9)
     static_assert(C == 10, "the zero columns of the K = 12 product are written for 10 classes");
 
+    TNN_STEP_STAMP_ACKED(g_step_trace_head, 0, 1);
     head_stage_store<C, NP>(p, t, stg, zs, ys);
     __syncthreads();
     float zc[3], yc[3];
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     for (int r = 0; r < 4; ++r) redm[wid][r][lane] = acc[r];
     bsum[wid][lane] = bs;
     __syncthreads();
+    TNN_STEP_STAMP(g_step_trace_head, 0, 2);
     if (t < 256) {
         float s = 0.f;
 #pragma unroll
@@ -508,6 +516,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         for (int w = 0; w < 8; ++w) s += (bsum[w][t] + bsum[w][16 + t]) + (bsum[w][32 + t] + bsum[w][48 + t]);
         q.db1[n0 + t] = s;
     }
+    TNN_STEP_STAMP_ACKED(g_step_trace_head, 0, 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1472,6 +1481,14 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
 }  // namespace
 
 extern "C" {
+
+#ifdef TNN_STEP_TRACE
+__attribute__((visibility("default"))) int tnn_debug_step_trace_head(unsigned long long* out, int n) {
+    TNN_CHECK_HIP(hipDeviceSynchronize());
+    TNN_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace_head), (size_t)(n < 4096 ? n : 4096) * 8));
+    return 0;
+}
+#endif
 
 int tnn_mlp_head(int64_t rows, int64_t n_hidden, int64_t n_classes, const void* a, const void* w,
                  const void* b, const void* y, void* logits, void* dz, void* stats, void* loss, void* dw,

@@ -49,6 +49,25 @@ void set_update_guard(const int* device_word);
         }                                   \
     } while (0)
 
+// Debug build only (make trace: -DTNN_STEP_TRACE): 100 MHz wall-clock stamps of the headline step's four launches, one row of
+// four words per workgroup — [0] entry, [1] every operand of the product in registers (s_waitcnt vmcnt(0) behind the last
+// load), [2] last MFMA issued and the cross-wave reduction read back, [3] last store acknowledged.  Kernel ids: 0 fwd0, 1 fwd1
+// + partial logits, 2 head + hidden backward, 3 first-layer backward + Adam.  tools/probes/step_stamps.py reads them.
+#ifdef TNN_STEP_TRACE
+#define TNN_STEP_STAMP(buf, kid, slot)                                                                              \
+    do {                                                                                                            \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) (buf)[((kid) * 1024 + blockIdx.x) * 4 + (slot)] = wall_clock64(); \
+    } while (0)
+#define TNN_STEP_STAMP_ACKED(buf, kid, slot)                                                                        \
+    do {                                                                                                            \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+        TNN_STEP_STAMP(buf, kid, slot);                                                                             \
+    } while (0)
+#else
+#define TNN_STEP_STAMP(buf, kid, slot) do { } while (0)
+#define TNN_STEP_STAMP_ACKED(buf, kid, slot) do { } while (0)
+#endif
+
 #define TNN_NEED_INIT() TNN_REQUIRE(tnn::initialised(), "tnn_init() has not been called")
 #define TNN_LAUNCH_OK() TNN_CHECK_HIP(hipGetLastError())
 
