@@ -166,7 +166,7 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
         if stats is not None:
             stats.append({"data": t_data - t_start, "capture": t_capture - t_data, "steps": t_train - t_capture,
                           "train": t_train - t_start, "eval": time.time() - t_train, "n_rows": len(train_x),
-                          "n_steps": len(batches),
+                          "n_steps": len(batches), "wall": (t_start, t_train),         # (time.time() at the epoch's start / end of training)
                           **({"launch": t_sub[0] - t_capture, "prefetch": t_sub[1] - t_sub[0], "readback": t_sub[2] - t_sub[1]}
                              if len(t_sub) == 3 else {})})
     return loss_list, preds, results

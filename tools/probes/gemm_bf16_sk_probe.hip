@@ -209,23 +209,23 @@ __global__ void transpose_probe_kernel(const bf16_t* __restrict__ src, bf16_t* _
     if (i < (int64_t)rows * cols) { const int r = (int)(i / cols), cc = (int)(i % cols); dst[(int64_t)cc * rows + r] = src[i]; }
 }
 
-template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL, int SYM = 0, int BNC = 0>
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL, int SYM = 0, int BNC = 0, int BMT = 256>
 void sk_variant(const char* name, Ctx& c, bool check) {
     auto launch = [&](int b) {
         BfArgs g = base_args(c, b);
         if (BNC == 1 || BNC == 2 || BNC == 5) { g.B = c.Bt[b]; g.ldb = c.N; }
-        g.tiles_m = (c.M + 255) / 256;
+        g.tiles_m = (c.M + BMT - 1) / BMT;
         g.tiles_n = (c.N + BN - 1) / BN;
         g.splitk = S;
-        if (SYM) g.sk_cnt = c.cnt + 2048;      // the symmetric hand-off's flags count launches; the ticket protocol's words return to zero
-        hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<BN, WM, WN, NSA, NSB, S, ABL, SYM, BNC>), dim3(g.tiles_m * g.tiles_n * S), 512, 0, 0, g);
+        if (SYM) g.sk_cnt = c.cnt + (BMT == 256 ? 2048 : 3072);      // the symmetric hand-off's flags count launches (a set per geometry); the ticket protocol's words return to zero
+        hipLaunchKernelGGL((sk::gemm_bf16_sk_kernel<BN, WM, WN, NSA, NSB, S, ABL, SYM, BNC, BMT>), dim3(g.tiles_m * g.tiles_n * S), 512, 0, 0, g);
     };
     run_variant(name, c, launch, check && ABL == 0);
     if constexpr ((ABL & 32) != 0) {
         for (int i = 0; i < 4; ++i) launch(i % (int)c.B.size());
         CK(hipDeviceSynchronize());
         // the last launch's timestamps: medians over the workgroups of {prologue, K loop, tail} in shader cycles and in us
-        const int nb = ((c.M + 255) / 256) * ((c.N + BN - 1) / BN) * S;
+        const int nb = ((c.M + BMT - 1) / BMT) * ((c.N + BN - 1) / BN) * S;
         std::vector<unsigned long long> t((size_t)nb * 10);
         CK(hipMemcpy(t.data(), c.trace, t.size() * 8, hipMemcpyDeviceToHost));
         std::vector<double> pro_u, loop_c, loop_u, xch_u, epi_u, start_u, end_u;
@@ -340,6 +340,12 @@ int main(int argc, char** argv) {
     sk_variant<128, 4, 2, 3, 4, 2, 4>("sk 256x128 S2 A3 B4 [no exchange]", c, false);
     sk_variant<128, 4, 2, 3, 4, 2, 4 + 2>("sk 256x128 S2 A3 B4 [no exchange, no DMA]", c, false);
     sk_variant<128, 4, 2, 3, 4, 2, 64>("sk 256x128 S2 A3 B4 [B tile-major]", c, false);
+    // round 6: 128 x 128 tiles x split-K 2 = 512 workgroups of 80 KB, TWO per CU (each with its own barrier and hand-off)
+    sk_variant<128, 2, 4, 2, 3, 2, 0, 1, 0, 128>("sk 128x128 S2 A2 B3 symmetric, 2 workgroups per CU", c, true);
+    sk_variant<128, 2, 4, 3, 2, 2, 0, 1, 0, 128>("sk 128x128 S2 A3 B2 symmetric, 2 workgroups per CU", c, true);
+    sk_variant<128, 2, 4, 2, 3, 2, 32, 1, 0, 128>("sk 128x128 S2 A2 B3 symmetric, 2 per CU [traced]", c, false);
+    sk_variant<128, 2, 4, 2, 3, 2, 4, 1, 0, 128>("sk 128x128 S2 A2 B3, 2 per CU [no exchange]", c, false);
+    sk_variant<128, 2, 4, 2, 3, 2, 4 + 2, 1, 0, 128>("sk 128x128 S2 A2 B3, 2 per CU [no exchange, no DMA]", c, false);
     sk_variant<256, 2, 4, 2, 3, 4, 0>("sk 256x256 S4 A2 B3", c, true);
     sk_variant<256, 2, 4, 2, 3, 4, 32>("sk 256x256 S4 A2 B3 [traced]", c, false);
     sk_variant<256, 2, 4, 2, 3, 4, 4>("sk 256x256 S4 A2 B3 [no exchange]", c, false);

@@ -75,9 +75,11 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 // the same bytes.  Bank conflicts: the 4 k-rows of a group are 256 B = one whole bank cycle apart, so 16-B chunk c of row k
 // lives at chunk c ^ ((k & 3) << 2): the 2 x 4 chunk pairs that the two groups of a 32-lane half touch are then all
 // different.
-template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0, int SYM = 0, int BNC = 0>
-__global__ __launch_bounds__(512) void gemm_bf16_sk_kernel(BfArgs g) {
-    constexpr int BM = 256, ROWB = 128, KK = 4;
+// BMT (round 6): rows of the tile — 256 everywhere above; 128 makes a workgroup's rings small enough (2 x 16 + 3 x 16 = 80 KB) for
+// TWO workgroups per CU, each with its own barrier: 256 tiles x 2 slices = 512 workgroups, all resident.
+template <int BN, int WM, int WN, int NSA, int NSB, int S, int ABL = 0, int SYM = 0, int BNC = 0, int BMT = 256>
+__global__ __launch_bounds__(512, BMT == 128 ? 4 : 2) void gemm_bf16_sk_kernel(BfArgs g) {
+    constexpr int BM = BMT, ROWB = 128, KK = 4;
     static_assert(!BNC || BN == 128, "the n-contiguous B image is laid out for 16 chunks per k-row");
     // (probe builds, timing without meaning: BNC = 2 takes the n-contiguous DMA with the k-contiguous fragment reads, 3 the reverse)
     // (4: k-contiguous DMA + tr reads addressed as [k/32][n/16][32][16] subtiles; 5: the DMA that would build those subtiles — each
