@@ -891,6 +891,104 @@ __device__ __forceinline__ void small_tile_coords(const GemmArgs& g, const int b
     }
 }
 
+// The first layer's weight gradient on 16 x 32 tiles (round 6): dW0 = X^T dZ of the MNIST net is 49 x 16 = 784 tiles of 16 x 16 —
+// 3.06 per CU, and the 16 workgroups that are a CU's FOURTH end 1.3 us behind the rest (profiles/r06_stepA_stamps.txt: 4.16 against
+// 2.85 / 3.04 / 3.55 us for the first / second / third 256).  Two column tiles per workgroup — ONE A fragment, two B fragments, two
+// accumulators per wave — make it 392 equal workgroups, at most two per CU, with 12 instead of 16 operand loads per 512 outputs.
+// TN form only (A [K][lda] and B [K][ldb], both MN-contiguous), EPI_AXPBY with beta = 0 (a gradient), N a multiple of 32.
+//   lane (i16, grp): a[j] = A[16 c + 4 grp + j][m0 + i16], b0 / b1[j] = B[.][n0 + i16] / B[.][n0 + 16 + i16]
+//   acc0 / acc1[r] = C[m0 + 4 grp + r][n0 + i16] / [.. + 16]   (16x16x4 C/D layout)
+// ADAM / TO_LDS as in small_tile; out_lds: [16][32] row-major, then the 32 column sums.
+template <int WAVES, bool ADAM, bool TO_LDS>
+__device__ __forceinline__ void dw_tile_wide(const GemmArgs& g, float* __restrict__ colsum, const int block, float (*red)[8][64],
+                                             float (*bsum)[2][64], const AdamEpi* ad = nullptr, float* out_lds = nullptr) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i16 = lane & 15, grp = lane >> 4;
+    int tm, tn;
+    small_tile_coords(g, block, tm, tn);                     // g.tiles_n counts 32-column tiles here
+    const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 32;
+    const int64_t am = m0 + i16, bn = n0 + i16;
+    const bool a_ok = am < g.M;
+    const int nchunks = (int)((g.K + 15) / 16);
+    // this thread's two outputs of the epilogue (threads < 256): rows m0 + 4 (ln >> 4) + r, columns n0 + (ln & 15) and + 16
+    const int e_r = tid >> 6, e_ln = tid & 63;
+    const int64_t e_row = m0 + (e_ln >> 4) * 4 + e_r, e_col = n0 + (e_ln & 15);
+    const bool e_live = tid < 256 && e_row < g.M;
+    float a_p[2] = {0.f, 0.f}, a_m[2] = {0.f, 0.f}, a_v[2] = {0.f, 0.f}, ab_p = 0.f, ab_m = 0.f, ab_v = 0.f, ic1 = 0.f, ic2 = 0.f;
+    if constexpr (ADAM) {
+        ic1 = (float)(1.0 / (1.0 - ad->pows[0]));
+        ic2 = (float)(1.0 / (1.0 - ad->pows[1]));
+        if (e_live) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t i = e_row * g.ldc + e_col + 16 * u;
+                a_p[u] = ad->pw[i]; a_m[u] = ad->mw[i]; a_v[u] = ad->vw[i];
+            }
+        }
+        if (tm == 0 && tid < 32) { ab_p = ad->pb[n0 + tid]; ab_m = ad->mb[n0 + tid]; ab_v = ad->vb[n0 + tid]; }
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float bs0 = 0.f, bs1 = 0.f;
+    if constexpr (ADAM) TNN_STEP_STAMP(g_step_trace, 3, 0);
+    for (int c = wid; c < nchunks; c += WAVES) {
+        const int64_t k = (int64_t)c * 16 + grp * 4;
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b0[4] = {0.f, 0.f, 0.f, 0.f}, b1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (k + j < g.K) {
+                if (a_ok) a[j] = g.A[(k + j) * g.lda + am];
+                b0[j] = g.B[(k + j) * g.ldb + bn];
+                b1[j] = g.B[(k + j) * g.ldb + bn + 16];
+            }
+        }
+        if constexpr (ADAM) { if (c == wid) TNN_STEP_STAMP_ACKED(g_step_trace, 3, 1); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc1, 0, 0, 0);
+        }
+        bs0 += (b0[0] + b0[1]) + (b0[2] + b0[3]);
+        bs1 += (b1[0] + b1[1]) + (b1[2] + b1[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[wid][r][lane] = acc0[r]; red[wid][4 + r][lane] = acc1[r]; }
+    bsum[wid][0][lane] = bs0;
+    bsum[wid][1][lane] = bs1;
+    __syncthreads();
+    if constexpr (ADAM) TNN_STEP_STAMP(g_step_trace, 3, 2);
+    if (e_live) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float sres = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) sres += red[w][4 * u + e_r][e_ln];
+            const float gval = g.alpha * sres;
+            const int64_t i = e_row * g.ldc + e_col + 16 * u;
+            if constexpr (TO_LDS) out_lds[(int)(e_row - m0) * 32 + (int)(e_col - n0) + 16 * u] = gval;
+            else if (!ADAM || g.C != nullptr) g.C[i] = gval;      // ADAM: the gradient itself only on request
+            if constexpr (ADAM) {
+                ad->pw[i] = adam_apply(*ad, ic1, ic2, gval, a_m[u], a_v[u], a_p[u]);
+                ad->mw[i] = a_m[u];
+                ad->vw[i] = a_v[u];
+            }
+        }
+    }
+    if ((TO_LDS || colsum != nullptr) && tm == 0 && tid < 32) {
+        const int u = tid >> 4, t = tid & 15;
+        float sres = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) sres += (bsum[w][u][t] + bsum[w][u][16 + t]) + (bsum[w][u][32 + t] + bsum[w][u][48 + t]);
+        if constexpr (TO_LDS) out_lds[512 + tid] = sres;
+        else colsum[n0 + tid] = sres;
+        if constexpr (ADAM) {
+            ad->pb[n0 + tid] = adam_apply(*ad, ic1, ic2, sres, ab_m, ab_v, ab_p);
+            ad->mb[n0 + tid] = ab_m;
+            ad->vb[n0 + tid] = ab_v;
+        }
+    }
+    if constexpr (ADAM) TNN_STEP_STAMP_ACKED(g_step_trace, 3, 3);
+}
+
 template <bool AKC, bool BKC, int WAVES, bool SYS_HEADZ = false>
 __device__ __forceinline__ void small_tile_fast(const GemmArgs& g, float* __restrict__ colsum, int block,
                                                 float (*red)[4][64], float (*bsum)[64], float* head_lds = nullptr) {
@@ -1429,13 +1527,14 @@ bool small_fast_ok(const GemmArgs& g, int transA, int transB) {
 // blocks [0, n_dw): dW0 = X^T dZ0 tiles + db0, Adam applied to W0 / b0 in the epilogue; blocks >= n_dw: Adam over
 // the flat range that holds every other layer's parameters (their gradients were finished by earlier launches).
 // The step then has no optimizer launch at all.
-template <int WAVES>
+template <int WAVES, bool WIDE = false>
 __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_adam_kernel(GemmArgs gw, float* __restrict__ db, AdamEpi ad,
                                                                      int n_dw) {
-    __shared__ float red[WAVES][4][64];
-    __shared__ float bsum[WAVES][64];
+    __shared__ float red[WAVES][WIDE ? 8 : 4][64];
+    __shared__ float bsum[WAVES][WIDE ? 2 : 1][64];
     if ((int)blockIdx.x < n_dw) {
-        small_tile<false, false, WAVES, true>(gw, db, (int)blockIdx.x, red, bsum, &ad);
+        if constexpr (WIDE) dw_tile_wide<WAVES, true, false>(gw, db, (int)blockIdx.x, red, bsum, &ad);
+        else small_tile<false, false, WAVES, true>(gw, db, (int)blockIdx.x, red, reinterpret_cast<float(*)[64]>(bsum), &ad);
         return;
     }
     const float ic1 = (float)(1.0 / (1.0 - ad.pows[0])), ic2 = (float)(1.0 / (1.0 - ad.pows[1]));
@@ -1471,14 +1570,15 @@ struct ArTileArgs {
 __device__ unsigned long long g_ar_trace[1024 * 4];
 #endif
 
-template <int WAVES>
+template <int WAVES, bool WIDE = false>
 __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_allreduce_adam_kernel(GemmArgs gw, ArTileArgs f,
                                                                                tnn::p2p::LaunchCtx ctx,
                                                                                tnn::p2p::AdamTail t) {
     using namespace tnn::p2p;
-    __shared__ float red[WAVES][4][64];
-    __shared__ float bsum[WAVES][64];
-    __shared__ __attribute__((aligned(16))) float tile[16 * 16 + 16];
+    constexpr int TW = WIDE ? 32 : 16;                     // columns of a tile
+    __shared__ float red[WAVES][WIDE ? 8 : 4][64];
+    __shared__ float bsum[WAVES][WIDE ? 2 : 1][64];
+    __shared__ __attribute__((aligned(16))) float tile[16 * TW + TW];
     const Peers& p = ctx.peers;
     const int tid = threadIdx.x, P = ctx.ar_grid;
 #ifdef TNN_AR_TRACE
@@ -1487,28 +1587,30 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_allreduce_adam_kernel(G
     if ((int)blockIdx.x < f.n_dw) {
         const int b = (int)blockIdx.x % P;
         const uint32_t tag = ctx.ar_epoch[b] + 1;
-        small_tile<false, false, WAVES, false, true>(gw, nullptr, (int)blockIdx.x, red, bsum, nullptr, tile);
+        if constexpr (WIDE) dw_tile_wide<WAVES, false, true>(gw, nullptr, (int)blockIdx.x, red, bsum, nullptr, tile);
+        else small_tile<false, false, WAVES, false, true>(gw, nullptr, (int)blockIdx.x, red, reinterpret_cast<float(*)[64]>(bsum), nullptr, tile);
         __syncthreads();
 #ifdef TNN_AR_TRACE
         if (tid == 0 && blockIdx.x < 1024) g_ar_trace[blockIdx.x * 4 + 1] = wall_clock64();
 #endif
-        if (tid < 68 && __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        constexpr int Q = TW / 4;                              // float4 per tile row
+        if (tid < 16 * Q + Q && __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
             int tm, tn;
             small_tile_coords(gw, (int)blockIdx.x, tm, tn);
-            const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * 16;
+            const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * TW;
             int64_t e;
             bool live;
             f32x4 v;
-            if (tid < 64) {
-                const int row = tid >> 2, c4 = tid & 3;
+            if (tid < 16 * Q) {
+                const int row = tid / Q, c4 = tid % Q;
                 live = m0 + row < gw.M && n0 + 4 * c4 < gw.N;
                 e = f.w_off + (m0 + row) * gw.ldc + n0 + 4 * c4;
-                v = *reinterpret_cast<const f32x4*>(tile + row * 16 + 4 * c4);
+                v = *reinterpret_cast<const f32x4*>(tile + row * TW + 4 * c4);
             } else {
-                const int c4 = tid - 64;
+                const int c4 = tid - 16 * Q;
                 live = tm == 0 && n0 + 4 * c4 < gw.N;
                 e = f.b_off + n0 + 4 * c4;
-                v = *reinterpret_cast<const f32x4*>(tile + 256 + 4 * c4);
+                v = *reinterpret_cast<const f32x4*>(tile + 16 * TW + 4 * c4);
             }
             if (live) {
                 const int q = (int)(e / f.slice);
@@ -2224,6 +2326,13 @@ int tnn_dense_bwd(int64_t rows, int64_t n_in, int64_t n_out, const void* x, cons
     return 0;
 }
 
+// the 16 x 32 tile form of the first layer's weight gradient (dw_tile_wide): N a multiple of 32, enough tiles to fill the chip
+// either way; TNN_DW0_WIDE=0 keeps the 16 x 16 tiles (A/B measurements)
+static bool dw0_wide_ok(const GemmArgs& g) {
+    static const bool off = getenv("TNN_DW0_WIDE") && atoi(getenv("TNN_DW0_WIDE")) == 0;
+    return !off && g.N % 32 == 0 && ((g.M + 15) / 16) * (g.N / 32) >= 256 && g.epi == EPI_AXPBY && g.beta == 0.f;
+}
+
 int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const void* x, const void* dz, void* dw, void* db,
                              void* p_w, void* m_w, void* v_w, void* p_b, void* m_b, void* v_b, void* flat_p,
                              const void* flat_g, void* flat_m, void* flat_v, int64_t flat_n, double lr, double b1,
@@ -2262,6 +2371,16 @@ int tnn_dense_bwd_first_adam(int64_t rows, int64_t n_in, int64_t n_out, const vo
         const int extra = ad.fn > 0 ? (int)std::min<int64_t>((ad.fn + W * 64 - 1) / (W * 64), 64) : 0;      \
         hipLaunchKernelGGL((dense_bwd0_adam_kernel<W>), n_dw + extra, W * 64, 0, s, gw, (float*)db, ad, n_dw); \
     } while (0)
+            // 16 x 32 tiles (dw_tile_wide): half the workgroups, at most two per CU for the MNIST net's 784 x 256 gradient
+            if (nchunks <= 16 && dw0_wide_ok(gw)) {
+                gw.tiles_n = (int)(gw.N / 32);
+                pick_xcd_cut(gw);
+                const int n_wide = gw.tiles_m * gw.tiles_n;
+                const int extra = ad.fn > 0 ? (int)std::min<int64_t>((ad.fn + 255) / 256, 64) : 0;
+                hipLaunchKernelGGL((dense_bwd0_adam_kernel<4, true>), n_wide + extra, 256, 0, s, gw, (float*)db, ad, n_wide);
+                TNN_LAUNCH_OK();
+                return 0;
+            }
             // measured at bs 128 (8 chunks): 4 waves with two chunks each 21.5 us/step, 8 waves with one chunk each 22.2, 16
             // waves 23.7 — the launch's 784 workgroups cost more per wave than the second load round trip saves
             const int waves = nchunks <= 16 ? 4 : nchunks <= 48 ? 8 : 16;
@@ -2349,7 +2468,14 @@ int tnn_dense_bwd_first_allreduce_adam(int64_t rows, int64_t n_in, int64_t n_out
             t.scalar_dst = (float*)scalar_dst;
             // the transport's polling workgroups (128 by default) behind the tiles, 256 threads each: with up to eight ranks'
             // launches on ONE GPU (the tests) they still leave half the wave slots to the producers
-            hipLaunchKernelGGL((dense_bwd0_allreduce_adam_kernel<4>), f.n_dw + ctx.ar_grid, 256, 0, tnn::stream(), gw, f, ctx, t);
+            if (dw0_wide_ok(gw)) {                           // 16 x 32 tiles: 392 equal tile workgroups for the MNIST net
+                gw.tiles_n = (int)(gw.N / 32);
+                pick_xcd_cut(gw);
+                f.n_dw = gw.tiles_m * gw.tiles_n;
+                hipLaunchKernelGGL((dense_bwd0_allreduce_adam_kernel<4, true>), f.n_dw + ctx.ar_grid, 256, 0, tnn::stream(), gw, f, ctx, t);
+            } else {
+                hipLaunchKernelGGL((dense_bwd0_allreduce_adam_kernel<4>), f.n_dw + ctx.ar_grid, 256, 0, tnn::stream(), gw, f, ctx, t);
+            }
             TNN_LAUNCH_OK();
             return 0;
         }

@@ -343,6 +343,9 @@ struct HeadBwdArgs {
     float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
     int n_in, tiles_in;              // tiles_in = n_in / 16
     int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8)
+    int dx_wide;                     // mlp_head_bwd_kernel (<= 128 rows): dx tiles of 16 rows x 32 inputs (tiles_in even) — for the MNIST
+                                     // net 16 + 128 + 64 = 208 workgroups instead of 272: the 16 that were a CU's SECOND workgroup ended
+                                     // 1.1 us behind the rest (round 6, profiles/r06_stepA_stamps.txt)
 };
 
 // CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
     __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];   // dz [row][12] (columns 10, 11 hold 0)
     __shared__ __attribute__((aligned(16))) float pan[16 * PS];     // dx tiles: dz1 [16 rows][H], stride H + 4
-    __shared__ float redm[8][4][64];
+    __shared__ float redm[8][8][64];                                // (registers 4 .. 7: the second column half of a wide dx tile)
     __shared__ float bsum[8][64];
     __shared__ double red[8][4];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
     const int n_dw = q.tiles_in * TH;
     const int blk = (int)blockIdx.x - G;
     const bool is_dw = blk < n_dw;
+    const bool wide = q.dx_wide != 0;                                 // block-uniform
     const int n_in = q.n_in;
     // tile coordinates.  dW: tm over the inputs, tn over the hidden units; dx: tm over the rows, tn over the inputs
     int tm, tn;
@@ -386,13 +390,14 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         } else { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
     } else {
         const int b2 = blk - n_dw, tr = (m + 15) / 16;
-        if (q.xcd && tr % 2 == 0 && q.tiles_in % 4 == 0 && n_dw % 8 == 0) {
+        const int tcols = wide ? q.tiles_in / 2 : q.tiles_in;        // dx tile columns (16 or 32 inputs each)
+        if (q.xcd && tr % 2 == 0 && tcols % 4 == 0 && n_dw % 8 == 0) {
             const int xcd = b2 & 7, idx = b2 >> 3, pm = tr / 2;
             tm = (xcd & 1) * pm + idx % pm;
-            tn = (xcd >> 1) * (q.tiles_in / 4) + idx / pm;
+            tn = (xcd >> 1) * (tcols / 4) + idx / pm;
         } else { tm = b2 % tr; tn = b2 / tr; }
     }
-    const int m0 = tm * 16, n0 = tn * 16;
+    const int m0 = tm * 16, n0 = tn * ((!is_dw && wide) ? 32 : 16);
 
     // ---- every global read, up front.  The dz1 slice of a tile is itself a 16x16x4 MFMA product
     //   P[row][unit] = sum_c dz[row][c] W2[unit][c]    (K = 12: 10 classes + 2 zero columns, 3 MFMAs per wave)
@@ -409,15 +414,20 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
 #pragma unroll
     for (int r = 0; r < 4; ++r) a1m[r] = p.a[(size_t)min(prow0 + r, m - 1) * H + urow];
     float af[4] = {0.f, 0.f, 0.f, 0.f};          // dW: x fragment
-    f32x4 bf = {0.f, 0.f, 0.f, 0.f};             // dx: W1 fragment
-    float e_pre = 0.f;                           // dx: mask source
+    f32x4 bf = {0.f, 0.f, 0.f, 0.f}, bf1 = {0.f, 0.f, 0.f, 0.f};     // dx: W1 fragment(s)
+    float e_pre = 0.f, e_pre1 = 0.f;             // dx: mask source(s)
     const int e_r = (t >> 6) & 3, e_ln = t & 63;
     if (is_dw) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) af[j] = q.x[(size_t)min(16 * wid + 4 * grp + j, m - 1) * n_in + m0 + i16];
     } else {
         bf = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + i16) * H + 16 * wid + 4 * grp);
-        if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, m - 1) * n_in + n0 + (e_ln & 15)];
+        if (wide) bf1 = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + 16 + i16) * H + 16 * wid + 4 * grp);
+        if (t < 256) {
+            const float* xr = q.x + (size_t)min(m0 + (e_ln >> 4) * 4 + e_r, m - 1) * n_in + n0 + (e_ln & 15);
+            e_pre = xr[0];
+            if (wide) e_pre1 = xr[16];
+        }
     }
     if (grp >= 2) w2f[2] = 0.f;                  // classes 10, 11 do not exist (the clamped address read class 9)
     static_assert(C == 10, "the zero columns of the K = 12 product are written for 10 classes");
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
 #pragma unroll
         for (int r = 0; r < 4; ++r) pz[r] = (__float_as_uint(a1m[r]) >> 31) ? 0.f : pz[r];   // rows >= m: dz = 0 there
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     if (is_dw) {
         if constexpr (CUT == 4) {
@@ -496,9 +506,17 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(pan + i16 * PS + 16 * wid + 4 * grp);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[j], acc, 0, 0, 0);
+        if (wide) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf1[j], acc1, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) redm[wid][r][lane] = acc[r];
+    if (!is_dw && wide) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redm[wid][4 + r][lane] = acc1[r];
+    }
     bsum[wid][lane] = bs;
     __syncthreads();
     TNN_STEP_STAMP(g_step_trace_head, 0, 2);
@@ -508,7 +526,15 @@ __global__ __launch_bounds__(512) void mlp_head_bwd_kernel(HeadMArgs p, HeadBwdA
         for (int w = 0; w < 8; ++w) s += redm[w][e_r][e_ln];
         const int row = m0 + (e_ln >> 4) * 4 + e_r, col = n0 + (e_ln & 15);           // 16x16x4 C/D layout
         if (is_dw) q.dw1[(size_t)row * H + col] = s;
-        else if (row < m) q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+        else if (row < m) {
+            q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+            if (wide) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s1 += redm[w][4 + e_r][e_ln];
+                q.dx[(size_t)row * n_in + col + 16] = (__float_as_uint(e_pre1) >> 31) ? 0.f : s1;
+            }
+        }
     }
     if (is_dw && tm == 0 && t < 16) {
         float s = 0.f;
@@ -1454,7 +1480,10 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
     q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
     q.xcd = 1;
-    const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * q.tiles_in;
+    // <= 128 rows: dx tiles of 32 inputs when that brings the launch under one workgroup per CU's worth of imbalance (TNN_HEAD_DX_WIDE=0: A/B)
+    static const bool dx_wide_off = getenv("TNN_HEAD_DX_WIDE") && atoi(getenv("TNN_HEAD_DX_WIDE")) == 0;
+    q.dx_wide = (rows <= 128 && q.tiles_in % 2 == 0 && !dx_wide_off) ? 1 : 0;
+    const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * (q.dx_wide ? q.tiles_in / 2 : q.tiles_in);
     if (xc != nullptr) {
         // data parallel, DEFERRED exchange: <= 128 rows — statistics inside as on one GPU, then exchanged; more — the panels' pairs
         // of THIS shard from memory (row-panel forward), merged, then exchanged
@@ -1587,7 +1616,9 @@ int tnn_mlp_head_bwd_xchg_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int
     const bool tuned = head_multi_fits(1, n_hidden, n_classes, dtype);
     int grid = 0, per_cu = 0;
     if (tuned && rows <= 1024) {
-        grid = 16 + (int)(n_in / 16) * 8 + (int)((rows + 15) / 16) * (int)(n_in / 16);
+        static const bool dx_wide_off = getenv("TNN_HEAD_DX_WIDE") && atoi(getenv("TNN_HEAD_DX_WIDE")) == 0;
+        const int ti = (int)(n_in / 16), dx_cols = (rows <= 128 && ti % 2 == 0 && !dx_wide_off) ? ti / 2 : ti;    // (head_bwd_launch's grid)
+        grid = 16 + ti * 8 + (int)((rows + 15) / 16) * dx_cols;
         static int per_cu_small = -1, per_cu_rb = -1;
         if (per_cu_small < 0) {
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_small, mlp_head_bwd_kernel<128, 10, 0, 3>, 512, 0) != hipSuccess) per_cu_small = 0;

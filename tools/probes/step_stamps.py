@@ -43,7 +43,8 @@ names = ["fwd0  gemm_small_f32_kernel<.., 16, ..>  (784 -> 256, bias + ReLU)",
          "fwd1  gemm_small_f32_kernel<.., 4, ..>   (256 -> 128, bias + ReLU, partial logits)",
          "head  mlp_head_bwd_kernel<128, 10>       (loss, dz, dW2 / db2, dW1 / db1, dx1)",
          "bwd0  dense_bwd0_adam_kernel<4>          (dW0 / db0 + Adam over the arena)"]
-grids = [8 * 16, 8 * 8, 16 + 16 * 8 + 8 * 16, 49 * 16]
+grids = [8 * 16, 8 * 8, 16 + 16 * 8 + (8 * 8 if os.environ.get("TNN_HEAD_DX_WIDE", "1") != "0" else 8 * 16),
+         49 * 8 if os.environ.get("TNN_DW0_WIDE", "1") != "0" else 49 * 16]
 print("# rows %d; us relative to the launch's first workgroup entry; min / median / max over workgroups (median over 40 steps)" % rows)
 for k in range(4):
     n = min(grids[k] if rows == 128 else 1024, 1024)
@@ -61,11 +62,19 @@ for k in range(4):
         print("    %-28s min %6.2f   med %6.2f   max %6.2f" % (label, np.nanmedian(np.nanmin(vv, axis=1)), np.nanmedian(vv),
                                                                 np.nanmedian(np.nanmax(vv, axis=1))))
     if k == 2:
-        head = rel[:, :16, 3]
-        print("    (of which the 16 head workgroups end at      med %6.2f   max %6.2f)" % (np.median(head), np.median(head.max(axis=1))))
+        for role, lo, hi in (("16 head workgroups", 0, 16), ("128 dW1 tiles", 16, 144), ("%d dx1 tiles" % (n - 144), 144, n)):
+            part = rel[:, lo:hi, 3]
+            print("    (%-20s end: med %6.2f   max %6.2f; entry max %5.2f)" % (role, np.median(part), np.median(part.max(axis=1)),
+                                                                              np.median(rel[:, lo:hi, 0].max(axis=1))))
+        done = rel[:, :, 3].mean(axis=0)
+        order = np.argsort(done)
+        print("    slowest workgroups (index: end):", ", ".join("%d: %.2f" % (i, done[i]) for i in order[-10:]))
     if k == 3:
         done = rel[:, :, 3].mean(axis=0)
         order = np.argsort(done)
         print("    slowest workgroups (index: end):", ", ".join("%d: %.2f" % (i, done[i]) for i in order[-8:]))
-        print("    end by position in the grid: first 256 %.2f, second 256 %.2f, third 256 %.2f, last 16 %.2f" % (
-            done[:256].mean(), done[256:512].mean(), done[512:768].mean(), done[768:].mean()))
+        if n == 784:
+            print("    end by position in the grid: first 256 %.2f, second 256 %.2f, third 256 %.2f, last 16 %.2f" % (
+                done[:256].mean(), done[256:512].mean(), done[512:768].mean(), done[768:].mean()))
+        else:
+            print("    end by position in the grid: first 256 %.2f, the other %d %.2f" % (done[:256].mean(), n - 256, done[256:].mean()))
