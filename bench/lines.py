@@ -59,8 +59,8 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
 def all_epochs_object(stats, steady, num_ep, n_train, train_all):
     """Everything from the first shuffle to the last loss — and the same WITHOUT the epochs that carry the one-off GPU-side pause
     (an epoch whose GPU time, `steps`, is more than 3x the steady median; profiles/r06_epoch_stall_clocks.txt: 35-80 ms, once or
-    twice per process, 0.3-0.6 s after a sustained power-limited load ended; no sclk / mclk / fclk / socclk level changes with it
-    and it does not depend on the large configuration's buffers being released)."""
+    twice per process, certain 0.3-0.6 s after a sustained power-limited load ended but seen without one too; no mclk / fclk /
+    socclk level changes with it and it does not depend on the large configuration's buffers being released)."""
     med = float(np.median([st["steps"] for st in stats[1:]])) if len(stats) > 1 else float(stats[0]["steps"])
     paused = [i for i, st in enumerate(stats) if st["steps"] > 3.0 * med]
     out = {"value": round(num_ep * n_train / train_all, 1), "train_ms": round(train_all * 1e3, 3), "paused_epochs": paused}

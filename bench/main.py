@@ -50,8 +50,8 @@ def single_gpu_secondary(line, args, widths, rows, kind, res, runner, solo, use_
             line["paths"] = paths
             # (before the large configurations: releasing their GBs of buffers stalls the GPU once, ~70 ms, some 50 ms later —
             # tools/probes/epoch_stall.py; the object's `value` is a median over the steady epochs anyway)
-            # (round 6: also before the 4096-wide GEMM replays — a sustained power-limited load in front is what brings the
-            # one-off 35-80 ms GPU-side pause into one of the epochs, profiles/r06_epoch_stall_clocks.txt)
+            # (round 6: also before the 4096-wide GEMM replays — a sustained power-limited load in front makes the one-off
+            # 35-80 ms GPU-side pause of one epoch certain; it is not the only way in: profiles/r06_epoch_stall_clocks.txt)
             line["epoch_loop"] = epoch_loop_object(res["value"])
             line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
             attach_gemm_traffic(line["roofline_gemm4096"], "C")
