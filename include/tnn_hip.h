@@ -611,6 +611,10 @@ TNN_API int tnn_p2p_connect(const void* handles /* world x 64 bytes, rank order 
 /* workgroups of the all-reduce kernel (0 = pick from the message size; TNN_P2P_BLOCKS sets the initial value).
  * Collective: every rank must set the same value before the next all-reduce. */
 TNN_API int tnn_p2p_tune(int allreduce_blocks);
+/* Start-up check of the deferred statistics exchange (tnn_mlp_head_bwd_tick_xchg): a 64-workgroup launch in which one workgroup
+ * pushes {m_mine, s_mine} to every peer and EVERY workgroup merges the ranks' pairs from its own tagged slots, as the head launch
+ * of a data-parallel step does; out_pairs_f32 (device, [64][2] float32) receives what each workgroup ended up with.  Collective. */
+TNN_API int tnn_p2p_xchg_selftest(double m_mine, double s_mine, void* out_pairs_f32);
 TNN_API int tnn_p2p_enable(int on);                         /* route eligible collectives here (default after connect) */
 /* dead != 0: a barrier timed out (TNN_P2P_TIMEOUT_MS, default 20000) - results since then are invalid; synchronises */
 TNN_API int tnn_p2p_status(int* connected, int* enabled, int* dead);

@@ -1289,6 +1289,7 @@ int tnn_p2p_create(int rank, int world, int64_t, void* h) {
 int tnn_p2p_connect(const void*) { g_comm = 1; return 0; }
 int tnn_p2p_enable(int) { return 0; }
 int tnn_p2p_tune(int) { return 0; }
+int tnn_p2p_xchg_selftest(double, double, void*) { REQ(false, "cpu twin: no peer-to-peer transport"); return 0; }
 int tnn_p2p_set_bulk_bytes(int64_t) { return 0; }          // (no peer-to-peer transport on the twin: tnn_p2p_create refuses)
 int tnn_p2p_status(int* c, int* e, int* d) {
     // with the collective callbacks installed there is no peer-to-peer transport: the step takes the RCCL-shaped path

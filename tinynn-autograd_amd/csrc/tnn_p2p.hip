@@ -224,6 +224,16 @@ __global__ __launch_bounds__(THREADS) void p2p_bulk_kernel(Peers p, const char* 
     if (threadIdx.x == 0) epoch[b] = e + 1;
 }
 
+// Start-up check of the deferred statistics exchange (xchg_merge): every workgroup of a 64-workgroup launch merges the ranks' pairs
+// exactly as the head kernels do and writes what it got; a one-thread launch in front advances the sequence number as the forward
+// launch of a step does.
+__global__ void p2p_xchg_bump_kernel(uint32_t* seq) { *seq += 1u; }
+__global__ __launch_bounds__(256) void p2p_xchg_test_kernel(const XchgCtx* xc, int world, float M, float S, float* __restrict__ out) {
+    __shared__ float xm[2];
+    xchg_merge<256>(xc, world, M, S, blockIdx.x == 0, xm);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = M; out[2 * blockIdx.x + 1] = S; }
+}
+
 int esize(int dtype) {
     switch (dtype) {
         case TNN_F32: return 4;
@@ -495,6 +505,18 @@ int tnn_p2p_status(int* connected, int* enabled, int* dead) {
             TNN_CHECK_HIP(hipMemcpy(dead, S.dead, sizeof(int), hipMemcpyDeviceToHost));
         }
     }
+    return 0;
+}
+
+int tnn_p2p_xchg_selftest(double m_mine, double s_mine, void* out_pairs_f32) {
+    // out_pairs_f32: device [64][2] floats — the pair every one of 64 workgroups ended up with (all equal to the merge of the ranks'
+    // {m_mine, s_mine} when the exchange works).  Collective: every rank calls it once per round.
+    TNN_NEED_INIT();
+    TNN_REQUIRE(S.open && S.enabled && S.xchg_dev != nullptr && out_pairs_f32 != nullptr, "tnn_p2p_xchg_selftest: the transport is not enabled");
+    if (int rc = tnn::p2p_refuse_if_failed("tnn_p2p_xchg_selftest")) return rc;
+    hipLaunchKernelGGL(p2p_xchg_bump_kernel, 1, 1, 0, tnn::stream(), S.xchg_seq);
+    hipLaunchKernelGGL(p2p_xchg_test_kernel, 64, 256, 0, tnn::stream(), S.xchg_dev, S.p.world, (float)m_mine, (float)s_mine, (float*)out_pairs_f32);
+    TNN_LAUNCH_OK();
     return 0;
 }
 

@@ -197,6 +197,27 @@ class DeviceCommunicator(Communicator):
             got = np.asarray(self.allgather(mine))
             want = np.array([[r + 0.25 * k, -1.0 - r] for r in range(self.world)], np.float32)
             ok = ok and np.array_equal(got, want)
+        # the deferred statistics exchange of the data-parallel head launch (every workgroup of a 64-workgroup launch merges the
+        # ranks' pairs: tnn_p2p_xchg_selftest) against the same merge on the host
+        for k in range(rounds):
+            pairs = [(np.float32(0.25 * r + 0.5 * k), np.float32(1.0 + 0.5 * r + k)) for r in range(self.world)]
+            out = da.empty((64, 2), np.float32)
+            _lib.get().p2p_xchg_selftest(float(pairs[self.rank][0]), float(pairs[self.rank][1]), out._ptr)
+            big = max(float(m) for m, _ in pairs)
+            want = (big, sum(float(s_) * float(np.exp(np.float32(float(m) - big))) for m, s_ in pairs))
+            got = np.asarray(out, dtype=np.float64)
+            ok = ok and bool(np.all(got[:, 0] == want[0]) and np.allclose(got[:, 1], want[1], rtol=1e-5, atol=0.0))
+        # ... and, on a group without an RCCL communicator, the bulk path (reduce-scatter with fp32 accumulation in rank order, all-gather)
+        if getattr(self, "p2p_bulk_bytes", 0) > 0 and not self._rccl and self.world > 1:
+            n = 4096 + 8
+            contrib = [np.random.RandomState(7 + q).uniform(-1, 1, n * self.world).astype(np.float32) for q in range(self.world)]
+            send, recv = da.asarray(contrib[self.rank]), da.zeros((n,), np.float32)
+            _lib.get().reduce_scatter(send._ptr, recv._ptr, n, _lib.F32)
+            ok = ok and np.array_equal(np.asarray(recv), _rank_order_sum(contrib, self.rank, n))
+            whole = da.zeros((n * self.world,), np.float32)
+            _lib.get().allgather(recv._ptr, whole._ptr, n, _lib.F32)
+            want = np.concatenate([_rank_order_sum(contrib, r, n) for r in range(self.world)])
+            ok = ok and np.array_equal(np.asarray(whole), want)
         return bool(ok and not self.p2p_status()["dead"])
 
     # ---- collectives
@@ -236,6 +257,13 @@ class DeviceCommunicator(Communicator):
             if self._rccl:
                 _lib.get().comm_destroy()
                 self._rccl = False
+
+
+def _rank_order_sum(contrib, r, n):
+    acc = contrib[0][r * n:(r + 1) * n].copy()
+    for q in range(1, len(contrib)):
+        acc = acc + contrib[q][r * n:(r + 1) * n]
+    return acc
 
 
 class RcclCommunicator(DeviceCommunicator):
