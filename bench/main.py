@@ -450,7 +450,12 @@ def main():
             line.setdefault("reference_example_net", {"widths": "-".join(map(str, ex_widths))})["dp_world1"] = ex_dp
 
     # ---------------------------------------------------------------- configs[4] (bf16, 8 GPUs) on the data-parallel line
-    if (comm is not None and (getattr(comm, "_rccl", False) or getattr(comm, "p2p_bulk_bytes", 0) > 0) and args.workload == "A" and args.path == "fused"
+    # (a peer-to-peer-only group carries the bandwidth-sized collectives on the transport's bulk path — but only two such ranks may
+    # SHARE a GPU: the skinny bf16 GEMM's in-launch split-K hand-off needs its whole 256-workgroup grid resident, which eight
+    # 8192-wide trainers time-slicing one device cannot give each other; measured: the bounded wait runs out, sticky fault 1)
+    e_leg_ok = getattr(comm, "_rccl", False) or (getattr(comm, "p2p_bulk_bytes", 0) > 0 and
+                                                 (os.environ.get("TNN_DEVICE") is None or world <= 2))
+    if (comm is not None and e_leg_ok and args.workload == "A" and args.path == "fused"
             and not args.no_extras and args.rows is None and os.environ.get("TNN_BENCH_CONFIG_E", "1") != "0"):
         # never at the price of the line: a watchdog on EVERY rank emits the line as it stands and ends the process if the
         # extra measurement does not come back (it is the first time this step form meets real links)
