@@ -100,6 +100,169 @@ def dp_world1_objects(line, args, widths, kind, warmup, steps, solo, use_graph):
             comm1.close()
 
 
+def data_parallel_primary(args, comm, clock, runner, widths, rows, kind, world, rank, warmup, steps, force_dp, emit, all_ranks,
+                          p2p_alive, replicas_identical):
+    """The primary measurement of a data-parallel line: the same runner timed on RCCL first (north_star's named transport), on the
+    xGMI peer-to-peer path second; both are reported, and `value` follows a RULE, not a best-of-two.  Returns (result, transports)."""
+    # Data-parallel run.  RCCL first (north_star's named transport), the xGMI peer-to-peer path second; both are
+    # reported.  The latency path carries f32 sums up to its mapped capacity: config A's 0.94 MB arena, not C's
+    # 134 MB or E's 1 GB — those go to RCCL whatever the transport's state.
+    transports = {}
+    arena_bytes = (int(runner.trainer.arena_size) + 1) * 4
+    have_rccl = bool(getattr(comm, "_rccl", False))
+    have_p2p = p2p_alive() and arena_bytes <= getattr(comm, "p2p_bytes", 0)
+    res_rccl = res_p2p = None
+    if have_rccl:
+        if have_p2p:
+            comm.set_p2p(False)
+            runner.capture()
+        res_rccl = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
+        transports["rccl"] = brief(res_rccl, replicas_identical=replicas_identical(runner),
+                                   graph_captured=runner.chunk is not None)
+    primary, used = res_rccl, "rccl"
+    if have_p2p:
+        # nothing below may cost the RCCL result: a watchdog emits the line as it stands (RCCL as `value`) and ends
+        # the process with a NON-ZERO code if the peer-to-peer run does not come back (bounded spins make that a
+        # 20 s affair per stuck barrier; a hard hang is what the timer is for)
+        limit = int(os.environ.get("TNN_BENCH_P2P_TIMEOUT_S", "120"))
+        partial = {"line": None}
+
+        def give_up():
+            if partial["line"] is not None:
+                partial["line"]["exit_code"] = 3
+                partial["line"]["config"]["collectives"]["xgmi_p2p"] = "did not finish in %d s" % limit
+                emit(partial["line"])
+            os._exit(3)
+        dog = threading.Timer(limit, give_up)
+        dog.daemon = True
+        if res_rccl is not None and rank == 0:
+            partial["line"] = make_line(args, widths, rows, kind, world, warmup, steps, res_rccl, runner,
+                                        dict(transports, used="rccl"), force_dp)
+        if res_rccl is not None:
+            dog.start()
+        comm.set_p2p(True)
+        try:
+            runner.capture()
+            res_p2p = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
+        except Exception as exc:                              # noqa: BLE001 - a peer timeout raises on every rank (comm.check votes)
+            sys.stderr.write("bench: the peer-to-peer leg raised: %s\n" % exc)
+            res_p2p = None
+        if res_p2p is None:
+            dog.cancel()
+            transports["xgmi_p2p"] = "failed (a peer barrier timed out); transport switched off"
+            if res_rccl is None:
+                raise SystemExit("bench: the peer-to-peer transport failed and no RCCL communicator exists")
+            comm.set_p2p(False)
+            runner.capture()
+        else:
+            alive = p2p_alive()
+            try:
+                verified = all_ranks(alive and comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6))
+            except Exception as exc:                          # noqa: BLE001 - every rank must reach the vote
+                sys.stderr.write("bench: post-run peer-to-peer check raised: %s\n" % exc)
+                verified = all_ranks(False)
+            same = replicas_identical(runner)
+            dog.cancel()
+            transports["xgmi_p2p"] = brief(res_p2p, barrier_timed_out=not alive, verified_after_run=verified,
+                                           replicas_identical=same, graph_captured=runner.chunk is not None)
+            if verified and same and alive:
+                primary, used = res_p2p, "xgmi-p2p"
+            elif res_rccl is None:
+                raise SystemExit("bench: the peer-to-peer transport failed its checks and no RCCL communicator exists")
+    transports["used"] = used
+    transports["rule"] = "value = xgmi_p2p when verified bit-exact after the run, no barrier timed out and replicas identical; else rccl"
+    if primary is None:
+        raise SystemExit("bench: no usable transport")
+    return primary, transports
+
+
+def scaling_curves(line, args, comm, clock, solo, res, widths, rows, kind, world, rank, warmup, steps, use_graph, transports,
+                   replicas_identical):
+    """Workload A: the three scaling definitions beside `value` — this N's weak / strong / 1024-rows-per-rank points, at N = 1 the
+    single-GPU batch sizes in between and the reference's own example net, at N > 1 rank 0's single-GPU references and the
+    speedups computed from them.  Adds its objects to `line` (rank 0)."""
+    other_rows = None
+    if world > 1:
+        other_rows = 128 if args.scaling == "strong" else GLOBAL_BATCH_D // world
+    point = {"global_batch": rows * world, "rows_per_rank": rows, "value": round(res["value"], 1),
+             "ms_per_step": round(res["ms_per_step"], 5)}
+    curves = {("strong_scaling" if (world > 1 and args.scaling == "strong") else "weak_scaling"): point}
+    strong_note = ("strong scaling of configs[3] (global batch 1024 split over N ranks) is bounded by launch latency, not by "
+                   "work: the per-rank step costs about the same number of dependent launches whatever its row count, so the "
+                   "ceiling at N ranks is (single-GPU bs-1024 step) / (bs-1024/N sharded step incl. two collectives); see "
+                   "DESIGN.md §7 for the measured per-row-count steps.  The weak curve (128 rows per rank) is reported beside it.")
+    if world == 1:
+        # N = 1 point of the strong curve: the whole global batch of config D on one GPU
+        d1 = FusedRun(widths, GLOBAL_BATCH_D, kind, 32, 0, 1, None, False, use_graph=use_graph)
+        r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, GLOBAL_BATCH_D)
+        curves["strong_scaling"] = brief(r1, global_batch=GLOBAL_BATCH_D, rows_per_rank=GLOBAL_BATCH_D,
+                                         launches_per_step=d1.launches_per_step(), note=strong_note)
+        del d1
+        if not args.no_extras and args.rows is None:
+            # the same net at the batch sizes in between (the per-rank batches of the strong curve at N = 4 / 2)
+            between = {}
+            for rows_b in (256, 512):
+                rb_run = FusedRun(widths, rows_b, kind, 32, 0, 1, None, False, use_graph=use_graph)
+                between[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
+                                             launches_per_step=rb_run.launches_per_step())
+                del rb_run
+            curves["batch_sizes"] = between
+            # the reference's OWN example net (examples/mnist/run.py:59-69), same batch size and optimizer: the trainer's
+            # 2 L - 2 = 8 launch step (hidden widths padded to multiples of 16, generic merged head kernel); pinned against the reference
+            # by tests/golden/traj_R_example.npz
+            ex_widths = [784, 200, 100, 70, 30, 10]
+            ex_run = FusedRun(ex_widths, 128, kind, 64, 0, 1, None, False, use_graph=use_graph)
+            curves["reference_example_net"] = brief(measure(solo, ex_run, warmup, steps, 3, args.min_ms, 128),
+                                                    widths="-".join(map(str, ex_widths)), rows=128,
+                                                    launches_per_step=ex_run.launches_per_step())
+            del ex_run
+            ex_sizes = {}
+            for rows_b in (256, 512, 1024):              # the generic merged head walking 2 / 4 / 8 blocks of 128 rows
+                rb_run = FusedRun(ex_widths, rows_b, kind, 32, 0, 1, None, False, use_graph=use_graph)
+                ex_sizes[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
+                                              launches_per_step=rb_run.launches_per_step())
+                del rb_run
+            curves["reference_example_net"]["batch_sizes"] = ex_sizes
+        curves["weak_scaling_1024"] = dict(curves["strong_scaling"], note="N = 1 point of the third curve (1024 rows per rank): "
+                                           "the same measurement as strong_scaling's N = 1 point")
+    elif other_rows != rows:
+        other = FusedRun(widths, other_rows, kind, 64 if other_rows <= 256 else 32, rank, world, comm, False,
+                         use_graph=use_graph)
+        ro = measure(clock, other, warmup, steps, 3, args.min_ms, other_rows * world)
+        curves["weak_scaling" if args.scaling == "strong" else "strong_scaling"] = brief(
+            ro, global_batch=other_rows * world, rows_per_rank=other_rows, transport=transports["used"],
+            replicas_identical=replicas_identical(other))
+        del other
+    if world > 1:
+        # third curve: 1024 rows per rank (global batch 1024 N) — the definition under which the step is long enough for the
+        # exchange to amortise (DESIGN.md §7: ceilings of the three curves)
+        w1024 = FusedRun(widths, 1024, kind, 32, rank, world, comm, False, use_graph=use_graph)
+        rw = measure(clock, w1024, warmup, steps, 3, args.min_ms, 1024 * world)
+        curves["weak_scaling_1024"] = brief(rw, global_batch=1024 * world, rows_per_rank=1024, transport=transports["used"],
+                                            replicas_identical=replicas_identical(w1024))
+        del w1024
+        # the single-GPU references of ALL curves, measured in THIS run on rank 0 while the others wait; each curve's
+        # speedup is computed on its own definition (weak: 128 rows on one GPU; strong: the whole 1024 rows on one GPU)
+        if rank == 0:
+            for rows_1 in (128, GLOBAL_BATCH_D):
+                d1 = FusedRun(widths, rows_1, kind, 64 if rows_1 <= 256 else 32, 0, 1, None, False, use_graph=use_graph)
+                r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, rows_1)
+                curves["single_gpu_bs%d" % rows_1] = brief(r1, note="rank 0 alone, no communicator")
+                del d1
+            for name, rows_1 in (("weak_scaling", 128), ("strong_scaling", GLOBAL_BATCH_D), ("weak_scaling_1024", 1024)):
+                if name in curves:
+                    curves[name]["speedup_vs_n1"] = round(
+                        curves[name]["value"] / curves["single_gpu_bs%d" % rows_1]["value"], 4)
+            own = "strong_scaling" if args.scaling == "strong" else "weak_scaling"
+            if line is not None:
+                line["speedup_vs_n1"] = curves[own]["speedup_vs_n1"]
+        comm.barrier()
+    if "strong_scaling" in curves:
+        curves["strong_scaling"].setdefault("note", strong_note)
+    if line is not None:
+        line.update(curves)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,76 +385,8 @@ def main():
     if comm is not None and args.path == "fused":
         selftest_before = collective_selftest(comm, world, rank, all_ranks)
     if comm is not None and args.path == "fused" and isinstance(runner, FusedRun):
-        # Data-parallel run.  RCCL first (north_star's named transport), the xGMI peer-to-peer path second; both are
-        # reported.  The latency path carries f32 sums up to its mapped capacity: config A's 0.94 MB arena, not C's
-        # 134 MB or E's 1 GB — those go to RCCL whatever the transport's state.
-        transports = {}
-        arena_bytes = (int(runner.trainer.arena_size) + 1) * 4
-        have_rccl = bool(getattr(comm, "_rccl", False))
-        have_p2p = p2p_alive() and arena_bytes <= getattr(comm, "p2p_bytes", 0)
-        res_rccl = res_p2p = None
-        if have_rccl:
-            if have_p2p:
-                comm.set_p2p(False)
-                runner.capture()
-            res_rccl = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
-            transports["rccl"] = brief(res_rccl, replicas_identical=replicas_identical(runner),
-                                       graph_captured=runner.chunk is not None)
-        primary, used = res_rccl, "rccl"
-        if have_p2p:
-            # nothing below may cost the RCCL result: a watchdog emits the line as it stands (RCCL as `value`) and ends
-            # the process with a NON-ZERO code if the peer-to-peer run does not come back (bounded spins make that a
-            # 20 s affair per stuck barrier; a hard hang is what the timer is for)
-            limit = int(os.environ.get("TNN_BENCH_P2P_TIMEOUT_S", "120"))
-            partial = {"line": None}
-
-            def give_up():
-                if partial["line"] is not None:
-                    partial["line"]["exit_code"] = 3
-                    partial["line"]["config"]["collectives"]["xgmi_p2p"] = "did not finish in %d s" % limit
-                    emit(partial["line"])
-                os._exit(3)
-            dog = threading.Timer(limit, give_up)
-            dog.daemon = True
-            if res_rccl is not None and rank == 0:
-                partial["line"] = make_line(args, widths, rows, kind, world, warmup, steps, res_rccl, runner,
-                                            dict(transports, used="rccl"), force_dp)
-            if res_rccl is not None:
-                dog.start()
-            comm.set_p2p(True)
-            try:
-                runner.capture()
-                res_p2p = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
-            except Exception as exc:                              # noqa: BLE001 - a peer timeout raises on every rank (comm.check votes)
-                sys.stderr.write("bench: the peer-to-peer leg raised: %s\n" % exc)
-                res_p2p = None
-            if res_p2p is None:
-                dog.cancel()
-                transports["xgmi_p2p"] = "failed (a peer barrier timed out); transport switched off"
-                if res_rccl is None:
-                    raise SystemExit("bench: the peer-to-peer transport failed and no RCCL communicator exists")
-                comm.set_p2p(False)
-                runner.capture()
-            else:
-                alive = p2p_alive()
-                try:
-                    verified = all_ranks(alive and comm.p2p_selftest(sizes=(235147, 4099, 65536), rounds=6))
-                except Exception as exc:                          # noqa: BLE001 - every rank must reach the vote
-                    sys.stderr.write("bench: post-run peer-to-peer check raised: %s\n" % exc)
-                    verified = all_ranks(False)
-                same = replicas_identical(runner)
-                dog.cancel()
-                transports["xgmi_p2p"] = brief(res_p2p, barrier_timed_out=not alive, verified_after_run=verified,
-                                               replicas_identical=same, graph_captured=runner.chunk is not None)
-                if verified and same and alive:
-                    primary, used = res_p2p, "xgmi-p2p"
-                elif res_rccl is None:
-                    raise SystemExit("bench: the peer-to-peer transport failed its checks and no RCCL communicator exists")
-        transports["used"] = used
-        transports["rule"] = "value = xgmi_p2p when verified bit-exact after the run, no barrier timed out and replicas identical; else rccl"
-        if primary is None:
-            raise SystemExit("bench: no usable transport")
-        res = primary
+        res, transports = data_parallel_primary(args, comm, clock, runner, widths, rows, kind, world, rank, warmup, steps, force_dp, emit,
+                                                all_ranks, p2p_alive, replicas_identical)
     else:
         res = measure(clock, runner, warmup, steps, args.repeats, args.min_ms, rows * world)
 
@@ -330,86 +425,8 @@ def main():
 
     # ---------------------------------------------------------------- scaling curves (workload A)
     if args.workload == "A" and args.path == "fused" and not args.no_extras and args.rows is None:
-        other_rows = None
-        if world > 1:
-            other_rows = 128 if args.scaling == "strong" else GLOBAL_BATCH_D // world
-        point = {"global_batch": rows * world, "rows_per_rank": rows, "value": round(res["value"], 1),
-                 "ms_per_step": round(res["ms_per_step"], 5)}
-        curves = {("strong_scaling" if (world > 1 and args.scaling == "strong") else "weak_scaling"): point}
-        strong_note = ("strong scaling of configs[3] (global batch 1024 split over N ranks) is bounded by launch latency, not by "
-                       "work: the per-rank step costs about the same number of dependent launches whatever its row count, so the "
-                       "ceiling at N ranks is (single-GPU bs-1024 step) / (bs-1024/N sharded step incl. two collectives); see "
-                       "DESIGN.md §7 for the measured per-row-count steps.  The weak curve (128 rows per rank) is reported beside it.")
-        if world == 1:
-            # N = 1 point of the strong curve: the whole global batch of config D on one GPU
-            d1 = FusedRun(widths, GLOBAL_BATCH_D, kind, 32, 0, 1, None, False, use_graph=use_graph)
-            r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, GLOBAL_BATCH_D)
-            curves["strong_scaling"] = brief(r1, global_batch=GLOBAL_BATCH_D, rows_per_rank=GLOBAL_BATCH_D,
-                                             launches_per_step=d1.launches_per_step(), note=strong_note)
-            del d1
-            if not args.no_extras and args.rows is None:
-                # the same net at the batch sizes in between (the per-rank batches of the strong curve at N = 4 / 2)
-                between = {}
-                for rows_b in (256, 512):
-                    rb_run = FusedRun(widths, rows_b, kind, 32, 0, 1, None, False, use_graph=use_graph)
-                    between[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
-                                                 launches_per_step=rb_run.launches_per_step())
-                    del rb_run
-                curves["batch_sizes"] = between
-                # the reference's OWN example net (examples/mnist/run.py:59-69), same batch size and optimizer: the trainer's
-                # 2 L - 2 = 8 launch step (hidden widths padded to multiples of 16, generic merged head kernel); pinned against the reference
-                # by tests/golden/traj_R_example.npz
-                ex_widths = [784, 200, 100, 70, 30, 10]
-                ex_run = FusedRun(ex_widths, 128, kind, 64, 0, 1, None, False, use_graph=use_graph)
-                curves["reference_example_net"] = brief(measure(solo, ex_run, warmup, steps, 3, args.min_ms, 128),
-                                                        widths="-".join(map(str, ex_widths)), rows=128,
-                                                        launches_per_step=ex_run.launches_per_step())
-                del ex_run
-                ex_sizes = {}
-                for rows_b in (256, 512, 1024):              # the generic merged head walking 2 / 4 / 8 blocks of 128 rows
-                    rb_run = FusedRun(ex_widths, rows_b, kind, 32, 0, 1, None, False, use_graph=use_graph)
-                    ex_sizes[str(rows_b)] = brief(measure(solo, rb_run, warmup, steps, 3, args.min_ms, rows_b),
-                                                  launches_per_step=rb_run.launches_per_step())
-                    del rb_run
-                curves["reference_example_net"]["batch_sizes"] = ex_sizes
-            curves["weak_scaling_1024"] = dict(curves["strong_scaling"], note="N = 1 point of the third curve (1024 rows per rank): "
-                                               "the same measurement as strong_scaling's N = 1 point")
-        elif other_rows != rows:
-            other = FusedRun(widths, other_rows, kind, 64 if other_rows <= 256 else 32, rank, world, comm, False,
-                             use_graph=use_graph)
-            ro = measure(clock, other, warmup, steps, 3, args.min_ms, other_rows * world)
-            curves["weak_scaling" if args.scaling == "strong" else "strong_scaling"] = brief(
-                ro, global_batch=other_rows * world, rows_per_rank=other_rows, transport=transports["used"],
-                replicas_identical=replicas_identical(other))
-            del other
-        if world > 1:
-            # third curve: 1024 rows per rank (global batch 1024 N) — the definition under which the step is long enough for the
-            # exchange to amortise (ceilings of the three curves)
-            w1024 = FusedRun(widths, 1024, kind, 32, rank, world, comm, False, use_graph=use_graph)
-            rw = measure(clock, w1024, warmup, steps, 3, args.min_ms, 1024 * world)
-            curves["weak_scaling_1024"] = brief(rw, global_batch=1024 * world, rows_per_rank=1024, transport=transports["used"],
-                                                replicas_identical=replicas_identical(w1024))
-            del w1024
-            # the single-GPU references of ALL curves, measured in THIS run on rank 0 while the others wait; each curve's
-            # speedup is computed on its own definition (weak: 128 rows on one GPU; strong: the whole 1024 rows on one GPU)
-            if rank == 0:
-                for rows_1 in (128, GLOBAL_BATCH_D):
-                    d1 = FusedRun(widths, rows_1, kind, 64 if rows_1 <= 256 else 32, 0, 1, None, False, use_graph=use_graph)
-                    r1 = measure(solo, d1, warmup, steps, 3, args.min_ms, rows_1)
-                    curves["single_gpu_bs%d" % rows_1] = brief(r1, note="rank 0 alone, no communicator")
-                    del d1
-                for name, rows_1 in (("weak_scaling", 128), ("strong_scaling", GLOBAL_BATCH_D), ("weak_scaling_1024", 1024)):
-                    if name in curves:
-                        curves[name]["speedup_vs_n1"] = round(
-                            curves[name]["value"] / curves["single_gpu_bs%d" % rows_1]["value"], 4)
-                own = "strong_scaling" if args.scaling == "strong" else "weak_scaling"
-                if line is not None:
-                    line["speedup_vs_n1"] = curves[own]["speedup_vs_n1"]
-            comm.barrier()
-        if "strong_scaling" in curves:
-            curves["strong_scaling"].setdefault("note", strong_note)
-        if line is not None:
-            line.update(curves)
+        scaling_curves(line, args, comm, clock, solo, res, widths, rows, kind, world, rank, warmup, steps, use_graph, transports,
+                       replicas_identical)
 
     # ---------------------------------------------------------------- what the communicator ran on (every line with one)
     if comm is not None and args.path == "fused" and not args.no_extras:

@@ -18,7 +18,7 @@ def test_entry_is_argument_parsing_and_dispatch_only():
     assert len(src.splitlines()) < 120
     main_src = open(os.path.join(ROOT, "bench", "main.py")).read()
     longest = max(n.end_lineno - n.lineno + 1 for n in ast.parse(main_src).body if isinstance(n, ast.FunctionDef))
-    assert longest < 420, "bench.main.main() keeps shrinking: %d lines" % longest
+    assert longest < 300, "bench.main.main() keeps shrinking: %d lines" % longest
 
 
 def test_package_imports_without_a_gpu_and_exports_what_the_probes_use():
