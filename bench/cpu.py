@@ -26,9 +26,11 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(widths, rows, kind, budget_s=8.0):
+def cpu_baseline(widths, rows, kind, budget_s=8.0, host_pool=None):
     """The numpy port of the reference on this host (bounded sample of the same workload): with every BLAS thread the host
-    offers, with 8 and with ONE thread (SURVEY §8d asks for all-threads and one); `value` = the fastest leg."""
+    offers, with 8 and with ONE thread (SURVEY §8d asks for all-threads and one); `value` = the fastest leg.
+    host_pool: what utils/host_threads.fit_blas_pool_to_cpu_quota() reported at start — the all-threads leg runs with the pool's
+    ORIGINAL size (the one numpy chose from the visible CPUs), whatever the process limited it to since."""
     from oracle import ref_nn                              # the reported baseline, never the measured path
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
@@ -61,14 +63,17 @@ def cpu_baseline(widths, rows, kind, budget_s=8.0):
 
     threads = os.cpu_count()
     blas_name = "?"
+    all_limit = None
     if threadpool_info is not None:
         blas = [p for p in threadpool_info() if p.get("user_api") == "blas"]
         if blas:
             threads, blas_name = blas[0]["num_threads"], "%s %s" % (blas[0].get("internal_api"), blas[0].get("version"))
+            if host_pool and host_pool.get("blas_threads_before") and host_pool["blas_threads_before"] > threads:
+                threads = all_limit = host_pool["blas_threads_before"]
     # every leg gets the same budget; `value` is the host's BEST leg (over-subscribed BLAS threads on 128-row GEMMs are slower
     # than one thread: the all-threads leg alone would understate the CPU), all legs stay on the line with their thread counts
     legs = []
-    plan = [("all_threads", None, threads)]
+    plan = [("all_threads", all_limit, threads)]
     if threadpool_limits is not None:
         if threads > 8:
             plan.append(("eight_threads", 8, 8))           # SURVEY §6's container measurement ran on 8 vCPUs
@@ -77,7 +82,7 @@ def cpu_baseline(widths, rows, kind, budget_s=8.0):
         s_l, el_l = leg(limit)
         legs.append({"name": name, "value": round(s_l * rows / el_l, 1), "unit": "samples/s", "cores": cores,
                      "sample": "%d steps in %.1f s with %s" % (s_l, el_l, "every BLAS thread the host offers (%d)" % cores
-                                                                if limit is None else "BLAS limited to %d thread%s" % (limit, "s" if limit > 1 else ""))})
+                                                                if name == "all_threads" else "BLAS limited to %d thread%s" % (limit, "s" if limit > 1 else ""))})
     best = max(legs, key=lambda l: l["value"])
     out = {"value": best["value"], "unit": "samples/s", "cores": best["cores"], "kind": "port", "best_leg": best["name"],
            "cpu_model": cpu_model_name(), "logical_cpus": os.cpu_count(), "numpy": np.__version__, "blas": blas_name,
@@ -86,4 +91,8 @@ def cpu_baseline(widths, rows, kind, budget_s=8.0):
                                                               ", ".join("%s %.0f" % (l["name"], l["value"]) for l in legs))}
     for l in legs:
         out[l["name"]] = {k: l[k] for k in ("value", "unit", "cores", "sample")}
+    if host_pool and host_pool.get("quota_cpus"):
+        out["cpu_quota"] = {"cpus_per_period": host_pool["quota_cpus"],
+                            "note": "the container's CPU bandwidth quota: a leg with more BLAS threads than this is throttled by the "
+                                    "kernel (all_threads is such a leg on a %d-CPU host) — why the 8-thread leg wins" % (os.cpu_count() or 0)}
     return out

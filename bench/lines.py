@@ -57,10 +57,11 @@ def config_e_object(clock, rank=0, world=1, comm=None, force_dp=False):
 
 
 def all_epochs_object(stats, steady, num_ep, n_train, train_all):
-    """Everything from the first shuffle to the last loss — and the same WITHOUT the epochs that carry the one-off GPU-side pause
-    (an epoch whose GPU time, `steps`, is more than 3x the steady median; profiles/r06_epoch_stall_clocks.txt: 35-80 ms, once or
-    twice per process, certain 0.3-0.6 s after a sustained power-limited load ended but seen without one too; no mclk / fclk /
-    socclk level changes with it and it does not depend on the large configuration's buffers being released)."""
+    """Everything from the first shuffle to the last loss — and the same WITHOUT any paused epoch (one whose `steps` time is more
+    than 3x the steady median).  The one-off 35-80 ms epoch of rounds 4-6 was the container's CPU-bandwidth controller stopping
+    every thread of the process: numpy's 64-thread BLAS pool spinning behind the dataset's matmul spent the 16-CPU quota
+    (profiles/r06_epoch_stall_root_cause.txt).  bench.py now sizes the pool to the quota at start (utils/host_threads.py), so
+    `paused_epochs` is expected to be empty; the detection stays as a tripwire."""
     med = float(np.median([st["steps"] for st in stats[1:]])) if len(stats) > 1 else float(stats[0]["steps"])
     paused = [i for i, st in enumerate(stats) if st["steps"] > 3.0 * med]
     out = {"value": round(num_ep * n_train / train_all, 1), "train_ms": round(train_all * 1e3, 3), "paused_epochs": paused}
@@ -125,10 +126,10 @@ def epoch_loop_object(headline_value, n_train=50000, n_test=10000, batch_size=12
     out["reference_example_net"] = ex
     out["note"] = ("headline = the timed replay of pre-captured step graphs over resident batches (`value` of this line); this object "
                    "is the loop a user of examples/mnist/run.py runs.  trainer: epoch 0 pays lazy init + trainer creation + the "
-                   "capture of the epoch graph (phases_per_epoch.capture[0]); epochs >= 1 replay it (capture 0.0).  One early epoch of "
-                   "the first path may carry a one-off 50-80 ms GPU-side pause (a light load following this line's heavy GEMM "
-                   "measurements: not a Python collection, not a HIP call — tools/probes/epoch_stall*.py, JOURNAL.md); `value` is the "
-                   "median of the steady epochs and every epoch is listed.")
+                   "capture of the epoch graph (phases_per_epoch.capture[0]); epochs >= 1 replay it (capture 0.0).  `value` is the "
+                   "median of the steady epochs and every epoch is listed.  (The one-off 50-80 ms epoch earlier rounds reported was the "
+                   "container's CPU quota throttling the process behind a 64-thread BLAS pool, not the GPU: "
+                   "profiles/r06_epoch_stall_root_cause.txt; the pool is now sized to the quota at start.)")
     return out
 
 

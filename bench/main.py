@@ -21,10 +21,13 @@ from .lines import config_e_object, epoch_loop_object, make_line
 from .multi_gpu import collective_latency_table, collective_selftest, rccl_version_string, self_launch, topology_object
 
 
+HOST_POOL = {}                                             # what fit_blas_pool_to_cpu_quota() found / did (main())
+
+
 def single_gpu_secondary(line, args, widths, rows, kind, res, runner, solo, use_graph, comm):
     """Rank 0, N = 1: the roofline objects, the drop-in API paths, the epoch loop, configs[2] and configs[4], the CPU baseline —
-    every one an extra measurement AFTER the line's own `value` exists.  Order matters: the epoch loop runs before every heavy
-    replay (profiles/r06_epoch_stall_clocks.txt)."""
+    every one an extra measurement AFTER the line's own `value` exists."""
+    line["host_blas_pool"] = dict(HOST_POOL)
     if args.workload == "E":
         line["roofline"] = dw_adam_roofline_in_step(runner, widths, rows, res["ms_per_step"])
         line["gemm_roofline"] = time_gemms_bf16(widths, rows)
@@ -48,10 +51,8 @@ def single_gpu_secondary(line, args, widths, rows, kind, res, runner, solo, use_
             paths["host_call_wrappers"] = ("%d of %d entry points called through generated C wrappers instead of ctypes "
                                            "(tinynn-autograd_amd/_fastcall_gen.py)" % (_lib.get().fast_calls, len(_lib._SIGNATURES)))
             line["paths"] = paths
-            # (before the large configurations: releasing their GBs of buffers stalls the GPU once, ~70 ms, some 50 ms later —
-            # tools/probes/epoch_stall.py; the object's `value` is a median over the steady epochs anyway)
-            # (round 6: also before the 4096-wide GEMM replays — a sustained power-limited load in front makes the one-off
-            # 35-80 ms GPU-side pause of one epoch certain; it is not the only way in: profiles/r06_epoch_stall_clocks.txt)
+            # (kept in front of the large configurations; the "pause" earlier rounds ordered around was CPU-quota throttling of the
+            # host threads — profiles/r06_epoch_stall_root_cause.txt — and is gone with the BLAS pool sized at start)
             line["epoch_loop"] = epoch_loop_object(res["value"])
             line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
             attach_gemm_traffic(line["roofline_gemm4096"], "C")
@@ -66,7 +67,7 @@ def single_gpu_secondary(line, args, widths, rows, kind, res, runner, solo, use_
             line["roofline_gemm4096"] = time_gemms(WIDTHS_C, 512, reps=20)
             attach_gemm_traffic(line["roofline_gemm4096"], "C")
     if not args.no_cpu_baseline and args.workload != "E":
-        line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0)
+        line["cpu_baseline"] = cpu_baseline(widths, rows, kind, budget_s=8.0 if args.workload == "A" else 15.0, host_pool=HOST_POOL)
 
 
 def dp_world1_objects(line, args, widths, kind, warmup, steps, solo, use_graph):
@@ -302,6 +303,11 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # numpy's BLAS pool is sized from the CPUs the host SHOWS (64 threads); the container may use 16 — idle pool threads spinning
+    # behind a matmul then get the whole cgroup throttled for the rest of the scheduling period (the "one-off 35-80 ms epoch" of
+    # rounds 4-6: profiles/r06_epoch_stall_root_cause.txt).  Every rank takes its share of half the quota.
+    from tinynn_autograd_amd.utils.host_threads import fit_blas_pool_to_cpu_quota
+    HOST_POOL.update(fit_blas_pool_to_cpu_quota(share=0.5 / max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     if args.gpus != world:
         args.gpus = world                                  # the launcher's WORLD_SIZE is authoritative
 

@@ -36,6 +36,7 @@ from tinynn_autograd_amd.core.nn import Net                                  # n
 from tinynn_autograd_amd.core.optimizer import Adam                          # noqa: E402
 from tinynn_autograd_amd.core.tensor import Tensor                           # noqa: E402
 from tinynn_autograd_amd.utils.data_iterator import BatchIterator            # noqa: E402
+from tinynn_autograd_amd.utils.host_threads import fit_blas_pool_to_cpu_quota  # noqa: E402
 from tinynn_autograd_amd.utils.seeder import random_seed                     # noqa: E402
 
 
@@ -175,6 +176,9 @@ def train(train_x, train_y, test_x, test_y, widths, num_ep, batch_size, lr, trai
 def main(args):
     if args.seed >= 0:
         random_seed(args.seed)
+    pool = fit_blas_pool_to_cpu_quota()                    # (a 64-thread BLAS pool in a 16-CPU container stalls the loop: utils/host_threads.py)
+    if pool["blas_threads"] != pool["blas_threads_before"]:
+        print("host BLAS pool: %d -> %d threads (CPU quota %.1f)" % (pool["blas_threads_before"], pool["blas_threads"], pool["quota_cpus"]))
     (train_x, train_y), (test_x, test_y), source = prepare_dataset(args.data_dir)
     print("data: %s, %d train / %d test rows" % (source, len(train_x), len(test_x)))
     print("backend:", tn.backend_name())
