@@ -1587,6 +1587,9 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_allreduce_adam_kernel(G
     if ((int)blockIdx.x < f.n_dw) {
         const int b = (int)blockIdx.x % P;
         const uint32_t tag = ctx.ar_epoch[b] + 1;
+        // (requested in front of the product: behind it, this agent-scope load was a round trip on the way to the sends — 0.9 us
+        // between "product done" and "sends issued" in profiles/r06_dp_step_stamps.txt; the word is sticky, an earlier look is as good)
+        const int dead_at_entry = __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (WIDE) dw_tile_wide<WAVES, false, true>(gw, nullptr, (int)blockIdx.x, red, bsum, nullptr, tile);
         else small_tile<false, false, WAVES, false, true>(gw, nullptr, (int)blockIdx.x, red, reinterpret_cast<float(*)[64]>(bsum), nullptr, tile);
         __syncthreads();
@@ -1594,7 +1597,7 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_allreduce_adam_kernel(G
         if (tid == 0 && blockIdx.x < 1024) g_ar_trace[blockIdx.x * 4 + 1] = wall_clock64();
 #endif
         constexpr int Q = TW / 4;                              // float4 per tile row
-        if (tid < 16 * Q + Q && __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (tid < 16 * Q + Q && dead_at_entry == 0) {
             int tm, tn;
             small_tile_coords(gw, (int)blockIdx.x, tm, tn);
             const int64_t m0 = (int64_t)tm * 16, n0 = (int64_t)tn * TW;
@@ -1613,7 +1616,8 @@ __global__ __launch_bounds__(WAVES * 64) void dense_bwd0_allreduce_adam_kernel(G
                 v = *reinterpret_cast<const f32x4*>(tile + 16 * TW + 4 * c4);
             }
             if (live) {
-                const int q = (int)(e / f.slice);
+                // (the arena of a latency-size net is far below 2^31 elements: 32-bit division, a 64-bit one costs ~10x the instructions)
+                const int q = f.n < (int64_t(1) << 31) ? (int)((uint32_t)e / (uint32_t)f.slice) : (int)(e / f.slice);
                 ll_send(p.base[q] + ll_recv_off(p, p.rank, (e - (int64_t)q * f.slice) / 4), v, tag);
             }
         }
@@ -1922,9 +1926,10 @@ __global__ __launch_bounds__(512) void dense_bwd0_mid_allreduce_adam_kernel(Gemm
         const int b = (int)blockIdx.x % P;
         const uint32_t tag = ctx.ar_epoch[b] + 1;
         const AdamEpi none = {};
+        const int dead_at_entry = __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (see the 16-row kernel)
         mid_tile<false, false, false, true>(gw, nullptr, none, (int)blockIdx.x, red, bsum, tile);
         __syncthreads();
-        if (tid < 264 && __hip_atomic_load(ctx.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (tid < 264 && dead_at_entry == 0) {
             int tm, tn;
             small_tile_coords(gw, (int)blockIdx.x, tm, tn);            // (the same XCD-aware order as mid_tile)
             const int64_t m0 = (int64_t)tm * 32, n0 = (int64_t)tn * 32;
@@ -1943,7 +1948,8 @@ __global__ __launch_bounds__(512) void dense_bwd0_mid_allreduce_adam_kernel(Gemm
                 v = *reinterpret_cast<const f32x4*>(tile + 1024 + 4 * c4);
             }
             if (live) {
-                const int q = (int)(e / f.slice);
+                // (the arena of a latency-size net is far below 2^31 elements: 32-bit division, a 64-bit one costs ~10x the instructions)
+                const int q = f.n < (int64_t(1) << 31) ? (int)((uint32_t)e / (uint32_t)f.slice) : (int)(e / f.slice);
                 ll_send(p.base[q] + ll_recv_off(p, p.rank, (e - (int64_t)q * f.slice) / 4), v, tag);
             }
         }

@@ -327,7 +327,10 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
     const int64_t s4 = slice / 4;
     const int cnt = first < s4 ? (int)((s4 - first + stride - 1) / stride) : 0;
     const int items = cnt * W;                            // (element k, slice) pairs of this thread
-    bool ok = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    // (the sticky word is looked at once, and its load travels WITH the first batch of gradient loads: as the loop's entry condition
+    // it was a memory round trip of its own in front of them)
+    const int dead_at_entry = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool ok = true;
 
     // (A) slice order starts at my right-hand neighbour so the links fill evenly.  Loads first (L2 hits: the gradients
     // were just written), then the posted stores.
@@ -341,6 +344,7 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
                 v[u] = load_guarded(buf, (int64_t)q * slice + 4 * (first + (j / W) * stride), n);
             }
         }
+        if (dead_at_entry != 0) { ok = false; break; }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int j = j0 + u;
@@ -352,6 +356,7 @@ __device__ __forceinline__ void allreduce_body(const Peers& p, float* __restrict
         }
     }
 
+    ok = ok && dead_at_entry == 0;                          // (threads without an element of their own)
 #ifdef TNN_AR_TRACE
     if (skip.trace && threadIdx.x == 0) skip.trace[1] = wall_clock64();
 #endif

@@ -39,7 +39,8 @@ for it in range(40):
         acc.append(buf.reshape(1024, 4).astype(np.int64).copy())
         assert fh(fbuf.ctypes.data, 1024) == 0
         facc.append(fbuf.reshape(128, 8).astype(np.int64).copy())
-n_dw, P = 784, 128
+# tile workgroups of the fused launch: 49 x 8 tiles of 16 x 32 (round 6; TNN_DW0_WIDE=0: 49 x 16 of 16 x 16), then P polling workgroups
+n_dw, P = (392 if os.environ.get("TNN_DW0_WIDE", "1") != "0" else 784), 128
 tr = np.stack(acc)                                     # [launch][block][stamp]
 t0 = tr[:, :n_dw + P, 0].min(axis=1)[:, None, None]
 rel = (tr - t0) / 100.0                                # us
@@ -58,19 +59,25 @@ print("polling blocks stage A done", q(poll[:, :, 1]))
 print("polling blocks stage B done", q(poll[:, :, 2]))
 print("polling blocks stage C done", q(poll[:, :, 3]))
 
-# the hidden layer's forward + statistics launch (dense_fwd_head_kernel): 64 tile blocks, the last arrival does the tail
+print("(launch: %d tile workgroups + %d polling workgroups; us relative to the launch's first workgroup entry; max = median over launches of the last workgroup)" % (n_dw, P))
+# the hidden layer's forward + statistics launch (dense_fwd_head_kernel): 64 tile blocks, the last arrival does the tail —
+# only in the forward-tail form of the step (TNN_DP_XCHG=0); the deferred form's forward is the single-GPU launch (no stamps)
 ft = np.stack(facc)[:, :64]
-f0 = ft[:, :, 0].min(axis=1)[:, None]
-rel = lambda k: (ft[:, :, k] - f0) / 100.0
-print("fwd1 tile blocks start        ", q(rel(0)))
-print("fwd1 tile + partial logits    ", q(rel(1)))
-print("fwd1 partial logits acked     ", q(rel(2)))
-print("fwd1 ticket drawn             ", q(rel(3)))
-last = ft[:, :, 6] == 1
-lastrel = lambda k: np.array([(ft[i, last[i], k] - f0[i]) / 100.0 for i in range(ft.shape[0])]).ravel()
-print("fwd1 last block: ticket        med %6.2f" % np.median(lastrel(3)))
-print("fwd1 last block: statistics    med %6.2f" % np.median(lastrel(4)))
-print("fwd1 last block: exchange done med %6.2f" % np.median(lastrel(5)))
+if not ft.any():
+    print("fwd1: the deferred-exchange step runs the plain forward launch (no statistics tail to stamp)")
+    ft = None
+if ft is not None:
+    f0 = ft[:, :, 0].min(axis=1)[:, None]
+    rel = lambda k: (ft[:, :, k] - f0) / 100.0
+    print("fwd1 tile blocks start        ", q(rel(0)))
+    print("fwd1 tile + partial logits    ", q(rel(1)))
+    print("fwd1 partial logits acked     ", q(rel(2)))
+    print("fwd1 ticket drawn             ", q(rel(3)))
+    last = ft[:, :, 6] == 1
+    lastrel = lambda k: np.array([(ft[i, last[i], k] - f0[i]) / 100.0 for i in range(ft.shape[0])]).ravel()
+    print("fwd1 last block: ticket        med %6.2f" % np.median(lastrel(3)))
+    print("fwd1 last block: statistics    med %6.2f" % np.median(lastrel(4)))
+    print("fwd1 last block: exchange done med %6.2f" % np.median(lastrel(5)))
 
 # which tile blocks are the slow ones?  (mean product-done time per block index over the traced launches)
 import collections
@@ -83,5 +90,5 @@ for i in range(n_dw):
     byx[i % 8].append(mean_done[i])
 print("mean product-done time by block index mod 8 (XCD):", ", ".join("%d: %.2f" % (x, np.mean(byx[x])) for x in range(8)))
 dur = (tiles[:, :, 1] - tiles[:, :, 0]).mean(axis=0)
-print("product duration (start -> done) by position in the grid: first 98 blocks %.2f, middle %.2f, last 98 %.2f" % (
-    dur[:98].mean(), dur[98:-98].mean(), dur[-98:].mean()))
+print("product duration (start -> done) by position in the grid: first 256 workgroups %.2f, the rest %.2f" % (
+    dur[:256].mean(), dur[256:].mean()))
