@@ -292,9 +292,10 @@ __device__ __forceinline__ bool ll_poll(const char* const (&src)[N], const bool 
             out[k] = f32x4{__uint_as_float(lo[k][0]), __uint_as_float(lo[k][2]), __uint_as_float(hi[k][0]), __uint_as_float(hi[k][2])};
         }
         if (ok) return true;
-        if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
         poll_pause(p.poll_gap);
         if ((++polls & 63u) == 0) {
+            // (the sticky word every 64th poll, ~0.1 ms: looked at after EVERY poll it put an agent-scope round trip between two polls)
+            if (__hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
             const uint64_t now = wall_clock64();
             if (t0 == 0) t0 = now;
             if ((int64_t)(now - t0) > timeout_ticks) {
