@@ -756,14 +756,17 @@ __device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
     }
 
     HeadStats st;
-    if constexpr (SH >= 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, g == 0, ext_ms, 0);
+    // RB: the loss-writing workgroup keeps each row's log term in a register and reduces ONCE behind the walk — the per-block
+    // reduction (a barrier + f64 DPP sums) made workgroup 0 the launch's last by 4 us at 1024 rows (17.2 against 13.1 for its peers)
+    if constexpr (SH >= 2) head_stats<C, true, true>(zc, yc, slive, sub, lane, wid, red, st, !RB && g == 0, ext_ms, 0);
     else head_stats<C>(zc, yc, slive, sub, lane, wid, red, st, g == 0);     // only workgroup 0 writes the loss
     const bool (&valid)[3] = st.valid;
     const float (&ec)[3] = st.ec, (&eyc)[3] = st.eyc;
     const float mx = st.mx, urow = st.urow;
     M = st.M;
     S = st.S;
-    Lsum += st.L;
+    if constexpr (RB) { if (g == 0 && slive && sub == 0) Lsum += (double)logf(urow) + (double)mx; }
+    else Lsum += st.L;
     double inv_m = 1.0 / (double)m;
     if constexpr (SH != 0) inv_m = 1.0 / (double)p.m_global;
     if constexpr (CUT == 2) {
@@ -848,6 +851,15 @@ __device__ __forceinline__ void head_block_rb(const HeadMArgs& p, const int g) {
         if (q == 0) p.dw[(size_t)(g * JPB + jl) * C + c] = s;
     }
     if constexpr (CUT == 5) return;
+    if constexpr (RB) {
+        if (g == 0) {                                            // block-uniform: the rows' log terms, lanes -> waves -> thread 0
+            const double wl = tnn::wave_sum_dpp(Lsum);
+            __syncthreads();                                    // (red was last read inside the walk)
+            if (lane == 0) red[wid][2] = wl;
+            __syncthreads();
+            Lsum = ((red[0][2] + red[1][2]) + (red[2][2] + red[3][2])) + ((red[4][2] + red[5][2]) + (red[6][2] + red[7][2]));
+        }
+    }
     if (g == 0) {
         if (wid == 7) {
             float s = (dbacc[0] + dbacc[1]) + (dbacc[2] + dbacc[3]);
@@ -871,14 +883,16 @@ template <int H, int C, int CUT = 0, int SH = 0, bool RB = false>
 __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMArgs p, HeadBwdArgs q) {
     constexpr int ROWS = 128, WS = 12, NP = H / 16, G = H / 8, TH = H / 16, PS = H + 4;
     static_assert(H == 128 && NP == 8, "one 16-deep K chunk per wave, 8 waves");
+    TNN_STEP_STAMP(g_step_trace_head, 0, 0);                     // (trace build: entry / end of every workgroup, tools/probes/step_stamps.py)
     if ((int)blockIdx.x < G) {
         head_block_rb<H, C, true, 0, false, SH, RB>(p, (int)blockIdx.x);
+        TNN_STEP_STAMP_ACKED(g_step_trace_head, 0, 3);
         return;
     }
     __shared__ __attribute__((aligned(16))) float zs[ROWS * C], ys[ROWS * C];     // staged logits / labels
     __shared__ __attribute__((aligned(16))) float dzr[ROWS * WS];   // dz [row][12] (columns 10, 11 hold 0)
     __shared__ __attribute__((aligned(16))) float pan[16 * PS];     // dx tiles: dz1 [16 rows][H], stride H + 4
-    __shared__ float redm[8][4][64];
+    __shared__ float redm[8][8][64];                                // (registers 4 .. 7: the second column half of a wide dx tile)
     __shared__ float bsum[8][64];
     __shared__ double red[8][4];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -888,6 +902,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
     const int n_dw = q.tiles_in * TH;
     const int blk = (int)blockIdx.x - G;
     const bool is_dw = blk < n_dw;
+    const bool wide = q.dx_wide != 0;                                // block-uniform: dx tiles of 16 rows x 32 inputs
     const int n_in = q.n_in;
     // tile coordinates.  dW: tm over the inputs, tn over the hidden units; dx: tm over the rows, tn over the inputs
     int tm, tn;
@@ -899,13 +914,14 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
         } else { tm = blk % q.tiles_in; tn = blk / q.tiles_in; }
     } else {
         const int b2 = blk - n_dw, tr = (mt + 15) / 16;
-        if (q.xcd && tr % 2 == 0 && q.tiles_in % 4 == 0 && n_dw % 8 == 0) {
+        const int tcols = wide ? q.tiles_in / 2 : q.tiles_in;        // dx tile columns (16 or 32 inputs each)
+        if (q.xcd && tr % 2 == 0 && tcols % 4 == 0 && n_dw % 8 == 0) {
             const int xcd = b2 & 7, idx = b2 >> 3, pm = tr / 2;
             tm = (xcd & 1) * pm + idx % pm;
-            tn = (xcd >> 1) * (q.tiles_in / 4) + idx / pm;
+            tn = (xcd >> 1) * (tcols / 4) + idx / pm;
         } else { tm = b2 % tr; tn = b2 / tr; }
     }
-    const int m0 = tm * 16, n0 = tn * 16;
+    const int m0 = tm * 16, n0 = tn * ((!is_dw && wide) ? 32 : 16);
     // SH == 2 (statistics from memory): any number of rows in blocks of 128.  A dW tile contracts over ALL rows — it walks the
     // blocks and keeps accumulating; a dx tile lives in ONE block (its 16 rows) and derives only that block's dz
     const int nb = RB ? (mt + ROWS - 1) / ROWS : 1;
@@ -922,17 +938,22 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
     float w2f[3];
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) w2f[s3] = p.w[(size_t)urow * C + min(4 * s3 + grp, C - 1)];
-    f32x4 bf = {0.f, 0.f, 0.f, 0.f};             // dx: W1 fragment
-    float e_pre = 0.f;                           // dx: mask source
+    f32x4 bf = {0.f, 0.f, 0.f, 0.f}, bf1 = {0.f, 0.f, 0.f, 0.f};     // dx: W1 fragment(s)
+    float e_pre = 0.f, e_pre1 = 0.f;             // dx: mask source(s)
     const int e_r = (t >> 6) & 3, e_ln = t & 63;
     if (!is_dw) {
         bf = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + i16) * H + 16 * wid + 4 * grp);
-        if (t < 256) e_pre = q.x[(size_t)min(m0 + (e_ln >> 4) * 4 + e_r, mt - 1) * n_in + n0 + (e_ln & 15)];
+        if (wide) bf1 = *reinterpret_cast<const f32x4*>(q.w1 + (size_t)(n0 + 16 + i16) * H + 16 * wid + 4 * grp);
+        if (t < 256) {
+            const float* xr = q.x + (size_t)min(m0 + (e_ln >> 4) * 4 + e_r, mt - 1) * n_in + n0 + (e_ln & 15);
+            e_pre = xr[0];
+            if (wide) e_pre1 = xr[16];
+        }
     }
     if (grp >= 2) w2f[2] = 0.f;                  // classes 10, 11 do not exist (the clamped address read class 9)
     static_assert(C == 10, "the zero columns of the K = 12 product are written for 10 classes");
 
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     float bs = 0.f;
     const f32x4 bias4 = head_stage_bias<C, NP>(p, t);
     float ext_ms[2] = {0.f, 0.f};                // SH >= 2: the batch's {max, sum-exp}, merged once for all row blocks
@@ -1035,10 +1056,18 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
         const f32x4 a4 = *reinterpret_cast<const f32x4*>(pan + i16 * PS + 16 * wid + 4 * grp);
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[j], acc, 0, 0, 0);
+        if (wide) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf1[j], acc1, 0, 0, 0);
+        }
     }
     }   // row blocks
 #pragma unroll
     for (int r = 0; r < 4; ++r) redm[wid][r][lane] = acc[r];
+    if (!is_dw && wide) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) redm[wid][4 + r][lane] = acc1[r];
+    }
     bsum[wid][lane] = bs;
     __syncthreads();
     if (t < 256) {
@@ -1047,7 +1076,15 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
         for (int w = 0; w < 8; ++w) s += redm[w][e_r][e_ln];
         const int row = m0 + (e_ln >> 4) * 4 + e_r, col = n0 + (e_ln & 15);           // 16x16x4 C/D layout
         if (is_dw) q.dw1[(size_t)row * H + col] = s;
-        else if (row < mt) q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+        else if (row < mt) {
+            q.dx[(size_t)row * n_in + col] = (__float_as_uint(e_pre) >> 31) ? 0.f : s;
+            if (wide) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) s1 += redm[w][4 + e_r][e_ln];
+                q.dx[(size_t)row * n_in + col + 16] = (__float_as_uint(e_pre1) >> 31) ? 0.f : s1;
+            }
+        }
     }
     if (is_dw && tm == 0 && t < 16) {
         float s = 0.f;
@@ -1055,6 +1092,7 @@ __global__ __launch_bounds__(512, RB ? 4 : 2) void mlp_head_bwd_rb_kernel(HeadMA
         for (int w = 0; w < 8; ++w) s += (bsum[w][t] + bsum[w][16 + t]) + (bsum[w][32 + t] + bsum[w][48 + t]);
         q.db1[n0 + t] = s;
     }
+    TNN_STEP_STAMP_ACKED(g_step_trace_head, 0, 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1482,7 +1520,8 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     q.xcd = 1;
     // <= 128 rows: dx tiles of 32 inputs when that brings the launch under one workgroup per CU's worth of imbalance (TNN_HEAD_DX_WIDE=0: A/B)
     static const bool dx_wide_off = getenv("TNN_HEAD_DX_WIDE") && atoi(getenv("TNN_HEAD_DX_WIDE")) == 0;
-    q.dx_wide = (rows <= 128 && q.tiles_in % 2 == 0 && !dx_wide_off) ? 1 : 0;
+    static const bool dx_wide_rb_off = getenv("TNN_HEAD_DX_WIDE_RB") && atoi(getenv("TNN_HEAD_DX_WIDE_RB")) == 0;
+    q.dx_wide = (q.tiles_in % 2 == 0 && !dx_wide_off && (rows <= 128 || !dx_wide_rb_off)) ? 1 : 0;
     const int grid = 16 + q.tiles_in * 8 + (int)((rows + 15) / 16) * (q.dx_wide ? q.tiles_in / 2 : q.tiles_in);
     if (xc != nullptr) {
         // data parallel, DEFERRED exchange: <= 128 rows — statistics inside as on one GPU, then exchanged; more — the panels' pairs
@@ -1617,7 +1656,8 @@ int tnn_mlp_head_bwd_xchg_fits(int64_t rows, int64_t n_in, int64_t n_hidden, int
     int grid = 0, per_cu = 0;
     if (tuned && rows <= 1024) {
         static const bool dx_wide_off = getenv("TNN_HEAD_DX_WIDE") && atoi(getenv("TNN_HEAD_DX_WIDE")) == 0;
-        const int ti = (int)(n_in / 16), dx_cols = (rows <= 128 && ti % 2 == 0 && !dx_wide_off) ? ti / 2 : ti;    // (head_bwd_launch's grid)
+        static const bool dx_wide_rb_off = getenv("TNN_HEAD_DX_WIDE_RB") && atoi(getenv("TNN_HEAD_DX_WIDE_RB")) == 0;
+        const int ti = (int)(n_in / 16), dx_cols = (ti % 2 == 0 && !dx_wide_off && (rows <= 128 || !dx_wide_rb_off)) ? ti / 2 : ti;    // (head_bwd_launch's grid)
         grid = 16 + ti * 8 + (int)((rows + 15) / 16) * dx_cols;
         static int per_cu_small = -1, per_cu_rb = -1;
         if (per_cu_small < 0) {

@@ -62,7 +62,7 @@ for k in range(4):
         print("    %-28s min %6.2f   med %6.2f   max %6.2f" % (label, np.nanmedian(np.nanmin(vv, axis=1)), np.nanmedian(vv),
                                                                 np.nanmedian(np.nanmax(vv, axis=1))))
     if k == 2:
-        for role, lo, hi in (("16 head workgroups", 0, 16), ("128 dW1 tiles", 16, 144), ("%d dx1 tiles" % (n - 144), 144, n)):
+        for role, lo, hi in (("16 head workgroups", 0, 16), ("128 dW1 tiles", 16, 144), ("%d dx1 tiles (those among the first 1024 workgroups)" % (n - 144), 144, n)):
             part = rel[:, lo:hi, 3]
             print("    (%-20s end: med %6.2f   max %6.2f; entry max %5.2f)" % (role, np.median(part), np.median(part.max(axis=1)),
                                                                               np.median(rel[:, lo:hi, 0].max(axis=1))))
