@@ -46,8 +46,14 @@ names = ["fwd0  gemm_small_f32_kernel<.., 16, ..>  (784 -> 256, bias + ReLU)",
 grids = [8 * 16, 8 * 8, 16 + 16 * 8 + (8 * 8 if os.environ.get("TNN_HEAD_DX_WIDE", "1") != "0" else 8 * 16),
          49 * 8 if os.environ.get("TNN_DW0_WIDE", "1") != "0" else 49 * 16]
 print("# rows %d; us relative to the launch's first workgroup entry; min / median / max over workgroups (median over 40 steps)" % rows)
+if rows > 128:
+    # the row-blocked head launch: 16 head + 128 dW1 workgroups, then ceil(rows / 16) x (8 or 16) dx tiles; only it is stamped
+    dxc = 8 if (os.environ.get("TNN_HEAD_DX_WIDE", "1") != "0" and os.environ.get("TNN_HEAD_DX_WIDE_RB", "1") != "0") else 16
+    grids[2] = 16 + 128 + (rows + 15) // 16 * dxc
 for k in range(4):
-    n = min(grids[k] if rows == 128 else 1024, 1024)
+    if rows > 128 and k != 2:
+        continue
+    n = min(grids[k], 1024)
     blk = tr[:, k, :n, :]
     live = blk[:, :, 0] > 0
     t0 = np.where(live, blk[:, :, 0], np.iinfo(np.int64).max).min(axis=1)[:, None, None]
@@ -69,6 +75,12 @@ for k in range(4):
         done = rel[:, :, 3].mean(axis=0)
         order = np.argsort(done)
         print("    slowest workgroups (index: end):", ", ".join("%d: %.2f" % (i, done[i]) for i in order[-10:]))
+        dur = (rel[:, 144:n, 3] - rel[:, 144:n, 0])
+        print("    dx tiles, entry -> end: min %.2f  10%% %.2f  med %.2f  90%% %.2f  max %.2f" % (
+            np.median(dur.min(axis=1)), np.median(np.percentile(dur, 10, axis=1)), np.median(dur), np.median(np.percentile(dur, 90, axis=1)),
+            np.median(dur.max(axis=1))))
+        byx = [np.median(dur[:, x::8]) for x in range(8)]
+        print("    dx tiles, median duration by XCD (index mod 8):", " ".join("%.2f" % v for v in byx))
     if k == 3:
         done = rel[:, :, 3].mean(axis=0)
         order = np.argsort(done)
