@@ -27,7 +27,6 @@ HOST_POOL = {}                                             # what fit_blas_pool_
 def single_gpu_secondary(line, args, widths, rows, kind, res, runner, solo, use_graph, comm):
     """Rank 0, N = 1: the roofline objects, the drop-in API paths, the epoch loop, configs[2] and configs[4], the CPU baseline —
     every one an extra measurement AFTER the line's own `value` exists."""
-    line["host_blas_pool"] = dict(HOST_POOL)
     if args.workload == "E":
         line["roofline"] = dw_adam_roofline_in_step(runner, widths, rows, res["ms_per_step"])
         line["gemm_roofline"] = time_gemms_bf16(widths, rows)
@@ -420,6 +419,7 @@ def main():
                 check_timed["ok"] = ok_t
     if rank == 0:
         line = make_line(args, widths, rows, kind, world, warmup, steps, res, runner, transports, force_dp)
+        line["host_blas_pool"] = dict(HOST_POOL)          # (rank 0's; every rank takes its share of half the CPU quota)
         if check is not None:
             line["parity_vs_reference_fixture"] = check
             if not check["ok"]:
