@@ -343,9 +343,10 @@ struct HeadBwdArgs {
     float *dw1, *db1, *dx;           // [n_in][H], [H], [m][n_in]
     int n_in, tiles_in;              // tiles_in = n_in / 16
     int xcd;                         // XCD-aware tile order (workgroup b runs on XCD b % 8)
-    int dx_wide;                     // mlp_head_bwd_kernel (<= 128 rows): dx tiles of 16 rows x 32 inputs (tiles_in even) — for the MNIST
-                                     // net 16 + 128 + 64 = 208 workgroups instead of 272: the 16 that were a CU's SECOND workgroup ended
-                                     // 1.1 us behind the rest (round 6, profiles/r06_stepA_stamps.txt)
+    int dx_wide;                     // dx tiles of 16 rows x 32 inputs (tiles_in even).  <= 128 rows: for the MNIST net 16 + 128 + 64 = 208
+                                     // workgroups instead of 272 — the 16 that were a CU's SECOND workgroup ended 1.1 us behind the rest
+                                     // (profiles/r06_stepA_stamps.txt).  Row-blocked kernel: half the dx workgroups for its two slots per CU
+                                     // (1024 rows: 656 instead of 1168 workgroups, profiles/r06_head_rb_stamps.txt)
 };
 
 // CUT (ablation builds of round 2, template parameter only): tile roles stop after 1 = the logits, 2 = the statistics, 3 = dz, 4 = the dz1 panel.
@@ -1518,7 +1519,7 @@ int head_bwd_launch(const char* fn, const float* ext_pairs, int ext_n, bool whol
     q.dw1 = (float*)dw1; q.db1 = (float*)db1; q.dx = (float*)dx;
     q.n_in = (int)n_in; q.tiles_in = (int)(n_in / 16);
     q.xcd = 1;
-    // <= 128 rows: dx tiles of 32 inputs when that brings the launch under one workgroup per CU's worth of imbalance (TNN_HEAD_DX_WIDE=0: A/B)
+    // dx tiles of 32 inputs (HeadBwdArgs::dx_wide; TNN_HEAD_DX_WIDE=0 / TNN_HEAD_DX_WIDE_RB=0: the 16-wide tiles at every row count / above 128 rows, A/B)
     static const bool dx_wide_off = getenv("TNN_HEAD_DX_WIDE") && atoi(getenv("TNN_HEAD_DX_WIDE")) == 0;
     static const bool dx_wide_rb_off = getenv("TNN_HEAD_DX_WIDE_RB") && atoi(getenv("TNN_HEAD_DX_WIDE_RB")) == 0;
     q.dx_wide = (q.tiles_in % 2 == 0 && !dx_wide_off && (rows <= 128 || !dx_wide_rb_off)) ? 1 : 0;
